@@ -1,0 +1,81 @@
+"""ctypes binding of libaspire_hip.so (the C ABI declared in include/aspire_hip.h).
+
+The library is the product: there is no CPU or PyTorch-eager fallback.  If it is missing the import
+fails loudly; if it is present but no GPU is visible, every compute entry point raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libaspire_hip.so')
+
+c_void_p, c_int, c_int32, c_int64, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
+                                                         ctypes.c_int64, ctypes.c_double, ctypes.c_size_t)
+
+ASPIRE_OK, ASPIRE_ERR_INVALID_ARG, ASPIRE_ERR_UNSUPPORTED, ASPIRE_ERR_HIP = 0, 1, 2, 3
+CDIST_AUTO, CDIST_DIRECT, CDIST_MM = 0, 1, 2
+PAIR_CROSS, PAIR_PAIRED = 0, 1
+OT_DISTANCE, OT_PLAN_SIM = 0, 1
+
+
+class RepSet(ctypes.Structure):
+    """struct aspire_repset"""
+    _fields_ = [('rows', c_void_p), ('start', c_void_p), ('len', c_void_p), ('n', c_int64),
+                ('ext', c_int32), ('max_len', c_int32)]
+
+
+class OtParams(ctypes.Structure):
+    """struct aspire_ot_params"""
+    _fields_ = [('blur', c_double), ('scaling', c_double), ('sent_sm_temp', c_double), ('cdist_mode', c_int32)]
+
+
+class AspireHipError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); must list every function include/aspire_hip.h declares.
+SIGNATURES = {
+    'aspire_abi_version': (c_int, []),
+    'aspire_last_error': (ctypes.c_char_p, []),
+    'aspire_max_sents': (c_int, []),
+    'aspire_span_mean_pool_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                          c_void_p, c_void_p, c_void_p]),
+    'aspire_l2max_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]),
+    'aspire_ot_sinkhorn_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int,
+                                       ctypes.POINTER(OtParams), c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    'aspire_group_diameter_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int64,
+                                          c_void_p, c_void_p]),
+    'aspire_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64]),
+    'aspire_topk_desc_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
+    'aspire_selftest_xlane': (c_int, [ctypes.POINTER(c_int)]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build it first with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(hipcc --offload-arch=gfx950).  aspire_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status):
+    if status != ASPIRE_OK:
+        msg = lib.aspire_last_error().decode('utf-8', 'replace')
+        if status == ASPIRE_ERR_INVALID_ARG:
+            # the reference signals these with `assert`, keep the exception type
+            raise AssertionError(msg)
+        if status == ASPIRE_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise AspireHipError(msg)

@@ -1,0 +1,73 @@
+// Error reporting, ABI version, and the cross-lane primitive self test.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace aspire {
+namespace {
+thread_local char g_err[512] = "";
+}
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+// Every fast cross-lane form against ds_bpermute (__shfl_xor) on lane-distinct data.
+__global__ void xlane_selftest_kernel(int* mismatch) {
+    const int lane = threadIdx.x;
+    const float v = (float)(lane * 7 + 3);
+    int bad = 0;
+    bad += lane_xor<1>(v) != __shfl_xor(v, 1);
+    bad += lane_xor<2>(v) != __shfl_xor(v, 2);
+    bad += lane_xor<4>(v) != __shfl_xor(v, 4);
+    bad += lane_xor<8>(v) != __shfl_xor(v, 8);
+    bad += lane_xor<16>(v) != __shfl_xor(v, 16);
+    bad += lane_xor<32>(v) != __shfl_xor(v, 32);
+    // reductions
+    float rs = v;
+    for (int m = 1; m < 8; m <<= 1) rs += __shfl_xor(rs, m);
+    bad += row8_sum(v) != rs;
+    float cs = v;
+    for (int m = 8; m < 64; m <<= 1) cs += __shfl_xor(cs, m);
+    bad += col8_sum(v) != cs;
+    float rm = v, cm = v;
+    for (int m = 1; m < 8; m <<= 1) rm = fmaxf(rm, __shfl_xor(rm, m));
+    for (int m = 8; m < 64; m <<= 1) cm = fmaxf(cm, __shfl_xor(cm, m));
+    bad += row8_max(v) != rm;
+    bad += col8_max(v) != cm;
+    // butterflies: element k of lane l is (l + 1) * (k + 1); sum over lanes = (k + 1) * 2080
+    {
+        float a[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) a[k] = (float)((lane + 1) * (k + 1));
+        bad += butterfly_sum<64>(a, lane) != (float)((lane + 1) * 2080);
+        float b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = (float)((lane + 1) * (k + 1));
+        bad += butterfly_sum<16>(b, lane) != (float)(((lane >> 2) + 1) * 2080);
+    }
+    atomicAdd(mismatch, bad);
+}
+}  // namespace
+}  // namespace aspire
+
+using namespace aspire;
+
+extern "C" int aspire_abi_version(void) { return ASPIRE_ABI_VERSION; }
+extern "C" const char* aspire_last_error(void) { return g_err; }
+
+extern "C" int aspire_selftest_xlane(int* out_mismatch_host) {
+    ASPIRE_REQUIRE(out_mismatch_host, ASPIRE_ERR_INVALID_ARG, "null output");
+    int* d = nullptr;
+    ASPIRE_HIP_OK(hipMalloc(&d, sizeof(int)));
+    ASPIRE_HIP_OK(hipMemset(d, 0, sizeof(int)));
+    hipLaunchKernelGGL(xlane_selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+    ASPIRE_LAUNCH_OK();
+    ASPIRE_HIP_OK(hipMemcpy(out_mismatch_host, d, sizeof(int), hipMemcpyDeviceToHost));
+    ASPIRE_HIP_OK(hipFree(d));
+    return ASPIRE_OK;
+}

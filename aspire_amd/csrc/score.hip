@@ -1,0 +1,689 @@
+// Scoring kernels: masked pairwise L2 (A5), soft-max marginals (A6), geomloss-0.2.4 Sinkhorn (A7/A8),
+// max-sim (A9), batch bounding-box diameter.  Reference arithmetic:
+//   src/learning/facetid_models/pair_distances.py:21-92, :138-186 (allenai/aspire)
+//   geomloss==0.2.4 sinkhorn_tensorized / sinkhorn_loop (third party; restated, parity unpinned).
+//
+// Data layout and work decomposition (gfx950, wave = 64 lanes):
+//   * one workgroup = 3 waves = one candidate document x a chunk of queries.  Wave w owns encoding
+//     coordinates [256w, 256w+256): lane l holds the float4 at d = 256w + 4l of every sentence row, so a
+//     768-float row is ONE global_load_dwordx4 per lane, perfectly coalesced, no LDS staging.
+//   * sentence-pair sums are formed 8x8 rows at a time ("tile"): each lane accumulates the 64
+//     (i,j) partial sums over its 4 coordinates, then a 63-exchange halving butterfly
+//     (v_permlane32_swap / v_permlane16_swap / DPP) leaves lane l = 8*i + j holding the wave's sum for
+//     (i,j).  The three waves' partials meet in LDS (6 KB per tile).
+//   * the Sinkhorn solve of one (query, candidate) pair runs in ONE wave with lane (li,lj) = (l>>3,l&7)
+//     holding the T x T entries (8a+li, 8b+lj): row log-sum-exps are DPP reductions over lane bits 0-2,
+//     column ones over bits 3-5 (permlane swaps); potentials stay in registers for all ~70 eps-steps.
+#include <math.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace aspire {
+namespace {
+
+constexpr int kWaves = 3;
+constexpr int kBlock = 64 * kWaves;
+constexpr int kMaxT = 4;  // sentence rows per document <= 8 * kMaxT
+
+struct RepSet {
+    const float* rows;
+    const int32_t* start;
+    const int32_t* len;
+    int64_t n;
+    int32_t ext;
+};
+
+struct ScoreArgs {
+    RepSet q, c;
+    int pairing;     // ASPIRE_PAIR_*
+    int cdist_mode;  // ASPIRE_CDIST_*
+    int q_per_block; // CROSS: queries handled by one block (grid.y chunks)
+    // OT
+    double blur, scaling, temp;
+    const float* diameter;
+    int64_t diam_group;
+    int64_t n_groups;
+    int want;
+    float* scores;
+    float* out_qdistr;
+    float* out_cdistr;
+    float* out_pairsims;
+    float* out_plan;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Load 8 sentence rows (this lane's float4 slice) of one document; rows >= navail read as zero.
+template <bool BBOX>
+__device__ __forceinline__ void load_tile(float4 (&r)[8], const float* doc, int row0, int navail, int dofs, int nbox,
+                                          float4& mn, float4& mx) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + i;
+        if (row < navail) {
+            r[i] = ld4(doc + (size_t)row * kD + dofs);
+        } else {
+            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (BBOX && row < nbox) {
+            mn.x = fminf(mn.x, r[i].x); mn.y = fminf(mn.y, r[i].y); mn.z = fminf(mn.z, r[i].z); mn.w = fminf(mn.w, r[i].w);
+            mx.x = fmaxf(mx.x, r[i].x); mx.y = fmaxf(mx.y, r[i].y); mx.z = fmaxf(mx.z, r[i].z); mx.w = fmaxf(mx.w, r[i].w);
+        }
+    }
+}
+
+// Per-wave partial sums of one 8x8 tile -> LDS.  red layout: [tile][2][64] (0: x.y dot, 1: sum (x-y)^2).
+template <bool NEED_G, bool NEED_D2>
+__device__ __forceinline__ void tile_partials(const float4 (&x)[8], const float4 (&y)[8], float* red_tile, int lane) {
+    if constexpr (NEED_D2) {
+        float acc[64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dx = x[i].x - y[j].x, dy = x[i].y - y[j].y, dz = x[i].z - y[j].z, dw = x[i].w - y[j].w;
+                acc[i * 8 + j] = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            }
+        red_tile[64 + lane] = butterfly_sum<64>(acc, lane);
+    }
+    if constexpr (NEED_G) {
+        float acc[64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i * 8 + j] = fmaf(x[i].w, y[j].w, fmaf(x[i].z, y[j].z, fmaf(x[i].y, y[j].y, x[i].x * y[j].x)));
+        red_tile[lane] = butterfly_sum<64>(acc, lane);
+    }
+}
+
+// |x_i|^2 (8 rows) and |y_j|^2 (8 rows) partials -> LDS [16] per wave.
+__device__ __forceinline__ void norm_partials(const float4 (&x)[8], const float4 (&y)[8], float* rednorm, int lane) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = fmaf(x[i].w, x[i].w, fmaf(x[i].z, x[i].z, fmaf(x[i].y, x[i].y, x[i].x * x[i].x)));
+        v[8 + i] = fmaf(y[i].w, y[i].w, fmaf(y[i].z, y[i].z, fmaf(y[i].y, y[i].y, y[i].x * y[i].x)));
+    }
+    const float r = butterfly_sum<16>(v, lane);
+    if ((lane & 3) == 0) rednorm[lane >> 2] = r;
+}
+
+// x / e with e's reciprocal r: one Newton step makes the quotient correctly rounded in all but
+// pathological cases (what the v_div_* sequence does, minus its denormal scaling).
+__device__ __forceinline__ float div_r(float x, float e, float r) {
+    const float q = x * r;
+    return fmaf(fmaf(-q, e, x), r, q);
+}
+__device__ __forceinline__ float rcp_refined(float e) {
+    float r = __builtin_amdgcn_rcpf(e);
+    return fmaf(fmaf(-e, r, 1.0f), r, r);
+}
+
+__device__ __forceinline__ bool use_mm_formula(int mode, int nq, int nc) {
+    // torch.cdist default: matmul expansion iff either side has more than 25 rows.
+    return mode == ASPIRE_CDIST_MM || (mode == ASPIRE_CDIST_AUTO && (nq > 25 || nc > 25));
+}
+
+// LDS carve (floats): red[kWaves][T*T][128] | rednorm[kWaves][T][16] | reddiam[kWaves]
+template <int T>
+struct Lds {
+    static constexpr int kRed = kWaves * T * T * 128;
+    static constexpr int kNorm = kWaves * T * 16;
+    static constexpr int kTotal = kRed + kNorm + 4;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Phase 1: all three waves form the partial sums of (query doc, candidate doc) for every tile.
+// ---------------------------------------------------------------------------------------------
+template <int T, bool NEED_G, bool NEED_D2, bool BBOX>
+__device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, int q_box, const float* cdoc, int c_avail,
+                                              int c_box, float* lds, int wave, int lane) {
+    const int dofs = wave * 256 + lane * 4;
+    float* red = lds + wave * (T * T * 128);
+    float* rednorm = lds + Lds<T>::kRed + wave * (T * 16);
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll 1
+    for (int ti = 0; ti < T; ++ti) {
+        float4 x[8];
+        load_tile<BBOX>(x, qdoc, ti * 8, q_avail, dofs, q_box, mn, mx);
+#pragma unroll 1
+        for (int tj = 0; tj < T; ++tj) {
+            float4 y[8];
+            load_tile<BBOX>(y, cdoc, tj * 8, c_avail, dofs, c_box, mn, mx);  // min/max are idempotent
+            tile_partials<NEED_G, NEED_D2>(x, y, red + (ti * T + tj) * 128, lane);
+            if (NEED_G && ti == tj) norm_partials(x, y, rednorm + ti * 16, lane);
+        }
+    }
+    if (BBOX) {
+        const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
+        const float s = wave_sum(fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx))));
+        if (lane == 0) lds[Lds<T>::kRed + Lds<T>::kNorm + wave] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// max-sim kernel (A9)
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(kBlock) l2max_kernel(ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t c_idx = blockIdx.x;
+    const int c_len = a.c.len[c_idx];
+    const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
+    const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
+    const int64_t q_begin = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx : (int64_t)blockIdx.y * a.q_per_block;
+    const int64_t q_end = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx + 1 : min(a.q.n, q_begin + a.q_per_block);
+    const int li = lane >> 3, lj = lane & 7;
+    for (int64_t q_idx = q_begin; q_idx < q_end; ++q_idx) {
+        const int q_len = a.q.len[q_idx];
+        const int q_avail = a.q.ext > 0 ? a.q.ext : q_len;
+        const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
+        const bool mm = use_mm_formula(a.cdist_mode, q_avail, c_avail);
+        if (mm) {
+            pair_partials<T, true, false, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
+        } else {
+            pair_partials<T, false, true, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int64_t p = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx : q_idx * a.c.n + c_idx;
+            float best = -INFINITY;
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < T; ++tb) {
+                    const int i = ta * 8 + li, j = tb * 8 + lj;
+                    const float* r = lds + (ta * T + tb) * 128;
+                    float d2;
+                    if (mm) {
+                        float g = 0.f, xx = 0.f, yy = 0.f;
+#pragma unroll
+                        for (int w = 0; w < kWaves; ++w) {
+                            g += r[w * T * T * 128 + lane];
+                            xx += lds[Lds<T>::kRed + w * T * 16 + ta * 16 + li];
+                            yy += lds[Lds<T>::kRed + w * T * 16 + tb * 16 + 8 + lj];
+                        }
+                        d2 = fmaxf(fmaf(-2.f, g, xx) + yy, 0.f);
+                    } else {
+                        d2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < kWaves; ++w) d2 += r[w * T * T * 128 + 64 + lane];
+                    }
+                    const float neg = -sqrtf(d2);
+                    const bool valid = i < q_len && j < c_len;
+                    if (valid) best = fmaxf(best, neg);
+                    if (a.out_pairsims && i < a.q.ext && j < a.c.ext)
+                        a.out_pairsims[(p * a.q.ext + i) * a.c.ext + j] = neg + (valid ? 0.f : -10e8f);
+                }
+            best = wave_max(best);
+            if (lane == 0) a.scores[p] = best;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// otAspire kernel (A5-A8)
+// ---------------------------------------------------------------------------------------------
+template <int T>
+struct PairState {
+    float cost[T][T];  // geomloss cost: sqrt(max(|x|^2 - 2 x.y + |y|^2, 1e-8))
+    float neg[T][T];   // -cdist (torch formula)
+    float diam2;       // sum over coordinates of (max-min)^2 (only when computed in-kernel)
+};
+
+template <int T>
+__device__ __forceinline__ void gather_pair(PairState<T>& s, const float* lds, bool mm, int lane, bool want_diam) {
+    const int li = lane >> 3, lj = lane & 7;
+#pragma unroll
+    for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < T; ++tb) {
+            const float* r = lds + (ta * T + tb) * 128;
+            float g = 0.f, d2 = 0.f, xx = 0.f, yy = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                g += r[w * T * T * 128 + lane];
+                d2 += r[w * T * T * 128 + 64 + lane];
+                xx += lds[Lds<T>::kRed + w * T * 16 + ta * 16 + li];
+                yy += lds[Lds<T>::kRed + w * T * 16 + tb * 16 + 8 + lj];
+            }
+            const float sq = fmaf(-2.f, g, xx) + yy;
+            s.cost[ta][tb] = sqrtf(fmaxf(sq, 1e-8f));
+            s.neg[ta][tb] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);
+        }
+    if (want_diam) {
+        const float* dd = lds + Lds<T>::kRed + Lds<T>::kNorm;
+        s.diam2 = dd[0] + dd[1] + dd[2];
+    }
+}
+
+template <int T>
+__device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_len, int c_len, float diam, int64_t p,
+                              int lane) {
+    const int li = lane >> 3, lj = lane & 7;
+    bool rv[T], cv[T];  // row / column validity
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        rv[t] = t * 8 + li < q_len;
+        cv[t] = t * 8 + lj < c_len;
+    }
+    // ---- marginals (pair_distances.py:57-60): softmax over sentences of the best match / temp -----
+    const float temp = (float)a.temp;
+    float la[T], lb[T], wa[T], wb[T];  // log-weights and weights
+    {
+        float qm[T], cm[T];
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : -INFINITY);
+            qm[ta] = row8_max(m) / temp;
+        }
+#pragma unroll
+        for (int tb = 0; tb < T; ++tb) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : -INFINITY);
+            cm[tb] = col8_max(m) / temp;
+        }
+        float mq = -INFINITY, mc = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            mq = fmaxf(mq, rv[t] ? qm[t] : -INFINITY);
+            mc = fmaxf(mc, cv[t] ? cm[t] : -INFINITY);
+        }
+        mq = col8_max(mq);  // rows are spread over lane bits 3-5
+        mc = row8_max(mc);  // columns over lane bits 0-2
+        float sq = 0.f, sc = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            sq += rv[t] ? __expf(qm[t] - mq) : 0.f;
+            sc += cv[t] ? __expf(cm[t] - mc) : 0.f;
+        }
+        const float lsq = __logf(col8_sum(sq)), lsc = __logf(row8_sum(sc));
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            // log_softmax(...).exp(), then geomloss log_weights: log(a), a <= 0 -> -100000
+            wa[t] = rv[t] ? __expf(qm[t] - mq - lsq) : 0.f;
+            wb[t] = cv[t] ? __expf(cm[t] - mc - lsc) : 0.f;
+            la[t] = wa[t] > 0.f ? __logf(wa[t]) : -100000.f;
+            lb[t] = wb[t] > 0.f ? __logf(wb[t]) : -100000.f;
+        }
+    }
+    // ---- epsilon schedule (geomloss epsilon_schedule, p = 1) --------------------------------------
+    //   [diam] + [exp(e) for e in arange(log diam, log blur, log scaling)] + [blur]
+    const double ld = log((double)diam), lbl = log(a.blur), lsc = log(a.scaling);
+    int n_mid = (int)ceil((lbl - ld) / lsc);
+    if (n_mid < 0) n_mid = 0;
+    const float eps_last = (float)a.blur;
+
+    float f[T], g[T];
+    auto softmin_rows = [&](float eps, float reps, const float (&h)[T], float (&out)[T]) {
+        // out_i = -eps * logsumexp_j(h_j - C_ij/eps), j over valid columns
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta) {
+            float tv[T];
+            float m = -INFINITY;
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb) {
+                tv[tb] = cv[tb] ? h[tb] - div_r(s.cost[ta][tb], eps, reps) : -INFINITY;
+                m = fmaxf(m, tv[tb]);
+            }
+            m = row8_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb) sum += __expf(tv[tb] - m);
+            out[ta] = -eps * (m + __logf(row8_sum(sum)));
+        }
+    };
+    auto softmin_cols = [&](float eps, float reps, const float (&h)[T], float (&out)[T]) {
+#pragma unroll
+        for (int tb = 0; tb < T; ++tb) {
+            float tv[T];
+            float m = -INFINITY;
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta) {
+                tv[ta] = rv[ta] ? h[ta] - div_r(s.cost[ta][tb], eps, reps) : -INFINITY;
+                m = fmaxf(m, tv[ta]);
+            }
+            m = col8_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta) sum += __expf(tv[ta] - m);
+            out[tb] = -eps * (m + __logf(col8_sum(sum)));
+        }
+    };
+    auto step = [&](float eps, bool averaged) {
+        const float reps = rcp_refined(eps);
+        float ha[T], hb[T], ft[T], gt[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            ha[t] = la[t] + div_r(f[t], eps, reps);
+            hb[t] = lb[t] + div_r(g[t], eps, reps);
+        }
+        softmin_cols(eps, reps, ha, gt);
+        softmin_rows(eps, reps, hb, ft);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            g[t] = averaged ? 0.5f * (g[t] + gt[t]) : gt[t];
+            f[t] = averaged ? 0.5f * (f[t] + ft[t]) : ft[t];
+        }
+    };
+    {   // initialisation at eps_s[0] = diam
+        const float reps = rcp_refined(diam);
+        softmin_cols(diam, reps, la, g);
+        softmin_rows(diam, reps, lb, f);
+    }
+    step(diam, true);
+    for (int base = 0; base < n_mid; base += 64) {
+        // lane k of this chunk evaluates eps_{base+k} in double exactly as numpy does, rounds to fp32.
+        const float my_eps = (float)exp(ld + (double)(base + lane) * lsc);
+        const int cnt = min(64, n_mid - base);
+        for (int k = 0; k < cnt; ++k) {
+            const float eps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eps), k));
+            step(eps, true);
+        }
+    }
+    step(eps_last, true);
+    step(eps_last, false);  // last extrapolation: simultaneous, not averaged
+
+    // ---- outputs ------------------------------------------------------------------------------
+    float score;
+    if (a.want == ASPIRE_OT_DISTANCE) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
+            acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
+        }
+        score = wave_sum(acc);
+    } else {
+        score = 0.f;
+    }
+    const bool dump = a.out_plan != nullptr || a.out_pairsims != nullptr;
+    if (a.want == ASPIRE_OT_PLAN_SIM || dump) {
+        const float rb = rcp_refined(eps_last);
+        float acc = 0.f;
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb) {
+                const bool valid = rv[ta] && cv[tb];
+                const float negm = valid ? s.neg[ta][tb] : 0.f;
+                const float outer = valid ? f[ta] + g[tb] : 0.f;
+                const float plan = __expf(div_r(outer + negm, eps_last, rb)) * (wa[ta] * wb[tb]);
+                acc += plan * negm;
+                const int i = ta * 8 + li, j = tb * 8 + lj;
+                if (dump && i < a.q.ext && j < a.c.ext) {
+                    const int64_t o = (p * a.q.ext + i) * a.c.ext + j;
+                    if (a.out_plan) a.out_plan[o] = plan;
+                    if (a.out_pairsims) a.out_pairsims[o] = negm;
+                }
+            }
+        if (a.want == ASPIRE_OT_PLAN_SIM) score = wave_sum(acc);
+    }
+    if (lane == 0) a.scores[p] = score;
+    if (a.out_qdistr) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (lj == 0 && t * 8 + li < a.q.ext) a.out_qdistr[p * a.q.ext + t * 8 + li] = wa[t];
+    }
+    if (a.out_cdistr) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (li == 0 && t * 8 + lj < a.c.ext) a.out_cdistr[p * a.c.ext + t * 8 + lj] = wb[t];
+    }
+}
+
+template <int T>
+__global__ void __launch_bounds__(kBlock) ot_kernel(ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t c_idx = blockIdx.x;
+    const int c_len = a.c.len[c_idx];
+    const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
+    const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
+    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const int64_t q_begin = paired ? c_idx : (int64_t)blockIdx.y * a.q_per_block;
+    const int64_t q_end = paired ? c_idx + 1 : min(a.q.n, q_begin + a.q_per_block);
+    const bool own_diam = a.diameter == nullptr;
+
+    // Queries are taken three at a time: the three waves build the sums of each query together,
+    // then wave k solves query k.
+    for (int64_t q0 = q_begin; q0 < q_end; q0 += kWaves) {
+        PairState<T> mine;
+        int my_qlen = 0;
+        int64_t my_q = -1;
+#pragma unroll 1
+        for (int slot = 0; slot < kWaves; ++slot) {
+            const int64_t q_idx = q0 + slot;
+            if (q_idx >= q_end) break;  // uniform across the block
+            const int q_len = a.q.len[q_idx];
+            const int q_avail = a.q.ext > 0 ? a.q.ext : q_len;
+            const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
+            if (own_diam) {
+                pair_partials<T, true, true, true>(qdoc, q_avail, q_len, cdoc, c_avail, c_len, lds, wave, lane);
+            } else {
+                pair_partials<T, true, true, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
+            }
+            __syncthreads();
+            if (wave == slot) {
+                gather_pair<T>(mine, lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), lane, own_diam);
+                my_qlen = q_len;
+                my_q = q_idx;
+            }
+            __syncthreads();
+        }
+        if (my_q >= 0) {
+            const int64_t p = paired ? c_idx : my_q * a.c.n + c_idx;
+            float diam;
+            if (own_diam) {
+                diam = sqrtf(mine.diam2);
+            } else {
+                diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[my_q * a.n_groups + c_idx / a.diam_group];
+            }
+            sinkhorn_pair<T>(a, mine, my_qlen, c_len, diam, p, lane);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch bounding-box diameter (geomloss max_diameter over the call's x and y tensors)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) diameter_kernel(ScoreArgs a, int64_t group, float* out) {
+    __shared__ float part[kWaves];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int dofs = threadIdx.x * 4;
+    const int64_t g = blockIdx.x;
+    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const int64_t c_lo = g * group, c_hi = min(a.c.n, c_lo + group);
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    auto add_rows = [&](const RepSet& s, int64_t k, bool use_ext) {
+        const int n = (use_ext && s.ext > 0) ? s.ext : s.len[k];
+        const float* doc = s.rows + (size_t)s.start[k] * kD;
+        for (int r = 0; r < n; ++r) {
+            const float4 v = ld4(doc + (size_t)r * kD + dofs);
+            mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+            mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+        }
+    };
+    bool zero_row = false;
+    if (paired) {
+        for (int64_t k = c_lo; k < c_hi; ++k) {
+            add_rows(a.q, k, true);
+            add_rows(a.c, k, true);
+        }
+    } else {
+        add_rows(a.q, blockIdx.y, false);
+        int lmin = 1 << 30, lmax = 0;
+        for (int64_t k = c_lo; k < c_hi; ++k) {
+            add_rows(a.c, k, false);
+            lmin = min(lmin, a.c.len[k]);
+            lmax = max(lmax, a.c.len[k]);
+        }
+        zero_row = lmin != lmax;  // caching_score zero-pads shorter candidates to the group max
+    }
+    if (zero_row) {
+        mn.x = fminf(mn.x, 0.f); mn.y = fminf(mn.y, 0.f); mn.z = fminf(mn.z, 0.f); mn.w = fminf(mn.w, 0.f);
+        mx.x = fmaxf(mx.x, 0.f); mx.y = fmaxf(mx.y, 0.f); mx.z = fmaxf(mx.z, 0.f); mx.w = fmaxf(mx.w, 0.f);
+    }
+    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
+    const float s = wave_sum(fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx))));
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t o = paired ? g : (int64_t)blockIdx.y * gridDim.x + g;
+        out[o] = sqrtf(part[0] + part[1] + part[2]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int check_repsets(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing) {
+    ASPIRE_REQUIRE(q && c, ASPIRE_ERR_INVALID_ARG, "null repset");
+    ASPIRE_REQUIRE(D == kD, ASPIRE_ERR_UNSUPPORTED, "encoding dim %lld unsupported (kernels are built for 768)",
+                   (long long)D);
+    ASPIRE_REQUIRE(pairing == ASPIRE_PAIR_CROSS || pairing == ASPIRE_PAIR_PAIRED, ASPIRE_ERR_INVALID_ARG,
+                   "bad pairing %d", pairing);
+    ASPIRE_REQUIRE(q->n >= 0 && c->n >= 0, ASPIRE_ERR_INVALID_ARG, "negative document count");
+    // pair_distances.py:46  assert (qef_batch_size == cef_batch_size)
+    ASPIRE_REQUIRE(pairing != ASPIRE_PAIR_PAIRED || q->n == c->n, ASPIRE_ERR_INVALID_ARG,
+                   "paired scoring needs equal batch sizes (query %lld vs cand %lld)", (long long)q->n, (long long)c->n);
+    ASPIRE_REQUIRE(q->ext >= 0 && c->ext >= 0, ASPIRE_ERR_INVALID_ARG, "negative ext");
+    return ASPIRE_OK;
+}
+
+RepSet to_dev(const aspire_repset* s) { return RepSet{s->rows, s->start, s->len, s->n, s->ext}; }
+
+int max_rows_of(const aspire_repset* q, const aspire_repset* c) {
+    const int mq = q->ext > 0 ? q->ext : q->max_len;
+    const int mc = c->ext > 0 ? c->ext : c->max_len;
+    return mq > mc ? mq : mc;
+}
+
+template <typename F>
+int dispatch_T(int max_rows, F&& f) {
+    if (max_rows <= 8) return f(std::integral_constant<int, 1>{});
+    if (max_rows <= 16) return f(std::integral_constant<int, 2>{});
+    if (max_rows <= 24) return f(std::integral_constant<int, 3>{});
+    if (max_rows <= 32) return f(std::integral_constant<int, 4>{});
+    set_error("documents with more than %d sentence rows are not supported (got %d)", 8 * kMaxT, max_rows);
+    return ASPIRE_ERR_UNSUPPORTED;
+}
+
+void grid_for(const ScoreArgs& a, dim3& grid, int& q_per_block) {
+    if (a.pairing == ASPIRE_PAIR_PAIRED) {
+        grid = dim3((unsigned)a.c.n, 1, 1);
+        q_per_block = 1;
+        return;
+    }
+    // CROSS: grid.x = candidates; split queries over grid.y only while the grid is too small to fill
+    // 256 CUs several times over (each block re-reads its candidate from L2 per query chunk).
+    int64_t chunks = 1;
+    const int64_t target_blocks = 256 * 8;
+    while (a.c.n * chunks < target_blocks && chunks * kWaves < a.q.n) chunks *= 2;
+    int64_t qpb = (a.q.n + chunks - 1) / chunks;
+    qpb = (qpb + kWaves - 1) / kWaves * kWaves;
+    chunks = (a.q.n + qpb - 1) / qpb;
+    grid = dim3((unsigned)a.c.n, (unsigned)chunks, 1);
+    q_per_block = (int)qpb;
+}
+
+}  // namespace
+}  // namespace aspire
+
+using namespace aspire;
+
+extern "C" int aspire_max_sents(void) { return 8 * kMaxT; }
+
+extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                       int cdist_mode, float* scores, float* pair_sims, void* stream) {
+    if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "scores is null");
+    ASPIRE_REQUIRE(!pair_sims || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
+                   "pair_sims output needs padded extents (ext > 0)");
+    if (q->n == 0 || c->n == 0) return ASPIRE_OK;
+    ScoreArgs a{};
+    a.q = to_dev(q);
+    a.c = to_dev(c);
+    a.pairing = pairing;
+    a.cdist_mode = cdist_mode;
+    a.scores = scores;
+    a.out_pairsims = pair_sims;
+    dim3 grid;
+    grid_for(a, grid, a.q_per_block);
+    return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
+        constexpr int T = decltype(tc)::value;
+        hipLaunchKernelGGL(l2max_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);
+        ASPIRE_LAUNCH_OK();
+        return (int)ASPIRE_OK;
+    });
+}
+
+extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                      const aspire_ot_params* prm, const float* diameter, int64_t diam_group, int want,
+                                      float* scores, float* out_qdistr, float* out_cdistr, float* out_pairsims,
+                                      float* out_plan, void* stream) {
+    if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    ASPIRE_REQUIRE(prm && scores, ASPIRE_ERR_INVALID_ARG, "null params/scores");
+    ASPIRE_REQUIRE(want == ASPIRE_OT_DISTANCE || want == ASPIRE_OT_PLAN_SIM, ASPIRE_ERR_INVALID_ARG, "bad want %d", want);
+    ASPIRE_REQUIRE(prm->blur > 0 && prm->scaling > 0 && prm->scaling < 1 && prm->sent_sm_temp > 0,
+                   ASPIRE_ERR_INVALID_ARG, "need blur > 0, 0 < scaling < 1, temp > 0");
+    const bool extra = out_qdistr || out_cdistr || out_pairsims || out_plan;
+    ASPIRE_REQUIRE(!extra || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
+                   "pair outputs need padded extents (ext > 0)");
+    ASPIRE_REQUIRE(!diameter || diam_group > 0, ASPIRE_ERR_INVALID_ARG, "diam_group must be positive");
+    if (q->n == 0 || c->n == 0) return ASPIRE_OK;
+    ScoreArgs a{};
+    a.q = to_dev(q);
+    a.c = to_dev(c);
+    a.pairing = pairing;
+    a.cdist_mode = prm->cdist_mode;
+    a.blur = prm->blur;
+    a.scaling = prm->scaling;
+    a.temp = prm->sent_sm_temp;
+    a.diameter = diameter;
+    a.diam_group = diameter ? diam_group : 1;
+    a.n_groups = diameter ? (c->n + diam_group - 1) / diam_group : 0;
+    a.want = want;
+    a.scores = scores;
+    a.out_qdistr = out_qdistr;
+    a.out_cdistr = out_cdistr;
+    a.out_pairsims = out_pairsims;
+    a.out_plan = out_plan;
+    dim3 grid;
+    grid_for(a, grid, a.q_per_block);
+    return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
+        constexpr int T = decltype(tc)::value;
+        hipLaunchKernelGGL(ot_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);
+        ASPIRE_LAUNCH_OK();
+        return (int)ASPIRE_OK;
+    });
+}
+
+extern "C" int aspire_group_diameter_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                         int64_t group, float* diameter, void* stream) {
+    if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    ASPIRE_REQUIRE(group > 0 && diameter, ASPIRE_ERR_INVALID_ARG, "group must be positive, diameter non-null");
+    if (q->n == 0 || c->n == 0) return ASPIRE_OK;
+    ScoreArgs a{};
+    a.q = to_dev(q);
+    a.c = to_dev(c);
+    a.pairing = pairing;
+    const int64_t ngroups = (c->n + group - 1) / group;
+    dim3 grid((unsigned)ngroups, pairing == ASPIRE_PAIR_PAIRED ? 1u : (unsigned)q->n, 1);
+    hipLaunchKernelGGL(diameter_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a, group, diameter);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}

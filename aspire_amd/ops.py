@@ -1,0 +1,155 @@
+"""Torch-tensor front end of the C ABI: device memory and streams come from PyTorch-ROCm, every
+computation happens in libaspire_hip.so.  All tensors given here must already live on the GPU."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import RepSet, OtParams, lib, check
+
+D = 768
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('aspire_amd needs an AMD GPU (PyTorch-ROCm sees none); there is no CPU fallback.')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _f32(t, name):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), f'{name}: need contiguous fp32 GPU tensor'
+    return t
+
+
+def _i32(t, name):
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous(), f'{name}: need contiguous int32 GPU tensor'
+    return t
+
+
+class DeviceRepSet:
+    """Rows + CSR view of sentence reps resident in HBM (struct aspire_repset).
+
+    rows [total, 768] fp32; start/len int32 [n]; ext > 0 marks a padded [n, ext, 768] tensor."""
+
+    def __init__(self, rows, start, lens, ext=0, max_len=None):
+        self.rows = _f32(rows, 'rows')
+        assert rows.shape[-1] == D, f'encoding dim must be {D}'
+        self.start = _i32(start, 'start')
+        self.len = _i32(lens, 'len')
+        self.n = int(start.numel())
+        assert lens.numel() == self.n
+        self.ext = int(ext)
+        self.max_len = int(max_len if max_len is not None else (ext if ext > 0 else (int(lens.max()) if self.n else 0)))
+
+    @classmethod
+    def from_padded(cls, reps, abs_lens):
+        """reps [B, S, 768] (any device) + abs_lens list -> padded repset on the GPU."""
+        dev = require_gpu()
+        reps = reps.to(device=dev, dtype=torch.float32).contiguous()
+        b, s, _ = reps.shape
+        start = torch.arange(b, device=dev, dtype=torch.int32) * s
+        lens = torch.as_tensor(list(abs_lens), dtype=torch.int32).to(dev)
+        assert lens.numel() == b, 'abs_lens must have one entry per batch element'
+        return cls(reps.view(b * s, D), start, lens, ext=s)
+
+    @classmethod
+    def from_list(cls, reps_list):
+        """list of [S_i, 768] arrays/tensors -> CSR repset on the GPU (no padding rows)."""
+        dev = require_gpu()
+        ts = [torch.as_tensor(r, dtype=torch.float32) for r in reps_list]
+        lens_host = [int(t.shape[0]) for t in ts]
+        rows = torch.cat(ts, dim=0).to(dev).contiguous() if ts else torch.zeros(0, D, device=dev)
+        lens = torch.tensor(lens_host, dtype=torch.int32)
+        start = (torch.cumsum(lens, 0) - lens).to(torch.int32)
+        return cls(rows, start.to(dev), lens.to(dev), ext=0, max_len=max(lens_host) if lens_host else 0)
+
+    def struct(self):
+        return RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len)
+
+    def slice(self, lo, hi):
+        return DeviceRepSet(self.rows, self.start[lo:hi].contiguous(), self.len[lo:hi].contiguous(), self.ext,
+                            self.max_len)
+
+
+def _npairs(q, c, pairing):
+    return q.n if pairing == _lib.PAIR_PAIRED else q.n * c.n
+
+
+def span_mean_pool(hidden, tok_idx, span_off, max_sents, want_cls=True):
+    """A2/A3 (ex_aspire_consent.py:75-100).  hidden [B,L,768] GPU fp32 -> (cls [B,768], sent [B,S,768])."""
+    _f32(hidden, 'hidden')
+    b, l, d = hidden.shape
+    sent = torch.empty(b, max_sents, d, device=hidden.device, dtype=torch.float32)
+    cls = torch.empty(b, d, device=hidden.device, dtype=torch.float32) if want_cls else None
+    check(lib.aspire_span_mean_pool_f32(_ptr(hidden), b, l, d, _ptr(_i32(tok_idx, 'tok_idx')),
+                                        _ptr(_i32(span_off, 'span_off')), max_sents, _ptr(sent), _ptr(cls), _stream()))
+    return cls, sent
+
+
+def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want_pair_sims=False):
+    """A9 (pair_distances.py:138-186).  Returns sims [P] (and pair_sims [P, q.ext, c.ext])."""
+    p = _npairs(q, c, pairing)
+    dev = q.rows.device
+    scores = torch.empty(p, device=dev, dtype=torch.float32)
+    pair = torch.empty(p, q.ext, c.ext, device=dev, dtype=torch.float32) if want_pair_sims else None
+    qs, cs = q.struct(), c.struct()
+    check(lib.aspire_l2max_scores_f32(ctypes.byref(qs), ctypes.byref(cs), D, pairing, cdist_mode, _ptr(scores),
+                                      _ptr(pair), _stream()))
+    return (scores, pair) if want_pair_sims else scores
+
+
+def group_diameter(q, c, pairing, group):
+    ngroups = (c.n + group - 1) // group
+    n = ngroups if pairing == _lib.PAIR_PAIRED else q.n * ngroups
+    out = torch.empty(max(n, 1), device=q.rows.device, dtype=torch.float32)
+    qs, cs = q.struct(), c.struct()
+    check(lib.aspire_group_diameter_f32(ctypes.byref(qs), ctypes.byref(cs), D, pairing, group, _ptr(out), _stream()))
+    return out
+
+
+def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.CDIST_AUTO,
+                diameter=None, diam_group=0, want=_lib.OT_DISTANCE, want_extras=False, out=None):
+    """A5-A8 (pair_distances.py:21-92).  Returns scores [P]; with want_extras also
+    (query_distr [P,q.ext], cand_distr [P,c.ext], pair_sims [P,q.ext,c.ext], plan [P,q.ext,c.ext])."""
+    p = _npairs(q, c, pairing)
+    dev = q.rows.device
+    scores = out if out is not None else torch.empty(p, device=dev, dtype=torch.float32)
+    assert scores.numel() >= p
+    extras = [None] * 4
+    if want_extras:
+        extras = [torch.empty(p, q.ext, device=dev), torch.empty(p, c.ext, device=dev),
+                  torch.empty(p, q.ext, c.ext, device=dev), torch.empty(p, q.ext, c.ext, device=dev)]
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode)
+    qs, cs = q.struct(), c.struct()
+    check(lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, pairing, ctypes.byref(prm),
+                                     _ptr(diameter), diam_group, want, _ptr(scores), _ptr(extras[0]), _ptr(extras[1]),
+                                     _ptr(extras[2]), _ptr(extras[3]), _stream()))
+    return (scores, extras) if want_extras else scores
+
+
+def topk_desc(scores, k, idx_base=0):
+    """A12 (evaluate.py:76): scores [Q, C] -> (top_scores [Q,k], top_idx [Q,k] int64), stable descending."""
+    _f32(scores, 'scores')
+    qn, cn = scores.shape
+    top_s = torch.empty(qn, k, device=scores.device, dtype=torch.float32)
+    top_i = torch.empty(qn, k, device=scores.device, dtype=torch.int64)
+    nbytes = lib.aspire_topk_workspace_bytes(qn, cn, k)
+    ws = torch.empty(max(nbytes, 8), device=scores.device, dtype=torch.uint8)
+    check(lib.aspire_topk_desc_f32(_ptr(scores), qn, cn, k, idx_base, _ptr(top_s), _ptr(top_i), _ptr(ws), nbytes,
+                                   _stream()))
+    return top_s, top_i
+
+
+def selftest_xlane():
+    require_gpu()
+    n = ctypes.c_int(-1)
+    check(lib.aspire_selftest_xlane(ctypes.byref(n)))
+    return n.value

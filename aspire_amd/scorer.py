@@ -1,0 +1,130 @@
+"""Ranking-loop entry points: the callers either side of the distance functions.
+
+Reference call stacks:
+  evaluate.py:58-76      per query: get_similarity(query, cand) for every candidate, one pair per call
+                         (src/evaluation/utils/models.py:190-197), then a stable descending sort
+  pp_gen_nearest.py:131-204  per query: caching_score on consecutive groups of 64 candidates
+                         (src/learning/facetid_models/disent_models.py:256-342), then sorted(...)
+
+Here a whole candidate pool is scored by ONE launch against sentence reps that stay resident in HBM; the
+two reference loops differ only in how geomloss's epsilon schedule is grouped, which is the
+``schedule`` argument.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .pair_distances import rep_len_tup, AllPairMaskedWasserstein, allpair_masked_dist_l2max
+
+
+class CandidatePool:
+    """Sentence reps of a candidate pool, resident on the GPU as rows + CSR (struct aspire_repset)."""
+
+    def __init__(self, reps_list, pids=None):
+        self.repset = ops.DeviceRepSet.from_list(reps_list)
+        self.pids = list(pids) if pids is not None else list(range(self.repset.n))
+        assert len(self.pids) == self.repset.n
+
+    def __len__(self):
+        return self.repset.n
+
+
+def _as_pool(x):
+    return x if isinstance(x, CandidatePool) else CandidatePool(x)
+
+
+def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None, score_batch_size=64):
+    """Scores [Q, C] (GPU tensor, higher = more similar) of every query against every candidate.
+
+    method   'ot'     otAspire.  schedule 'pair': -OT_eps distance, one epsilon schedule per pair, exactly
+                      AspireModel.get_similarity (models.py:190-197).  schedule 'batch': plan-weighted
+                      similarity with one schedule per consecutive group of `score_batch_size`
+                      candidates, exactly caching_score with return_pair_sims=True
+                      (disent_models.py:297, pp_gen_nearest.py:182-196).
+             'l2max'  tsAspire max-sim (caching_score's 'l2lse' branch, disent_models.py:294-295).
+    """
+    hparams = hparams or {}
+    pool = _as_pool(pool)
+    q = ops.DeviceRepSet.from_list(query_reps_list)
+    c = pool.repset
+    if method == 'l2max':
+        # cdist's formula switch looks at the padded batch extents in the reference; per pair here.
+        return ops.l2max_scores(q, c, pairing=_lib.PAIR_CROSS).view(q.n, c.n)
+    if method != 'ot':
+        raise ValueError(f'Unknown aggregation: {method}')
+    kw = dict(blur=hparams.get('geoml_blur', 0.05), scaling=hparams.get('geoml_scaling', 0.9),
+              sent_sm_temp=hparams.get('sent_sm_temp', 1.0))
+    if hparams.get('geoml_reach', None) is not None:
+        raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
+    if schedule == 'pair':
+        dist = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_DISTANCE, **kw)
+        return (-dist).view(q.n, c.n)
+    if schedule == 'batch':
+        diam = ops.group_diameter(q, c, _lib.PAIR_CROSS, group=score_batch_size)
+        sims = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_PLAN_SIM, diameter=diam,
+                               diam_group=score_batch_size, **kw)
+        return sims.view(q.n, c.n)
+    raise ValueError(f'Unknown schedule: {schedule}')
+
+
+def rank_pool(query_reps_list, pool, k=None, **kw):
+    """Per query: [(pid, score), ...] best first, ties in pool order (evaluate.py:76)."""
+    pool = _as_pool(pool)
+    scores = score_pool(query_reps_list, pool, **kw)
+    k = len(pool) if k is None else min(k, len(pool))
+    top_s, top_i = ops.topk_desc(scores.contiguous(), k)
+    top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
+    return [[(pool.pids[i], float(s)) for s, i in zip(rs, ri) if i >= 0] for rs, ri in zip(top_s, top_i)]
+
+
+def get_similarity(x, y, hparams=None):
+    """AspireModel.get_similarity (src/evaluation/utils/models.py:190-197): one pair, -OT distance."""
+    dist_func = AllPairMaskedWasserstein(hparams or {})
+    x, y = torch.as_tensor(x), torch.as_tensor(y)
+    xt = rep_len_tup(embed=x[None, :].permute(0, 2, 1), abs_lens=[len(x)])
+    yt = rep_len_tup(embed=y[None, :].permute(0, 2, 1), abs_lens=[len(y)])
+    ot_dist = dist_func.compute_distance(query=xt, cand=yt).item()
+    return -ot_dist
+
+
+def caching_score(query_encode_ret_dict, cand_encode_ret_dicts, score_agg_type='l2wasserstein', hparams=None,
+                  sent_loss_prop=1.0):
+    """WordSentAlignBiEnc.caching_score (src/learning/facetid_models/disent_models.py:256-342) for the
+    sentence-level term (abs_loss_prop = 0.0 in every Aspire model class, :253).
+    Returns {'batch_scores': np.ndarray [B], 'pair_scores': un-padded per-candidate extras}."""
+    query_sent_reps = np.asarray(query_encode_ret_dict['sent_reps'])
+    cand_sent_reps = [np.asarray(d['sent_reps']) for d in cand_encode_ret_dicts]
+    batch_size = len(cand_sent_reps)
+    cand_lens = [r.shape[0] for r in cand_sent_reps]
+    cmax_sents = max(cand_lens)
+    qmax_sents, encoding_dim = query_sent_reps.shape
+    query_lens = [qmax_sents] * batch_size
+    dev = ops.require_gpu()
+    padded_cand = torch.zeros(batch_size, cmax_sents, encoding_dim, device=dev)
+    for bi, ex_reps in enumerate(cand_sent_reps):
+        padded_cand[bi, :cand_lens[bi], :] = torch.as_tensor(ex_reps, dtype=torch.float32)
+    padded_query = torch.as_tensor(query_sent_reps, dtype=torch.float32, device=dev).unsqueeze(0) \
+        .expand(batch_size, -1, -1).contiguous()
+    qt = rep_len_tup(embed=padded_query.permute(0, 2, 1), abs_lens=query_lens)
+    ct = rep_len_tup(embed=padded_cand.permute(0, 2, 1), abs_lens=cand_lens)
+    if score_agg_type in {'l2lse', 'l2max'}:
+        batch_sent_sims, pair_sims = allpair_masked_dist_l2max(query=qt, cand=ct, return_pair_sims=True)
+    elif score_agg_type == 'l2wasserstein':
+        batch_sent_sims, pair_sims = AllPairMaskedWasserstein(hparams or {}).compute_distance(
+            query=qt, cand=ct, return_pair_sims=True)
+    else:
+        raise ValueError(f'Unknown aggregation: {score_agg_type}')
+    batch_scores = (sent_loss_prop * batch_sent_sims).cpu().numpy()
+    if isinstance(pair_sims, list):
+        pair_sims = [t.cpu().numpy() for t in pair_sims]
+    else:
+        pair_sims = pair_sims.cpu().numpy()
+    unpadded = []
+    for i, (clen, qlen) in enumerate(zip(cand_lens, query_lens)):
+        if len(pair_sims) == 5 and isinstance(pair_sims, list):
+            upsm = [pair_sims[0][i, :qlen], pair_sims[1][i, :clen], pair_sims[2][i, :qlen, :clen],
+                    pair_sims[3][i, :qlen, :clen], pair_sims[4][i, :qlen, :clen]]
+        else:
+            upsm = pair_sims[i, :qlen, :clen]
+        unpadded.append(upsm)
+    return {'batch_scores': batch_scores, 'pair_scores': unpadded}

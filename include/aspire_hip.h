@@ -1,0 +1,166 @@
+/*
+ * aspire_hip.h -- C ABI of libaspire_hip.so: the MI355X (gfx950) implementation of Aspire's
+ * query-vs-candidate scoring path.
+ *
+ * The reference (allenai/aspire) is pure Python and has no FFI; the drop-in boundary is the Python
+ * call surface of examples/ex_aspire_consent{,_multimatch}.py.  Every entry point below replaces the
+ * PyTorch-eager arithmetic of one reference function (cited per function, paths relative to the
+ * reference root) and is what a ctypes binding of that function calls.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch types.  All pointers are DEVICE pointers unless
+ *     the parameter name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
+ *     on that stream; inputs are borrowed, outputs must be pre-allocated by the caller.
+ *   - every function returns an aspire_status; aspire_last_error() gives the message (thread local).
+ *   - fp32 arithmetic throughout ("within 1e-4 of the reference CPU path").  D (encoding dim) must
+ *     be 768 (BERT-base, `bert_encoding_dim` at ex_aspire_consent.py:31).
+ *
+ * Rep store layout ("rows + CSR"): sentence reps of many documents are one row-major fp32 matrix
+ * rows[total_sents, D]; document k owns rows [start[k], start[k] + len[k]).  A padded reference
+ * tensor [B, S, D] is the special case start[k] = k*S.
+ */
+#ifndef ASPIRE_HIP_H
+#define ASPIRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASPIRE_ABI_VERSION 1
+
+typedef enum {
+    ASPIRE_OK = 0,
+    ASPIRE_ERR_INVALID_ARG = 1,  /* the reference would raise AssertionError / IndexError          */
+    ASPIRE_ERR_UNSUPPORTED = 2,  /* shape outside what the kernels are built for (message says)    */
+    ASPIRE_ERR_HIP = 3           /* a HIP runtime call failed                                      */
+} aspire_status;
+
+int aspire_abi_version(void);
+const char* aspire_last_error(void);
+/* number of sentence rows per document the scoring kernels accept (larger -> ASPIRE_ERR_UNSUPPORTED) */
+int aspire_max_sents(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * A2 + A3  CLS read-out and span mean pooling.
+ * Replaces AspireConSent.consent_reps_bert's pooling loop, examples/ex_aspire_consent.py:75-100
+ * (original src/learning/facetid_models/disent_models.py:487-535).
+ *   hidden    [B, L, D]  final hidden states
+ *   tok_idx   flat int32 token positions; slot (b, s) owns tok_idx[span_off[b*S+s] .. span_off[b*S+s+1])
+ *   span_off  [B*S + 1]; an empty slot (doc has fewer than S sentences) yields exact zeros
+ *   sent_reps [B, S, D]  out: sum of the slot's token rows / max(count, 1)
+ *   cls_reps  [B, D]     out (may be NULL): hidden[b, 0, :]
+ * ------------------------------------------------------------------------------------------- */
+int aspire_span_mean_pool_f32(const float* hidden, int64_t B, int64_t L, int64_t D,
+                              const int32_t* tok_idx, const int32_t* span_off, int64_t S,
+                              float* sent_reps, float* cls_reps, void* stream);
+
+/* cdist formula selection, mirroring torch.cdist's default compute mode (used at
+ * pair_distances.py:49 and :167): rows <= 25 on both sides -> direct sqrt(sum (x-y)^2),
+ * otherwise the matmul expansion. */
+#define ASPIRE_CDIST_AUTO 0
+#define ASPIRE_CDIST_DIRECT 1
+#define ASPIRE_CDIST_MM 2
+
+/* How documents are paired.  CROSS: every query with every candidate, P = Q*C, pair p = q*C + c
+ * (the ranking loops evaluate.py:72-74, pp_gen_nearest.py:182-202).  PAIRED: query p with candidate
+ * p, P = Q = C (the reference's batched `compute_distance(query, cand)` signature). */
+#define ASPIRE_PAIR_CROSS 0
+#define ASPIRE_PAIR_PAIRED 1
+
+typedef struct {
+    const float* rows;     /* [total_rows, D] */
+    const int32_t* start;  /* [n] first row of each document */
+    const int32_t* len;    /* [n] valid sentence rows (abs_lens) */
+    int64_t n;             /* number of documents */
+    /* Padded extent: if > 0 every document has `ext` readable rows (len[k] <= ext) and pair outputs
+     * are laid out [.., ext, ..] with the reference's padding semantics; 0 = no padding (ext = len). */
+    int32_t ext;
+    /* Host-known upper bound of len[] (lens live on the device; the launcher needs the bound to size
+     * the tile).  Ignored when ext > 0.  A document longer than the bound yields a NaN score. */
+    int32_t max_len;
+} aspire_repset;
+
+/* ---------------------------------------------------------------------------------------------
+ * A9  tsAspire max-sim.  Replaces allpair_masked_dist_l2max,
+ * src/learning/facetid_models/pair_distances.py:138-186.
+ *   scores    [P]  out: max over valid (i < q_len, j < c_len) of -||q_i - c_j||   (the "sims";
+ *                  the reference's distance output is its negation)
+ *   pair_sims [P, q.ext, c.ext] out, optional (NULL): -cdist + pad_mask, pad_mask = -10e8 outside
+ *                  the valid block (pair_distances.py:156-170); requires q.ext > 0 and c.ext > 0.
+ * ------------------------------------------------------------------------------------------- */
+int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                            int cdist_mode, float* scores, float* pair_sims, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A5-A8  otAspire.  Replaces AllPairMaskedWasserstein.compute_distance,
+ * src/learning/facetid_models/pair_distances.py:21-92 (copy at
+ * examples/ex_aspire_consent_multimatch.py:118-189), including the geomloss==0.2.4
+ * SamplesLoss("sinkhorn", p=1, blur, reach=None, scaling, debias=False) solver it calls.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    /* doubles: the reference holds these as Python floats and geomloss builds the epsilon schedule
+     * from them in float64 (np.log / np.arange / np.exp) before any fp32 arithmetic. */
+    double blur;         /* geoml_blur    (default 0.05) */
+    double scaling;      /* geoml_scaling (default 0.9)  */
+    double sent_sm_temp; /* sent_sm_temp  (default 1.0)  */
+    int32_t cdist_mode;  /* ASPIRE_CDIST_*               */
+} aspire_ot_params;
+
+#define ASPIRE_OT_DISTANCE 0 /* return_pair_sims=False: OT_eps = <a,f> + <b,g>  (positive)          */
+#define ASPIRE_OT_PLAN_SIM 1 /* return_pair_sims=True : sum_ij P_ij * neg_ij     (negative)         */
+
+/*   diameter   NULL: each pair uses the bounding-box diameter of its own valid rows (what the
+ *              reference computes when called with B = 1, src/evaluation/utils/models.py:190-197).
+ *              else: pair (q, c) uses diameter[q * ngroups + c / diam_group]
+ *              with ngroups = ceil(C / diam_group) in CROSS mode, diameter[p / diam_group] in PAIRED
+ *              mode -- geomloss derives ONE epsilon schedule per call from the whole batch
+ *              (consecutive groups of 64 candidates in pp_gen_nearest.py:182-196); compute it with
+ *              aspire_group_diameter_f32.
+ *   scores     [P] out
+ *   out_qdistr [P, q.ext], out_cdistr [P, c.ext], out_pairsims / out_plan [P, q.ext, c.ext]:
+ *              optional (NULL) extra outputs of return_pair_sims=True (pair_distances.py:86):
+ *              query_distr, cand_distr, pair_sims (masked neg L2, pads = 0), transport_plan.
+ *              masked_sims = plan * pair_sims is left to the caller.  Require ext > 0.
+ */
+int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                           const aspire_ot_params* prm, const float* diameter, int64_t diam_group,
+                           int want, float* scores, float* out_qdistr, float* out_cdistr,
+                           float* out_pairsims, float* out_plan, void* stream);
+
+/* geomloss max_diameter (sinkhorn_divergence.py of geomloss 0.2.4) for batched calls: the L2 norm of
+ * the per-coordinate bounding box over ALL rows of the call's x and y tensors, zero pad rows included.
+ *   CROSS : diameter[q * ngroups + g] covers query q's rows and the rows of candidates
+ *           [g*group, min(C, (g+1)*group)); a zero row joins the box iff the group's candidates have
+ *           unequal lengths (caching_score pads them to the group max, disent_models.py:269-281).
+ *   PAIRED: diameter[g] covers queries and candidates [g*group, (g+1)*group); with ext > 0 all ext
+ *           rows are read (the padded tensors as they are), else len rows.
+ */
+int aspire_group_diameter_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                              int64_t group, float* diameter, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A12  rank.  Per-query top-k of a [Q, C] score matrix, descending, ties by ascending candidate
+ * index -- the order Python's stable sorted(..., reverse=True) gives (src/evaluation/evaluate.py:76,
+ * src/pre_process/pp_gen_nearest.py:266,339).
+ *   idx_base  added to every output index (the shard's first global candidate id)
+ *   top_scores [Q, k], top_idx [Q, k] out; if C < k the tail is (-inf, -1).
+ *   workspace  device scratch of at least aspire_topk_workspace_bytes(Q, C, k) bytes (0 when C <= 4096).
+ *   Limits: C <= 4096 for any k (full sort), otherwise k < 4096.
+ */
+size_t aspire_topk_workspace_bytes(int64_t Q, int64_t C, int64_t k);
+int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
+                         float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* Cross-lane primitive self test (DPP / permlane forms vs ds_bpermute); out_mismatch_host receives the
+ * number of mismatching lanes (0 = ok).  Synchronous. */
+int aspire_selftest_xlane(int* out_mismatch_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASPIRE_HIP_H */

@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library loads and exports every symbol include/aspire_hip.h declares (no compute
+calls -- there is no GPU here), argument validation that needs no device, and the host-side prep."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+
+def _header_functions(root):
+    src = open(os.path.join(root, 'include', 'aspire_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(aspire_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from aspire_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = _header_functions(root)
+    assert len(declared) >= 9
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f'{name} declared in aspire_hip.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes signature in aspire_amd/_lib.py'
+    assert sorted(_lib.SIGNATURES) == declared
+    assert _lib.lib.aspire_abi_version() == 1
+    assert _lib.lib.aspire_max_sents() == 32
+
+
+def test_no_product_module_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, 'aspire_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in text.replace('the oracle', '').replace("oracle's", ''), f
+
+
+def test_argument_validation_without_gpu():
+    import ctypes
+    from aspire_amd import _lib
+    q = _lib.RepSet(0, 0, 0, 2, 4, 4)
+    c = _lib.RepSet(0, 0, 0, 3, 4, 4)
+    # pair_distances.py:46 assert (qef_batch_size == cef_batch_size)
+    rc = _lib.lib.aspire_l2max_scores_f32(ctypes.byref(q), ctypes.byref(c), 768, _lib.PAIR_PAIRED, 0, 1, 0, None)
+    assert rc == _lib.ASPIRE_ERR_INVALID_ARG
+    with pytest.raises(AssertionError):
+        _lib.check(rc)
+    rc = _lib.lib.aspire_l2max_scores_f32(ctypes.byref(q), ctypes.byref(c), 512, _lib.PAIR_CROSS, 0, 1, 0, None)
+    assert rc == _lib.ASPIRE_ERR_UNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        _lib.check(rc)
+    assert b'768' in _lib.lib.aspire_last_error()
+
+
+def test_compute_requires_gpu():
+    from aspire_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.DeviceRepSet.from_list([torch.zeros(2, 768)])
+
+
+def _tokenizer(vocab, tmp_path):
+    from transformers import BertTokenizer
+    p = tmp_path / 'vocab.txt'
+    p.write_text('\n'.join(vocab) + '\n')
+    return BertTokenizer(str(p), do_lower_case=True)
+
+
+def test_prepare_abstracts_matches_reference(golden_dir, tmp_path):
+    """A0 against the reference's own prepare_abstracts output (tests/golden/prep.json), including the
+    500-word-piece cap hit mid sentence, hit exactly (sentence dropped), and a one-piece remainder."""
+    from aspire_amd import prepare_abstracts
+    z = json.load(open(os.path.join(golden_dir, 'prep.json')))
+    tok = _tokenizer(z['vocab'], tmp_path)
+    for case in z['cases']:
+        batch = [z['docs'][i] for i in case['doc_ids']]
+        bert_batch, abs_lens, sent_token_idxs = prepare_abstracts(batch, tok)
+        assert bert_batch['tokid_tt'].tolist() == case['tokid_tt']
+        assert bert_batch['seg_tt'].tolist() == case['seg_tt']
+        assert bert_batch['attnmask_tt'].tolist() == case['attnmask_tt']
+        assert bert_batch['seq_lens'] == case['seq_lens']
+        assert abs_lens == case['abs_lens']
+        assert sent_token_idxs == case['sent_token_idxs']
+        assert bert_batch['tokid_tt'].dtype == torch.int64
+
+
+def test_spans_to_csr():
+    from aspire_amd.batch_prep import spans_to_csr
+    tok, off = spans_to_csr([[[1, 2], [3]], [[5, 6, 7]]], 3)
+    assert tok.tolist() == [1, 2, 3, 5, 6, 7]
+    assert off.tolist() == [0, 2, 3, 3, 6, 6, 6]
+    assert tok.dtype == torch.int32 and off.dtype == torch.int32

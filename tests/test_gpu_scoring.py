@@ -1,0 +1,222 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against the CPU oracle on identical seeded inputs and against the committed golden fixtures.
+
+Tolerance: 1e-4 absolute in fp32 on distances / similarities / sentence reps (BASELINE.json north_star);
+ranking identical except between candidates whose oracle scores differ by less than that noise floor.
+OT numbers inherit the oracle's caveat: the geomloss solver restatement is parity-unpinned.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CASES = ['s8', 'rag', 'one', 'big']
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import aspire_amd
+    from aspire_amd import ops, scorer, pair_distances
+    assert torch.cuda.is_available(), 'these tests need the GPU'
+    return type('NS', (), dict(ops=ops, scorer=scorer, pd=pair_distances, pkg=aspire_amd))
+
+
+@pytest.fixture(scope='module')
+def scores(golden_dir):
+    return np.load(os.path.join(golden_dir, 'scores.npz'))
+
+
+def _reps(z, name, pd):
+    q, c = torch.from_numpy(z[f'{name}_q']), torch.from_numpy(z[f'{name}_c'])
+    return (pd.rep_len_tup(q.permute(0, 2, 1), z[f'{name}_qlens'].tolist()),
+            pd.rep_len_tup(c.permute(0, 2, 1), z[f'{name}_clens'].tolist()))
+
+
+def test_xlane_primitives(amd):
+    assert amd.ops.selftest_xlane() == 0
+
+
+def test_pooling_golden(amd, golden_dir):
+    from aspire_amd.batch_prep import spans_to_csr
+    z = np.load(os.path.join(golden_dir, 'pool.npz'))
+    for k in 'ab':
+        hidden = torch.from_numpy(z[f'{k}_hidden']).cuda()
+        idxs = json.loads(str(z[f'{k}_idxs']))
+        s = max(len(x) for x in idxs)
+        tok_idx, span_off = spans_to_csr(idxs, s)
+        cls, sent = amd.ops.span_mean_pool(hidden, tok_idx.cuda(), span_off.cuda(), s)
+        assert np.array_equal(cls.cpu().numpy(), z[f'{k}_cls'])
+        np.testing.assert_allclose(sent.cpu().numpy(), z[f'{k}_sent'], atol=2e-6, rtol=0)
+        if k == 'a':
+            assert torch.all(sent[1, 1:] == 0)      # empty slots: exact zeros
+
+
+def test_pooling_large_vs_oracle(amd):
+    from aspire_amd.batch_prep import spans_to_csr
+    g = torch.Generator().manual_seed(5)
+    b, l, s = 16, 256, 12
+    hidden = torch.randn(b, l, 768, generator=g)
+    idxs = []
+    for bi in range(b):
+        n = int(torch.randint(1, s + 1, (1,), generator=g))
+        cuts = sorted(torch.randperm(l - 12, generator=g)[:n].add(11).tolist()) + [l - 1]
+        idxs.append([list(range(cuts[i], cuts[i + 1])) for i in range(n)])
+    tok_idx, span_off = spans_to_csr(idxs, s)
+    cls, sent = amd.ops.span_mean_pool(hidden.cuda(), tok_idx.cuda(), span_off.cuda(), s)
+    wcls, wsent = orc.span_mean_pool(hidden, idxs, [len(x) for x in idxs] + [s])
+    np.testing.assert_allclose(sent.cpu().numpy(), wsent.numpy()[:, :s], atol=1e-5, rtol=0)
+    assert torch.equal(cls.cpu(), wcls)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_l2max_golden(amd, scores, name):
+    qt, ct = _reps(scores, name, amd.pd)
+    d = amd.pd.allpair_masked_dist_l2max(qt, ct)
+    np.testing.assert_allclose(d.numpy(), scores[f'{name}_l2max_dist'], atol=TOL, rtol=0)
+    sims, pair = amd.pd.allpair_masked_dist_l2max(qt, ct, return_pair_sims=True)
+    np.testing.assert_allclose(sims.numpy(), scores[f'{name}_l2max_sims'], atol=TOL, rtol=0)
+    # pads hold -cdist - 1e9 (spacing of fp32 there is 64): compare relatively
+    np.testing.assert_allclose(pair.numpy(), scores[f'{name}_l2max_pair'], atol=TOL, rtol=1e-7)
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('temp', [1.0, 5000.0])
+def test_ot_golden(amd, scores, name, temp):
+    qt, ct = _reps(scores, name, amd.pd)
+    t = 't1' if temp == 1.0 else 't5000'
+    ot = amd.pd.AllPairMaskedWasserstein({'sent_sm_temp': temp})
+    wd = ot.compute_distance(qt, ct)
+    np.testing.assert_allclose(wd.numpy(), scores[f'{name}_{t}_wdist'], atol=TOL, rtol=0)
+    ws, (qd, cd, ps, plan, ms) = ot.compute_distance(qt, ct, return_pair_sims=True)
+    np.testing.assert_allclose(qd.numpy(), scores[f'{name}_{t}_qdistr'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(cd.numpy(), scores[f'{name}_{t}_cdistr'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(ps.numpy(), scores[f'{name}_{t}_pairsims'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(plan.numpy(), scores[f'{name}_{t}_plan'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(ms.numpy(), scores[f'{name}_{t}_maskedsims'], atol=4e-3, rtol=0)
+    np.testing.assert_allclose(ws.numpy(), scores[f'{name}_{t}_wsims'], atol=5e-4, rtol=0)
+
+
+def test_ot_batch_mismatch_asserts(amd):
+    q = amd.pd.rep_len_tup(torch.randn(2, 768, 4), [4, 4])
+    c = amd.pd.rep_len_tup(torch.randn(3, 768, 4), [4, 4, 4])
+    with pytest.raises(AssertionError):
+        amd.pd.AllPairMaskedWasserstein({}).compute_distance(q, c)
+
+
+def _pool(seed, n, smin, smax):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(int(torch.randint(smin, smax + 1, (1,), generator=g)), 768, generator=g) for _ in range(n)]
+
+
+def _rank_agrees(got, want, tol):
+    """Orderings agree except where the oracle's own scores are closer than `tol` (fp32 noise)."""
+    got, want = np.asarray(got), np.asarray(want)
+    order_g = sorted(range(len(got)), key=lambda i: got[i], reverse=True)
+    order_w = sorted(range(len(want)), key=lambda i: want[i], reverse=True)
+    for a, b in zip(order_g, order_w):
+        if a != b and abs(want[a] - want[b]) > tol:
+            return False
+    return True
+
+
+def test_ot_pair_schedule_vs_get_similarity(amd):
+    """evaluate.py loop: every (query, candidate) pair scored alone (models.py:190-197)."""
+    queries = _pool(11, 3, 3, 8)
+    cands = _pool(12, 40, 1, 8)
+    got = amd.scorer.score_pool(queries, cands, method='ot', schedule='pair').cpu().numpy()
+    want = np.array([[orc.get_similarity(q, c) for c in cands] for q in queries], dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    for qi in range(len(queries)):
+        assert _rank_agrees(got[qi], want[qi], 2e-5)
+    # the one-pair wrapper too
+    assert amd.scorer.get_similarity(queries[0], cands[0]) == pytest.approx(float(want[0, 0]), abs=TOL)
+
+
+def test_ot_batch_schedule_vs_caching_score(amd):
+    """pp_gen_nearest loop: consecutive groups of 64 through caching_score (ragged, zero padded)."""
+    query = _pool(21, 1, 6, 6)[0]
+    cands = _pool(22, 150, 2, 12)
+    got = amd.scorer.score_pool([query], cands, method='ot', schedule='batch').cpu().numpy()[0]
+    want = np.array(orc.rank_pool_caching(query.numpy(), [c.numpy() for c in cands]), dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=5e-4, rtol=0)
+    # drop-in caching_score on one group, with the un-padded extras
+    qd = {'sent_reps': query.numpy()}
+    cds = [{'sent_reps': c.numpy()} for c in cands[:64]]
+    ret = amd.scorer.caching_score(qd, cds)
+    wsc, wextra = orc.caching_score(query.numpy(), [c.numpy() for c in cands[:64]])
+    np.testing.assert_allclose(ret['batch_scores'], wsc, atol=5e-4, rtol=0)
+    for g_, w_ in zip(ret['pair_scores'], wextra):
+        for k in range(4):
+            assert g_[k].shape == w_[k].shape
+            np.testing.assert_allclose(g_[k], w_[k], atol=1e-4, rtol=0)
+
+
+def test_l2max_pool_and_topk(amd):
+    queries = _pool(31, 5, 3, 12)
+    cands = _pool(32, 300, 1, 20)
+    got = amd.scorer.score_pool(queries, cands, method='l2max').cpu().numpy()
+    want = np.zeros_like(got)
+    for qi, q in enumerate(queries):
+        for s in range(0, len(cands), 64):
+            sc, _ = orc.caching_score(q.numpy(), [c.numpy() for c in cands[s:s + 64]], score_agg_type='l2max')
+            want[qi, s:s + 64] = sc
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    ranked = amd.scorer.rank_pool(queries, cands, k=10, method='l2max')
+    for qi in range(len(queries)):
+        ids = [pid for pid, _ in ranked[qi]]
+        assert ids == orc.rank_descending(got[qi].tolist())[:10]
+
+
+def test_topk_ties_and_sizes(amd):
+    g = torch.Generator().manual_seed(3)
+    for qn, cn, k in [(3, 10, 4), (2, 4096, 4096), (4, 20000, 100), (1, 5, 8), (2, 70000, 1000)]:
+        s = torch.randn(qn, cn, generator=g)
+        s[:, ::7] = 0.25          # many exact ties
+        s[0, :3] = float('inf') if cn > 3 else s[0, :3]
+        ts, ti = amd.ops.topk_desc(s.cuda(), k, idx_base=1000)
+        ts, ti = ts.cpu(), ti.cpu()
+        for q in range(qn):
+            order = orc.rank_descending(s[q].tolist())[:k]
+            kk = min(k, cn)
+            assert ti[q, :kk].tolist() == [1000 + i for i in order]
+            assert torch.equal(ts[q, :kk], s[q][order])
+            assert torch.all(ti[q, kk:] == -1)
+
+
+def test_duplicate_sentence_pair(amd):
+    """A candidate sentence identical to a query sentence: cdist gives exactly 0 there while geomloss's
+    expansion |x|^2 - 2xy + |y|^2 leaves fp32 cancellation noise of ~1e-2 inside the solver's cost
+    (SURVEY.md section 8a).  That noise is rounding-order dependent, so only a loose bound holds."""
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(6, 768, generator=g)
+    c = torch.randn(5, 768, generator=g)
+    c[2] = q[4]
+    got = amd.scorer.get_similarity(q, c)
+    want = orc.get_similarity(q, c)
+    assert got == pytest.approx(want, abs=5e-2)
+    got_l2 = amd.scorer.score_pool([q], [c], method='l2max').item()
+    assert got_l2 == 0.0
+
+
+def test_full_size_config2_properties(amd):
+    """BASELINE config 2 (1 x 1000, 8 sents x 768): size-independent properties at full size --
+    permutation of the pool permutes the scores, and a subset scored alone reproduces its scores."""
+    g = torch.Generator().manual_seed(0)
+    query = torch.randn(8, 768, generator=g)
+    cands = [torch.randn(8, 768, generator=g) for _ in range(1000)]
+    s = amd.scorer.score_pool([query], cands, method='ot', schedule='pair')[0]
+    perm = torch.randperm(1000, generator=g)
+    sp = amd.scorer.score_pool([query], [cands[i] for i in perm.tolist()], method='ot', schedule='pair')[0]
+    assert torch.equal(sp.cpu(), s.cpu()[perm])
+    sub = amd.scorer.score_pool([query], cands[100:130], method='ot', schedule='pair')[0]
+    assert torch.equal(sub.cpu(), s.cpu()[100:130])
+    idx = list(range(0, 1000, 37))
+    want = np.array([orc.get_similarity(query, cands[i]) for i in idx], dtype=np.float32)
+    np.testing.assert_allclose(s.cpu().numpy()[idx], want, atol=TOL, rtol=0)
+    assert torch.isfinite(s).all() and (s < 0).all()

@@ -1,0 +1,126 @@
+"""CPU suite: the oracle against the golden vectors generated from the reference's own code
+(tests/golden/make_golden.py), and self-consistency of the (unpinned) Sinkhorn restatement."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+CASES = ['s8', 'rag', 'one', 'big']
+
+
+@pytest.fixture(scope='module')
+def scores(golden_dir):
+    return np.load(os.path.join(golden_dir, 'scores.npz'))
+
+
+def _reps(z, name):
+    q, c = torch.from_numpy(z[f'{name}_q']), torch.from_numpy(z[f'{name}_c'])
+    return (orc.RepLen(q.permute(0, 2, 1), z[f'{name}_qlens'].tolist()),
+            orc.RepLen(c.permute(0, 2, 1), z[f'{name}_clens'].tolist()))
+
+
+def test_pooling_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'pool.npz'))
+    for k in 'ab':
+        hidden = torch.from_numpy(z[f'{k}_hidden'])
+        idxs = json.loads(str(z[f'{k}_idxs']))
+        cls, sent = orc.span_mean_pool(hidden, idxs, [len(x) for x in idxs])
+        assert np.array_equal(cls.numpy(), z[f'{k}_cls'])
+        assert np.array_equal(sent.numpy(), z[f'{k}_sent'])
+    # empty trailing slots are exact zeros (doc 1 of case a has 1 of 4 sentences)
+    assert np.all(z['a_sent'][1, 1:] == 0.0)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_l2max_matches_reference(scores, name):
+    qt, ct = _reps(scores, name)
+    assert np.array_equal(orc.allpair_masked_dist_l2max(qt, ct).numpy(), scores[f'{name}_l2max_dist'])
+    sims, pair = orc.allpair_masked_dist_l2max(qt, ct, return_pair_sims=True)
+    assert np.array_equal(sims.numpy(), scores[f'{name}_l2max_sims'])
+    assert np.array_equal(pair.numpy(), scores[f'{name}_l2max_pair'])
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('temp', [1.0, 5000.0])
+def test_ot_wrapper_matches_reference(scores, name, temp):
+    """query_distr / cand_distr / pair_sims are pure reference arithmetic (PINNED); plan and distances
+    went through the reference's wrapper code around the oracle's solver (solver unpinned)."""
+    qt, ct = _reps(scores, name)
+    t = 't1' if temp == 1.0 else 't5000'
+    ot = orc.AllPairMaskedWasserstein({'sent_sm_temp': temp})
+    wd = ot.compute_distance(qt, ct)
+    ws, (qd, cd, ps, plan, ms) = ot.compute_distance(qt, ct, return_pair_sims=True)
+    for got, key in ((qd, 'qdistr'), (cd, 'cdistr'), (ps, 'pairsims'), (plan, 'plan'), (ms, 'maskedsims'),
+                     (ws, 'wsims'), (wd, 'wdist')):
+        assert np.array_equal(got.numpy(), scores[f'{name}_{t}_{key}']), key
+
+
+def test_metrics_kats(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, 'metrics.json')))
+    assert orc.average_precision(kat['ap_in']) == pytest.approx(kat['ap_out'], abs=1e-15)
+    assert orc.average_precision(kat['ap_in2']) == pytest.approx(kat['ap_out2'], abs=1e-15)
+    assert orc.mean_average_precision(kat['map_in']) == pytest.approx(kat['map_out'], abs=1e-15)
+    # the reference's own doctest values (src/evaluation/utils/metrics.py:103-108, 129-134)
+    assert kat['ap_out'] == pytest.approx(0.78333333333333333)
+    assert kat['map_out'] == pytest.approx(0.39166666666666666)
+
+
+def test_rank_is_stable_descending():
+    assert orc.rank_descending([0.5, 0.9, 0.5, 0.1, 0.9]) == [1, 4, 0, 2, 3]
+
+
+# ---- self-consistency of the geomloss restatement (the only check available: parity unpinned) ----
+def _toy(seed, n, m, d=768):
+    g = torch.Generator().manual_seed(seed)
+    x, y = torch.randn(1, n, d, generator=g), torch.randn(1, m, d, generator=g)
+    a = torch.softmax(torch.randn(1, n, generator=g), 1)
+    b = torch.softmax(torch.randn(1, m, generator=g), 1)
+    return a, x, b, y
+
+
+@pytest.mark.parametrize('n,m', [(8, 8), (7, 6), (3, 12)])
+def test_sinkhorn_plan_marginals_and_emd(n, m):
+    a, x, b, y = _toy(3, n, m)
+    cost = orc._distances(x, y)[0]
+    emd = orc.exact_emd(a[0].double().numpy(), b[0].double().numpy(), cost.double().numpy())
+    # geomloss runs ONE symmetrised iteration per epsilon of the annealing schedule, so at the reference's
+    # scaling = 0.9 the plan's marginals are only ~1e-2 accurate; they tighten as scaling -> 1.
+    for scaling, tol in ((0.9, 6e-2), (0.99, 1.5e-2), (0.999, 3e-3)):
+        f, g = orc.geomloss_sinkhorn_tensorized(a, x, b, y, scaling=scaling, potentials=True)
+        plan = torch.exp((f[0][:, None] + g[0][None, :] - cost) / 0.05) * a[0][:, None] * b[0][None, :]
+        # (i) the plan's marginals are the input measures
+        assert torch.allclose(plan.sum(1), a[0], atol=tol)
+        assert torch.allclose(plan.sum(0), b[0], atol=tol)
+        # (ii) transport cost close to the exact EMD
+        val = (plan * cost).sum().item()
+        assert abs(val - emd) < 10 * tol
+    # the dual value OT_eps = <a,f> + <b,g> is close to it too
+    ot_eps = orc.geomloss_sinkhorn_tensorized(a, x, b, y).item()
+    assert abs(ot_eps - emd) < 0.05 * np.log(n * m) + 0.05
+
+
+def test_sinkhorn_permutation_equivariance():
+    a, x, b, y = _toy(5, 8, 6)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
+    f, g = orc.geomloss_sinkhorn_tensorized(a, x, b, y, potentials=True)
+    fp, gp = orc.geomloss_sinkhorn_tensorized(a[:, perm], x[:, perm], b, y, potentials=True)
+    assert torch.allclose(fp, f[:, perm], atol=2e-4) and torch.allclose(gp, g, atol=2e-4)
+
+
+def test_pads_carry_zero_mass(scores):
+    qt, ct = _reps(scores, 'rag')
+    _, (qd, cd, ps, plan, ms) = orc.AllPairMaskedWasserstein({}).compute_distance(qt, ct, return_pair_sims=True)
+    for i, (ql, cl) in enumerate(zip(qt.abs_lens, ct.abs_lens)):
+        assert torch.all(plan[i, ql:, :] == 0) and torch.all(plan[i, :, cl:] == 0)
+        assert torch.all(qd[i, ql:] == 0) and torch.all(cd[i, cl:] == 0)
+        assert plan[i].sum().item() == pytest.approx(1.0, abs=5e-3)
+
+
+def test_epsilon_schedule_shape():
+    eps = orc.epsilon_schedule(1, 30.0, 0.05, 0.9)
+    assert eps[0] == 30.0 and eps[-1] == 0.05 and eps[1] == pytest.approx(30.0)
+    assert all(e > 0.05 for e in eps[1:-1]) and len(eps) == 2 + int(np.ceil(np.log(0.05 / 30.0) / np.log(0.9)))
