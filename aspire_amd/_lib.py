@@ -6,6 +6,11 @@ fails loudly; if it is present but no GPU is visible, every compute entry point 
 import ctypes
 import os
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE
+# libaspire_hip.so is dlopen'ed so that both resolve the same runtime: device pointers and streams that
+# torch hands out are only meaningful to the runtime that created them.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libaspire_hip.so')
 

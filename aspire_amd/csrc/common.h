@@ -82,13 +82,19 @@ template <int M>
 __device__ __forceinline__ float swap_add(float a, float b) {
     static_assert(M == 16 || M == 32, "swap width");
     const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
+    // NB: copy the two results to ints first.  __builtin_bit_cast applied directly to the vector element
+    // r[1] reads element 0 with this clang (ROCm 7.2): r[0] + r[1] silently became r[0] + r[0].
+    int x0, x1;
     if constexpr (M == 32) {
         auto r = __builtin_amdgcn_permlane32_swap(ia, ib, false, false);
-        return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+        x0 = r[0];
+        x1 = r[1];
     } else {
         auto r = __builtin_amdgcn_permlane16_swap(ia, ib, false, false);
-        return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+        x0 = r[0];
+        x1 = r[1];
     }
+    return __builtin_bit_cast(float, x0) + __builtin_bit_cast(float, x1);
 }
 
 // Halving butterfly: every lane holds N partial sums v[0..N); afterwards lane l holds (in the return
@@ -154,10 +160,12 @@ __device__ __forceinline__ float col8_max(float v) {
     v = fmaxf(v, lane_xor<8>(v));
     const int iv = __builtin_bit_cast(int, v);
     auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
-    v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    const int r0 = r[0], r1 = r[1];  // see swap_add: no bit_cast on vector elements
+    v = fmaxf(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
     const int iw = __builtin_bit_cast(int, v);
     auto s = __builtin_amdgcn_permlane32_swap(iw, iw, false, false);
-    return fmaxf(__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1]));
+    const int s0 = s[0], s1 = s[1];
+    return fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
 }
 __device__ __forceinline__ float col8_sum(float v) {
     v += lane_xor<8>(v);

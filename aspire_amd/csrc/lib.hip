@@ -20,37 +20,38 @@ namespace {
 __global__ void xlane_selftest_kernel(int* mismatch) {
     const int lane = threadIdx.x;
     const float v = (float)(lane * 7 + 3);
-    int bad = 0;
-    bad += lane_xor<1>(v) != __shfl_xor(v, 1);
-    bad += lane_xor<2>(v) != __shfl_xor(v, 2);
-    bad += lane_xor<4>(v) != __shfl_xor(v, 4);
-    bad += lane_xor<8>(v) != __shfl_xor(v, 8);
-    bad += lane_xor<16>(v) != __shfl_xor(v, 16);
-    bad += lane_xor<32>(v) != __shfl_xor(v, 32);
+    int n = 0;
+#define CHECK(expr) atomicAdd(mismatch + (n++), (expr) ? 1 : 0)
+    CHECK(lane_xor<1>(v) != __shfl_xor(v, 1));
+    CHECK(lane_xor<2>(v) != __shfl_xor(v, 2));
+    CHECK(lane_xor<4>(v) != __shfl_xor(v, 4));
+    CHECK(lane_xor<8>(v) != __shfl_xor(v, 8));
+    CHECK(lane_xor<16>(v) != __shfl_xor(v, 16));
+    CHECK(lane_xor<32>(v) != __shfl_xor(v, 32));
     // reductions
     float rs = v;
     for (int m = 1; m < 8; m <<= 1) rs += __shfl_xor(rs, m);
-    bad += row8_sum(v) != rs;
+    CHECK(row8_sum(v) != rs);
     float cs = v;
     for (int m = 8; m < 64; m <<= 1) cs += __shfl_xor(cs, m);
-    bad += col8_sum(v) != cs;
+    CHECK(col8_sum(v) != cs);
     float rm = v, cm = v;
     for (int m = 1; m < 8; m <<= 1) rm = fmaxf(rm, __shfl_xor(rm, m));
     for (int m = 8; m < 64; m <<= 1) cm = fmaxf(cm, __shfl_xor(cm, m));
-    bad += row8_max(v) != rm;
-    bad += col8_max(v) != cm;
+    CHECK(row8_max(v) != rm);
+    CHECK(col8_max(v) != cm);
     // butterflies: element k of lane l is (l + 1) * (k + 1); sum over lanes = (k + 1) * 2080
     {
         float a[64];
 #pragma unroll
         for (int k = 0; k < 64; ++k) a[k] = (float)((lane + 1) * (k + 1));
-        bad += butterfly_sum<64>(a, lane) != (float)((lane + 1) * 2080);
+        CHECK(butterfly_sum<64>(a, lane) != (float)((lane + 1) * 2080));
         float b[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) b[k] = (float)((lane + 1) * (k + 1));
-        bad += butterfly_sum<16>(b, lane) != (float)(((lane >> 2) + 1) * 2080);
+        CHECK(butterfly_sum<16>(b, lane) != (float)(((lane >> 2) + 1) * 2080));
     }
-    atomicAdd(mismatch, bad);
+#undef CHECK
 }
 }  // namespace
 }  // namespace aspire
@@ -63,11 +64,11 @@ extern "C" const char* aspire_last_error(void) { return g_err; }
 extern "C" int aspire_selftest_xlane(int* out_mismatch_host) {
     ASPIRE_REQUIRE(out_mismatch_host, ASPIRE_ERR_INVALID_ARG, "null output");
     int* d = nullptr;
-    ASPIRE_HIP_OK(hipMalloc(&d, sizeof(int)));
-    ASPIRE_HIP_OK(hipMemset(d, 0, sizeof(int)));
+    ASPIRE_HIP_OK(hipMalloc(&d, 16 * sizeof(int)));
+    ASPIRE_HIP_OK(hipMemset(d, 0, 16 * sizeof(int)));
     hipLaunchKernelGGL(xlane_selftest_kernel, dim3(1), dim3(64), 0, 0, d);
     ASPIRE_LAUNCH_OK();
-    ASPIRE_HIP_OK(hipMemcpy(out_mismatch_host, d, sizeof(int), hipMemcpyDeviceToHost));
+    ASPIRE_HIP_OK(hipMemcpy(out_mismatch_host, d, 16 * sizeof(int), hipMemcpyDeviceToHost));
     ASPIRE_HIP_OK(hipFree(d));
     return ASPIRE_OK;
 }

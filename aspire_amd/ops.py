@@ -150,6 +150,6 @@ def topk_desc(scores, k, idx_base=0):
 
 def selftest_xlane():
     require_gpu()
-    n = ctypes.c_int(-1)
-    check(lib.aspire_selftest_xlane(ctypes.byref(n)))
-    return n.value
+    n = (ctypes.c_int * 16)()
+    check(lib.aspire_selftest_xlane(n))
+    return sum(n), list(n)

@@ -156,8 +156,9 @@ int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, i
                          float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
                          void* stream);
 
-/* Cross-lane primitive self test (DPP / permlane forms vs ds_bpermute); out_mismatch_host receives the
- * number of mismatching lanes (0 = ok).  Synchronous. */
+/* Cross-lane primitive self test (DPP / permlane forms vs ds_bpermute); out_mismatch_host[16] receives
+ * the number of mismatching lanes per check (all 0 = ok; order: xor 1,2,4,8,16,32, row sum, col sum,
+ * row max, col max, butterfly 64, butterfly 16).  Synchronous. */
 int aspire_selftest_xlane(int* out_mismatch_host);
 
 #ifdef __cplusplus
