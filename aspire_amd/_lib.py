@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libaspire_hip.so')
+# ASPIRE_HIP_LIB: developer override (instrumented builds under build/); the product path is in-tree.
+LIB_PATH = os.environ.get('ASPIRE_HIP_LIB') or os.path.join(_HERE, 'lib', 'libaspire_hip.so')
 
 c_void_p, c_int, c_int32, c_int64, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                                          ctypes.c_int64, ctypes.c_double, ctypes.c_size_t)

@@ -97,51 +97,43 @@ __device__ __forceinline__ float swap_add(float a, float b) {
     return __builtin_bit_cast(float, x0) + __builtin_bit_cast(float, x1);
 }
 
-// Halving butterfly: every lane holds N partial sums v[0..N); afterwards lane l holds (in the return
-// value) the sum over all 64 lanes of v[l >> log2(64/N)] -- for N == 64 lane l owns element l.
-// For N < 64 the result is replicated over the low log2(64/N) lane bits.
+// Halving butterfly: every lane holds N partial sums v[0..N) (N = 64, 32 or 16); afterwards lane l
+// holds (in the return value) the sum over all 64 lanes of element l >> log2(64/N), replicated over the
+// low log2(64/N) lane bits.  Each level halves the live values: the lane-bit-b partner pairs exchange the
+// half the other one keeps.  Levels for lane bits 5 and 4 are one v_permlane{32,16}_swap + add per value;
+// lower bits are a DPP add per value plus a select.
+template <int M>
+__device__ __forceinline__ float pair_fold(float keep0, float keep1, int lane) {
+    // lanes with bit M clear keep element keep0, the others keep1
+    const float t = keep0 + lane_xor<M>(keep0);
+    const float u = keep1 + lane_xor<M>(keep1);
+    return (lane & M) ? u : t;
+}
+
 template <int N>
 __device__ __forceinline__ float butterfly_sum(float (&v)[N], int lane) {
-    static_assert(N == 64 || N == 16, "sizes used here");
-    int n = N;
-    // lane bit 5
-    n >>= 1;
+    static_assert(N == 64 || N == 32 || N == 16, "sizes used here");
 #pragma unroll
     for (int k = 0; k < N / 2; ++k) v[k] = swap_add<32>(v[k], v[k + N / 2]);
-    // lane bit 4
 #pragma unroll
     for (int k = 0; k < N / 4; ++k) v[k] = swap_add<16>(v[k], v[k + N / 4]);
-    // lane bit 3
 #pragma unroll
-    for (int k = 0; k < N / 8; ++k) {
-        const float t = v[k] + lane_xor<8>(v[k]);
-        const float u = v[k + N / 8] + lane_xor<8>(v[k + N / 8]);
-        v[k] = (lane & 8) ? u : t;
-    }
-    // lane bit 2
+    for (int k = 0; k < N / 8; ++k) v[k] = pair_fold<8>(v[k], v[k + N / 8], lane);
 #pragma unroll
-    for (int k = 0; k < N / 16; ++k) {
-        const float t = v[k] + lane_xor<4>(v[k]);
-        const float u = v[k + N / 16] + lane_xor<4>(v[k + N / 16]);
-        v[k] = (lane & 4) ? u : t;
-    }
-    if constexpr (N == 64) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float t = v[k] + lane_xor<2>(v[k]);
-            const float u = v[k + 2] + lane_xor<2>(v[k + 2]);
-            v[k] = (lane & 2) ? u : t;
-        }
-        const float t = v[0] + lane_xor<1>(v[0]);
-        const float u = v[1] + lane_xor<1>(v[1]);
-        return (lane & 1) ? u : t;
-    } else {
+    for (int k = 0; k < N / 16; ++k) v[k] = pair_fold<4>(v[k], v[k + N / 16], lane);
+    if constexpr (N == 16) {
         float r = v[0];
         r += lane_xor<2>(r);
-        r += lane_xor<1>(r);
-        return r;
+        return r + lane_xor<1>(r);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N / 32; ++k) v[k] = pair_fold<2>(v[k], v[k + N / 32], lane);
+        if constexpr (N == 32) {
+            return v[0] + lane_xor<1>(v[0]);
+        } else {
+            return pair_fold<1>(v[0], v[1], lane);
+        }
     }
-    (void)n;
 }
 
 // All-reduce over the 8 lanes that share lane>>3 (the "row" of an 8x8 tile: varies lane bits 0..2).

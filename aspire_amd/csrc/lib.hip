@@ -46,6 +46,10 @@ __global__ void xlane_selftest_kernel(int* mismatch) {
 #pragma unroll
         for (int k = 0; k < 64; ++k) a[k] = (float)((lane + 1) * (k + 1));
         CHECK(butterfly_sum<64>(a, lane) != (float)((lane + 1) * 2080));
+        float c[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) c[k] = (float)((lane + 1) * (k + 1));
+        CHECK(butterfly_sum<32>(c, lane) != (float)(((lane >> 1) + 1) * 2080));
         float b[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) b[k] = (float)((lane + 1) * (k + 1));

@@ -40,6 +40,7 @@ struct ScoreArgs {
     int pairing;     // ASPIRE_PAIR_*
     int cdist_mode;  // ASPIRE_CDIST_*
     int q_per_block; // CROSS: queries handled by one block (grid.y chunks)
+    int c_per_block; // candidates handled by one block (grid.x chunks)
     // OT
     double blur, scaling, temp;
     const float* diameter;
@@ -51,22 +52,19 @@ struct ScoreArgs {
     float* out_cdistr;
     float* out_pairsims;
     float* out_plan;
+    long long* dbg;  // phase cycle stamps (only with -DASPIRE_PHASE_CLOCK)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// Load 8 sentence rows (this lane's float4 slice) of one document; rows >= navail read as zero.
-template <bool BBOX>
-__device__ __forceinline__ void load_tile(float4 (&r)[8], const float* doc, int row0, int navail, int dofs, int nbox,
+// Load N sentence rows (this lane's float4 slice) of one document; rows >= navail read as zero.
+template <int N, bool BBOX>
+__device__ __forceinline__ void load_rows(float4 (&r)[N], const float* doc, int row0, int navail, int dofs, int nbox,
                                           float4& mn, float4& mx) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
         const int row = row0 + i;
-        if (row < navail) {
-            r[i] = ld4(doc + (size_t)row * kD + dofs);
-        } else {
-            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        r[i] = row < navail ? ld4(doc + (size_t)row * kD + dofs) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (BBOX && row < nbox) {
             mn.x = fminf(mn.x, r[i].x); mn.y = fminf(mn.y, r[i].y); mn.z = fminf(mn.z, r[i].z); mn.w = fminf(mn.w, r[i].w);
             mx.x = fmaxf(mx.x, r[i].x); mx.y = fmaxf(mx.y, r[i].y); mx.z = fmaxf(mx.z, r[i].z); mx.w = fmaxf(mx.w, r[i].w);
@@ -74,41 +72,40 @@ __device__ __forceinline__ void load_tile(float4 (&r)[8], const float* doc, int 
     }
 }
 
-// Per-wave partial sums of one 8x8 tile -> LDS.  red layout: [tile][2][64] (0: x.y dot, 1: sum (x-y)^2).
+__device__ __forceinline__ float sq4(const float4& a) { return fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x))); }
+
+// Per-wave partial sums of half an 8x8 tile (4 query rows x 8 candidate rows) -> LDS.
+// red layout: [tile][2][64] (0: x.y dot, 1: sum (x-y)^2), element 8*i + j.  Only 32 accumulators, 4 query
+// rows and 8 candidate rows are live at a time (64 accumulators + both 8-row operand tiles cap the kernel
+// at 2 waves/SIMD and a 1000-block grid then runs in two rounds).  The 32-value butterfly leaves element
+// e in lanes 2e and 2e+1; even lanes write it.
 template <bool NEED_G, bool NEED_D2>
-__device__ __forceinline__ void tile_partials(const float4 (&x)[8], const float4 (&y)[8], float* red_tile, int lane) {
+__device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const float4 (&y)[8], float* red_half,
+                                                   int lane) {
     if constexpr (NEED_D2) {
-        float acc[64];
+        float acc[32];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float dx = x[i].x - y[j].x, dy = x[i].y - y[j].y, dz = x[i].z - y[j].z, dw = x[i].w - y[j].w;
                 acc[i * 8 + j] = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
             }
-        red_tile[64 + lane] = butterfly_sum<64>(acc, lane);
+        const float r = butterfly_sum<32>(acc, lane);
+        if ((lane & 1) == 0) red_half[64 + (lane >> 1)] = r;
     }
+    __builtin_amdgcn_sched_barrier(0);  // do not overlap the passes: that doubles the live accumulators
     if constexpr (NEED_G) {
-        float acc[64];
+        float acc[32];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 acc[i * 8 + j] = fmaf(x[i].w, y[j].w, fmaf(x[i].z, y[j].z, fmaf(x[i].y, y[j].y, x[i].x * y[j].x)));
-        red_tile[lane] = butterfly_sum<64>(acc, lane);
+        const float r = butterfly_sum<32>(acc, lane);
+        if ((lane & 1) == 0) red_half[(lane >> 1)] = r;
     }
-}
-
-// |x_i|^2 (8 rows) and |y_j|^2 (8 rows) partials -> LDS [16] per wave.
-__device__ __forceinline__ void norm_partials(const float4 (&x)[8], const float4 (&y)[8], float* rednorm, int lane) {
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        v[i] = fmaf(x[i].w, x[i].w, fmaf(x[i].z, x[i].z, fmaf(x[i].y, x[i].y, x[i].x * x[i].x)));
-        v[8 + i] = fmaf(y[i].w, y[i].w, fmaf(y[i].z, y[i].z, fmaf(y[i].y, y[i].y, y[i].x * y[i].x)));
-    }
-    const float r = butterfly_sum<16>(v, lane);
-    if ((lane & 3) == 0) rednorm[lane >> 2] = r;
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // x / e with e's reciprocal r: one Newton step makes the quotient correctly rounded in all but
@@ -147,15 +144,34 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
     float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll 1
-    for (int ti = 0; ti < T; ++ti) {
-        float4 x[8];
-        load_tile<BBOX>(x, qdoc, ti * 8, q_avail, dofs, q_box, mn, mx);
+    for (int tj = 0; tj < T; ++tj) {
+        float4 y[8];
+        load_rows<8, BBOX>(y, cdoc, tj * 8, c_avail, dofs, c_box, mn, mx);
 #pragma unroll 1
-        for (int tj = 0; tj < T; ++tj) {
-            float4 y[8];
-            load_tile<BBOX>(y, cdoc, tj * 8, c_avail, dofs, c_box, mn, mx);  // min/max are idempotent
-            tile_partials<NEED_G, NEED_D2>(x, y, red + (ti * T + tj) * 128, lane);
-            if (NEED_G && ti == tj) norm_partials(x, y, rednorm + ti * 16, lane);
+        for (int ti = 0; ti < T; ++ti) {
+            float nrm[16];  // |x_i|^2 of the 8 query rows, |y_j|^2 of the 8 candidate rows (diagonal tiles only)
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                float4 x[4];
+                load_rows<4, BBOX>(x, qdoc, ti * 8 + half * 4, q_avail, dofs, q_box, mn, mx);  // min/max idempotent
+                half_tile_partials<NEED_G, NEED_D2>(x, y, red + (ti * T + tj) * 128 + half * 32, lane);
+                if (NEED_G && ti == tj) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (half == 0) {
+                            nrm[i] = sq4(x[i]);
+                            nrm[8 + i] = sq4(y[i]);
+                            nrm[12 + i] = sq4(y[4 + i]);
+                        } else {
+                            nrm[4 + i] = sq4(x[i]);
+                        }
+                    }
+                }
+            }
+            if (NEED_G && ti == tj) {
+                const float r = butterfly_sum<16>(nrm, lane);
+                if ((lane & 3) == 0) rednorm[ti * 16 + (lane >> 2)] = r;
+            }
         }
     }
     if (BBOX) {
@@ -264,10 +280,38 @@ __device__ __forceinline__ void gather_pair(PairState<T>& s, const float* lds, b
     }
 }
 
+// Masked entries carry this instead of -inf so that fully masked (pad) lanes never form inf - inf.
+constexpr float kNegBig = -1.0e30f;
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+// exp / log on the hardware transcendentals: v_exp_f32 / v_log_f32 are base 2, ~1 ulp.  The arguments
+// met here are <= 0 (or within a few units of 0) for exp and in [2^-100, 2^100] for log: no denormal
+// or range handling is needed, which is what makes libm's logf 12 instructions instead of 2.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
+
+#ifdef ASPIRE_PHASE_CLOCK
+#define PHASE_STAMP(k)                                                             \
+    do {                                                                           \
+        if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_ok) { \
+            a.dbg[(k)] = (long long)__builtin_readcyclecounter();                  \
+            a.dbg[16 + (k)] = (long long)wall_clock64();                           \
+        }                                                                          \
+        if (a.dbg && blockIdx.x < 1000 && blockIdx.y == 0 && lane == 0 && stamp_ok)  \
+            a.dbg[4096 + 16 * blockIdx.x + (k)] = (long long)wall_clock64();       \
+    } while (0)
+#else
+#define PHASE_STAMP(k) \
+    do {               \
+    } while (0)
+#endif
+
 template <int T>
 __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_len, int c_len, float diam, int64_t p,
                               int lane) {
     const int li = lane >> 3, lj = lane & 7;
+    const bool stamp_ok = true;
+    (void)stamp_ok;
     bool rv[T], cv[T];  // row / column validity
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -281,118 +325,176 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
         float qm[T], cm[T];
 #pragma unroll
         for (int ta = 0; ta < T; ++ta) {
-            float m = -INFINITY;
+            float m = kNegBig;
 #pragma unroll
-            for (int tb = 0; tb < T; ++tb) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : -INFINITY);
+            for (int tb = 0; tb < T; ++tb) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : kNegBig);
             qm[ta] = row8_max(m) / temp;
         }
 #pragma unroll
         for (int tb = 0; tb < T; ++tb) {
-            float m = -INFINITY;
+            float m = kNegBig;
 #pragma unroll
-            for (int ta = 0; ta < T; ++ta) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : -INFINITY);
+            for (int ta = 0; ta < T; ++ta) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : kNegBig);
             cm[tb] = col8_max(m) / temp;
         }
-        float mq = -INFINITY, mc = -INFINITY;
+        float mq = kNegBig, mc = kNegBig;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            mq = fmaxf(mq, rv[t] ? qm[t] : -INFINITY);
-            mc = fmaxf(mc, cv[t] ? cm[t] : -INFINITY);
+            mq = fmaxf(mq, rv[t] ? qm[t] : kNegBig);
+            mc = fmaxf(mc, cv[t] ? cm[t] : kNegBig);
         }
         mq = col8_max(mq);  // rows are spread over lane bits 3-5
         mc = row8_max(mc);  // columns over lane bits 0-2
         float sq = 0.f, sc = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            sq += rv[t] ? __expf(qm[t] - mq) : 0.f;
-            sc += cv[t] ? __expf(cm[t] - mc) : 0.f;
+            sq += rv[t] ? fast_exp(qm[t] - mq) : 0.f;
+            sc += cv[t] ? fast_exp(cm[t] - mc) : 0.f;
         }
-        const float lsq = __logf(col8_sum(sq)), lsc = __logf(row8_sum(sc));
+        const float lsq = fast_log(col8_sum(sq)), lsc = fast_log(row8_sum(sc));
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             // log_softmax(...).exp(), then geomloss log_weights: log(a), a <= 0 -> -100000
-            wa[t] = rv[t] ? __expf(qm[t] - mq - lsq) : 0.f;
-            wb[t] = cv[t] ? __expf(cm[t] - mc - lsc) : 0.f;
-            la[t] = wa[t] > 0.f ? __logf(wa[t]) : -100000.f;
-            lb[t] = wb[t] > 0.f ? __logf(wb[t]) : -100000.f;
+            wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;
+            wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;
+            la[t] = wa[t] > 0.f ? fast_log(wa[t]) : -100000.f;
+            lb[t] = wb[t] > 0.f ? fast_log(wb[t]) : -100000.f;
         }
     }
+    PHASE_STAMP(4);
     // ---- epsilon schedule (geomloss epsilon_schedule, p = 1) --------------------------------------
     //   [diam] + [exp(e) for e in arange(log diam, log blur, log scaling)] + [blur]
     const double ld = log((double)diam), lbl = log(a.blur), lsc = log(a.scaling);
     int n_mid = (int)ceil((lbl - ld) / lsc);
     if (n_mid < 0) n_mid = 0;
     const float eps_last = (float)a.blur;
+    PHASE_STAMP(5);
 
     float f[T], g[T];
-    auto softmin_rows = [&](float eps, float reps, const float (&h)[T], float (&out)[T]) {
-        // out_i = -eps * logsumexp_j(h_j - C_ij/eps), j over valid columns
+    // out_i = -eps * logsumexp_j(hb_j - C_ij/eps) over valid j   (rows; `shift` = the caller's estimate of
+    // -logsumexp, see step()).  With EXACT the shift is the true maximum, as torch.logsumexp does.
+    auto lse_rows = [&](float eps, const float (&qc)[T][T], const float (&h)[T], const float (&shift)[T], bool exact,
+                        float (&out)[T]) {
 #pragma unroll
         for (int ta = 0; ta < T; ++ta) {
             float tv[T];
-            float m = -INFINITY;
 #pragma unroll
-            for (int tb = 0; tb < T; ++tb) {
-                tv[tb] = cv[tb] ? h[tb] - div_r(s.cost[ta][tb], eps, reps) : -INFINITY;
-                m = fmaxf(m, tv[tb]);
+            for (int tb = 0; tb < T; ++tb) tv[tb] = cv[tb] ? h[tb] - qc[ta][tb] : kNegBig;
+            float m = -shift[ta];
+            if (exact) {
+                m = tv[0];
+#pragma unroll
+                for (int tb = 1; tb < T; ++tb) m = fmaxf(m, tv[tb]);
+                m = row8_max(m);
             }
-            m = row8_max(m);
             float sum = 0.f;
 #pragma unroll
-            for (int tb = 0; tb < T; ++tb) sum += __expf(tv[tb] - m);
-            out[ta] = -eps * (m + __logf(row8_sum(sum)));
+            for (int tb = 0; tb < T; ++tb) sum += fast_exp(tv[tb] - m);
+            out[ta] = -eps * (m + fast_log(row8_sum(sum)));
         }
     };
-    auto softmin_cols = [&](float eps, float reps, const float (&h)[T], float (&out)[T]) {
+    auto lse_cols = [&](float eps, const float (&qc)[T][T], const float (&h)[T], const float (&shift)[T], bool exact,
+                        float (&out)[T]) {
 #pragma unroll
         for (int tb = 0; tb < T; ++tb) {
             float tv[T];
-            float m = -INFINITY;
 #pragma unroll
-            for (int ta = 0; ta < T; ++ta) {
-                tv[ta] = rv[ta] ? h[ta] - div_r(s.cost[ta][tb], eps, reps) : -INFINITY;
-                m = fmaxf(m, tv[ta]);
+            for (int ta = 0; ta < T; ++ta) tv[ta] = rv[ta] ? h[ta] - qc[ta][tb] : kNegBig;
+            float m = -shift[tb];
+            if (exact) {
+                m = tv[0];
+#pragma unroll
+                for (int ta = 1; ta < T; ++ta) m = fmaxf(m, tv[ta]);
+                m = col8_max(m);
             }
-            m = col8_max(m);
             float sum = 0.f;
 #pragma unroll
-            for (int ta = 0; ta < T; ++ta) sum += __expf(tv[ta] - m);
-            out[tb] = -eps * (m + __logf(col8_sum(sum)));
+            for (int ta = 0; ta < T; ++ta) sum += fast_exp(tv[ta] - m);
+            out[tb] = -eps * (m + fast_log(col8_sum(sum)));
         }
     };
-    auto step = [&](float eps, bool averaged) {
-        const float reps = rcp_refined(eps);
-        float ha[T], hb[T], ft[T], gt[T];
+    // One symmetric Sinkhorn update at `eps` (reps = 1/eps):
+    //   gt_j = -eps*LSE_i(la_i + f_i/eps - C_ij/eps),  ft_i = -eps*LSE_j(lb_j + g_j/eps - C_ij/eps)
+    // The log-sum-exps are stabilised by shifting with -g_j/eps resp. -f_i/eps -- the previous
+    // potentials, which ARE (-eps times) the previous log-sum-exps -- instead of the running maximum:
+    // mathematically identical, the sum then sits near 1, and six dependent cross-lane max steps leave
+    // the critical path.  If a sum ever leaves [1e-30, 1e30] (it cannot while potentials move by less
+    // than ~69*eps per step) the step is redone with the exact maximum.
+    auto step = [&](float eps, float reps, bool averaged, bool exact) {
+        float qc[T][T], qf[T], qg[T], ha[T], hb[T], ft[T], gt[T];
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb) qc[ta][tb] = div_r(s.cost[ta][tb], eps, reps);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            ha[t] = la[t] + div_r(f[t], eps, reps);
-            hb[t] = lb[t] + div_r(g[t], eps, reps);
+            qf[t] = div_r(f[t], eps, reps);
+            qg[t] = div_r(g[t], eps, reps);
+            ha[t] = la[t] + qf[t];
+            hb[t] = lb[t] + qg[t];
         }
-        softmin_cols(eps, reps, ha, gt);
-        softmin_rows(eps, reps, hb, ft);
+        lse_cols(eps, qc, ha, qg, exact, gt);
+        lse_rows(eps, qc, hb, qf, exact, ft);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             g[t] = averaged ? 0.5f * (g[t] + gt[t]) : gt[t];
             f[t] = averaged ? 0.5f * (f[t] + ft[t]) : ft[t];
         }
     };
-    {   // initialisation at eps_s[0] = diam
-        const float reps = rcp_refined(diam);
-        softmin_cols(diam, reps, la, g);
-        softmin_rows(diam, reps, lb, f);
-    }
-    step(diam, true);
-    for (int base = 0; base < n_mid; base += 64) {
-        // lane k of this chunk evaluates eps_{base+k} in double exactly as numpy does, rounds to fp32.
-        const float my_eps = (float)exp(ld + (double)(base + lane) * lsc);
-        const int cnt = min(64, n_mid - base);
-        for (int k = 0; k < cnt; ++k) {
-            const float eps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eps), k));
-            step(eps, true);
+    // The whole annealing loop.  exact = false uses the shifted log-sum-exp; an overflowed / vanished
+    // sum turns into inf / nan that then sticks to the potentials, so ONE finiteness test at the end
+    // (instead of a compare + branch on every step's critical path) decides whether the solve has to be
+    // repeated with exact maxima.
+    auto solve = [&](bool exact) {
+        {   // initialisation at eps_s[0] = diam: softmin of the bare log-weights (always exact maximum)
+            const float reps = rcp_refined(diam);
+            float qc[T][T], zero[T];
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < T; ++tb) qc[ta][tb] = div_r(s.cost[ta][tb], diam, reps);
+#pragma unroll
+            for (int t = 0; t < T; ++t) zero[t] = 0.f;
+            lse_cols(diam, qc, la, zero, true, g);
+            lse_rows(diam, qc, lb, zero, true, f);
+            step(diam, reps, true, exact);
+        }
+        for (int base = 0; base < n_mid; base += 64) {
+            // lane k of this chunk evaluates eps_{base+k} in double exactly as numpy does, rounds to fp32,
+            // and keeps its refined reciprocal; the loop below broadcasts both with v_readlane.
+            const float my_eps = (float)exp(ld + (double)(base + lane) * lsc);
+            const float my_reps = rcp_refined(my_eps);
+            const int cnt = min(64, n_mid - base);
+            for (int k = 0; k < cnt; ++k) {
+                const float eps =
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eps), k));
+                const float reps =
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_reps), k));
+                step(eps, reps, true, exact);
+            }
+        }
+        const float rb = rcp_refined(eps_last);
+        step(eps_last, rb, true, exact);
+        step(eps_last, rb, false, exact);  // last extrapolation: simultaneous, not averaged
+    };
+    PHASE_STAMP(6);
+    solve(false);
+    {
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            bad |= rv[t] && !(fabsf(f[t]) < 1e30f);
+            bad |= cv[t] && !(fabsf(g[t]) < 1e30f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#ifdef ASPIRE_PHASE_CLOCK
+            if (a.dbg && lane == 0) atomicAdd((unsigned long long*)&a.dbg[46], 1ull);
+#endif
+            solve(true);
         }
     }
-    step(eps_last, true);
-    step(eps_last, false);  // last extrapolation: simultaneous, not averaged
+    const float rb = rcp_refined(eps_last);
+    PHASE_STAMP(7);
 
     // ---- outputs ------------------------------------------------------------------------------
     float score;
@@ -409,7 +511,6 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     }
     const bool dump = a.out_plan != nullptr || a.out_pairsims != nullptr;
     if (a.want == ASPIRE_OT_PLAN_SIM || dump) {
-        const float rb = rcp_refined(eps_last);
         float acc = 0.f;
 #pragma unroll
         for (int ta = 0; ta < T; ++ta)
@@ -418,7 +519,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
                 const bool valid = rv[ta] && cv[tb];
                 const float negm = valid ? s.neg[ta][tb] : 0.f;
                 const float outer = valid ? f[ta] + g[tb] : 0.f;
-                const float plan = __expf(div_r(outer + negm, eps_last, rb)) * (wa[ta] * wb[tb]);
+                const float plan = fast_exp(div_r(outer + negm, eps_last, rb)) * (wa[ta] * wb[tb]);
                 acc += plan * negm;
                 const int i = ta * 8 + li, j = tb * 8 + lj;
                 if (dump && i < a.q.ext && j < a.c.ext) {
@@ -429,6 +530,8 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             }
         if (a.want == ASPIRE_OT_PLAN_SIM) score = wave_sum(acc);
     }
+    // a document longer than the launcher's tile bound would have been truncated silently: poison it
+    if (q_len > 8 * T || c_len > 8 * T) score = __builtin_nanf("");
     if (lane == 0) a.scores[p] = score;
     if (a.out_qdistr) {
 #pragma unroll
@@ -440,6 +543,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
         for (int t = 0; t < T; ++t)
             if (li == 0 && t * 8 + lj < a.c.ext) a.out_cdistr[p * a.c.ext + t * 8 + lj] = wb[t];
     }
+    PHASE_STAMP(8);
 }
 
 template <int T>
@@ -447,25 +551,38 @@ __global__ void __launch_bounds__(kBlock) ot_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t c_idx = blockIdx.x;
-    const int c_len = a.c.len[c_idx];
-    const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
-    const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
     const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-    const int64_t q_begin = paired ? c_idx : (int64_t)blockIdx.y * a.q_per_block;
-    const int64_t q_end = paired ? c_idx + 1 : min(a.q.n, q_begin + a.q_per_block);
+    // This block's work items: candidates [c_lo, c_hi) x queries [q_begin, q_end), candidate-major so
+    // that consecutive items reuse the candidate rows (L1/L2 hits).
+    const int64_t c_lo = (int64_t)blockIdx.x * a.c_per_block;
+    const int64_t c_hi = min(a.c.n, c_lo + a.c_per_block);
+    const int64_t q_begin = paired ? 0 : (int64_t)blockIdx.y * a.q_per_block;
+    const int64_t nq = paired ? 1 : min(a.q.n, q_begin + a.q_per_block) - q_begin;
+    const int64_t n_items = (c_hi - c_lo) * nq;
     const bool own_diam = a.diameter == nullptr;
+    const bool stamp_ok = wave == 0;
+    (void)stamp_ok;
+    PHASE_STAMP(0);
+#ifdef ASPIRE_PHASE_CLOCK
+    const long long t_entry = (long long)wall_clock64();
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 1000 && blockIdx.y == 0) a.dbg[64 + 2 * blockIdx.x] = (long long)wall_clock64();
+#endif
 
-    // Queries are taken three at a time: the three waves build the sums of each query together,
-    // then wave k solves query k.
-    for (int64_t q0 = q_begin; q0 < q_end; q0 += kWaves) {
+    // Items are taken three at a time: the three waves build the sums of each item together (each wave
+    // owns a third of the 768 coordinates), then wave k solves item k -- three Sinkhorn chains in flight.
+    for (int64_t item0 = 0; item0 < n_items; item0 += kWaves) {
         PairState<T> mine;
-        int my_qlen = 0;
-        int64_t my_q = -1;
+        int my_qlen = 0, my_clen = 0;
+        int64_t my_q = -1, my_c = -1;
 #pragma unroll 1
         for (int slot = 0; slot < kWaves; ++slot) {
-            const int64_t q_idx = q0 + slot;
-            if (q_idx >= q_end) break;  // uniform across the block
+            const int64_t item = item0 + slot;
+            if (item >= n_items) break;  // uniform across the block
+            const int64_t c_idx = c_lo + item / nq;
+            const int64_t q_idx = paired ? c_idx : q_begin + item % nq;
+            const int c_len = a.c.len[c_idx];
+            const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
+            const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
             const int q_len = a.q.len[q_idx];
             const int q_avail = a.q.ext > 0 ? a.q.ext : q_len;
             const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
@@ -474,25 +591,43 @@ __global__ void __launch_bounds__(kBlock) ot_kernel(ScoreArgs a) {
             } else {
                 pair_partials<T, true, true, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
             }
+            PHASE_STAMP(1);
             __syncthreads();
+            PHASE_STAMP(2);
             if (wave == slot) {
                 gather_pair<T>(mine, lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), lane, own_diam);
                 my_qlen = q_len;
+                my_clen = c_len;
                 my_q = q_idx;
+                my_c = c_idx;
             }
             __syncthreads();
+            PHASE_STAMP(3);
         }
         if (my_q >= 0) {
-            const int64_t p = paired ? c_idx : my_q * a.c.n + c_idx;
+            const int64_t p = paired ? my_c : my_q * a.c.n + my_c;
             float diam;
             if (own_diam) {
                 diam = sqrtf(mine.diam2);
             } else {
-                diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[my_q * a.n_groups + c_idx / a.diam_group];
+                diam = paired ? a.diameter[my_c / a.diam_group] : a.diameter[my_q * a.n_groups + my_c / a.diam_group];
             }
-            sinkhorn_pair<T>(a, mine, my_qlen, c_len, diam, p, lane);
+            sinkhorn_pair<T>(a, mine, my_qlen, my_clen, diam, p, lane);
         }
     }
+#ifdef ASPIRE_PHASE_CLOCK
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 1000 && blockIdx.y == 0) a.dbg[64 + 2 * blockIdx.x + 1] = (long long)wall_clock64();
+    if (a.dbg && lane == 0 && blockIdx.x < 1000 && blockIdx.y == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+        long long* w = a.dbg + 32768 + (blockIdx.x * 3 + wave) * 4;
+        w[0] = hw; w[1] = xcc; w[2] = t_entry; w[3] = (long long)wall_clock64();
+    }
+    if (a.dbg && lane == 0) {
+        atomicMax((unsigned long long*)&a.dbg[40 + wave], (unsigned long long)wall_clock64());   // last end per wave id
+        atomicMin((unsigned long long*)&a.dbg[44], (unsigned long long)t_entry);                 // first start
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -582,28 +717,44 @@ int dispatch_T(int max_rows, F&& f) {
     return ASPIRE_ERR_UNSUPPORTED;
 }
 
-void grid_for(const ScoreArgs& a, dim3& grid, int& q_per_block) {
+// Grid shape.  CROSS: grid.x = candidate chunks, grid.y = query chunks.  Queries are split over grid.y only
+// while the grid is too small to fill 256 CUs several times over (each block re-reads its candidates from
+// L2 per query chunk).  `max_resident_blocks` > 0 (the OT kernel: ~200 VGPRs = 2 waves/SIMD = 682 blocks
+// of 3 waves) asks for several candidates per block when that makes the WHOLE grid co-resident: a
+// 1000-pair launch is latency bound by the ~75 dependent Sinkhorn steps, and a second round of blocks
+// would double it.
+void grid_for(ScoreArgs& a, dim3& grid, int64_t max_resident_blocks) {
+    a.c_per_block = 1;
+    a.q_per_block = 1;
     if (a.pairing == ASPIRE_PAIR_PAIRED) {
-        grid = dim3((unsigned)a.c.n, 1, 1);
-        q_per_block = 1;
+        if (max_resident_blocks > 0 && a.c.n > max_resident_blocks && a.c.n <= kWaves * max_resident_blocks)
+            a.c_per_block = (int)((a.c.n + max_resident_blocks - 1) / max_resident_blocks);
+        grid = dim3((unsigned)((a.c.n + a.c_per_block - 1) / a.c_per_block), 1, 1);
         return;
     }
-    // CROSS: grid.x = candidates; split queries over grid.y only while the grid is too small to fill
-    // 256 CUs several times over (each block re-reads its candidate from L2 per query chunk).
     int64_t chunks = 1;
     const int64_t target_blocks = 256 * 8;
     while (a.c.n * chunks < target_blocks && chunks * kWaves < a.q.n) chunks *= 2;
     int64_t qpb = (a.q.n + chunks - 1) / chunks;
     qpb = (qpb + kWaves - 1) / kWaves * kWaves;
     chunks = (a.q.n + qpb - 1) / qpb;
-    grid = dim3((unsigned)a.c.n, (unsigned)chunks, 1);
-    q_per_block = (int)qpb;
+    a.q_per_block = (int)qpb;
+    const int64_t blocks = a.c.n * chunks;
+    if (max_resident_blocks > 0 && blocks > max_resident_blocks && blocks <= kWaves * max_resident_blocks &&
+        a.q.n < kWaves)
+        a.c_per_block = (int)((blocks + max_resident_blocks - 1) / max_resident_blocks);
+    grid = dim3((unsigned)((a.c.n + a.c_per_block - 1) / a.c_per_block), (unsigned)chunks, 1);
 }
 
 }  // namespace
 }  // namespace aspire
 
 using namespace aspire;
+
+#ifdef ASPIRE_PHASE_CLOCK
+static long long* g_phase_buf = nullptr;
+extern "C" void aspire_debug_phase_buffer(void* p) { g_phase_buf = (long long*)p; }
+#endif
 
 extern "C" int aspire_max_sents(void) { return 8 * kMaxT; }
 
@@ -622,7 +773,7 @@ extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_reps
     a.scores = scores;
     a.out_pairsims = pair_sims;
     dim3 grid;
-    grid_for(a, grid, a.q_per_block);
+    grid_for(a, grid, 0);
     return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         hipLaunchKernelGGL(l2max_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);
@@ -662,8 +813,11 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
     a.out_cdistr = out_cdistr;
     a.out_pairsims = out_pairsims;
     a.out_plan = out_plan;
+#ifdef ASPIRE_PHASE_CLOCK
+    a.dbg = g_phase_buf;
+#endif
     dim3 grid;
-    grid_for(a, grid, a.q_per_block);
+    grid_for(a, grid, 256 * 2);  // 2 waves/SIMD -> 8 wave slots per CU -> 2 three-wave blocks per CU
     return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         hipLaunchKernelGGL(ot_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);

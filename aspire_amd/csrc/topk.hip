@@ -26,11 +26,13 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
                                                              const uint64_t* __restrict__ keys_in, int64_t n_in,
                                                              int64_t in_stride, int64_t kk, uint64_t* __restrict__ keys_out,
                                                              int64_t out_stride, int64_t idx_base, int64_t k_final,
-                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx) {
+                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
+                                                             int sort_n) {
     __shared__ uint64_t key[kChunk];
     const int64_t q = blockIdx.x, chunk = blockIdx.y;
     const int64_t base = chunk * kChunk;
-    for (int t = threadIdx.x; t < kChunk; t += kThreads) {
+    // sort_n = power of two >= the keys in this chunk: a 1000-candidate pool sorts 1024 keys, not 4096
+    for (int t = threadIdx.x; t < sort_n; t += kThreads) {
         const int64_t i = base + t;
         uint64_t kv = 0;  // pad: below every real key
         if (i < n_in) {
@@ -44,9 +46,9 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
     }
     __syncthreads();
     // bitonic sort, descending
-    for (int size = 2; size <= kChunk; size <<= 1) {
+    for (int size = 2; size <= sort_n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < kChunk / 2; t += kThreads) {
+            for (int t = threadIdx.x; t < sort_n / 2; t += kThreads) {
                 const int lo = 2 * t - (t & (stride - 1));
                 const int hi = lo + stride;
                 const bool desc = (lo & size) == 0;
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
         for (int t = threadIdx.x; t < kk; t += kThreads) keys_out[q * out_stride + chunk * kk + t] = key[t];
     } else {
         for (int t = threadIdx.x; t < k_final; t += kThreads) {
-            const uint64_t kv = t < kChunk ? key[t] : 0;
+            const uint64_t kv = t < sort_n ? key[t] : 0;
             const bool real = kv != 0;
             top_scores[q * k_final + t] = real ? unorder_bits((uint32_t)(kv >> 32)) : -INFINITY;
             top_idx[q * k_final + t] = real ? idx_base + (int64_t)(0xFFFFFFFFu - (uint32_t)kv) : -1;
@@ -109,9 +111,11 @@ extern "C" int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, i
         const int64_t nch = n == 0 ? 1 : (n + kChunk - 1) / kChunk;
         const bool final_pass = nch == 1;
         const int64_t out_stride = nch * kk;
+        int sort_n = 64;
+        while (sort_n < kChunk && sort_n < n) sort_n <<= 1;
         hipLaunchKernelGGL(topk_pass_kernel, dim3((unsigned)Q, (unsigned)nch), dim3(kThreads), 0, (hipStream_t)stream, sc,
                            kin, n, in_stride, kk, final_pass ? nullptr : bufs[which], out_stride, idx_base, k,
-                           final_pass ? top_scores : nullptr, final_pass ? top_idx : nullptr);
+                           final_pass ? top_scores : nullptr, final_pass ? top_idx : nullptr, sort_n);
         ASPIRE_LAUNCH_OK();
         if (final_pass) break;
         sc = nullptr;

@@ -1,0 +1,87 @@
+"""Candidate-pool sharding across the GPUs of one node.
+
+Every (query, candidate) pair is independent, so the pool is split into contiguous blocks in pool
+order, one per rank (one process per GPU); queries are replicated.  Each rank scores its block with the
+HIP kernels and keeps a per-query local top-k; the only exchange is one all-gather of k (score, global
+index) pairs per query per rank -- RCCL over xGMI on the GPUs (torch.distributed backend "nccl"),
+gloo in the CPU tests -- followed by a k-way merge.  The reference has no collective on this path
+(its ranking loops are single process: evaluate.py:58-76, pp_gen_nearest.py:131-204).
+
+Tie rule: equal scores are ordered by ascending GLOBAL candidate index, which is what Python's stable
+sorted(..., reverse=True) over the un-sharded pool gives (evaluate.py:76).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world_size, rank, multiple=1):
+    """Contiguous block [lo, hi) of rank `rank`; block edges fall on multiples of `multiple` (64 keeps
+    caching_score's batch-of-64 epsilon-schedule groups intact across shards, pp_gen_nearest.py:182)."""
+    units = (n_items + multiple - 1) // multiple
+    base, extra = divmod(units, world_size)
+    lo_u = rank * base + min(rank, extra)
+    hi_u = lo_u + base + (1 if rank < extra else 0)
+    return min(lo_u * multiple, n_items), min(hi_u * multiple, n_items)
+
+
+def merge_topk(scores, idx, k):
+    """scores/idx [Q, M] candidates from all shards (idx = global ids, -1 = padding) ->
+    (top scores [Q, k], top idx [Q, k]) descending, ties by ascending global index.
+    Plain torch ops on whatever device the tensors live on: M = world_size * k is tiny."""
+    pad = idx < 0
+    scores = torch.where(pad, torch.full_like(scores, float('-inf')), scores)
+    # order by index first, then a stable descending sort on score keeps index order inside ties
+    key = torch.where(pad, torch.full_like(idx, torch.iinfo(idx.dtype).max), idx)
+    by_idx = torch.argsort(key, dim=1, stable=True)
+    s1, i1 = torch.gather(scores, 1, by_idx), torch.gather(idx, 1, by_idx)
+    by_score = torch.argsort(s1, dim=1, descending=True, stable=True)
+    s2, i2 = torch.gather(s1, 1, by_score), torch.gather(i1, 1, by_score)
+    k = min(k, scores.shape[1])
+    return s2[:, :k].contiguous(), i2[:, :k].contiguous()
+
+
+def all_gather_topk(local_scores, local_idx, k, group=None):
+    """All-gather every rank's per-query local top-k and merge.  local_* are [Q, k_local]."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return merge_topk(local_scores, local_idx, k)
+    world = dist.get_world_size(group)
+    qn, kl = local_scores.shape
+    # one fused buffer per rank: scores as fp32 bits next to int64 indices would need two collectives;
+    # pack both into int64 (score bits in the low word) so ONE all_gather moves everything.
+    packed = torch.stack([local_scores.contiguous().view(torch.int32).to(torch.int64), local_idx], dim=-1)
+    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+    out = out.permute(1, 0, 2, 3).reshape(qn, world * kl, 2)
+    scores = out[..., 0].to(torch.int32).view(torch.float32)
+    return merge_topk(scores, out[..., 1].contiguous(), k)
+
+
+class ShardedPoolRanker:
+    """Holds this rank's block of a candidate pool resident in HBM and ranks queries against the whole
+    pool.  `pool_reps` is the FULL pool (list of [S_i, 768] arrays) or, with `presharded=True`, only this
+    rank's block together with `global_offset`."""
+
+    def __init__(self, pool_reps, presharded=False, global_offset=0, multiple=64, group=None):
+        from .scorer import CandidatePool
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if presharded:
+            self.lo = global_offset
+            block = pool_reps
+        else:
+            self.lo, hi = shard_bounds(len(pool_reps), self.world, self.rank, multiple)
+            block = pool_reps[self.lo:hi]
+        self.pool = CandidatePool(block, pids=list(range(self.lo, self.lo + len(block))))
+
+    def rank_queries(self, query_reps_list, k, **score_kw):
+        from . import ops
+        from .scorer import score_pool
+        if len(self.pool) > 0:
+            scores = score_pool(query_reps_list, self.pool, **score_kw)
+            ls, li = ops.topk_desc(scores.contiguous(), k, idx_base=self.lo)
+        else:
+            dev = ops.require_gpu()
+            ls = torch.full((len(query_reps_list), k), float('-inf'), device=dev)
+            li = torch.full((len(query_reps_list), k), -1, dtype=torch.int64, device=dev)
+        return all_gather_topk(ls, li, k, self.group)

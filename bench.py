@@ -1,0 +1,252 @@
+"""bench.py -- query x candidate OT alignments per second (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload at N=1 = BASELINE.json configs[1]: otAspire, 1 query x 1000 candidates, 8 sentences x 768 d,
+reps ~ N(0,1) fp32 (seed 0), resident in HBM before the timed region.  One step = one pass of the hot
+path over that batch: the fused cost + marginals + Sinkhorn kernel over all 1000 pairs (one epsilon
+schedule per pair, the reference's evaluate.py / AspireModel.get_similarity pattern), then the
+per-query stable descending rank (top-k with k = 100).  At N>1 every rank holds its own 1000-candidate
+block of an N*1000 pool (weak scaling), ranks locally, and the per-query top-k lists are merged with one
+RCCL all-gather per step.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (ot_kernel) against HBM:
+algorithmic bytes per launch = 24 605 B/pair x pairs (each candidate and query rep
+read once, each score written once) over the kernel's mean duration measured with HIP events inside the
+timed region.  `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch CPU path; its
+Sinkhorn solver is a parity-unpinned restatement of geomloss 0.2.4) on the host cores of this box.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q, C, S, D = 1, 1000, 8, 768
+TOPK = 100
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(q, c, s_q, s_c):
+    return 4 * D * (c * s_c + q * s_q) + 4 * q * c
+
+
+def make_inputs(seed, device):
+    g = torch.Generator().manual_seed(seed)
+    query = torch.randn(Q * S, D, generator=g)
+    cands = torch.randn(C * S, D, generator=g)
+    return query.to(device), cands.to(device)
+
+
+def cpu_baseline(query, cands, budget_s=20.0):
+    """The oracle on this box's host cores, same workload, bounded wall time."""
+    from oracle import aspire_oracle as orc
+    ncpu = os.cpu_count() or 1
+    q = query.cpu().view(S, D)
+    c = cands.cpu().view(C, S, D)
+    # The ops are 8x8: intra-op threading only adds dispatch cost.  Probe 1 thread and all cores on a few
+    # pairs and keep the faster setting (the reference never sets a thread count: torch's default is all).
+    best = None
+    for nt in sorted({1, ncpu}):
+        torch.set_num_threads(nt)
+        orc.get_similarity(q, c[0])
+        t0 = time.perf_counter()
+        for i in range(3):
+            orc.get_similarity(q, c[i])
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    cores = best[0]
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    n = 0
+    while n < C and time.perf_counter() - t0 < budget_s:
+        orc.get_similarity(q, c[n])
+        n += 1
+    dt_pair = time.perf_counter() - t0
+    # the reference's other calling pattern: groups of 64 through caching_score (pp_gen_nearest.py:182)
+    t0 = time.perf_counter()
+    nb = 0
+    qn = q.numpy()
+    while nb < C and time.perf_counter() - t0 < budget_s / 2:
+        orc.caching_score(qn, [c[i].numpy() for i in range(nb, min(C, nb + 64))])
+        nb = min(C, nb + 64)
+    dt_batch = time.perf_counter() - t0
+    return {
+        'value': n / dt_pair, 'unit': 'alignments/s', 'cores': cores, 'kind': 'port',
+        'sample': f'{n} of the {C} pairs of the same workload, one pair per call (models.py:190-197 pattern), '
+                  f'{dt_pair:.1f} s; torch.set_num_threads({cores}) (faster of 1 and {ncpu} host threads)',
+        'batched64_value': nb / dt_batch,
+        'batched64_sample': f'{nb} pairs in caching_score groups of 64 (disent_models.py:256), {dt_batch:.1f} s',
+        'note': 'oracle = PyTorch CPU port of the reference path; Sinkhorn = restated geomloss 0.2.4 (parity unpinned)',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--graph-unroll', type=int, default=25, help='steps per captured graph')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from aspire_amd import _lib, ops
+    from aspire_amd.parallel import all_gather_topk
+
+    # ---- inputs resident in HBM (rank r owns global candidates [r*C, (r+1)*C)) ------------------
+    query, cands = make_inputs(0, device)
+    if rank > 0:
+        _, cands = make_inputs(rank, device)
+    ar = torch.arange(max(Q, C), device=device, dtype=torch.int32)
+    qset = ops.DeviceRepSet(query, (ar[:Q] * S).contiguous(), torch.full((Q,), S, device=device, dtype=torch.int32),
+                            ext=0, max_len=S)
+    cset = ops.DeviceRepSet(cands, (ar[:C] * S).contiguous(), torch.full((C,), S, device=device, dtype=torch.int32),
+                            ext=0, max_len=S)
+    qs, cs = qset.struct(), cset.struct()
+    prm = _lib.OtParams(0.05, 0.9, 1.0, _lib.CDIST_AUTO)
+    scores = torch.empty(Q, C, device=device, dtype=torch.float32)
+    top_s = torch.empty(Q, TOPK, device=device, dtype=torch.float32)
+    top_i = torch.empty(Q, TOPK, device=device, dtype=torch.int64)
+    null = ctypes.c_void_p(0)
+
+    def stream():  # looked up per call: under graph capture torch's current stream is the capture stream
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p_scores, p_ts, p_ti = (ctypes.c_void_p(t.data_ptr()) for t in (scores, top_s, top_i))
+    lib = _lib.lib
+
+    def score():
+        rc = lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, _lib.PAIR_CROSS, ctypes.byref(prm),
+                                        null, 0, _lib.OT_DISTANCE, p_scores, null, null, null, null, stream())
+        if rc:
+            _lib.check(rc)
+
+    def rank_step():
+        rc = lib.aspire_topk_desc_f32(p_scores, Q, C, TOPK, rank * C, p_ts, p_ti, null, 0, stream())
+        if rc:
+            _lib.check(rc)
+        if world > 1:
+            return all_gather_topk(top_s, top_i, TOPK)
+        return top_s, top_i
+
+    def step():
+        score()
+        return rank_step()
+
+    # ---- the step loop is launch bound (two ~10-20 us kernels per step): capture it in hipGraphs ------
+    # `unroll` steps per graph replay; the remainder runs eagerly.  RCCL collectives are captured too.
+    unroll = max(1, min(args.graph_unroll, args.steps))
+
+    def capture(fn, n):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                fn()
+        return g
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    use_graph = not args.no_graph
+    if use_graph:
+        g_step = capture(step, unroll)
+        g_step.replay()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    if use_graph:
+        while done + unroll <= args.steps:
+            g_step.replay()
+            done += unroll
+    while done < args.steps:
+        step()
+        done += 1
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- dominant kernel duration, live: HIP events (torch's current stream = the launch stream) around
+    # replays of a graph holding ONLY ot_kernel launches, so host launch latency is not in the bracket.
+    kern_ms = None
+    if rank == 0:
+        n_k = 20
+        g_k = capture(score, n_k) if use_graph else None
+        reps = 10
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            if g_k is not None:
+                g_k.replay()
+            else:
+                for _ in range(n_k):
+                    score()
+            b.record()
+        torch.cuda.synchronize()
+        kern_ms = min(a.elapsed_time(b) for a, b in evs) / n_k
+    assert torch.isfinite(scores).all(), 'non-finite scores'
+
+    if rank == 0:
+        bytes_per_launch = algorithmic_bytes(Q, C, S, S)
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('ot_kernel_hbm_bytes_per_launch')
+        out = {
+            'metric': 'query x candidate OT alignments/sec', 'value': world * Q * C * args.steps / elapsed,
+            'unit': 'alignments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'otAspire compsci: {Q} query x {C} candidates per GPU, {S} sents x {D}d, '
+                                   f'Sinkhorn OT (blur 0.05, scaling 0.9, one eps schedule per pair) + per-query '
+                                   f'top-{TOPK} rank' + (', RCCL all-gather top-k merge' if world > 1 else ''),
+                       'queries': Q, 'candidates_per_gpu': C, 'sents': S, 'dim': D, 'topk': TOPK,
+                       'parallelism': f'candidate-pool shards x{world}',
+                       'launch': f'hipGraph replay, {unroll} steps per graph' if use_graph else 'eager'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'ot_kernel<1>',
+                         'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(query, cands)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -172,7 +172,8 @@ def test_ot_batch_schedule_vs_caching_score(amd):
     for g_, w_ in zip(ret['pair_scores'], wextra):
         for k in range(4):
             assert g_[k].shape == w_[k].shape
-            np.testing.assert_allclose(g_[k], w_[k], atol=1e-4, rtol=0)
+            # k == 3 is the transport plan: same exp((f+g-d)/blur) conditioning as PLAN_SIM_TOL
+            np.testing.assert_allclose(g_[k], w_[k], atol=5e-4 if k == 3 else 1e-4, rtol=0)
 
 
 def test_l2max_pool_and_topk(amd):
