@@ -35,6 +35,20 @@ class OtParams(ctypes.Structure):
     _fields_ = [('blur', c_double), ('scaling', c_double), ('sent_sm_temp', c_double), ('cdist_mode', c_int32)]
 
 
+class BertLayer(ctypes.Structure):
+    """struct aspire_bert_layer"""
+    _fields_ = [(n, c_void_p) for n in ('w_qkv', 'b_qkv', 'w_o', 'b_o', 'ln1_g', 'ln1_b', 'w_ffn1', 'b_ffn1',
+                                        'w_ffn2', 'b_ffn2', 'ln2_g', 'ln2_b')]
+
+
+class BertWeights(ctypes.Structure):
+    """struct aspire_bert_weights"""
+    _fields_ = [('word_emb', c_void_p), ('pos_emb', c_void_p), ('type_emb', c_void_p), ('emb_ln_g', c_void_p),
+                ('emb_ln_b', c_void_p), ('layers', ctypes.POINTER(BertLayer)), ('n_layers', c_int32),
+                ('n_heads', c_int32), ('hidden', c_int32), ('ffn_dim', c_int32), ('vocab', c_int32),
+                ('max_pos', c_int32), ('n_types', c_int32), ('ln_eps', ctypes.c_float)]
+
+
 class AspireHipError(RuntimeError):
     pass
 
@@ -46,6 +60,9 @@ SIGNATURES = {
     'aspire_max_sents': (c_int, []),
     'aspire_span_mean_pool_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                           c_void_p, c_void_p, c_void_p]),
+    'aspire_bert_workspace_bytes': (c_size_t, [ctypes.POINTER(BertWeights), c_int64, c_int64]),
+    'aspire_bert_forward_f32': (c_int, [ctypes.POINTER(BertWeights), c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     'aspire_l2max_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
     'aspire_ot_sinkhorn_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int,

@@ -1,0 +1,399 @@
+// A1: the BERT-base encoder forward that AspireConSent runs before pooling
+// (examples/ex_aspire_consent.py:72-73: self.bert_encoder(tokid_tt, token_type_ids=seg_tt,
+// attention_mask=attnmask_tt).last_hidden_state; the arithmetic itself is HuggingFace transformers'
+// BertModel, pinned 4.5.1 in the reference's requirements.txt:14).
+//
+// Precision: the north star asks for sentence reps within 1e-4 of the fp32 CPU path through 12 layers, so
+// every GEMM runs on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, 157 TFLOP/s
+// peak on MI355X = the roofline denominator for this path), not bf16.
+//
+// Kernels
+//   embed_layernorm_kernel   word + position + token-type gather, LayerNorm          (one wave per token)
+//   gemm_f32_kernel          C = alpha * A.B^T (+bias)(+GELU)(+residual), batched/strided; A [M,K] k-contiguous,
+//                            B either [N,K] k-contiguous (nn.Linear weight, K^T of attention) or [K,N]
+//                            n-contiguous (V of attention).  128x128 / 128x64 / 64x64 block tiles, BK = 16,
+//                            4 waves as 2x2, LDS tiles stored k-major so MFMA operand reads are
+//                            conflict-free ds_read_b32, register-staged double buffering.
+//   softmax_mask_kernel      rows of scores: x*scale + key-padding bias, softmax in place (one wave per row)
+//   layernorm_kernel         y = LN(x) * gamma + beta, eps 1e-12                       (one wave per token)
+#include <math.h>
+
+#include "common.h"
+
+namespace aspire {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kBK = 16;
+
+struct GemmArgs {
+    const float* A;     // [batch][M][lda]
+    const float* B;     // B_KN ? [batch][K][ldb] : [batch][N][ldb]
+    float* C;           // [batch][M][ldc]
+    const float* bias;  // [N] or null
+    const float* res;   // [M][ldr] residual or null (not batched)
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    // batch index z = z1 * nz2 + z2; operand offsets are z1 * s?1 + z2 * s?2 (attention: z1 = doc, z2 = head)
+    int nz2;
+    long long sa1, sa2, sb1, sb2, sc1, sc2;
+    float alpha;
+    int gelu;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int BM, int BN, bool B_KN>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
+    constexpr int LDA = BM + 4, LDB = BN + 4;  // k-major LDS rows; +4 keeps float4 alignment and staggers banks
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_F4 = BM * kBK / 4 / 256;  // float4 loads per thread per tile
+    constexpr int B_F4 = BN * kBK / 4 / 256;
+    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float As[2][kBK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBK][LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z1 = blockIdx.z / g.nz2, z2 = blockIdx.z % g.nz2;
+    const float* A = g.A + z1 * g.sa1 + z2 * g.sa2;
+    const float* B = g.B + z1 * g.sb1 + z2 * g.sb2;
+    float* C = g.C + z1 * g.sc1 + z2 * g.sc2;
+
+    float4 ra[A_F4], rb[B_F4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_F4; ++p) {
+            const int idx = tid + 256 * p, row = idx >> 2, k4 = idx & 3;
+            const int m = m0 + row, k = k0 + 4 * k4;
+            ra[p] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(A + (size_t)m * g.lda + k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < B_F4; ++p) {
+            const int idx = tid + 256 * p;
+            if constexpr (B_KN) {
+                constexpr int N4 = BN / 4;
+                const int kr = idx / N4, n4 = idx % N4;
+                const int k = k0 + kr, n = n0 + 4 * n4;
+                rb[p] = (k < g.K && n < g.N) ? *reinterpret_cast<const float4*>(B + (size_t)k * g.ldb + n)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int row = idx >> 2, k4 = idx & 3;
+                const int n = n0 + row, k = k0 + 4 * k4;
+                rb[p] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(B + (size_t)n * g.ldb + k)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_F4; ++p) {
+            const int idx = tid + 256 * p, row = idx >> 2, k4 = idx & 3;
+            As[buf][4 * k4 + 0][row] = ra[p].x;
+            As[buf][4 * k4 + 1][row] = ra[p].y;
+            As[buf][4 * k4 + 2][row] = ra[p].z;
+            As[buf][4 * k4 + 3][row] = ra[p].w;
+        }
+#pragma unroll
+        for (int p = 0; p < B_F4; ++p) {
+            const int idx = tid + 256 * p;
+            if constexpr (B_KN) {
+                constexpr int N4 = BN / 4;
+                const int kr = idx / N4, n4 = idx % N4;
+                *reinterpret_cast<float4*>(&Bs[buf][kr][4 * n4]) = rb[p];
+            } else {
+                const int row = idx >> 2, k4 = idx & 3;
+                Bs[buf][4 * k4 + 0][row] = rb[p].x;
+                Bs[buf][4 * k4 + 1][row] = rb[p].y;
+                Bs[buf][4 * k4 + 2][row] = rb[p].z;
+                Bs[buf][4 * k4 + 3][row] = rb[p].w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (g.K + kBK - 1) / kBK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) load_tiles((t + 1) * kBK);  // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < kBK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kk + lk][wr * WM + 32 * i + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kk + lk][wc * WN + 32 * j + lr];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * WN + 32 * j + lr;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] * g.alpha + bv;
+                if (g.gelu) v = gelu_erf(v);
+                if (g.res) v += g.res[(size_t)m * g.ldr + n];
+                C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+}
+
+// One wave per row of 768: lane holds 3 float4 (d = 4*lane + 256*c).
+__device__ __forceinline__ void layernorm_row(float4 (&v)[3], const float* gamma, const float* beta, float eps,
+                                              float* out, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    const float mean = wave_sum(s) * (1.0f / kD);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kD) + eps);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int d = 4 * lane + 256 * c;
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + d), bt = *reinterpret_cast<const float4*>(beta + d);
+        float4 o;
+        o.x = (v[c].x - mean) * rstd * gm.x + bt.x;
+        o.y = (v[c].y - mean) * rstd * gm.y + bt.y;
+        o.z = (v[c].z - mean) * rstd * gm.z + bt.z;
+        o.w = (v[c].w - mean) * rstd * gm.w + bt.w;
+        *reinterpret_cast<float4*>(out + d) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float* __restrict__ y,
+                                                        int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const float4*>(x + row * kD + 4 * lane + 256 * c);
+    layernorm_row(v, gamma, beta, eps, y + row * kD, lane);
+}
+
+__global__ void __launch_bounds__(256) embed_layernorm_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ typ,
+                                                              const float* __restrict__ word, const float* __restrict__ pos,
+                                                              const float* __restrict__ type_emb, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float* __restrict__ y,
+                                                              int64_t rows, int64_t L) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t t = tok[row], ty = typ ? typ[row] : 0, p = row % L;
+    float4 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int d = 4 * lane + 256 * c;
+        const float4 a = *reinterpret_cast<const float4*>(word + t * kD + d);
+        const float4 b = *reinterpret_cast<const float4*>(type_emb + ty * kD + d);
+        const float4 e = *reinterpret_cast<const float4*>(pos + p * kD + d);
+        // BertEmbeddings: inputs_embeds + token_type_embeddings, then + position_embeddings
+        v[c] = make_float4((a.x + b.x) + e.x, (a.y + b.y) + e.y, (a.z + b.z) + e.z, (a.w + b.w) + e.w);
+    }
+    layernorm_row(v, gamma, beta, eps, y + row * kD, lane);
+}
+
+// scores [rows = B*H*L][ld] in place: softmax_j(x_j * scale + (mask[b][j] ? 0 : -FLT_MAX)); columns in [L, ld)
+// are written as zeros so that the P.V GEMM can run K up to ld.
+__global__ void __launch_bounds__(256) softmax_mask_kernel(float* __restrict__ s, const int64_t* __restrict__ mask, int64_t rows,
+                                                           int L, int ld, int rows_per_doc, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t b = row / rows_per_doc;
+    float* p = s + row * ld;
+    const int64_t* mk = mask + b * L;
+    constexpr int kMaxPer = 8;  // L <= 512
+    float v[kMaxPer];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kMaxPer; ++c) {
+        const int j = lane + 64 * c;
+        if (j < L) {
+            // (1 - mask) * finfo(float32).min added to the scaled scores, as BertModel's extended mask
+            v[c] = p[j] * scale + (mk[j] != 0 ? 0.f : -3.4028234663852886e38f);
+            m = fmaxf(m, v[c]);
+        } else {
+            v[c] = -INFINITY;
+        }
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxPer; ++c) {
+        v[c] = (lane + 64 * c < L) ? expf(v[c] - m) : 0.f;
+        sum += v[c];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int c = 0; c < kMaxPer; ++c) {
+        const int j = lane + 64 * c;
+        if (j < ld) p[j] = v[c] * inv;
+    }
+}
+
+template <bool B_KN>
+int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+    // Tile choice: the largest tile that still gives >= ~2 blocks per CU; small-N GEMMs (N = 768 on 8192 rows is
+    // only 384 blocks of 128x128) drop to 128x64 / 64x64 to avoid a half-empty last wave of blocks.
+    const long long b128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
+    const long long b12864 = (long long)((g.M + 127) / 128) * ((g.N + 63) / 64) * batch;
+    if (b128 >= 512 && g.N >= 128) {
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 128, B_KN>), grid, dim3(256), 0, st, g);
+    } else if (b12864 >= 512) {
+        dim3 grid((g.N + 63) / 64, (g.M + 127) / 128, batch);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 64, B_KN>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64, B_KN>), grid, dim3(256), 0, st, g);
+    }
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+    float *x, *qkv, *scores, *ctx, *tmp, *ffn;
+    size_t total;
+};
+
+Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim) {
+    const size_t M = (size_t)B * L, Lp = (size_t)(L + 3) / 4 * 4;
+    char* p = (char*)base;
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float* r = (float*)(p + off);
+        off += align_up(nfloats * sizeof(float));
+        return r;
+    };
+    w.x = take(M * kD);
+    w.qkv = take(M * 3 * kD);
+    w.scores = take((size_t)B * heads * L * Lp);
+    w.ctx = take(M * kD);
+    w.tmp = take(M * kD);
+    w.ffn = take(M * ffn_dim);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+}  // namespace aspire
+
+using namespace aspire;
+
+extern "C" size_t aspire_bert_workspace_bytes(const aspire_bert_weights* w, int64_t B, int64_t L) {
+    if (!w || B <= 0 || L <= 0) return 0;
+    return carve(nullptr, B, L, w->n_heads, w->ffn_dim).total;
+}
+
+extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64_t* tok_ids, const int64_t* type_ids,
+                                       const int64_t* attn_mask, int64_t B, int64_t L, float* hidden_out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    ASPIRE_REQUIRE(w && tok_ids && attn_mask && hidden_out, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    ASPIRE_REQUIRE(w->hidden == kD && w->n_heads == 12 && w->ffn_dim % 64 == 0 && w->ffn_dim > 0, ASPIRE_ERR_UNSUPPORTED,
+                   "only BERT-base geometry is built (hidden 768, 12 heads); got hidden %d heads %d", w->hidden, w->n_heads);
+    ASPIRE_REQUIRE(B >= 0 && L > 0 && L <= 512 && L <= w->max_pos, ASPIRE_ERR_INVALID_ARG,
+                   "sequence length %lld outside (0, min(512, max_position_embeddings=%d)]", (long long)L, w->max_pos);
+    ASPIRE_REQUIRE(w->n_layers >= 0 && (w->n_layers == 0 || w->layers), ASPIRE_ERR_INVALID_ARG, "bad layer table");
+    if (B == 0) return ASPIRE_OK;
+    const size_t need = carve(nullptr, B, L, w->n_heads, w->ffn_dim).total;
+    ASPIRE_REQUIRE(workspace && workspace_bytes >= need, ASPIRE_ERR_INVALID_ARG, "workspace too small: need %zu bytes", need);
+    hipStream_t st = (hipStream_t)stream;
+    Workspace ws = carve(workspace, B, L, w->n_heads, w->ffn_dim);
+    const int64_t M = B * L;
+    const int Lp = (int)((L + 3) / 4 * 4), H = w->n_heads, dh = kD / H;
+    const unsigned row_blocks = (unsigned)((M + 3) / 4);
+
+    float* x = w->n_layers == 0 ? hidden_out : ws.x;
+    hipLaunchKernelGGL(embed_layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, tok_ids, type_ids, w->word_emb, w->pos_emb,
+                       w->type_emb, w->emb_ln_g, w->emb_ln_b, w->ln_eps, x, M, L);
+    ASPIRE_LAUNCH_OK();
+
+    for (int l = 0; l < w->n_layers; ++l) {
+        const aspire_bert_layer& ly = w->layers[l];
+        float* out = (l == w->n_layers - 1) ? hidden_out : ws.x;  // LN2 writes the layer output (x is dead by then)
+        GemmArgs g{};
+        // 1. fused QKV projection: qkv [M, 2304] = x . Wqkv^T + bqkv
+        g = GemmArgs{};
+        g.A = x; g.B = ly.w_qkv; g.C = ws.qkv; g.bias = ly.b_qkv;
+        g.M = (int)M; g.N = 3 * kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = 3 * kD; g.nz2 = 1; g.alpha = 1.f;
+        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        // 2. scores[b,h] = Q_bh . K_bh^T   (scale and mask are applied by the softmax kernel)
+        g = GemmArgs{};
+        g.A = ws.qkv; g.B = ws.qkv + kD; g.C = ws.scores;
+        g.M = (int)L; g.N = (int)L; g.K = dh; g.lda = 3 * kD; g.ldb = 3 * kD; g.ldc = Lp; g.nz2 = H; g.alpha = 1.f;
+        g.sa1 = (long long)L * 3 * kD; g.sa2 = dh; g.sb1 = g.sa1; g.sb2 = dh;
+        g.sc1 = (long long)H * L * Lp; g.sc2 = (long long)L * Lp;
+        if (int rc = launch_gemm<false>(g, (int)(B * H), st)) return rc;
+        // 3. masked softmax over keys
+        const int64_t srows = B * H * L;
+        hipLaunchKernelGGL(softmax_mask_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, st, ws.scores, attn_mask, srows,
+                           (int)L, Lp, (int)(H * L), 1.0f / sqrtf((float)dh));
+        ASPIRE_LAUNCH_OK();
+        // 4. ctx[b, :, h*64:(h+1)*64] = P_bh . V_bh        (V is [K = L keys, N = 64] n-contiguous)
+        g = GemmArgs{};
+        g.A = ws.scores; g.B = ws.qkv + 2 * kD; g.C = ws.ctx;
+        g.M = (int)L; g.N = dh; g.K = (int)L; g.lda = Lp; g.ldb = 3 * kD; g.ldc = kD; g.nz2 = H; g.alpha = 1.f;
+        g.sa1 = (long long)H * L * Lp; g.sa2 = (long long)L * Lp; g.sb1 = (long long)L * 3 * kD; g.sb2 = dh;
+        g.sc1 = (long long)L * kD; g.sc2 = dh;
+        if (int rc = launch_gemm<true>(g, (int)(B * H), st)) return rc;
+        // 5. attention output projection + residual, LayerNorm
+        g = GemmArgs{};
+        g.A = ws.ctx; g.B = ly.w_o; g.C = ws.tmp; g.bias = ly.b_o; g.res = x; g.ldr = kD;
+        g.M = (int)M; g.N = kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
+        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln1_g, ly.ln1_b, w->ln_eps, ws.ctx, M);
+        ASPIRE_LAUNCH_OK();
+        // 6. FFN: GELU(h . W1^T + b1) . W2^T + b2 + h, LayerNorm          (h = ws.ctx)
+        g = GemmArgs{};
+        g.A = ws.ctx; g.B = ly.w_ffn1; g.C = ws.ffn; g.bias = ly.b_ffn1; g.gelu = 1;
+        g.M = (int)M; g.N = w->ffn_dim; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = w->ffn_dim; g.nz2 = 1; g.alpha = 1.f;
+        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        g = GemmArgs{};
+        g.A = ws.ffn; g.B = ly.w_ffn2; g.C = ws.tmp; g.bias = ly.b_ffn2; g.res = ws.ctx; g.ldr = kD;
+        g.M = (int)M; g.N = kD; g.K = w->ffn_dim; g.lda = w->ffn_dim; g.ldb = w->ffn_dim; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
+        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln2_g, ly.ln2_b, w->ln_eps, out, M);
+        ASPIRE_LAUNCH_OK();
+        x = out;
+    }
+    return ASPIRE_OK;
+}

@@ -1,0 +1,84 @@
+"""A1: BERT-base encoder on the GPU through libaspire_hip.so (aspire_bert_forward_f32).
+
+``HipBertEncoder`` takes its weights from a HuggingFace ``BertModel`` (the object the reference builds with
+``AutoModel.from_pretrained`` at examples/ex_aspire_consent.py:33) and exposes the one call the reference
+makes on it: ``encoder(tokid_tt, token_type_ids=seg_tt, attention_mask=attnmask_tt).last_hidden_state``
+(:72-73).  Weights are copied to HBM once, in nn.Linear layout; query/key/value are concatenated so the three
+projections are one GEMM.
+"""
+import ctypes
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from ._lib import BertLayer, BertWeights, lib, check
+
+
+class HipBertEncoder:
+    def __init__(self, bert_model):
+        dev = ops.require_gpu()
+        cfg = bert_model.config
+        if cfg.hidden_size != 768 or cfg.num_attention_heads != 12:
+            raise NotImplementedError('only BERT-base geometry (hidden 768, 12 heads) is built')
+        if cfg.hidden_act != 'gelu':
+            raise NotImplementedError(f'hidden_act {cfg.hidden_act!r}: only erf-GELU is built')
+        if getattr(cfg, 'position_embedding_type', 'absolute') != 'absolute':
+            raise NotImplementedError('only absolute position embeddings are built')
+        sd = {k: v.detach() for k, v in bert_model.state_dict().items()}
+        self.config = cfg
+        self.device = dev
+        self._keep = []
+
+        def put(t):
+            t = t.to(device=dev, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return ctypes.c_void_p(t.data_ptr())
+
+        pre = 'bert.' if any(k.startswith('bert.') for k in sd) else ''
+        emb = pre + 'embeddings.'
+        n_layers = cfg.num_hidden_layers
+        self._layers = (BertLayer * max(n_layers, 1))()
+        for i in range(n_layers):
+            p = f'{pre}encoder.layer.{i}.'
+            att = p + 'attention.self.'
+            ly = self._layers[i]
+            ly.w_qkv = put(torch.cat([sd[att + 'query.weight'], sd[att + 'key.weight'], sd[att + 'value.weight']], 0))
+            ly.b_qkv = put(torch.cat([sd[att + 'query.bias'], sd[att + 'key.bias'], sd[att + 'value.bias']], 0))
+            ly.w_o, ly.b_o = put(sd[p + 'attention.output.dense.weight']), put(sd[p + 'attention.output.dense.bias'])
+            ly.ln1_g = put(sd[p + 'attention.output.LayerNorm.weight'])
+            ly.ln1_b = put(sd[p + 'attention.output.LayerNorm.bias'])
+            ly.w_ffn1, ly.b_ffn1 = put(sd[p + 'intermediate.dense.weight']), put(sd[p + 'intermediate.dense.bias'])
+            ly.w_ffn2, ly.b_ffn2 = put(sd[p + 'output.dense.weight']), put(sd[p + 'output.dense.bias'])
+            ly.ln2_g, ly.ln2_b = put(sd[p + 'output.LayerNorm.weight']), put(sd[p + 'output.LayerNorm.bias'])
+        self._w = BertWeights(
+            put(sd[emb + 'word_embeddings.weight']), put(sd[emb + 'position_embeddings.weight']),
+            put(sd[emb + 'token_type_embeddings.weight']), put(sd[emb + 'LayerNorm.weight']),
+            put(sd[emb + 'LayerNorm.bias']), self._layers, n_layers, cfg.num_attention_heads, cfg.hidden_size,
+            cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size,
+            float(cfg.layer_norm_eps))
+        self._ws = None
+
+    def eval(self):
+        return self
+
+    def forward_hidden(self, tokid_tt, token_type_ids=None, attention_mask=None):
+        """int64 [B, L] tensors (any device) -> last_hidden_state [B, L, 768] on the GPU."""
+        dev = self.device
+        tok = tokid_tt.to(device=dev, dtype=torch.int64).contiguous()
+        b, l = tok.shape
+        if int(tok.max()) >= self.config.vocab_size or int(tok.min()) < 0:
+            raise IndexError('token id out of range')   # nn.Embedding raises IndexError on the reference path
+        typ = token_type_ids.to(device=dev, dtype=torch.int64).contiguous() if token_type_ids is not None else None
+        msk = attention_mask.to(device=dev, dtype=torch.int64).contiguous() if attention_mask is not None \
+            else torch.ones_like(tok)
+        out = torch.empty(b, l, 768, device=dev, dtype=torch.float32)
+        need = lib.aspire_bert_workspace_bytes(ctypes.byref(self._w), b, l)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        check(lib.aspire_bert_forward_f32(ctypes.byref(self._w), ops._ptr(tok), ops._ptr(typ), ops._ptr(msk), b, l,
+                                          ops._ptr(out), ops._ptr(self._ws), self._ws.numel(), ops._stream()))
+        return out
+
+    def __call__(self, tokid_tt, token_type_ids=None, attention_mask=None):
+        return SimpleNamespace(last_hidden_state=self.forward_hidden(tokid_tt, token_type_ids, attention_mask))

@@ -58,6 +58,40 @@ int aspire_span_mean_pool_f32(const float* hidden, int64_t B, int64_t L, int64_t
                               const int32_t* tok_idx, const int32_t* span_off, int64_t S,
                               float* sent_reps, float* cls_reps, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A1  BERT-base encoder forward.  Replaces `self.bert_encoder(tokid_tt, token_type_ids=seg_tt,
+ * attention_mask=attnmask_tt).last_hidden_state` at examples/ex_aspire_consent.py:72-73 (HuggingFace
+ * BertModel: embeddings + LayerNorm, 12 x [QKV, masked softmax attention, output proj + residual +
+ * LayerNorm, 768->3072 GELU(erf) 3072->768 + residual + LayerNorm]; the pooler is not computed, the
+ * reference never reads it).  fp32 throughout on the fp32-input MFMA matrix cores.
+ *   weights are borrowed device pointers in nn.Linear layout ([out, in] row-major);
+ *   w_qkv is query/key/value weights concatenated along `out` ([2304, 768]), b_qkv likewise.
+ *   tok_ids / type_ids / attn_mask  int64 [B, L] (type_ids may be NULL = all zero); attn_mask != 0 = real token
+ *   hidden_out [B, L, 768]
+ *   workspace  device scratch of aspire_bert_workspace_bytes(w, B, L) bytes
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *w_qkv, *b_qkv;      /* [2304, 768], [2304] */
+    const float *w_o, *b_o;          /* [768, 768],  [768]  */
+    const float *ln1_g, *ln1_b;      /* attention.output.LayerNorm */
+    const float *w_ffn1, *b_ffn1;    /* intermediate.dense [ffn, 768], [ffn] */
+    const float *w_ffn2, *b_ffn2;    /* output.dense       [768, ffn], [768] */
+    const float *ln2_g, *ln2_b;      /* output.LayerNorm */
+} aspire_bert_layer;
+
+typedef struct {
+    const float *word_emb, *pos_emb, *type_emb; /* [vocab,768] [max_pos,768] [n_types,768] */
+    const float *emb_ln_g, *emb_ln_b;
+    const aspire_bert_layer* layers;            /* HOST array of n_layers entries (device pointers inside) */
+    int32_t n_layers, n_heads, hidden, ffn_dim, vocab, max_pos, n_types;
+    float ln_eps;                               /* layer_norm_eps (1e-12) */
+} aspire_bert_weights;
+
+size_t aspire_bert_workspace_bytes(const aspire_bert_weights* w, int64_t B, int64_t L);
+int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64_t* tok_ids, const int64_t* type_ids,
+                            const int64_t* attn_mask, int64_t B, int64_t L, float* hidden_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* cdist formula selection, mirroring torch.cdist's default compute mode (used at
  * pair_distances.py:49 and :167): rows <= 25 on both sides -> direct sqrt(sum (x-y)^2),
  * otherwise the matmul expansion. */

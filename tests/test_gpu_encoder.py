@@ -1,0 +1,109 @@
+"""GPU parity of the encoder path (A1-A3): HIP BERT forward + span pooling against HuggingFace BertModel on
+the CPU (the third-party arithmetic the reference calls at ex_aspire_consent.py:72) and the oracle's pooling.
+Weights are random-init from a fixed seed (no checkpoints offline).  Tolerance 1e-4 on hidden states and
+sentence reps (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _bert(n_layers, seed=0, vocab=3000):
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(seed)
+    cfg = BertConfig(vocab_size=vocab, hidden_size=768, num_hidden_layers=n_layers, num_attention_heads=12,
+                     intermediate_size=3072, max_position_embeddings=512)
+    m = BertModel(cfg, add_pooling_layer=False).eval()
+    # random-init LayerNorms are identity and biases zero: perturb them so every parameter matters
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'LayerNorm' in n or n.endswith('.bias'):
+                p.add_(0.1 * torch.randn_like(p))
+    return m
+
+
+def _batch(b, l, vocab, seed, ragged=True):
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.randint(5, vocab, (b, l), generator=g)
+    lens = torch.randint(l // 3, l + 1, (b,), generator=g) if ragged else torch.full((b,), l)
+    lens[0] = l
+    mask = (torch.arange(l)[None, :] < lens[:, None]).long()
+    tok = tok * mask  # pad id 0, like the reference's batches
+    return tok, torch.zeros_like(tok), mask, lens.tolist()
+
+
+@pytest.mark.parametrize('n_layers,b,l', [(0, 2, 16), (1, 3, 37), (2, 4, 128), (12, 2, 64)])
+def test_bert_forward_matches_transformers(n_layers, b, l):
+    from aspire_amd.encoder import HipBertEncoder
+    m = _bert(n_layers)
+    tok, seg, mask, _ = _batch(b, l, 3000, seed=l)
+    with torch.no_grad():
+        want = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
+    got = HipBertEncoder(m)(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+    valid = mask.bool()
+    err = (got - want).abs()[valid].max().item()
+    assert err < TOL, err
+    # padded query rows still attend to the real keys in BertModel; they agree too
+    assert (got - want).abs().max().item() < TOL
+
+
+def test_bert_full_length_512():
+    from aspire_amd.encoder import HipBertEncoder
+    m = _bert(2, seed=3)
+    tok, seg, mask, _ = _batch(2, 502, 3000, seed=9)
+    with torch.no_grad():
+        want = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
+    got = HipBertEncoder(m)(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+    assert (got - want).abs().max().item() < TOL
+
+
+def test_consent_forward_matches_reference_path():
+    """AspireConSent.forward end to end: BertModel (CPU) + the oracle's mask-multiply pooling."""
+    from aspire_amd import AspireConSent
+    m = _bert(12, seed=1)
+    b, l = 3, 96
+    tok, seg, mask, lens = _batch(b, l, 3000, seed=4)
+    idxs = []
+    for bi in range(b):
+        n = lens[bi] - 1
+        cuts = list(range(6, n, 13)) + [n]
+        idxs.append([list(range(cuts[i], cuts[i + 1])) for i in range(len(cuts) - 1)][:7])
+    abs_lens = [len(x) for x in idxs]
+    batch = {'tokid_tt': tok, 'seg_tt': seg, 'attnmask_tt': mask, 'seq_lens': [l] + lens[1:]}
+    batch['seq_lens'][0] = l
+    model = AspireConSent(bert_model=m)
+    cls, sent = model.forward(batch, abs_lens, idxs)
+    with torch.no_grad():
+        hidden = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
+    wcls, wsent = orc.span_mean_pool(hidden, idxs, abs_lens)
+    assert cls.shape == (b, 768) and sent.shape == (b, max(abs_lens), 768)
+    assert not cls.is_cuda and not sent.is_cuda          # CPU in, CPU out like the reference's example
+    np.testing.assert_allclose(sent.numpy(), wsent.numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(cls.numpy(), wcls.numpy(), atol=TOL, rtol=0)
+    for bi in range(b):
+        assert torch.all(sent[bi, abs_lens[bi]:] == 0)
+
+
+def test_readme_example_shapes(tmp_path, golden_dir):
+    """BASELINE config 1 (README.md:58-93 with an offline tokenizer): 2 abstracts through
+    prepare_abstracts -> AspireConSent -> tsAspire / otAspire scores."""
+    import json, os
+    from transformers import BertTokenizer
+    from aspire_amd import AspireConSent, prepare_abstracts, AllPairMaskedWasserstein, rep_len_tup
+    z = json.load(open(os.path.join(golden_dir, 'prep.json')))
+    (tmp_path / 'vocab.txt').write_text('\n'.join(z['vocab']) + '\n')
+    tok = BertTokenizer(str(tmp_path / 'vocab.txt'), do_lower_case=True)
+    docs = [z['docs'][0], z['docs'][4]]
+    bert_batch, abs_lens, sent_token_idxs = prepare_abstracts(docs, tok)
+    model = AspireConSent(bert_model=_bert(2, seed=5, vocab=len(z['vocab'])))
+    cls, sent = model.forward(bert_batch, abs_lens, sent_token_idxs)
+    assert cls.shape == (2, 768) and sent.shape == (2, max(abs_lens), 768)
+    q = rep_len_tup(embed=sent[:1].permute(0, 2, 1), abs_lens=abs_lens[:1])
+    c = rep_len_tup(embed=sent[1:].permute(0, 2, 1), abs_lens=abs_lens[1:])
+    sims, extras = AllPairMaskedWasserstein({}).compute_distance(q, c, return_pair_sims=True)
+    assert sims.shape == (1,) and extras[3].shape == (1, sent.shape[1], sent.shape[1])
+    assert np.isfinite(sims.numpy()).all()
