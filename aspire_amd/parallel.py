@@ -49,9 +49,10 @@ def all_gather_topk(local_scores, local_idx, k, group=None):
     # one fused buffer per rank: scores as fp32 bits next to int64 indices would need two collectives;
     # pack both into int64 (score bits in the low word) so ONE all_gather moves everything.
     packed = torch.stack([local_scores.contiguous().view(torch.int32).to(torch.int64), local_idx], dim=-1)
-    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
-    out = out.permute(1, 0, 2, 3).reshape(qn, world * kl, 2)
+    flat = packed.contiguous().view(-1)
+    out = torch.empty(world * flat.numel(), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, flat, group=group)   # rank-major concatenation on every backend
+    out = out.view(world, qn, kl, 2).permute(1, 0, 2, 3).reshape(qn, world * kl, 2)
     scores = out[..., 0].to(torch.int32).view(torch.float32)
     return merge_topk(scores, out[..., 1].contiguous(), k)
 
