@@ -173,7 +173,9 @@ def main():
     for _ in range(max(args.warmup, 3)):
         step()
     torch.cuda.synchronize()
-    use_graph = not args.no_graph
+    # N > 1: the per-step RCCL all-gather stays eager (capturing collectives buys nothing at this size and a
+    # capture-time hang on a multi-GPU node would cost the whole scaling run).
+    use_graph = not args.no_graph and world == 1
     if use_graph:
         g_step = capture(step, unroll)
         g_step.replay()
@@ -203,7 +205,7 @@ def main():
     kern_ms = None
     if rank == 0:
         n_k = 20
-        g_k = capture(score, n_k) if use_graph else None
+        g_k = capture(score, n_k) if not args.no_graph else None
         reps = 10
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in evs:
