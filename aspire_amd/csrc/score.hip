@@ -547,7 +547,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
 }
 
 template <int T>
-__global__ void __launch_bounds__(kBlock) ot_kernel(ScoreArgs a) {
+__global__ void __launch_bounds__(kBlock, T == 1 ? 3 : 2) ot_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -817,7 +817,8 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
     a.dbg = g_phase_buf;
 #endif
     dim3 grid;
-    grid_for(a, grid, 256 * 2);  // 2 waves/SIMD -> 8 wave slots per CU -> 2 three-wave blocks per CU
+    // T == 1 is built for 3 waves/SIMD (12 wave slots per CU = 4 three-wave blocks), larger tiles for 2.
+    grid_for(a, grid, max_rows_of(q, c) <= 8 ? 256 * 4 : 256 * 2);
     return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         hipLaunchKernelGGL(ot_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);

@@ -2,15 +2,19 @@
 // order of Python's stable sorted(..., reverse=True) (src/evaluation/evaluate.py:76).
 //
 // Scores become 64-bit keys (monotone score bits << 32 | ~index) so one unsigned descending sort yields
-// both rules.  Each workgroup bitonic-sorts a 4096-key chunk in LDS (32 KB) and keeps its top k; chunk
-// winners are re-sorted by further passes until one chunk is left.
+// both rules.  One workgroup (256 threads) bitonic-sorts a chunk of N = 1024 or 4096 keys held E = N/256 per
+// thread IN REGISTERS: compare-exchange partners at distance < E are in the same thread, at distance
+// < 64*E in the same wave (DPP / v_permlane*_swap lane exchange, no barrier, no LDS), and only the levels at
+// distance >= 64*E cross waves through LDS -- 3 exchanges for 1024 keys instead of 55 barriers.  The network
+// is fully unrolled at compile time so every exchange distance is a constant.  Chunk winners are re-sorted by further
+// passes until one chunk is left.
 #include "common.h"
 
 namespace aspire {
 namespace {
 
-constexpr int kChunk = 4096;
 constexpr int kThreads = 256;
+constexpr int kMaxChunk = 4096;
 
 __device__ __forceinline__ uint32_t order_bits(float f) {
     const uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -20,20 +24,89 @@ __device__ __forceinline__ float unorder_bits(uint32_t u) {
     return __builtin_bit_cast(float, (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
 }
 
+template <int M>
+__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v) {
+    // DPP / v_permlane*_swap forms (common.h): a few cycles each, where ds_bpermute costs ~150 per dependent hop
+    const float lo = lane_xor<M>(__builtin_bit_cast(float, (uint32_t)v));
+    const float hi = lane_xor<M>(__builtin_bit_cast(float, (uint32_t)(v >> 32)));
+    return ((uint64_t)__builtin_bit_cast(uint32_t, hi) << 32) | __builtin_bit_cast(uint32_t, lo);
+}
+
+__device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t b, bool take_max) {
+    return take_max ? (a > b ? a : b) : (a < b ? a : b);
+}
+
+// One compare-exchange level of the bitonic network (partner = idx ^ STRIDE, direction from idx & SIZE).
+// Element index of register r of thread t: idx = t * E + r.
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_level(uint64_t (&key)[E], uint64_t* lds, int tid) {
+    if constexpr (STRIDE >= 64 * E) {
+        // partner lives in another wave: exchange through LDS
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) lds[tid * E + r] = key[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int idx = tid * E + r;
+            key[r] = pick(key[r], lds[idx ^ STRIDE], ((idx & SIZE) == 0) == ((idx & STRIDE) == 0));
+        }
+    } else if constexpr (STRIDE >= E) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int idx = tid * E + r;
+            key[r] = pick(key[r], lane_xor_u64<STRIDE / E>(key[r]), ((idx & SIZE) == 0) == ((idx & STRIDE) == 0));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            if ((r & STRIDE) == 0) {
+                const int idx = tid * E + r;
+                const bool desc = (idx & SIZE) == 0;
+                const uint64_t a = key[r], b = key[r | STRIDE];
+                const bool swap = desc ? (a < b) : (a > b);
+                key[r] = swap ? b : a;
+                key[r | STRIDE] = swap ? a : b;
+            }
+        }
+    }
+}
+
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(uint64_t (&key)[E], uint64_t* lds, int tid) {
+    bitonic_level<E, SIZE, STRIDE>(key, lds, tid);
+    if constexpr (STRIDE > 1) bitonic_merge<E, SIZE, STRIDE / 2>(key, lds, tid);
+}
+
+template <int E, int SIZE>
+__device__ __forceinline__ void bitonic_sort(uint64_t (&key)[E], uint64_t* lds, int tid) {
+    if constexpr (SIZE > 2) bitonic_sort<E, SIZE / 2>(key, lds, tid);
+    bitonic_merge<E, SIZE, SIZE / 2>(key, lds, tid);
+}
+
+// Sorts the block's E * 256 keys descending (fully unrolled network: every exchange distance is a constant).
+template <int E>
+__device__ __forceinline__ void block_bitonic_desc(uint64_t (&key)[E], uint64_t* lds, int tid) {
+    bitonic_sort<E, E * kThreads>(key, lds, tid);
+}
+
 // in: either scores (first pass; index = position) or keys.  n_in per query; chunk c covers
-// [c*kChunk, (c+1)*kChunk).  Writes kk = min(k, kChunk) keys per chunk, or the final outputs.
+// [c*N, (c+1)*N).  Writes kk = min(k, N) keys per chunk, or the final outputs.
+template <int E>
 __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __restrict__ scores,
                                                              const uint64_t* __restrict__ keys_in, int64_t n_in,
                                                              int64_t in_stride, int64_t kk, uint64_t* __restrict__ keys_out,
                                                              int64_t out_stride, int64_t idx_base, int64_t k_final,
-                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
-                                                             int sort_n) {
-    __shared__ uint64_t key[kChunk];
+                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx) {
+    constexpr int N = E * kThreads;
+    __shared__ uint64_t lds[N];
+    const int tid = threadIdx.x;
     const int64_t q = blockIdx.x, chunk = blockIdx.y;
-    const int64_t base = chunk * kChunk;
-    // sort_n = power of two >= the keys in this chunk: a 1000-candidate pool sorts 1024 keys, not 4096
-    for (int t = threadIdx.x; t < sort_n; t += kThreads) {
-        const int64_t i = base + t;
+    const int64_t base = chunk * N;
+    uint64_t key[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int64_t i = base + tid * E + r;
         uint64_t kv = 0;  // pad: below every real key
         if (i < n_in) {
             if (scores) {
@@ -42,36 +115,31 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
                 kv = keys_in[q * in_stride + i];
             }
         }
-        key[t] = kv;
+        key[r] = kv;
     }
-    __syncthreads();
-    // bitonic sort, descending
-    for (int size = 2; size <= sort_n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < sort_n / 2; t += kThreads) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const uint64_t a = key[lo], b = key[hi];
-                if ((a < b) == desc) {
-                    key[lo] = b;
-                    key[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (top_scores == nullptr) {
-        for (int t = threadIdx.x; t < kk; t += kThreads) keys_out[q * out_stride + chunk * kk + t] = key[t];
-    } else {
-        for (int t = threadIdx.x; t < k_final; t += kThreads) {
-            const uint64_t kv = t < sort_n ? key[t] : 0;
+    block_bitonic_desc<E>(key, lds, tid);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int t = tid * E + r;
+        const uint64_t kv = key[r];
+        if (top_scores == nullptr) {
+            if (t < kk) keys_out[q * out_stride + chunk * kk + t] = kv;
+        } else if (t < k_final) {
             const bool real = kv != 0;
             top_scores[q * k_final + t] = real ? unorder_bits((uint32_t)(kv >> 32)) : -INFINITY;
             top_idx[q * k_final + t] = real ? idx_base + (int64_t)(0xFFFFFFFFu - (uint32_t)kv) : -1;
         }
     }
+    if (top_scores != nullptr) {
+        // k_final beyond the chunk (C < k): the tail is (-inf, -1)
+        for (int64_t t = N + tid; t < k_final; t += kThreads) {
+            top_scores[q * k_final + t] = -INFINITY;
+            top_idx[q * k_final + t] = -1;
+        }
+    }
 }
+
+int chunk_for(int64_t n) { return n <= 1024 ? 1024 : kMaxChunk; }
 
 }  // namespace
 }  // namespace aspire
@@ -79,10 +147,11 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
 using namespace aspire;
 
 extern "C" size_t aspire_topk_workspace_bytes(int64_t Q, int64_t C, int64_t k) {
-    if (Q <= 0 || C <= kChunk) return 0;
-    const int64_t kk = k < kChunk ? k : kChunk;
-    const int64_t n1 = (C + kChunk - 1) / kChunk * kk;
-    const int64_t n2 = (n1 + kChunk - 1) / kChunk * kk;
+    if (Q <= 0 || C <= kMaxChunk) return 0;
+    const int64_t kk = k < kMaxChunk ? k : kMaxChunk;
+    const int64_t n1 = (C + kMaxChunk - 1) / kMaxChunk * kk;
+    const int64_t c2 = chunk_for(n1);
+    const int64_t n2 = (n1 + c2 - 1) / c2 * kk;
     return (size_t)(Q * (n1 + n2)) * sizeof(uint64_t);
 }
 
@@ -93,29 +162,35 @@ extern "C" int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, i
                    (long long)C, (long long)k);
     ASPIRE_REQUIRE(scores && top_scores && top_idx, ASPIRE_ERR_INVALID_ARG, "null pointer");
     ASPIRE_REQUIRE(C < (int64_t)0xFFFFFFFF, ASPIRE_ERR_UNSUPPORTED, "C too large for 32-bit local indices");
-    ASPIRE_REQUIRE(C <= kChunk || k < kChunk, ASPIRE_ERR_UNSUPPORTED,
-                   "k=%lld >= %d with C=%lld > %d: full sorts beyond one chunk are not built", (long long)k, kChunk,
-                   (long long)C, kChunk);
+    ASPIRE_REQUIRE(C <= kMaxChunk || k < 1024, ASPIRE_ERR_UNSUPPORTED,
+                   "k=%lld >= 1024 with C=%lld > %d: full sorts beyond one chunk are not built", (long long)k,
+                   (long long)C, kMaxChunk);
     if (Q == 0) return ASPIRE_OK;
     ASPIRE_REQUIRE(workspace_bytes >= aspire_topk_workspace_bytes(Q, C, k), ASPIRE_ERR_INVALID_ARG,
                    "workspace too small: need %zu bytes", aspire_topk_workspace_bytes(Q, C, k));
-    const int64_t kk = k < kChunk ? k : kChunk;
+    const int64_t kk = k < kMaxChunk ? k : kMaxChunk;
     int64_t n = C, in_stride = C;
     const float* sc = scores;
     const uint64_t* kin = nullptr;
     uint64_t* bufs[2];
     bufs[0] = (uint64_t*)workspace;
-    bufs[1] = bufs[0] + (workspace ? Q * ((C + kChunk - 1) / kChunk * kk) : 0);
+    bufs[1] = bufs[0] + (workspace ? Q * ((C + kMaxChunk - 1) / kMaxChunk * kk) : 0);
     int which = 0;
     for (;;) {
-        const int64_t nch = n == 0 ? 1 : (n + kChunk - 1) / kChunk;
+        const int chunk = chunk_for(n);
+        const int64_t nch = n == 0 ? 1 : (n + chunk - 1) / chunk;
         const bool final_pass = nch == 1;
         const int64_t out_stride = nch * kk;
-        int sort_n = 64;
-        while (sort_n < kChunk && sort_n < n) sort_n <<= 1;
-        hipLaunchKernelGGL(topk_pass_kernel, dim3((unsigned)Q, (unsigned)nch), dim3(kThreads), 0, (hipStream_t)stream, sc,
-                           kin, n, in_stride, kk, final_pass ? nullptr : bufs[which], out_stride, idx_base, k,
-                           final_pass ? top_scores : nullptr, final_pass ? top_idx : nullptr, sort_n);
+        dim3 grid((unsigned)Q, (unsigned)nch);
+        if (chunk == 1024) {
+            hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk,
+                               final_pass ? nullptr : bufs[which], out_stride, idx_base, k, final_pass ? top_scores : nullptr,
+                               final_pass ? top_idx : nullptr);
+        } else {
+            hipLaunchKernelGGL(topk_pass_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk,
+                               final_pass ? nullptr : bufs[which], out_stride, idx_base, k, final_pass ? top_scores : nullptr,
+                               final_pass ? top_idx : nullptr);
+        }
         ASPIRE_LAUNCH_OK();
         if (final_pass) break;
         sc = nullptr;

@@ -183,7 +183,7 @@ int aspire_group_diameter_f32(const aspire_repset* q, const aspire_repset* c, in
  *   idx_base  added to every output index (the shard's first global candidate id)
  *   top_scores [Q, k], top_idx [Q, k] out; if C < k the tail is (-inf, -1).
  *   workspace  device scratch of at least aspire_topk_workspace_bytes(Q, C, k) bytes (0 when C <= 4096).
- *   Limits: C <= 4096 for any k (full sort), otherwise k < 4096.
+ *   Limits: C <= 4096 for any k (full sort), otherwise k < 1024.
  */
 size_t aspire_topk_workspace_bytes(int64_t Q, int64_t C, int64_t k);
 int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
