@@ -67,7 +67,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p]),
     'aspire_ot_sinkhorn_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int,
                                        ctypes.POINTER(OtParams), c_void_p, c_int64, c_int, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'aspire_ot_workspace_bytes': (c_size_t, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int]),
     'aspire_group_diameter_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int64,
                                           c_void_p, c_void_p]),
     'aspire_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64]),

@@ -40,7 +40,7 @@ struct ScoreArgs {
     int pairing;     // ASPIRE_PAIR_*
     int cdist_mode;  // ASPIRE_CDIST_*
     int q_per_block; // CROSS: queries handled by one block (grid.y chunks)
-    int c_per_block; // candidates handled by one block (grid.x chunks)
+    int64_t cand0, cand1;  // otAspire: the chunk of candidates this launch covers
     // OT
     double blur, scaling, temp;
     const float* diameter;
@@ -251,33 +251,55 @@ template <int T>
 struct PairState {
     float cost[T][T];  // geomloss cost: sqrt(max(|x|^2 - 2 x.y + |y|^2, 1e-8))
     float neg[T][T];   // -cdist (torch formula)
-    float diam2;       // sum over coordinates of (max-min)^2 (only when computed in-kernel)
 };
 
+// Per-pair intermediates between the two kernels of the otAspire path, one slot per pair of the current
+// chunk: cost [8T x 8T] row-major, neg [8T x 8T], diam2 (sum over coordinates of (max-min)^2).
 template <int T>
-__device__ __forceinline__ void gather_pair(PairState<T>& s, const float* lds, bool mm, int lane, bool want_diam) {
+struct PairWs {
+    static constexpr int kEntries = 64 * T * T;
+    float* cost;
+    float* neg;
+    float* diam2;
+};
+
+// After the three waves' partial sums of one pair met in LDS: all 192 threads finish the entries
+// (sum of partials, both L2 formulas) and store them to the pair's workspace slot.
+template <int T>
+__device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want_diam, const PairWs<T>& ws, int64_t slot) {
+    for (int e = threadIdx.x; e < 64 * T * T; e += kBlock) {
+        const int tile = e >> 6, l = e & 63, ta = tile / T, tb = tile % T, li = l >> 3, lj = l & 7;
+        const float* r = lds + tile * 128;
+        float g = 0.f, d2 = 0.f, xx = 0.f, yy = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            g += r[w * T * T * 128 + l];
+            d2 += r[w * T * T * 128 + 64 + l];
+            xx += lds[Lds<T>::kRed + w * T * 16 + ta * 16 + li];
+            yy += lds[Lds<T>::kRed + w * T * 16 + tb * 16 + 8 + lj];
+        }
+        const float sq = fmaf(-2.f, g, xx) + yy;
+        const int64_t o = slot * (64 * T * T) + (ta * 8 + li) * (8 * T) + tb * 8 + lj;
+        ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
+        ws.neg[o] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);
+    }
+    if (want_diam && threadIdx.x == 0) {
+        const float* dd = lds + Lds<T>::kRed + Lds<T>::kNorm;
+        ws.diam2[slot] = dd[0] + dd[1] + dd[2];
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void load_pair(PairState<T>& s, const PairWs<T>& ws, int64_t slot, int lane) {
     const int li = lane >> 3, lj = lane & 7;
 #pragma unroll
     for (int ta = 0; ta < T; ++ta)
 #pragma unroll
         for (int tb = 0; tb < T; ++tb) {
-            const float* r = lds + (ta * T + tb) * 128;
-            float g = 0.f, d2 = 0.f, xx = 0.f, yy = 0.f;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                g += r[w * T * T * 128 + lane];
-                d2 += r[w * T * T * 128 + 64 + lane];
-                xx += lds[Lds<T>::kRed + w * T * 16 + ta * 16 + li];
-                yy += lds[Lds<T>::kRed + w * T * 16 + tb * 16 + 8 + lj];
-            }
-            const float sq = fmaf(-2.f, g, xx) + yy;
-            s.cost[ta][tb] = sqrtf(fmaxf(sq, 1e-8f));
-            s.neg[ta][tb] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);
+            const int64_t o = slot * (64 * T * T) + (ta * 8 + li) * (8 * T) + tb * 8 + lj;
+            s.cost[ta][tb] = ws.cost[o];
+            s.neg[ta][tb] = ws.neg[o];
         }
-    if (want_diam) {
-        const float* dd = lds + Lds<T>::kRed + Lds<T>::kNorm;
-        s.diam2 = dd[0] + dd[1] + dd[2];
-    }
 }
 
 // Masked entries carry this instead of -inf so that fully masked (pad) lanes never form inf - inf.
@@ -441,6 +463,75 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             f[t] = averaged ? 0.5f * (f[t] + ft[t]) : ft[t];
         }
     };
+    // The same update with the critical path cut to the bone (the kernel's time at ~1000 pairs IS 75 x this
+    // chain): everything in base 2 so v_exp_f32 / v_log_f32 need no scaling multiplies -- r2 = log2(e)/eps
+    // turns f, g, C into base-2 exponent units in ONE multiply each (r2 is rounded once from float64), the
+    // shift by the previous potential makes the summand exp2((lb2 + g2 - C2) + f2), and the new potential is
+    // (eps*ln2) * (f2 - log2(sum)).  Measured against a float64 evaluation this is as accurate as the fp32 CPU
+    // path (tools/oterr.py).
+    float la2[T], lb2[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        la2[t] = la[t] * kLog2e;
+        lb2[t] = lb[t] * kLog2e;
+    }
+    auto step2 = [&](float r2, float eln2, bool averaged) {
+        float f2[T], g2[T], ft[T], gt[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f2[t] = f[t] * r2;
+            g2[t] = g[t] * r2;
+        }
+        if constexpr (T == 1) {
+            // One entry per lane.  The column chain (DPP row_ror:8, v_permlane16_swap, v_permlane32_swap) and
+            // the row chain (three DPP quad ops) are independent; a single wave issues in order, so they are
+            // interleaved level by level here and pinned with sched_barrier -- a cross-lane op costs 17-26
+            // cycles of dependent latency (tools: build/dbg/lat.hip), overlapped they cost it once, not twice.
+            const float c2 = s.cost[0][0] * r2;
+            const float uc = ((la2[0] + f2[0]) - c2) + g2[0];
+            const float ur = ((lb2[0] + g2[0]) - c2) + f2[0];
+            float sc = __builtin_amdgcn_exp2f(rv[0] ? uc : kNegBig);
+            float sr = __builtin_amdgcn_exp2f(cv[0] ? ur : kNegBig);
+            __builtin_amdgcn_sched_barrier(0);
+            sc += lane_xor<8>(sc);
+            sr += lane_xor<1>(sr);
+            __builtin_amdgcn_sched_barrier(0);
+            sc = swap_add<16>(sc, sc);
+            sr += lane_xor<2>(sr);
+            __builtin_amdgcn_sched_barrier(0);
+            sc = swap_add<32>(sc, sc);
+            sr += dpp_mov<0x141>(sr, sr);
+            __builtin_amdgcn_sched_barrier(0);
+            gt[0] = eln2 * (g2[0] - __builtin_amdgcn_logf(sc));
+            ft[0] = eln2 * (f2[0] - __builtin_amdgcn_logf(sr));
+        } else {
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb) {   // columns: g~_j
+                float sum = 0.f;
+#pragma unroll
+                for (int ta = 0; ta < T; ++ta) {
+                    const float u = ((la2[ta] + f2[ta]) - s.cost[ta][tb] * r2) + g2[tb];
+                    sum += __builtin_amdgcn_exp2f(rv[ta] ? u : kNegBig);
+                }
+                gt[tb] = eln2 * (g2[tb] - __builtin_amdgcn_logf(col8_sum(sum)));
+            }
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta) {   // rows: f~_i
+                float sum = 0.f;
+#pragma unroll
+                for (int tb = 0; tb < T; ++tb) {
+                    const float u = ((lb2[tb] + g2[tb]) - s.cost[ta][tb] * r2) + f2[ta];
+                    sum += __builtin_amdgcn_exp2f(cv[tb] ? u : kNegBig);
+                }
+                ft[ta] = eln2 * (f2[ta] - __builtin_amdgcn_logf(row8_sum(sum)));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            g[t] = averaged ? 0.5f * (g[t] + gt[t]) : gt[t];
+            f[t] = averaged ? 0.5f * (f[t] + ft[t]) : ft[t];
+        }
+    };
     // The whole annealing loop.  exact = false uses the shifted log-sum-exp; an overflowed / vanished
     // sum turns into inf / nan that then sticks to the potentials, so ONE finiteness test at the end
     // (instead of a compare + branch on every step's critical path) decides whether the solve has to be
@@ -457,25 +548,45 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             for (int t = 0; t < T; ++t) zero[t] = 0.f;
             lse_cols(diam, qc, la, zero, true, g);
             lse_rows(diam, qc, lb, zero, true, f);
-            step(diam, reps, true, exact);
+            step(diam, reps, true, true);
         }
         for (int base = 0; base < n_mid; base += 64) {
-            // lane k of this chunk evaluates eps_{base+k} in double exactly as numpy does, rounds to fp32,
-            // and keeps its refined reciprocal; the loop below broadcasts both with v_readlane.
-            const float my_eps = (float)exp(ld + (double)(base + lane) * lsc);
-            const float my_reps = rcp_refined(my_eps);
+            // lane k of this chunk evaluates eps_{base+k} in double exactly as numpy does and rounds to fp32;
+            // the per-step constants derived from it are broadcast with v_readlane inside the loop.
+            const double eps_d = exp(ld + (double)(base + lane) * lsc);
+            const float my_eps = (float)eps_d;
             const int cnt = min(64, n_mid - base);
-            for (int k = 0; k < cnt; ++k) {
-                const float eps =
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eps), k));
-                const float reps =
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_reps), k));
-                step(eps, reps, true, exact);
+            if (exact) {
+                const float my_reps = rcp_refined(my_eps);
+                for (int k = 0; k < cnt; ++k) {
+                    const float eps =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eps), k));
+                    const float reps =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_reps), k));
+                    step(eps, reps, true, true);
+                }
+            } else {
+                const float my_r2 = (float)(1.4426950408889634 / (double)my_eps);
+                const float my_eln2 = (float)((double)my_eps * 0.6931471805599453);
+                for (int k = 0; k < cnt; ++k) {
+                    const float r2 =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r2), k));
+                    const float eln2 =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eln2), k));
+                    step2(r2, eln2, true);
+                }
             }
         }
-        const float rb = rcp_refined(eps_last);
-        step(eps_last, rb, true, exact);
-        step(eps_last, rb, false, exact);  // last extrapolation: simultaneous, not averaged
+        if (exact) {
+            const float rb = rcp_refined(eps_last);
+            step(eps_last, rb, true, true);
+            step(eps_last, rb, false, true);  // last extrapolation: simultaneous, not averaged
+        } else {
+            const float r2 = (float)(1.4426950408889634 / (double)eps_last);
+            const float eln2 = (float)((double)eps_last * 0.6931471805599453);
+            step2(r2, eln2, true);
+            step2(r2, eln2, false);
+        }
     };
     PHASE_STAMP(6);
     solve(false);
@@ -487,9 +598,6 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             bad |= cv[t] && !(fabsf(g[t]) < 1e30f);
         }
         if (__builtin_expect(__any(bad), 0)) {
-#ifdef ASPIRE_PHASE_CLOCK
-            if (a.dbg && lane == 0) atomicAdd((unsigned long long*)&a.dbg[46], 1ull);
-#endif
             solve(true);
         }
     }
@@ -546,88 +654,61 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     PHASE_STAMP(8);
 }
 
+// Kernel 1 of the otAspire path: pairwise sentence costs of the pairs of one chunk of candidates
+// [a.cand0, a.cand1) -> workspace.  Streams every candidate row once; HBM bound for few queries.
 template <int T>
-__global__ void __launch_bounds__(kBlock, T == 1 ? 3 : 2) ot_kernel(ScoreArgs a) {
+__global__ void __launch_bounds__(kBlock) pair_cost_kernel(ScoreArgs a, PairWs<T> ws) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-    // This block's work items: candidates [c_lo, c_hi) x queries [q_begin, q_end), candidate-major so
-    // that consecutive items reuse the candidate rows (L1/L2 hits).
-    const int64_t c_lo = (int64_t)blockIdx.x * a.c_per_block;
-    const int64_t c_hi = min(a.c.n, c_lo + a.c_per_block);
-    const int64_t q_begin = paired ? 0 : (int64_t)blockIdx.y * a.q_per_block;
-    const int64_t nq = paired ? 1 : min(a.q.n, q_begin + a.q_per_block) - q_begin;
-    const int64_t n_items = (c_hi - c_lo) * nq;
+    const int64_t c_idx = a.cand0 + blockIdx.x;
+    const int64_t ncand = a.cand1 - a.cand0;
+    const int64_t q_begin = paired ? c_idx : (int64_t)blockIdx.y * a.q_per_block;
+    const int64_t q_end = paired ? c_idx + 1 : min(a.q.n, q_begin + a.q_per_block);
     const bool own_diam = a.diameter == nullptr;
-    const bool stamp_ok = wave == 0;
-    (void)stamp_ok;
-    PHASE_STAMP(0);
-#ifdef ASPIRE_PHASE_CLOCK
-    const long long t_entry = (long long)wall_clock64();
-    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 1000 && blockIdx.y == 0) a.dbg[64 + 2 * blockIdx.x] = (long long)wall_clock64();
-#endif
+    const int c_len = a.c.len[c_idx];
+    const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
+    const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
+    for (int64_t q_idx = q_begin; q_idx < q_end; ++q_idx) {
+        const int q_len = a.q.len[q_idx];
+        const int q_avail = a.q.ext > 0 ? a.q.ext : q_len;
+        const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
+        if (own_diam) {
+            pair_partials<T, true, true, true>(qdoc, q_avail, q_len, cdoc, c_avail, c_len, lds, wave, lane);
+        } else {
+            pair_partials<T, true, true, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
+        }
+        __syncthreads();
+        const int64_t slot = paired ? (c_idx - a.cand0) : q_idx * ncand + (c_idx - a.cand0);
+        finish_pair<T>(lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), own_diam, ws, slot);
+        __syncthreads();
+    }
+}
 
-    // Items are taken three at a time: the three waves build the sums of each item together (each wave
-    // owns a third of the 768 coordinates), then wave k solves item k -- three Sinkhorn chains in flight.
-    for (int64_t item0 = 0; item0 < n_items; item0 += kWaves) {
-        PairState<T> mine;
-        int my_qlen = 0, my_clen = 0;
-        int64_t my_q = -1, my_c = -1;
-#pragma unroll 1
-        for (int slot = 0; slot < kWaves; ++slot) {
-            const int64_t item = item0 + slot;
-            if (item >= n_items) break;  // uniform across the block
-            const int64_t c_idx = c_lo + item / nq;
-            const int64_t q_idx = paired ? c_idx : q_begin + item % nq;
-            const int c_len = a.c.len[c_idx];
-            const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
-            const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
-            const int q_len = a.q.len[q_idx];
-            const int q_avail = a.q.ext > 0 ? a.q.ext : q_len;
-            const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
-            if (own_diam) {
-                pair_partials<T, true, true, true>(qdoc, q_avail, q_len, cdoc, c_avail, c_len, lds, wave, lane);
-            } else {
-                pair_partials<T, true, true, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
-            }
-            PHASE_STAMP(1);
-            __syncthreads();
-            PHASE_STAMP(2);
-            if (wave == slot) {
-                gather_pair<T>(mine, lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), lane, own_diam);
-                my_qlen = q_len;
-                my_clen = c_len;
-                my_q = q_idx;
-                my_c = c_idx;
-            }
-            __syncthreads();
-            PHASE_STAMP(3);
-        }
-        if (my_q >= 0) {
-            const int64_t p = paired ? my_c : my_q * a.c.n + my_c;
-            float diam;
-            if (own_diam) {
-                diam = sqrtf(mine.diam2);
-            } else {
-                diam = paired ? a.diameter[my_c / a.diam_group] : a.diameter[my_q * a.n_groups + my_c / a.diam_group];
-            }
-            sinkhorn_pair<T>(a, mine, my_qlen, my_clen, diam, p, lane);
-        }
+// Kernel 2: one wave = one Sinkhorn solve, four pairs per workgroup; only registers and cross-lane ops.
+// ~50 VGPRs at T = 1, so up to 8 solves share a SIMD and hide each other's cross-lane / transcendental
+// latencies.
+template <int T>
+__global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws, int64_t n_slots) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+    if (slot >= n_slots) return;
+    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const int64_t ncand = a.cand1 - a.cand0;
+    const int64_t q_idx = paired ? a.cand0 + slot : slot / ncand;
+    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + slot % ncand;
+    const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
+    PairState<T> st;
+    load_pair<T>(st, ws, slot, lane);
+    float diam;
+    if (a.diameter == nullptr) {
+        diam = sqrtf(ws.diam2[slot]);
+    } else {
+        diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
     }
-#ifdef ASPIRE_PHASE_CLOCK
-    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 1000 && blockIdx.y == 0) a.dbg[64 + 2 * blockIdx.x + 1] = (long long)wall_clock64();
-    if (a.dbg && lane == 0 && blockIdx.x < 1000 && blockIdx.y == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
-        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
-        long long* w = a.dbg + 32768 + (blockIdx.x * 3 + wave) * 4;
-        w[0] = hw; w[1] = xcc; w[2] = t_entry; w[3] = (long long)wall_clock64();
-    }
-    if (a.dbg && lane == 0) {
-        atomicMax((unsigned long long*)&a.dbg[40 + wave], (unsigned long long)wall_clock64());   // last end per wave id
-        atomicMin((unsigned long long*)&a.dbg[44], (unsigned long long)t_entry);                 // first start
-    }
-#endif
+    sinkhorn_pair<T>(a, st, a.q.len[q_idx], a.c.len[c_idx], diam, p, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -717,44 +798,27 @@ int dispatch_T(int max_rows, F&& f) {
     return ASPIRE_ERR_UNSUPPORTED;
 }
 
-// Grid shape.  CROSS: grid.x = candidate chunks, grid.y = query chunks.  Queries are split over grid.y only
-// while the grid is too small to fill 256 CUs several times over (each block re-reads its candidates from
-// L2 per query chunk).  `max_resident_blocks` > 0 (the OT kernel: ~200 VGPRs = 2 waves/SIMD = 682 blocks
-// of 3 waves) asks for several candidates per block when that makes the WHOLE grid co-resident: a
-// 1000-pair launch is latency bound by the ~75 dependent Sinkhorn steps, and a second round of blocks
-// would double it.
-void grid_for(ScoreArgs& a, dim3& grid, int64_t max_resident_blocks) {
-    a.c_per_block = 1;
-    a.q_per_block = 1;
+// Query chunking.  CROSS: grid.x = candidates, grid.y = query chunks; queries are split over grid.y only while
+// the grid is too small to fill 256 CUs several times over (each block re-reads its candidate from L2 per
+// query chunk).
+int query_chunks(ScoreArgs& a) {
     if (a.pairing == ASPIRE_PAIR_PAIRED) {
-        if (max_resident_blocks > 0 && a.c.n > max_resident_blocks && a.c.n <= kWaves * max_resident_blocks)
-            a.c_per_block = (int)((a.c.n + max_resident_blocks - 1) / max_resident_blocks);
-        grid = dim3((unsigned)((a.c.n + a.c_per_block - 1) / a.c_per_block), 1, 1);
-        return;
+        a.q_per_block = 1;
+        return 1;
     }
     int64_t chunks = 1;
     const int64_t target_blocks = 256 * 8;
-    while (a.c.n * chunks < target_blocks && chunks * kWaves < a.q.n) chunks *= 2;
+    while (a.c.n * chunks < target_blocks && chunks < a.q.n) chunks *= 2;
     int64_t qpb = (a.q.n + chunks - 1) / chunks;
-    qpb = (qpb + kWaves - 1) / kWaves * kWaves;
     chunks = (a.q.n + qpb - 1) / qpb;
     a.q_per_block = (int)qpb;
-    const int64_t blocks = a.c.n * chunks;
-    if (max_resident_blocks > 0 && blocks > max_resident_blocks && blocks <= kWaves * max_resident_blocks &&
-        a.q.n < kWaves)
-        a.c_per_block = (int)((blocks + max_resident_blocks - 1) / max_resident_blocks);
-    grid = dim3((unsigned)((a.c.n + a.c_per_block - 1) / a.c_per_block), (unsigned)chunks, 1);
+    return (int)chunks;
 }
 
 }  // namespace
 }  // namespace aspire
 
 using namespace aspire;
-
-#ifdef ASPIRE_PHASE_CLOCK
-static long long* g_phase_buf = nullptr;
-extern "C" void aspire_debug_phase_buffer(void* p) { g_phase_buf = (long long*)p; }
-#endif
 
 extern "C" int aspire_max_sents(void) { return 8 * kMaxT; }
 
@@ -773,7 +837,7 @@ extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_reps
     a.scores = scores;
     a.out_pairsims = pair_sims;
     dim3 grid;
-    grid_for(a, grid, 0);
+    grid = dim3((unsigned)a.c.n, (unsigned)query_chunks(a), 1);
     return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         hipLaunchKernelGGL(l2max_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);
@@ -782,10 +846,27 @@ extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_reps
     });
 }
 
+namespace {
+// bytes of workspace per pair slot at tile size T
+size_t slot_bytes(int max_rows) {
+    const int T = (max_rows + 7) / 8;
+    return (size_t)(2 * 64 * T * T + 1) * sizeof(float);
+}
+constexpr size_t kWsCap = (size_t)1 << 30;  // suggested workspace is capped at 1 GiB; larger jobs run in chunks
+}  // namespace
+
+extern "C" size_t aspire_ot_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int pairing) {
+    if (!q || !c || q->n <= 0 || c->n <= 0) return 0;
+    const size_t per_cand = slot_bytes(max_rows_of(q, c)) * (pairing == ASPIRE_PAIR_PAIRED ? 1 : (size_t)q->n);
+    const size_t full = per_cand * (size_t)c->n;
+    if (full <= kWsCap) return full;
+    return per_cand > kWsCap ? per_cand : kWsCap / per_cand * per_cand;
+}
+
 extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
                                       const aspire_ot_params* prm, const float* diameter, int64_t diam_group, int want,
                                       float* scores, float* out_qdistr, float* out_cdistr, float* out_pairsims,
-                                      float* out_plan, void* stream) {
+                                      float* out_plan, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_repsets(q, c, D, pairing)) return rc;
     ASPIRE_REQUIRE(prm && scores, ASPIRE_ERR_INVALID_ARG, "null params/scores");
     ASPIRE_REQUIRE(want == ASPIRE_OT_DISTANCE || want == ASPIRE_OT_PLAN_SIM, ASPIRE_ERR_INVALID_ARG, "bad want %d", want);
@@ -796,6 +877,11 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
                    "pair outputs need padded extents (ext > 0)");
     ASPIRE_REQUIRE(!diameter || diam_group > 0, ASPIRE_ERR_INVALID_ARG, "diam_group must be positive");
     if (q->n == 0 || c->n == 0) return ASPIRE_OK;
+    const int max_rows = max_rows_of(q, c);
+    const size_t per_cand = slot_bytes(max_rows) * (pairing == ASPIRE_PAIR_PAIRED ? 1 : (size_t)q->n);
+    ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand, ASPIRE_ERR_INVALID_ARG,
+                   "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
+                   workspace_bytes, per_cand, aspire_ot_workspace_bytes(q, c, pairing));
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
@@ -813,16 +899,26 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
     a.out_cdistr = out_cdistr;
     a.out_pairsims = out_pairsims;
     a.out_plan = out_plan;
-#ifdef ASPIRE_PHASE_CLOCK
-    a.dbg = g_phase_buf;
-#endif
-    dim3 grid;
-    // T == 1 is built for 3 waves/SIMD (12 wave slots per CU = 4 three-wave blocks), larger tiles for 2.
-    grid_for(a, grid, max_rows_of(q, c) <= 8 ? 256 * 4 : 256 * 2);
-    return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
+    const int qchunks = query_chunks(a);
+    const int64_t cand_per_chunk = (int64_t)(workspace_bytes / per_cand);
+    const int64_t pairs_per_cand = pairing == ASPIRE_PAIR_PAIRED ? 1 : q->n;
+    return dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
-        hipLaunchKernelGGL(ot_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);
-        ASPIRE_LAUNCH_OK();
+        for (int64_t c0 = 0; c0 < c->n; c0 += cand_per_chunk) {
+            a.cand0 = c0;
+            a.cand1 = c0 + cand_per_chunk < c->n ? c0 + cand_per_chunk : c->n;
+            const int64_t n_slots = (a.cand1 - a.cand0) * pairs_per_cand;
+            PairWs<T> ws;
+            ws.cost = (float*)workspace;
+            ws.neg = ws.cost + n_slots * PairWs<T>::kEntries;
+            ws.diam2 = ws.neg + n_slots * PairWs<T>::kEntries;
+            hipLaunchKernelGGL(pair_cost_kernel<T>, dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
+                               Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
+            ASPIRE_LAUNCH_OK();
+            hipLaunchKernelGGL(sinkhorn_kernel<T>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a,
+                               ws, n_slots);
+            ASPIRE_LAUNCH_OK();
+        }
         return (int)ASPIRE_OK;
     });
 }

@@ -116,7 +116,7 @@ def group_diameter(q, c, pairing, group):
 
 
 def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.CDIST_AUTO,
-                diameter=None, diam_group=0, want=_lib.OT_DISTANCE, want_extras=False, out=None):
+                diameter=None, diam_group=0, want=_lib.OT_DISTANCE, want_extras=False, out=None, workspace=None):
     """A5-A8 (pair_distances.py:21-92).  Returns scores [P]; with want_extras also
     (query_distr [P,q.ext], cand_distr [P,c.ext], pair_sims [P,q.ext,c.ext], plan [P,q.ext,c.ext])."""
     p = _npairs(q, c, pairing)
@@ -129,9 +129,11 @@ def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_t
                   torch.empty(p, q.ext, c.ext, device=dev), torch.empty(p, q.ext, c.ext, device=dev)]
     prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode)
     qs, cs = q.struct(), c.struct()
+    nbytes = lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), pairing)
+    ws = workspace if workspace is not None else torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
     check(lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, pairing, ctypes.byref(prm),
                                      _ptr(diameter), diam_group, want, _ptr(scores), _ptr(extras[0]), _ptr(extras[1]),
-                                     _ptr(extras[2]), _ptr(extras[3]), _stream()))
+                                     _ptr(extras[2]), _ptr(extras[3]), _ptr(ws), ws.numel(), _stream()))
     return (scores, extras) if want_extras else scores
 
 

@@ -140,10 +140,13 @@ def main():
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p_scores, p_ts, p_ti = (ctypes.c_void_p(t.data_ptr()) for t in (scores, top_s, top_i))
     lib = _lib.lib
+    ws = torch.empty(lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), _lib.PAIR_CROSS), device=device,
+                     dtype=torch.uint8)
+    p_ws = ctypes.c_void_p(ws.data_ptr())
 
     def score():
         rc = lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, _lib.PAIR_CROSS, ctypes.byref(prm),
-                                        null, 0, _lib.OT_DISTANCE, p_scores, null, null, null, null, stream())
+                                        null, 0, _lib.OT_DISTANCE, p_scores, null, null, null, null, p_ws, ws.numel(), stream())
         if rc:
             _lib.check(rc)
 

@@ -159,11 +159,17 @@ typedef struct {
  *              optional (NULL) extra outputs of return_pair_sims=True (pair_distances.py:86):
  *              query_distr, cand_distr, pair_sims (masked neg L2, pads = 0), transport_plan.
  *              masked_sims = plan * pair_sims is left to the caller.  Require ext > 0.
+ *   workspace  device scratch for the per-pair cost matrices handed from the cost kernel to the Sinkhorn
+ *              kernel.  aspire_ot_workspace_bytes() gives the size that lets the whole job run in one
+ *              pass (capped at 1 GiB); any size that holds one candidate's pairs is accepted and larger jobs
+ *              are processed in candidate chunks.
  */
+size_t aspire_ot_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int pairing);
 int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
                            const aspire_ot_params* prm, const float* diameter, int64_t diam_group,
                            int want, float* scores, float* out_qdistr, float* out_cdistr,
-                           float* out_pairsims, float* out_plan, void* stream);
+                           float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* geomloss max_diameter (sinkhorn_divergence.py of geomloss 0.2.4) for batched calls: the L2 norm of
  * the per-coordinate bounding box over ALL rows of the call's x and y tensors, zero pad rows included.
