@@ -57,6 +57,48 @@ struct ScoreArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// LDS carve (floats): red[kWaves][T*T][128] | rednorm[kWaves][T][16] | reddiam[4] | xpose[kWaves][32][68]
+constexpr int kXpLd = 68;                 // row stride of the transpose scratch: 64 lanes + 4 (keeps b128 reads
+constexpr int kXpWave = 32 * kXpLd;       // 16 B aligned and spreads the 16-lane read groups over all bank slots)
+template <int T>
+struct Lds {
+    static constexpr int kRed = kWaves * T * T * 128;
+    static constexpr int kNorm = kWaves * T * 16;
+    static constexpr int kXp = kRed + kNorm + 4;
+    static constexpr int kTotal = kXp + kWaves * kXpWave;
+};
+
+// Sum N per-lane partials across the 64 lanes of a wave through LDS instead of cross-lane VALU ops: every lane
+// stores its N values as a column (conflict-free ds_write_b32), then lane l reads back 64*N/64... = a contiguous
+// piece of row (l * N / 64) as b128s and adds it up.  Element e ends up in the 64/N lanes e*64/N ...; returns it.
+// On gfx950 a v_permlane*_swap costs ~22 issue cycles and a DPP op ~8 (build/dbg/thr.hip), so the 31-exchange
+// register butterfly this replaces was 4x the cost of the 768 multiply-adds it served.
+template <int N>
+__device__ __forceinline__ float lds_wave_reduce(const float (&v)[N], float* xp, int lane) {
+    static_assert(N == 32 || N == 16, "sizes used here");
+#pragma unroll
+    for (int k = 0; k < N; ++k) xp[k * kXpLd + lane] = v[k];
+    // DS operations of one wave execute in order: the loads below see the stores above (other waves use
+    // their own scratch).  The fence only stops the compiler from reordering them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int kLanesPer = 64 / N;         // lanes sharing one element
+    constexpr int kFloats = 64 / kLanesPer;   // floats each of them adds up
+    const float4* row = reinterpret_cast<const float4*>(xp + (lane / kLanesPer) * kXpLd + (lane % kLanesPer) * kFloats);
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < kFloats / 4; ++m) {
+        const float4 t = row[m];
+        s += (t.x + t.y) + (t.z + t.w);
+    }
+    s += lane_xor<1>(s);
+    if constexpr (kLanesPer == 4) s += lane_xor<2>(s);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch is rewritten by the next call
+    __builtin_amdgcn_wave_barrier();
+    return s;
+}
+
 // Load N sentence rows (this lane's float4 slice) of one document; rows >= navail read as zero.
 template <int N, bool BBOX>
 __device__ __forceinline__ void load_rows(float4 (&r)[N], const float* doc, int row0, int navail, int dofs, int nbox,
@@ -77,11 +119,11 @@ __device__ __forceinline__ float sq4(const float4& a) { return fmaf(a.w, a.w, fm
 // Per-wave partial sums of half an 8x8 tile (4 query rows x 8 candidate rows) -> LDS.
 // red layout: [tile][2][64] (0: x.y dot, 1: sum (x-y)^2), element 8*i + j.  Only 32 accumulators, 4 query
 // rows and 8 candidate rows are live at a time (64 accumulators + both 8-row operand tiles cap the kernel
-// at 2 waves/SIMD and a 1000-block grid then runs in two rounds).  The 32-value butterfly leaves element
-// e in lanes 2e and 2e+1; even lanes write it.
+// at 2 waves/SIMD and a 1000-block grid then runs in two rounds).  lds_wave_reduce leaves element e in lanes
+// 2e and 2e+1; even lanes write it.
 template <bool NEED_G, bool NEED_D2>
 __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const float4 (&y)[8], float* red_half,
-                                                   int lane) {
+                                                   float* xp, int lane) {
     if constexpr (NEED_D2) {
         float acc[32];
 #pragma unroll
@@ -91,7 +133,7 @@ __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const f
                 const float dx = x[i].x - y[j].x, dy = x[i].y - y[j].y, dz = x[i].z - y[j].z, dw = x[i].w - y[j].w;
                 acc[i * 8 + j] = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
             }
-        const float r = butterfly_sum<32>(acc, lane);
+        const float r = lds_wave_reduce<32>(acc, xp, lane);
         if ((lane & 1) == 0) red_half[64 + (lane >> 1)] = r;
     }
     __builtin_amdgcn_sched_barrier(0);  // do not overlap the passes: that doubles the live accumulators
@@ -102,7 +144,7 @@ __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const f
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 acc[i * 8 + j] = fmaf(x[i].w, y[j].w, fmaf(x[i].z, y[j].z, fmaf(x[i].y, y[j].y, x[i].x * y[j].x)));
-        const float r = butterfly_sum<32>(acc, lane);
+        const float r = lds_wave_reduce<32>(acc, xp, lane);
         if ((lane & 1) == 0) red_half[(lane >> 1)] = r;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -124,14 +166,6 @@ __device__ __forceinline__ bool use_mm_formula(int mode, int nq, int nc) {
     return mode == ASPIRE_CDIST_MM || (mode == ASPIRE_CDIST_AUTO && (nq > 25 || nc > 25));
 }
 
-// LDS carve (floats): red[kWaves][T*T][128] | rednorm[kWaves][T][16] | reddiam[kWaves]
-template <int T>
-struct Lds {
-    static constexpr int kRed = kWaves * T * T * 128;
-    static constexpr int kNorm = kWaves * T * 16;
-    static constexpr int kTotal = kRed + kNorm + 4;
-};
-
 // ---------------------------------------------------------------------------------------------
 // Phase 1: all three waves form the partial sums of (query doc, candidate doc) for every tile.
 // ---------------------------------------------------------------------------------------------
@@ -141,6 +175,7 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
     const int dofs = wave * 256 + lane * 4;
     float* red = lds + wave * (T * T * 128);
     float* rednorm = lds + Lds<T>::kRed + wave * (T * 16);
+    float* xp = lds + Lds<T>::kXp + wave * kXpWave;
     float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll 1
@@ -154,7 +189,7 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
             for (int half = 0; half < 2; ++half) {
                 float4 x[4];
                 load_rows<4, BBOX>(x, qdoc, ti * 8 + half * 4, q_avail, dofs, q_box, mn, mx);  // min/max idempotent
-                half_tile_partials<NEED_G, NEED_D2>(x, y, red + (ti * T + tj) * 128 + half * 32, lane);
+                half_tile_partials<NEED_G, NEED_D2>(x, y, red + (ti * T + tj) * 128 + half * 32, xp, lane);
                 if (NEED_G && ti == tj) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -169,7 +204,7 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
                 }
             }
             if (NEED_G && ti == tj) {
-                const float r = butterfly_sum<16>(nrm, lane);
+                const float r = lds_wave_reduce<16>(nrm, xp, lane);
                 if ((lane & 3) == 0) rednorm[ti * 16 + (lane >> 2)] = r;
             }
         }
