@@ -1,0 +1,78 @@
+"""Sentence-rep stores -> HBM: the step before scoring.
+
+The reference keeps encoded papers in one of two host-side caches:
+  * h5py file, one dataset per paper id holding [num_sents, 768]   (src/evaluation/utils/models.py:68-124,
+    file name encodings.h5, utils/utils.py:63-64)
+  * an in-memory dict pid -> {'sent_reps': [S,768], 'doc_cls_reps': [768]} dumped with joblib gzip-3
+    (src/pre_process/pp_gen_nearest.py:123-129, :279)
+and row-selects the QUERY's sentences by facet label before scoring (models.py:127-163,
+pp_gen_nearest.py:173-181).  `RepStore` reads either (h5py / joblib are imported lazily; h5py is not in this
+image), plus a plain .npz it can write itself, and turns any subset into a CandidatePool: one [sum S, 768]
+fp32 matrix + CSR offsets uploaded once and kept resident.
+"""
+import numpy as np
+
+
+class RepStore:
+    def __init__(self, pid2reps=None):
+        # pid -> np.ndarray [S, 768] float32
+        self.pid2reps = dict(pid2reps or {})
+
+    # ---- loaders --------------------------------------------------------------------------------
+    @classmethod
+    def from_joblib(cls, path):
+        import joblib
+        d = joblib.load(path)
+        return cls({pid: np.asarray(v['sent_reps'] if isinstance(v, dict) else v, dtype=np.float32)
+                    for pid, v in d.items()})
+
+    @classmethod
+    def from_h5(cls, path):
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError('reading the reference\'s encodings.h5 needs h5py, which this image lacks') from e
+        with h5py.File(path, 'r') as f:
+            return cls({pid: np.asarray(f[pid], dtype=np.float32) for pid in f.keys()})
+
+    @classmethod
+    def from_npz(cls, path):
+        z = np.load(path, allow_pickle=False)
+        pids, off, rows = z['pids'], z['offsets'], z['rows']
+        return cls({str(p): rows[off[i]:off[i + 1]] for i, p in enumerate(pids)})
+
+    def save_npz(self, path):
+        pids = sorted(self.pid2reps)
+        lens = [self.pid2reps[p].shape[0] for p in pids]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        rows = np.concatenate([self.pid2reps[p] for p in pids], 0).astype(np.float32) if pids \
+            else np.zeros((0, 768), np.float32)
+        np.savez(path, pids=np.array(pids), offsets=off, rows=rows)
+
+    # ---- access ---------------------------------------------------------------------------------
+    def add(self, pid, sent_reps):
+        self.pid2reps[pid] = np.asarray(sent_reps, dtype=np.float32)
+
+    def __contains__(self, pid):
+        return pid in self.pid2reps
+
+    def __len__(self):
+        return len(self.pid2reps)
+
+    def get(self, pid):
+        return self.pid2reps[pid]
+
+    def faceted(self, pid, facet, pred_labels):
+        """Rows of `pid` whose sentence label is `<facet>_label`; 'objective_label' counts as background
+        (pp_gen_nearest.py:173-181).  facet 'all' / None returns every row."""
+        reps = self.pid2reps[pid]
+        if facet in (None, 'all'):
+            return reps
+        labs = ['background_label' if lab == 'objective_label' else lab for lab in pred_labels]
+        idxs = [i for i, lab in enumerate(labs) if lab == f'{facet}_label']
+        return reps[idxs, :]
+
+    def pool(self, pids):
+        """Upload the reps of `pids` (in this order = pool order) to the GPU."""
+        from .scorer import CandidatePool
+        return CandidatePool([self.pid2reps[p] for p in pids], pids=list(pids))

@@ -225,12 +225,31 @@ def make_scores():
 
 
 def make_metrics():
+    # NumPy 2 removed np.asfarray, which the reference's dcg_at_k calls (metrics.py:179); supply the NumPy 1
+    # behaviour so that compute_metrics can run here at all.  Environment shim only -- no arithmetic of ours.
+    if not hasattr(np, 'asfarray'):
+        np.asfarray = lambda a, dtype=float: np.asarray(a, dtype=dtype)
     r = [1, 1, 0, 1, 0, 1, 0, 0, 0, 1]
     kat = {
         'ap_in': r, 'ap_out': float(ref_metrics.average_precision(r)),
         'map_in': [r, [0]], 'map_out': float(ref_metrics.mean_average_precision([r, [0]])),
         'ap_in2': [0, 0, 1, 0, 1, 1, 0], 'ap_out2': float(ref_metrics.average_precision([0, 0, 1, 0, 1, 1, 0])),
     }
+    rng = np.random.RandomState(11)
+    cm = []
+    for n in (30, 125, 60):
+        graded = rng.choice([0, 0, 0, 1, 2, 3], size=n).tolist()
+        atks = [5, 10, 20]
+        cm.append({'graded': graded, 'pr_atks': atks, 'threshold': 2,
+                   'out': ref_metrics.compute_metrics(graded, atks, threshold_grade=2)})
+    kat['compute_metrics'] = cm
+    kat['ndcg'] = [{'r': [3, 2, 3, 0, 0, 1, 2, 2, 3, 0], 'k': k, 'method': m,
+                    'dcg': float(ref_metrics.dcg_at_k([3, 2, 3, 0, 0, 1, 2, 2, 3, 0], k, m)),
+                    'ndcg': float(ref_metrics.ndcg_at_k([3, 2, 3, 0, 0, 1, 2, 2, 3, 0], k, m))}
+                   for k in (1, 2, 10, 11) for m in (0, 1)]
+    kat['mrr'] = {'in': [[0, 0, 1], [0, 1, 0], [1, 0, 0], [0, 0, 0]],
+                  'out': float(ref_metrics.mean_reciprocal_rank([[0, 0, 1], [0, 1, 0], [1, 0, 0], [0, 0, 0]]))}
+    kat['r_precision'] = [{'in': r_, 'out': float(ref_metrics.r_precision(r_))} for r_ in ([0, 0, 1], [0, 1, 0], [1, 0, 0], [0, 0])]
     with open(os.path.join(HERE, 'metrics.json'), 'w') as f:
         json.dump(kat, f)
     print(kat)

@@ -1,0 +1,73 @@
+"""CPU: ranking metrics against values produced by the reference's own metrics.py (tests/golden/metrics.json),
+and the rep-store loaders / facet row-select."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from aspire_amd import metrics
+from aspire_amd.repstore import RepStore
+
+
+@pytest.fixture(scope='module')
+def kat(golden_dir):
+    return json.load(open(os.path.join(golden_dir, 'metrics.json')))
+
+
+def test_ap_map_doctest_values(kat):
+    assert metrics.average_precision(kat['ap_in']) == pytest.approx(0.78333333333333333, abs=1e-15)
+    assert metrics.mean_average_precision(kat['map_in']) == pytest.approx(0.39166666666666666, abs=1e-15)
+    assert metrics.average_precision(kat['ap_in2']) == pytest.approx(kat['ap_out2'], abs=1e-15)
+    assert metrics.average_precision([0, 0, 0]) == 0.0
+
+
+def test_dcg_ndcg_mrr_rprecision(kat):
+    for c in kat['ndcg']:
+        assert metrics.dcg_at_k(c['r'], c['k'], c['method']) == pytest.approx(c['dcg'], abs=1e-12)
+        assert metrics.ndcg_at_k(c['r'], c['k'], c['method']) == pytest.approx(c['ndcg'], abs=1e-12)
+    assert metrics.mean_reciprocal_rank(kat['mrr']['in']) == pytest.approx(kat['mrr']['out'], abs=1e-15)
+    for c in kat['r_precision']:
+        assert metrics.r_precision(c['in']) == pytest.approx(c['out'], abs=1e-15)
+    with pytest.raises(ValueError):
+        metrics.precision_at_k([0, 0, 1], 4)
+    with pytest.raises(ValueError):
+        metrics.dcg_at_k([1, 2], 2, method=2)
+
+
+def test_compute_metrics_matches_reference(kat):
+    for c in kat['compute_metrics']:
+        got = metrics.compute_metrics(c['graded'], c['pr_atks'], c['threshold'])
+        assert set(got) == set(c['out'])
+        for k, v in c['out'].items():
+            assert got[k] == pytest.approx(v, abs=1e-12), k
+
+
+def test_evaluate_ranked_pool():
+    ranked = {'q1': [('a', 0.9), ('b', 0.5), ('c', 0.1)], 'q2': [('x', 3.0), ('y', 1.0)]}
+    gold = {'q1': {'a': 3, 'b': 0, 'c': 2}, 'q2': {'x': 0, 'y': 1}}
+    per_q, agg = metrics.evaluate_ranked_pool(ranked, gold, pr_atks=(1, 2))
+    assert per_q['q1']['av_precision'] == pytest.approx((1.0 + 2 / 3) / 2)
+    assert per_q['q2']['av_precision'] == 0.0
+    assert agg['map'] == pytest.approx(((1.0 + 2 / 3) / 2) / 2)
+
+
+def test_repstore_roundtrip_and_facets(tmp_path):
+    rng = np.random.RandomState(0)
+    d = {f'p{i}': {'sent_reps': rng.randn(3 + i, 768).astype(np.float32), 'doc_cls_reps': rng.randn(768)} for i in range(4)}
+    import joblib
+    jp = tmp_path / 'reps.joblib'
+    joblib.dump(d, jp, compress=('gzip', 3))           # the reference's dump format, pp_gen_nearest.py:129
+    rs = RepStore.from_joblib(jp)
+    assert len(rs) == 4 and 'p2' in rs and rs.get('p2').shape == (5, 768)
+    npz = tmp_path / 'reps.npz'
+    rs.save_npz(npz)
+    rs2 = RepStore.from_npz(npz)
+    for pid in d:
+        assert np.array_equal(rs2.get(pid), d[pid]['sent_reps'])
+    labels = ['background_label', 'objective_label', 'method_label', 'result_label', 'method_label']
+    assert rs.faceted('p2', 'method', labels).shape == (2, 768)
+    assert np.array_equal(rs.faceted('p2', 'background', labels), d['p2']['sent_reps'][[0, 1]])
+    assert rs.faceted('p2', 'all', labels).shape == (5, 768)
+    with pytest.raises(ImportError):
+        RepStore.from_h5(tmp_path / 'missing.h5')
