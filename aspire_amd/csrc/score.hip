@@ -127,9 +127,9 @@ __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const f
     if constexpr (NEED_D2) {
         float acc[32];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j)      // candidate row outer: row j is needed only when its load has landed
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int i = 0; i < 4; ++i) {
                 const float dx = x[i].x - y[j].x, dy = x[i].y - y[j].y, dz = x[i].z - y[j].z, dw = x[i].w - y[j].w;
                 acc[i * 8 + j] = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
             }
@@ -140,9 +140,9 @@ __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const f
     if constexpr (NEED_G) {
         float acc[32];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int i = 0; i < 4; ++i)
                 acc[i * 8 + j] = fmaf(x[i].w, y[j].w, fmaf(x[i].z, y[j].z, fmaf(x[i].y, y[j].y, x[i].x * y[j].x)));
         const float r = lds_wave_reduce<32>(acc, xp, lane);
         if ((lane & 1) == 0) red_half[(lane >> 1)] = r;
@@ -178,6 +178,30 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
     float* xp = lds + Lds<T>::kXp + wave * kXpWave;
     float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if constexpr (T == 1) {
+        // One tile: issue every load up front -- the query rows first (L2-resident, they land early), then the
+        // candidate rows from HBM -- and let the accumulation start on y[0] while y[1..7] are still in flight
+        // (the j-outer loops below wait per row with counted vmcnt).  Both query halves are resident, so the
+        // second half starts without another exposed load latency.
+        float4 x0[4], x1[4], y[8];
+        load_rows<4, BBOX>(x0, qdoc, 0, q_avail, dofs, q_box, mn, mx);
+        load_rows<4, BBOX>(x1, qdoc, 4, q_avail, dofs, q_box, mn, mx);
+        load_rows<8, BBOX>(y, cdoc, 0, c_avail, dofs, c_box, mn, mx);
+        half_tile_partials<NEED_G, NEED_D2>(x0, y, red, xp, lane);
+        half_tile_partials<NEED_G, NEED_D2>(x1, y, red + 32, xp, lane);
+        if (NEED_G) {
+            float nrm[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                nrm[i] = sq4(x0[i]);
+                nrm[4 + i] = sq4(x1[i]);
+                nrm[8 + i] = sq4(y[i]);
+                nrm[12 + i] = sq4(y[4 + i]);
+            }
+            const float r = lds_wave_reduce<16>(nrm, xp, lane);
+            if ((lane & 3) == 0) rednorm[lane >> 2] = r;
+        }
+    } else {
 #pragma unroll 1
     for (int tj = 0; tj < T; ++tj) {
         float4 y[8];
@@ -209,6 +233,7 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
             }
         }
     }
+    }
     if (BBOX) {
         const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
         const float s = wave_sum(fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx))));
@@ -220,7 +245,7 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
 // max-sim kernel (A9)
 // ---------------------------------------------------------------------------------------------
 template <int T>
-__global__ void __launch_bounds__(kBlock) l2max_kernel(ScoreArgs a) {
+__global__ void __launch_bounds__(kBlock, 3) l2max_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -692,7 +717,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
 // Kernel 1 of the otAspire path: pairwise sentence costs of the pairs of one chunk of candidates
 // [a.cand0, a.cand1) -> workspace.  Streams every candidate row once; HBM bound for few queries.
 template <int T>
-__global__ void __launch_bounds__(kBlock) pair_cost_kernel(ScoreArgs a, PairWs<T> ws) {
+__global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairWs<T> ws) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -98,7 +98,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    ap.add_argument('--graph-unroll', type=int, default=25, help='steps per captured graph')
+    ap.add_argument('--graph-unroll', type=int, default=24, help='steps per captured graph')
+    ap.add_argument('--streams', type=int, default=2, help='HIP streams that independent steps alternate over')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -131,40 +132,108 @@ def main():
                             ext=0, max_len=S)
     qs, cs = qset.struct(), cset.struct()
     prm = _lib.OtParams(0.05, 0.9, 1.0, _lib.CDIST_AUTO)
-    scores = torch.empty(Q, C, device=device, dtype=torch.float32)
-    top_s = torch.empty(Q, TOPK, device=device, dtype=torch.float32)
-    top_i = torch.empty(Q, TOPK, device=device, dtype=torch.int64)
     null = ctypes.c_void_p(0)
+    lib = _lib.lib
 
     def stream():  # looked up per call: under graph capture torch's current stream is the capture stream
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    p_scores, p_ts, p_ti = (ctypes.c_void_p(t.data_ptr()) for t in (scores, top_s, top_i))
-    lib = _lib.lib
-    ws = torch.empty(lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), _lib.PAIR_CROSS), device=device,
-                     dtype=torch.uint8)
-    p_ws = ctypes.c_void_p(ws.data_ptr())
 
-    def score():
-        rc = lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, _lib.PAIR_CROSS, ctypes.byref(prm),
-                                        null, 0, _lib.OT_DISTANCE, p_scores, null, null, null, null, p_ws, ws.numel(), stream())
-        if rc:
-            _lib.check(rc)
+    class Lane:
+        """Output buffers + workspace of one in-flight step.  Steps are independent (each scores the resident
+        pool for a query and ranks it), so consecutive steps may run on different HIP streams, each with its own
+        Lane; the reps stay shared and read-only."""
 
-    def rank_step():
-        rc = lib.aspire_topk_desc_f32(p_scores, Q, C, TOPK, rank * C, p_ts, p_ti, null, 0, stream())
-        if rc:
-            _lib.check(rc)
+        def __init__(self):
+            self.scores = torch.empty(Q, C, device=device, dtype=torch.float32)
+            self.top_s = torch.empty(Q, TOPK, device=device, dtype=torch.float32)
+            self.top_i = torch.empty(Q, TOPK, device=device, dtype=torch.int64)
+            self.ws = torch.empty(lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), _lib.PAIR_CROSS),
+                                  device=device, dtype=torch.uint8)
+            self.p = [ctypes.c_void_p(t.data_ptr()) for t in (self.scores, self.top_s, self.top_i, self.ws)]
+
+        def score(self):
+            rc = lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, _lib.PAIR_CROSS, ctypes.byref(prm),
+                                            null, 0, _lib.OT_DISTANCE, self.p[0], null, null, null, null, self.p[3],
+                                            self.ws.numel(), stream())
+            if rc:
+                _lib.check(rc)
+
+        def step(self):
+            self.score()
+            rc = lib.aspire_topk_desc_f32(self.p[0], Q, C, TOPK, rank * C, self.p[1], self.p[2], null, 0, stream())
+            if rc:
+                _lib.check(rc)
+            if world > 1:
+                return all_gather_topk(self.top_s, self.top_i, TOPK)
+            return self.top_s, self.top_i
+
+    # N > 1: one stream, eager launches: the per-step RCCL all-gather orders the steps anyway, and a capture-time
+    # hang on a multi-GPU node would cost the whole scaling run.
+    use_graph = not args.no_graph and world == 1
+    n_streams = max(1, args.streams) if use_graph else 1
+    lanes = [Lane() for _ in range(n_streams)]
+    scores = lanes[0].scores
+
+    # ---- the step loop is launch bound (three 8-13 us kernels per step): capture it in hipGraphs, `unroll`
+    # steps per replay, step i on stream i % n_streams so that independent steps overlap (one step's top-k and
+    # latency-bound Sinkhorn kernel run beside the next step's HBM-bound cost kernel).
+    unroll = max(n_streams, min(args.graph_unroll, args.steps)) // n_streams * n_streams
+
+    def capture_steps(n, use_lanes):
+        g = torch.cuda.CUDAGraph()
+        side = [torch.cuda.Stream() for _ in range(len(use_lanes) - 1)]
+        with torch.cuda.graph(g):
+            main = torch.cuda.current_stream()
+            for st in side:
+                st.wait_stream(main)               # fork
+            for i in range(n):
+                k = i % len(use_lanes)
+                if k == 0:
+                    use_lanes[0].step()
+                else:
+                    with torch.cuda.stream(side[k - 1]):
+                        use_lanes[k].step()
+            for st in side:
+                main.wait_stream(st)               # join
+        return g
+
+    def timed(graph, per_replay, eager_lane):
         if world > 1:
-            return all_gather_topk(top_s, top_i, TOPK)
-        return top_s, top_i
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        if graph is not None:
+            while done + per_replay <= args.steps:
+                graph.replay()
+                done += per_replay
+        while done < args.steps:
+            eager_lane.step()
+            done += 1
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el
 
-    def step():
-        score()
-        return rank_step()
-
-    # ---- the step loop is launch bound (two ~10-20 us kernels per step): capture it in hipGraphs ------
-    # `unroll` steps per graph replay; the remainder runs eagerly.  RCCL collectives are captured too.
-    unroll = max(1, min(args.graph_unroll, args.steps))
+    for _ in range(max(args.warmup, 3)):
+        for ln in lanes:
+            ln.step()
+    torch.cuda.synchronize()
+    g_step = capture_steps(unroll, lanes) if use_graph else None
+    if g_step is not None:
+        g_step.replay()
+    elapsed = timed(g_step, unroll, lanes[0])
+    # the same K steps strictly one after the other on ONE stream, for reference
+    serial_elapsed = None
+    if use_graph and n_streams > 1:
+        g_serial = capture_steps(unroll, lanes[:1])
+        g_serial.replay()
+        serial_elapsed = timed(g_serial, unroll, lanes[0])
 
     def capture(fn, n):
         g = torch.cuda.CUDAGraph()
@@ -173,35 +242,7 @@ def main():
                 fn()
         return g
 
-    for _ in range(max(args.warmup, 3)):
-        step()
-    torch.cuda.synchronize()
-    # N > 1: the per-step RCCL all-gather stays eager (capturing collectives buys nothing at this size and a
-    # capture-time hang on a multi-GPU node would cost the whole scaling run).
-    use_graph = not args.no_graph and world == 1
-    if use_graph:
-        g_step = capture(step, unroll)
-        g_step.replay()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    done = 0
-    if use_graph:
-        while done + unroll <= args.steps:
-            g_step.replay()
-            done += unroll
-    while done < args.steps:
-        step()
-        done += 1
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    score = lanes[0].score
 
     # ---- dominant kernel duration, live: HIP events (torch's current stream = the launch stream) around
     # replays of a graph holding ONLY ot_kernel launches, so host launch latency is not in the bracket.
@@ -237,12 +278,14 @@ def main():
             'unit': 'alignments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'serial_value': (world * Q * C * args.steps / serial_elapsed) if serial_elapsed else None,
             'config': {'workload': f'otAspire compsci: {Q} query x {C} candidates per GPU, {S} sents x {D}d, '
                                    f'Sinkhorn OT (blur 0.05, scaling 0.9, one eps schedule per pair) + per-query '
                                    f'top-{TOPK} rank' + (', RCCL all-gather top-k merge' if world > 1 else ''),
                        'queries': Q, 'candidates_per_gpu': C, 'sents': S, 'dim': D, 'topk': TOPK,
                        'parallelism': f'candidate-pool shards x{world}',
-                       'launch': f'hipGraph replay, {unroll} steps per graph' if use_graph else 'eager'},
+                       'launch': (f'hipGraph replay, {unroll} steps per graph, independent steps alternate over '
+                                  f'{n_streams} HIP streams') if use_graph else 'eager, 1 stream'},
             # The scoring pass is two back-to-back kernels: pair_cost_kernel streams every rep once (the HBM side)
             # and sinkhorn_kernel solves from a 0.5 MB cost buffer (dependent-chain latency bound).  The
             # roofline prices BOTH durations against the algorithmic bytes; the per-kernel split measured by
