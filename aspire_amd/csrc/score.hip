@@ -746,6 +746,129 @@ __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairW
     }
 }
 
+// Kernel 1, single-tile (<= 8 sentence rows on both sides) persistent form: a fixed grid of workgroups walks the
+// items (candidate-major pairs) with a stride of gridDim.x, and the NEXT item's 16 rows are already in flight
+// (64 more VGPRs per lane) while the current item is accumulated, reduced and written -- the HBM latency that
+// the one-item-per-workgroup form exposes at the head of every workgroup is paid once per workgroup instead.
+struct RowSet {
+    float4 x0[4], x1[4], y[8];
+};
+#ifdef ASPIRE_PHASE_CLOCK
+static __device__ long long* g_k1dbg = nullptr;
+// stamps of workgroup 7, wave 1, its 10th item
+#define K1_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        if (g_k1dbg && blockIdx.x == 7 && wave == 1 && lane == 0 && item == 7 + 10 * gridDim.x)      \
+            g_k1dbg[k] = (long long)__builtin_readcyclecounter();                                           \
+    } while (0)
+#else
+#define K1_STAMP(k) \
+    do {            \
+    } while (0)
+#endif
+
+// Rows beyond a document's length are loaded as COPIES OF ITS LAST ROW (row index clamped): entries that involve
+// them are masked downstream, and duplicates leave the bounding box unchanged, so the box needs no per-row
+// predicate.  (Only used when ext == 0; padded tensors take the general kernel, which reads the real pad rows.)
+__device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_t item, uint32_t nq, bool paired, int dofs,
+                                          int& q_len, int& c_len) {
+    const uint32_t c_loc = nq == 1 ? item : item / nq;
+    const int64_t c_idx = a.cand0 + c_loc;
+    const int64_t q_idx = paired ? c_idx : (nq == 1 ? 0 : item - c_loc * nq);
+    c_len = a.c.len[c_idx];
+    q_len = a.q.len[q_idx];
+    const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
+    const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.x0[i] = ld4(qdoc + (size_t)min(i, q_len - 1) * kD);
+        r.x1[i] = ld4(qdoc + (size_t)min(4 + i, q_len - 1) * kD);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j, c_len - 1) * kD);
+}
+
+__device__ __forceinline__ float box_partial(const RowSet& r) {
+    float4 mn = r.y[0], mx = r.y[0];
+    auto upd = [&](const float4& v) {
+        mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        upd(r.x0[i]);
+        upd(r.x1[i]);
+    }
+#pragma unroll
+    for (int j = 1; j < 8; ++j) upd(r.y[j]);
+    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
+    return fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+}
+
+__global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dofs = wave * 256 + lane * 4;
+    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    // 32-bit item arithmetic: a chunk holds at most workspace / 516 B < 2^31 pairs, and 64-bit division costs
+    // hundreds of cycles per item on this hardware.
+    const uint32_t nq = paired ? 1u : (uint32_t)a.q.n;
+    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+    const uint32_t n_items = ncand * nq;
+    const bool own_diam = a.diameter == nullptr;
+    float* red = lds + wave * 128;
+    float* rednorm = lds + Lds<1>::kRed + wave * 16;
+    float* xp = lds + Lds<1>::kXp + wave * kXpWave;
+
+    RowSet cur, nxt;
+    int q_len = 0, c_len = 0, nq_len = 0, nc_len = 0;
+    uint32_t item = blockIdx.x;
+    if (item < n_items) load_item(cur, a, item, nq, paired, dofs, q_len, c_len);
+    for (; item < n_items; item += gridDim.x) {
+        const uint32_t next = item + gridDim.x;
+        if (next < n_items) load_item(nxt, a, next, nq, paired, dofs, nq_len, nc_len);
+        // ---- accumulate + reduce the current item (register operands only) ----
+        K1_STAMP(0);
+        half_tile_partials<true, true>(cur.x0, cur.y, red, xp, lane);
+        K1_STAMP(1);
+        half_tile_partials<true, true>(cur.x1, cur.y, red + 32, xp, lane);
+        K1_STAMP(2);
+        {
+            float nrm[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                nrm[i] = sq4(cur.x0[i]);
+                nrm[4 + i] = sq4(cur.x1[i]);
+                nrm[8 + i] = sq4(cur.y[i]);
+                nrm[12 + i] = sq4(cur.y[4 + i]);
+            }
+            const float r = lds_wave_reduce<16>(nrm, xp, lane);
+            if ((lane & 3) == 0) rednorm[lane >> 2] = r;
+        }
+        if (own_diam) {
+            const float sbox = wave_sum(box_partial(cur));
+            if (lane == 0) lds[Lds<1>::kRed + Lds<1>::kNorm + wave] = sbox;
+        }
+        K1_STAMP(3);
+        __syncthreads();
+        K1_STAMP(4);
+        const uint32_t c_loc = nq == 1 ? item : item / nq;
+        const uint32_t q_loc = nq == 1 ? 0 : item - c_loc * nq;
+        const int64_t slot = paired ? (int64_t)c_loc : (int64_t)q_loc * ncand + c_loc;
+        finish_pair<1>(lds, use_mm_formula(a.cdist_mode, q_len, c_len), own_diam, ws, slot);
+        K1_STAMP(5);
+        __syncthreads();
+        K1_STAMP(6);
+        if (next < n_items) {
+            cur = nxt;
+            q_len = nq_len;
+            c_len = nc_len;
+        }
+        K1_STAMP(7);
+    }
+}
+
 // Kernel 2: one wave = one Sinkhorn solve, four pairs per workgroup; only registers and cross-lane ops.
 // ~50 VGPRs at T = 1, so up to 8 solves share a SIMD and hide each other's cross-lane / transcendental
 // latencies.
@@ -756,9 +879,10 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
     const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
     if (slot >= n_slots) return;
     const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-    const int64_t ncand = a.cand1 - a.cand0;
-    const int64_t q_idx = paired ? a.cand0 + slot : slot / ncand;
-    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + slot % ncand;
+    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+    const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
+    const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
+    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
     const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
     PairState<T> st;
     load_pair<T>(st, ws, slot, lane);
@@ -880,6 +1004,13 @@ int query_chunks(ScoreArgs& a) {
 
 using namespace aspire;
 
+#ifdef ASPIRE_PHASE_CLOCK
+extern "C" void aspire_debug_k1_buffer(void* p) {
+    long long* q = (long long*)p;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k1dbg), &q, sizeof(q));
+}
+#endif
+
 extern "C" int aspire_max_sents(void) { return 8 * kMaxT; }
 
 extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
@@ -972,8 +1103,16 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
             ws.cost = (float*)workspace;
             ws.neg = ws.cost + n_slots * PairWs<T>::kEntries;
             ws.diam2 = ws.neg + n_slots * PairWs<T>::kEntries;
-            hipLaunchKernelGGL(pair_cost_kernel<T>, dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
-                               Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
+            if (T == 1 && q->ext == 0 && c->ext == 0) {
+                // persistent, software-pipelined form: two 3-wave workgroups per CU (it holds two items' rows)
+                const int64_t blocks = n_slots < 512 ? n_slots : 512;
+                PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
+                hipLaunchKernelGGL(pair_cost1_kernel, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
+                                   (hipStream_t)stream, a, ws1);
+            } else {
+                hipLaunchKernelGGL(pair_cost_kernel<T>, dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
+                                   Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
+            }
             ASPIRE_LAUNCH_OK();
             hipLaunchKernelGGL(sinkhorn_kernel<T>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a,
                                ws, n_slots);
