@@ -272,7 +272,7 @@ def main():
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = tj.get('hbm_bytes_per_launch')
-            breakdown = tj.get('breakdown')
+            breakdown = tj.get("breakdown")
         out = {
             'metric': 'query x candidate OT alignments/sec', 'value': world * Q * C * args.steps / elapsed,
             'unit': 'alignments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
