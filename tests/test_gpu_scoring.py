@@ -239,3 +239,21 @@ def test_full_size_config2_properties(amd):
     want = np.array([orc.get_similarity(query, cands[i]) for i in idx], dtype=np.float32)
     np.testing.assert_allclose(s.cpu().numpy()[idx], want, atol=TOL, rtol=0)
     assert torch.isfinite(s).all() and (s < 0).all()
+
+
+def test_packed_tile_kernel_matches_single(amd):
+    """Large pools take the 4-candidates-per-wave tile kernel (R = 2); it must reproduce what the
+    1-candidate-per-wave kernel gives for the same pairs (small pools), ragged lengths and a tail group included."""
+    g = torch.Generator().manual_seed(123)
+    n = 8203                                             # not a multiple of 4
+    lens = torch.randint(1, 9, (n,), generator=g).tolist()
+    cands = [torch.randn(l, 768, generator=g) for l in lens]
+    queries = [torch.randn(8, 768, generator=g), torch.randn(3, 768, generator=g)]
+    big = amd.scorer.score_pool(queries, cands, method='ot', schedule='pair').cpu()
+    for lo in (0, 4000, 8100):
+        small = amd.scorer.score_pool(queries, cands[lo:lo + 103], method='ot', schedule='pair').cpu()
+        # same arithmetic per entry, but the row norms are summed over 16-lane vs 32-lane partitions: last-bit noise
+        np.testing.assert_allclose(big[:, lo:lo + 103].numpy(), small.numpy(), atol=2e-5, rtol=0)
+    idx = [0, 1, 2, 3, 4097, 8200, 8201, 8202]
+    want = np.array([[orc.get_similarity(q, cands[i]) for i in idx] for q in queries], dtype=np.float32)
+    np.testing.assert_allclose(big.numpy()[:, idx], want, atol=TOL, rtol=0)
