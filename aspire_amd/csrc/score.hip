@@ -915,8 +915,9 @@ __global__ void __launch_bounds__(192) doc_box_kernel(RepSet d, float* __restric
     *reinterpret_cast<float4*>(box + k * 2 * kD + kD + threadIdx.x * 4) = mx;
 }
 
-// DS = 1: every wave takes its own items (throughput form).  DS = 4: the four waves of a workgroup share one item
-// and each walks a quarter of the stages, then wave 0 adds the four partial results (latency form for small grids).
+// DS = 1: every wave of the 4-wave workgroup takes its own items (throughput form).  DS > 1: the DS waves of a
+// workgroup share one item and each walks every DS-th stage, then wave 0 adds the partial results (latency form
+// for small grids).
 template <int R, int DS>
 __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> ws, const float* __restrict__ qbox) {
     using C = TileCfg<R>;
@@ -1076,7 +1077,7 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
                 continue;
             }
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < DS; ++w) {
                 const float* o = lds_all + w * C::kLdsFloats;
 #pragma unroll
                 for (int x = 0; x < R; ++x)
@@ -1404,7 +1405,7 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
                 } else {
                     // small grids are latency bound: three waves per pair (a third of the coordinates each),
                     // persistent and software pipelined (measured 15.6 us per launch at 50-250 pairs against
-                    // 22.6 us for the tiled form with its stages split over four waves)
+                    // 20-23 us for the tiled form with its stages split over three or four waves)
                     const int64_t blocks = n_slots < 512 ? n_slots : 512;
                     hipLaunchKernelGGL(pair_cost1_kernel, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
                                        (hipStream_t)stream, a, ws1);
