@@ -99,7 +99,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--graph-unroll', type=int, default=24, help='steps per captured graph')
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams that independent steps alternate over')
+    ap.add_argument('--streams', type=int, default=4, help='HIP streams that independent steps alternate over')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))

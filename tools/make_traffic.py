@@ -14,7 +14,7 @@ stats = {}
 for r in csv.DictReader(open('profiles/r01_bench_ot1x1000_kernel_stats.csv')):
     n = r['Name']
     k = 'pair_cost' if 'pair_cost' in n else 'sinkhorn' if 'sinkhorn_kernel' in n else 'topk' if 'topk' in n else None
-    if k: stats[k] = (float(r['AverageNs']), int(r['Calls']), n[:n.index('(')] if '(' in n else n)
+    if k: stats[k] = (float(r['AverageNs']), int(r['Calls']), n.split('(anonymous namespace)::')[1].split('(')[0] if '(anonymous namespace)::' in n else n)
 fetch = {k: m[(k, 'FETCH_SIZE')] for k in ('pair_cost', 'sinkhorn')}
 write = {k: m[(k, 'WRITE_SIZE')] for k in ('pair_cost', 'sinkhorn')}
 traffic = int(sum(2 * fetch[k] * 1024 + write[k] * 1024 for k in fetch))
@@ -26,7 +26,7 @@ json.dump({
     'correction': 'MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced (16 B/lane) read stream -> doubled; WRITE_SIZE uncalibrated, taken as is',
     'hbm_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': 24604576,
     'breakdown': {'source': 'profiles/r01_bench_ot1x1000_kernel_stats.csv (rocprofv3 --kernel-trace --stats on bench.py --steps 480 --streams 1)',
-                  'cost_kernel': stats['pair_cost'][2].split('::')[-1], 'cost_kernel_us': stats['pair_cost'][0] / 1e3,
+                  'cost_kernel': stats['pair_cost'][2], 'cost_kernel_us': stats['pair_cost'][0] / 1e3,
                   'sinkhorn_kernel_us': stats['sinkhorn'][0] / 1e3, 'topk_pass_kernel_us': stats['topk'][0] / 1e3,
                   'cost_kernel_GBs': 24604576 / stats['pair_cost'][0]},
 }, open('profiles/traffic.json', 'w'), indent=1)
