@@ -1176,6 +1176,212 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel 2, packed form for <= 8 x 8 problems: FOUR Sinkhorn solves per wave.  A pair lives in one DPP row of 16
+// lanes, lane (li, lj) = ((l >> 2) & 3, l & 3) owning the 2 x 2 entries (2 li + a, 2 lj + b).  Both reductions of
+// the update then stay inside a DPP row -- over j: in-register + quad_perm xor 1, xor 2; over i: in-register +
+// row_ror:4, row_ror:8 -- so the 22-cycle v_permlane swaps of the one-pair-per-wave layout disappear and a step
+// costs ~70 issue cycles per pair instead of ~145 (tools: build/dbg/thr.hip for the per-op prices).
+// Every pair follows its own epsilon schedule (own diameter): lane k of a pair evaluates steps k, k+16, ... in
+// float64 and parks the per-step constants {log2(e)/eps, eps*ln2} in an LDS table that its 16 lanes read back
+// (one broadcast ds_read_b64 per step, fetched a step ahead).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxSteps4 = 160;   // eps steps per pair the table holds (diam/blur up to ~1e7 at scaling 0.9)
+
+__device__ __forceinline__ float row16_sum_i(float v) {   // all-reduce over lane bits 2,3 (the 4 values of li)
+    v += dpp_mov<0x124>(v, v);                             // row_ror:4
+    return v + dpp_mov<0x128>(v, v);                       // row_ror:8
+}
+__device__ __forceinline__ float row16_max_i(float v) {
+    v = fmaxf(v, dpp_mov<0x124>(v, v));
+    return fmaxf(v, dpp_mov<0x128>(v, v));
+}
+__device__ __forceinline__ float quad_sum_j(float v) {     // all-reduce over lane bits 0,1 (the 4 values of lj)
+    v += lane_xor<1>(v);
+    return v + lane_xor<2>(v);
+}
+__device__ __forceinline__ float quad_max_j(float v) {
+    v = fmaxf(v, lane_xor<1>(v));
+    return fmaxf(v, lane_xor<2>(v));
+}
+
+__global__ void __launch_bounds__(256) sinkhorn4_kernel(ScoreArgs a, PairWs<1> ws, int64_t n_slots) {
+    __shared__ float2 sched[4][4][kMaxSteps4];               // [wave][pair][step] = {r2, eln2}
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pp = lane >> 4, l16 = lane & 15, li = (lane >> 2) & 3, lj = lane & 3;
+    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+    if (slot0 >= n_slots) return;
+    const bool real = slot0 + pp < n_slots;                  // tail wave: surplus groups redo the last pair, store nothing
+    const int64_t slot = real ? slot0 + pp : n_slots - 1;
+    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+    const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
+    const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
+    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
+    const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
+    const int q_len = a.q.len[q_idx], c_len = a.c.len[c_idx];
+
+    float cost[2][2], neg[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const float2 cc = *reinterpret_cast<const float2*>(ws.cost + slot * 64 + (2 * li + x) * 8 + 2 * lj);
+        const float2 nn = *reinterpret_cast<const float2*>(ws.neg + slot * 64 + (2 * li + x) * 8 + 2 * lj);
+        cost[x][0] = cc.x; cost[x][1] = cc.y;
+        neg[x][0] = nn.x; neg[x][1] = nn.y;
+    }
+    float diam;
+    if (a.diameter == nullptr) {
+        diam = sqrtf(ws.diam2[slot]);
+    } else {
+        diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
+    }
+    bool rv[2], cv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rv[t] = 2 * li + t < q_len;
+        cv[t] = 2 * lj + t < c_len;
+    }
+    // ---- marginals (pair_distances.py:57-60) -------------------------------------------------------------
+    const float temp = (float)a.temp;
+    float la2[2], lb2[2], wa[2], wb[2];
+    {
+        float qm[2], cm[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            float m = fmaxf((rv[x] && cv[0]) ? neg[x][0] : kNegBig, (rv[x] && cv[1]) ? neg[x][1] : kNegBig);
+            qm[x] = quad_max_j(m) / temp;
+        }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            float m = fmaxf((rv[0] && cv[y]) ? neg[0][y] : kNegBig, (rv[1] && cv[y]) ? neg[1][y] : kNegBig);
+            cm[y] = row16_max_i(m) / temp;
+        }
+        const float mq = row16_max_i(fmaxf(rv[0] ? qm[0] : kNegBig, rv[1] ? qm[1] : kNegBig));
+        const float mc = quad_max_j(fmaxf(cv[0] ? cm[0] : kNegBig, cv[1] ? cm[1] : kNegBig));
+        const float sq = (rv[0] ? fast_exp(qm[0] - mq) : 0.f) + (rv[1] ? fast_exp(qm[1] - mq) : 0.f);
+        const float sc = (cv[0] ? fast_exp(cm[0] - mc) : 0.f) + (cv[1] ? fast_exp(cm[1] - mc) : 0.f);
+        const float lsq = fast_log(row16_sum_i(sq)), lsc = fast_log(quad_sum_j(sc));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;
+            wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;
+            la2[t] = (wa[t] > 0.f ? fast_log(wa[t]) : -100000.f) * kLog2e;   // geomloss log_weights, in base-2 units
+            lb2[t] = (wb[t] > 0.f ? fast_log(wb[t]) : -100000.f) * kLog2e;
+        }
+    }
+    // ---- this pair's epsilon schedule -> LDS ---------------------------------------------------------------
+    const double ld = log((double)diam), lbl = log(a.blur), lsc = log(a.scaling);
+    int n_mid = (int)ceil((lbl - ld) / lsc);
+    n_mid = n_mid < 0 ? 0 : n_mid;
+    const bool overflow = n_mid + 3 > kMaxSteps4;             // schedule longer than the table: poison the score
+    if (overflow) n_mid = kMaxSteps4 - 3;
+    // table rows: 0 = diam (the first loop step), 1 .. n_mid = the annealed values, n_mid+1, n_mid+2 = blur
+    float2* tab = sched[wave][pp];
+    // The annealed values exp(ld + k*lsc) are formed in fp32 here (5 per lane; in float64 they cost more than the
+    // whole annealing loop): a relative 1e-6 on an intermediate temperature moves the final potentials by < 1e-7.
+    const float ldf = (float)(ld * 1.4426950408889634), lscf = (float)(lsc * 1.4426950408889634);
+    for (int k = l16; k < n_mid + 3; k += 16) {
+        float e;
+        if (k == 0) e = diam;
+        else if (k <= n_mid) e = __builtin_amdgcn_exp2f(fmaf((float)(k - 1), lscf, ldf));
+        else e = (float)a.blur;
+        tab[k] = make_float2(kLog2e * rcp_refined(e), e * kLn2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n_steps = n_mid + 3;                            // the last one is the un-averaged extrapolation
+    int max_steps = n_steps;
+    max_steps = max(max_steps, __shfl_xor(max_steps, 16));
+    max_steps = max(max_steps, __shfl_xor(max_steps, 32));
+
+    // ---- initialisation at eps = diam: softmin of the bare log-weights.  No max shift is needed: the largest
+    // weight of a probability vector over <= 8 atoms is >= 1/8 and C/diam <= ~1, so the sum stays in range. ----
+    float f[2], g[2];
+    {
+        const float2 e0 = tab[0];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            float sum = 0.f;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) sum += __builtin_amdgcn_exp2f(rv[x] ? fmaf(-cost[x][y], e0.x, la2[x]) : kNegBig);
+            g[y] = -e0.y * __builtin_amdgcn_logf(row16_sum_i(sum));
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            float sum = 0.f;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) sum += __builtin_amdgcn_exp2f(cv[y] ? fmaf(-cost[x][y], e0.x, lb2[y]) : kNegBig);
+            f[x] = -e0.y * __builtin_amdgcn_logf(quad_sum_j(sum));
+        }
+    }
+    // ---- the annealing loop (see step2 of sinkhorn_pair for the derivation of the shifted base-2 update) ----
+    float2 ek = tab[0];
+    for (int k = 0; k < max_steps; ++k) {
+        const float2 enext = tab[min(k + 1, n_steps - 1)];   // fetched a step ahead
+        const bool active = k < n_steps;
+        const bool averaged = k < n_steps - 1;
+        const float r2 = ek.x, eln2 = ek.y;
+        float f2[2], g2[2], av[2], bv[2], ft[2], gt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f2[t] = f[t] * r2;
+            g2[t] = g[t] * r2;
+            av[t] = la2[t] + f2[t];
+            bv[t] = lb2[t] + g2[t];
+        }
+        float sc_[2] = {0.f, 0.f}, sr_[2] = {0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const float uc = fmaf(-cost[x][y], r2, av[x]) + g2[y];
+                const float ur = fmaf(-cost[x][y], r2, bv[y]) + f2[x];
+                sc_[y] += __builtin_amdgcn_exp2f(rv[x] ? uc : kNegBig);
+                sr_[x] += __builtin_amdgcn_exp2f(cv[y] ? ur : kNegBig);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            gt[t] = eln2 * (g2[t] - __builtin_amdgcn_logf(row16_sum_i(sc_[t])));
+            ft[t] = eln2 * (f2[t] - __builtin_amdgcn_logf(quad_sum_j(sr_[t])));
+            const float gn = averaged ? 0.5f * (g[t] + gt[t]) : gt[t];
+            const float fn = averaged ? 0.5f * (f[t] + ft[t]) : ft[t];
+            g[t] = active ? gn : g[t];
+            f[t] = active ? fn : f[t];
+        }
+        ek = enext;
+    }
+    // ---- outputs ---------------------------------------------------------------------------------------------
+    float score;
+    if (a.want == ASPIRE_OT_DISTANCE) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
+            acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
+        }
+        score = row16_sum_i(quad_sum_j(acc));
+    } else {
+        const float eb = (float)a.blur, rb = rcp_refined(eb);
+        float acc = 0.f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const bool valid = rv[x] && cv[y];
+                const float negm = valid ? neg[x][y] : 0.f;
+                const float outer = valid ? f[x] + g[y] : 0.f;
+                acc += fast_exp(div_r(outer + negm, eb, rb)) * (wa[x] * wb[y]) * negm;
+            }
+        score = row16_sum_i(quad_sum_j(acc));
+    }
+    // the shifted log-sum-exp cannot leave fp32 range on sane inputs; if it did, or the schedule outgrew the
+    // table, or a document is longer than the tile, the pair is poisoned rather than silently wrong.
+    if (!(fabsf(score) < 1e30f) || overflow || q_len > 8 || c_len > 8) score = __builtin_nanf("");
+    if (real && l16 == 0) a.scores[p] = score;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batch bounding-box diameter (geomloss max_diameter over the call's x and y tensors)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) diameter_kernel(ScoreArgs a, int64_t group, float* out) {
@@ -1415,8 +1621,17 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
                                    Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
             }
             ASPIRE_LAUNCH_OK();
-            hipLaunchKernelGGL(sinkhorn_kernel<T>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a,
-                               ws, n_slots);
+            // Packed solves (4 per wave) have twice the throughput (1 x 20 000: 233 -> 197 us per call) but ~2x the
+            // latency of one solve per wave (26.7 vs 15.4 us per call at 50 pairs): use them once the grid is big
+            // enough that throughput is what counts.
+            if (T == 1 && !extra && n_slots >= 4096) {
+                PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
+                hipLaunchKernelGGL(sinkhorn4_kernel, dim3((unsigned)((n_slots + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a,
+                                   ws1, n_slots);
+            } else {
+                hipLaunchKernelGGL(sinkhorn_kernel<T>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                                   a, ws, n_slots);
+            }
             ASPIRE_LAUNCH_OK();
         }
         return (int)ASPIRE_OK;
