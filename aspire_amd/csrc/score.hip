@@ -1502,10 +1502,10 @@ extern "C" int aspire_max_sents(void) { return 8 * kMaxT; }
 extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
                                        int cdist_mode, float* scores, float* pair_sims, void* stream) {
     if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    if (q->n == 0 || c->n == 0) return ASPIRE_OK;   // nothing to score (an empty pool has no buffers either)
     ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "scores is null");
     ASPIRE_REQUIRE(!pair_sims || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
                    "pair_sims output needs padded extents (ext > 0)");
-    if (q->n == 0 || c->n == 0) return ASPIRE_OK;
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
@@ -1546,6 +1546,7 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
                                       float* scores, float* out_qdistr, float* out_cdistr, float* out_pairsims,
                                       float* out_plan, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    if (q->n == 0 || c->n == 0) return ASPIRE_OK;   // nothing to score (an empty pool has no buffers either)
     ASPIRE_REQUIRE(prm && scores, ASPIRE_ERR_INVALID_ARG, "null params/scores");
     ASPIRE_REQUIRE(want == ASPIRE_OT_DISTANCE || want == ASPIRE_OT_PLAN_SIM, ASPIRE_ERR_INVALID_ARG, "bad want %d", want);
     ASPIRE_REQUIRE(prm->blur > 0 && prm->scaling > 0 && prm->scaling < 1 && prm->sent_sm_temp > 0,

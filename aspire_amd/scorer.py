@@ -70,6 +70,8 @@ def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None
 def rank_pool(query_reps_list, pool, k=None, **kw):
     """Per query: [(pid, score), ...] best first, ties in pool order (evaluate.py:76)."""
     pool = _as_pool(pool)
+    if len(pool) == 0:
+        return [[] for _ in query_reps_list]
     scores = score_pool(query_reps_list, pool, **kw)
     k = len(pool) if k is None else min(k, len(pool))
     top_s, top_i = ops.topk_desc(scores.contiguous(), k)
