@@ -1,0 +1,443 @@
+// Pairwise sentence costs on the matrix cores, for the many-query / long-document regimes of A5.
+//
+// Reference arithmetic: src/learning/facetid_models/pair_distances.py:48-55 (torch.cdist of every query
+// sentence against every candidate sentence) and geomloss 0.2.4's squared_distances (|x|^2 - 2 x.y + |y|^2).
+//
+// With one query the cost stage streams every candidate row once and is HBM bound (score.hip: pair_tile_kernel).
+// With Q queries each candidate row meets Q * S_q query rows and the stage is 2 * 768 flops per (row, row) entry:
+// at 32 queries x 8 sentences that is 128 flop per candidate byte, far on the compute side of the ridge, and the
+// VALU kernels of score.hip top out near 20 T entries*coords/s.  The x.y term IS a GEMM (fp32 in, fp32 out), so
+// here it runs on v_mfma_f32_32x32x2_f32 -- exact fp32 multiply-adds, 4x the VALU rate -- and the epilogue turns the
+// Gram tile into the two distance forms.  torch.cdist's direct (x - y)^2 formula (used by the reference below 26
+// rows) is reproduced to ~1e-5 by the expansion except where x ~ y (cancellation); those entries -- squared distance
+// below 1e-4 of the squared norm sum -- are recomputed coordinate by coordinate.
+//
+// Tile = whole documents: a 128-row candidate tile holds floor(128 / mr_c) documents in slots of mr_c rows
+// (mr = the set's longest document, rounded up to 4), a 32/64/128-row query tile likewise; rows beyond a
+// document's length are zero and their entries are masked downstream exactly like the other kernels' pad entries.
+// Every (query doc, candidate doc) pair therefore lives in exactly one workgroup: the otAspire epilogue writes the
+// pair's cost / -cdist slot (16-byte stores, the 8T x 8T slot of a pair is contiguous), the tsAspire epilogue
+// reduces the pair's maximum in LDS and stores the score -- no global atomics, no second pass.
+//
+// Candidates are the MFMA M side (a lane's 4 consecutive accumulator rows = 4 consecutive candidate sentences = one
+// float4 of the pair's row-major cost matrix), queries the N side.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "score_types.h"
+
+namespace aspire {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kBM = 128;   // candidate rows per tile
+constexpr int kBK = 16;    // coordinates per LDS stage
+constexpr float kDirectTau = 1e-4f;   // recompute (x-y)^2 directly when d^2 < tau * (|x|^2 + |y|^2)^2
+
+struct GramArgs {
+    RepSet q, c;
+    int64_t cand0;
+    uint32_t ncand, nq;
+    int mr_q, mr_c;      // rows per document slot
+    int dpt_q, dpt_c;    // documents per tile
+    int n_qt, n_ct;      // tiles
+    int E, ld;           // otAspire slot: entries per pair (64 T^2), row stride (8 T)
+    int cdist_mode;
+    float* cost;
+    float* neg;
+    float* scores;       // tsAspire: [nq][c.n]
+};
+
+__device__ __forceinline__ uint32_t order_key(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorder_key(uint32_t u) {
+    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+__device__ __forceinline__ float sq4f(const float4& a) { return fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x))); }
+
+// sum_d (x_d - y_d)^2 over the 768 coordinates (rare path: near-coincident sentences)
+__device__ __noinline__ float direct_d2(const float* x, const float* y) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < kD; k += 8) {
+        const float4 a = ld4(x + k), b = ld4(y + k), c = ld4(x + k + 4), d = ld4(y + k + 4);
+        const float e0 = a.x - b.x, e1 = a.y - b.y, e2 = a.z - b.z, e3 = a.w - b.w;
+        const float f0 = c.x - d.x, f1 = c.y - d.y, f2 = c.z - d.z, f3 = c.w - d.w;
+        s0 = fmaf(e3, e3, fmaf(e2, e2, fmaf(e1, e1, fmaf(e0, e0, s0))));
+        s1 = fmaf(f3, f3, fmaf(f2, f2, fmaf(f1, f1, fmaf(f0, f0, s1))));
+    }
+    return s0 + s1;
+}
+
+template <int BN, bool L2MAX>
+__global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
+    constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int WM = kBM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int LDA = kBM + 4, LDB = BN + 4;
+    constexpr int A_F4 = kBM * kBK / 4 / 256;                        // 2
+    constexpr int B_F4 = (BN * kBK / 4 + 255) / 256;                 // 2, 1, 1 (half the threads at BN = 32)
+    constexpr bool B_ALL = BN * kBK / 4 >= 256;
+    __shared__ __attribute__((aligned(16))) float As[2][kBK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBK][LDB];
+    __shared__ const float* c_ptr[kBM];
+    __shared__ const float* q_ptr[BN];
+    __shared__ long long c_off[kBM];
+    __shared__ long long q_off[BN];
+    __shared__ __attribute__((aligned(16))) float c_nrm[kBM];
+    __shared__ float q_nrm[BN];
+    __shared__ unsigned char c_mm[kBM], q_mm[BN];
+    __shared__ uint32_t pairmax[L2MAX ? 256 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    // workgroups that share a candidate tile sit next to each other in an XCD's launch order (its L2 then serves
+    // the tile's second and later readers): linear id = position within the XCD's contiguous share
+    uint32_t L;
+    {
+        const uint32_t nb = gridDim.x, b = blockIdx.x, x = b & 7, q8 = nb >> 3, r8 = nb & 7;
+        L = x * q8 + (x < r8 ? x : r8) + (b >> 3);
+    }
+    const uint32_t ct = L / (uint32_t)g.n_qt, qt = L - ct * (uint32_t)g.n_qt;
+
+    // ---- tile tables -----------------------------------------------------------------------------------
+    if (tid < kBM) {
+        const int d = tid / g.mr_c, i = tid - d * g.mr_c;
+        const uint32_t c_loc = ct * g.dpt_c + d;
+        const bool doc_ok = d < g.dpt_c && c_loc < g.ncand;
+        int len = 0, start = 0;
+        if (doc_ok) {
+            len = g.c.len[g.cand0 + c_loc];
+            start = g.c.start[g.cand0 + c_loc];
+        }
+        c_ptr[tid] = (doc_ok && i < len) ? g.c.rows + (size_t)(start + i) * kD : nullptr;
+        c_off[tid] = !doc_ok ? -1 : L2MAX ? (long long)d : (long long)c_loc * g.E + i;
+        c_mm[tid] = len > 25;
+    } else if (tid < kBM + BN) {
+        const int r = tid - kBM;
+        const int d = r / g.mr_q, i = r - d * g.mr_q;
+        const uint32_t q_loc = qt * g.dpt_q + d;
+        const bool doc_ok = d < g.dpt_q && q_loc < g.nq;
+        int len = 0, start = 0;
+        if (doc_ok) {
+            len = g.q.len[q_loc];
+            start = g.q.start[q_loc];
+        }
+        q_ptr[r] = (doc_ok && i < len) ? g.q.rows + (size_t)(start + i) * kD : nullptr;
+        q_off[r] = !doc_ok ? -1 : L2MAX ? (long long)d : ((long long)q_loc * g.ncand) * g.E + (long long)i * g.ld;
+        q_mm[r] = len > 25;
+    }
+    if constexpr (L2MAX) pairmax[tid] = 0u;
+    __syncthreads();
+
+    // ---- operand staging: thread -> (row, 16-byte k chunk) ---------------------------------------------
+    const int lrow = tid >> 2, lk4 = tid & 3;
+    const float* pa[A_F4];
+    const float* pb[B_F4];
+#pragma unroll
+    for (int p = 0; p < A_F4; ++p) pa[p] = c_ptr[lrow + 64 * p];
+#pragma unroll
+    for (int p = 0; p < B_F4; ++p) pb[p] = (B_ALL || lrow < BN) ? q_ptr[(lrow + 64 * p) % BN] : nullptr;
+    float4 ra[A_F4], rb[B_F4];
+    float na[A_F4], nb[B_F4];
+#pragma unroll
+    for (int p = 0; p < A_F4; ++p) na[p] = 0.f;
+#pragma unroll
+    for (int p = 0; p < B_F4; ++p) nb[p] = 0.f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_F4; ++p) ra[p] = pa[p] ? ld4(pa[p] + k0 + 4 * lk4) : zero4;
+#pragma unroll
+        for (int p = 0; p < B_F4; ++p) rb[p] = pb[p] ? ld4(pb[p] + k0 + 4 * lk4) : zero4;
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_F4; ++p) {
+            const int row = lrow + 64 * p;
+            As[buf][4 * lk4 + 0][row] = ra[p].x;
+            As[buf][4 * lk4 + 1][row] = ra[p].y;
+            As[buf][4 * lk4 + 2][row] = ra[p].z;
+            As[buf][4 * lk4 + 3][row] = ra[p].w;
+            na[p] += sq4f(ra[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < B_F4; ++p) {
+            if (B_ALL || lrow < BN) {
+                const int row = lrow + 64 * p;
+                Bs[buf][4 * lk4 + 0][row] = rb[p].x;
+                Bs[buf][4 * lk4 + 1][row] = rb[p].y;
+                Bs[buf][4 * lk4 + 2][row] = rb[p].z;
+                Bs[buf][4 * lk4 + 3][row] = rb[p].w;
+                nb[p] += sq4f(rb[p]);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int nk = kD / kBK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) load_tiles((t + 1) * kBK);   // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < kBK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kk + lk][wr * WM + 32 * i + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kk + lk][wc * WN + 32 * j + lr];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- squared norms: the 4 threads of a row hold its 4 interleaved k-chunk partial sums ----------------
+#pragma unroll
+    for (int p = 0; p < A_F4; ++p) {
+        float s = na[p];
+        s += lane_xor<1>(s);
+        s += lane_xor<2>(s);
+        if (lk4 == 0) c_nrm[lrow + 64 * p] = s;
+    }
+#pragma unroll
+    for (int p = 0; p < B_F4; ++p) {
+        float s = nb[p];
+        s += lane_xor<1>(s);
+        s += lane_xor<2>(s);
+        if (lk4 == 0 && (B_ALL || lrow < BN)) q_nrm[lrow + 64 * p] = s;
+    }
+    __syncthreads();
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wc * WN + 32 * j + lr;
+            const long long qo = q_off[n];
+            const float xx = q_nrm[n];
+            const float* qp = q_ptr[n];
+            const bool qmm = q_mm[n];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int m0 = wr * WM + 32 * i + 8 * g4 + 4 * lk;
+                const long long co = c_off[m0];
+                if (qo < 0 || co < 0) continue;
+                const bool mm = g.cdist_mode == ASPIRE_CDIST_MM || (g.cdist_mode == ASPIRE_CDIST_AUTO && (qmm || c_mm[m0]));
+                const float4 yy4 = *reinterpret_cast<const float4*>(&c_nrm[m0]);
+                const float yy[4] = {yy4.x, yy4.y, yy4.z, yy4.w};
+                float cost[4], neg[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sq = fmaf(-2.f, acc[i][j][4 * g4 + k], xx) + yy[k];
+                    cost[k] = sqrtf(fmaxf(sq, 1e-8f));
+                    neg[k] = -sqrtf(fmaxf(sq, 0.f));
+                    const float ns = xx + yy[k];
+                    if (!mm && sq < kDirectTau * ns * ns && qp && c_ptr[m0 + k]) neg[k] = -sqrtf(direct_d2(qp, c_ptr[m0 + k]));
+                }
+                if constexpr (L2MAX) {
+                    float best = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (qp && c_ptr[m0 + k]) best = fmaxf(best, neg[k]);
+                    if (best > -INFINITY) atomicMax(&pairmax[(int)co * 16 + (int)qo], order_key(best));
+                } else {
+                    *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
+                    *reinterpret_cast<float4*>(g.neg + qo + co) = make_float4(neg[0], neg[1], neg[2], neg[3]);
+                }
+            }
+        }
+    if constexpr (L2MAX) {
+        __syncthreads();
+        const int cd = tid >> 4, qd = tid & 15;
+        const uint32_t c_loc = ct * g.dpt_c + cd, q_loc = qt * g.dpt_q + qd;
+        if (cd < g.dpt_c && qd < g.dpt_q && c_loc < g.ncand && q_loc < g.nq) {
+            const uint32_t key = pairmax[cd * 16 + qd];
+            g.scores[(int64_t)q_loc * g.c.n + g.cand0 + c_loc] = key ? unorder_key(key) : -INFINITY;
+        }
+    }
+}
+
+// Per-coordinate bounding box of documents [first, first + gridDim.x): box[k][0][768] = min, box[k][1][768] = max
+__global__ void __launch_bounds__(192) doc_box_range_kernel(RepSet d, int64_t first, float* __restrict__ box) {
+    const int64_t k = blockIdx.x;
+    const int n = d.len[first + k];
+    const float* doc = d.rows + (size_t)d.start[first + k] * kD + threadIdx.x * 4;
+    float4 mn = ld4(doc), mx = mn;
+    for (int r = 1; r < n; ++r) {
+        const float4 v = ld4(doc + (size_t)r * kD);
+        mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+    }
+    *reinterpret_cast<float4*>(box + k * 2 * kD + threadIdx.x * 4) = mn;
+    *reinterpret_cast<float4*>(box + k * 2 * kD + kD + threadIdx.x * 4) = mx;
+}
+
+// geomloss's diameter of one (query, candidate) call = norm of the joint bounding box's extent; squared here:
+// diam2[q_loc * ncand + c_loc] = sum_d (max(qmax_d, cmax_d) - min(qmin_d, cmin_d))^2.
+// Workgroup = 32 query docs x 32 candidate docs, thread = 2 x 2 of them, coordinates staged 64 at a time.
+constexpr int kBoxLd = 68;
+__global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__ qbox, const float* __restrict__ cbox,
+                                                       uint32_t nq, uint32_t ncand, float* __restrict__ diam2) {
+    __shared__ __attribute__((aligned(16))) float s[4][32][kBoxLd];   // qmin, qmax, cmin, cmax
+    const int tid = threadIdx.x;
+    const uint32_t c0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
+    const int tq = tid & 15, tc = tid >> 4;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int ch = 0; ch < kD / 64; ++ch) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int idx = tid + 256 * p;            // [arr 4][doc 32][f4 16]
+            const int arr = idx >> 9, doc = (idx >> 4) & 31, f4 = idx & 15;
+            const bool isq = arr < 2;
+            const uint32_t gdoc = isq ? min(q0 + doc, nq - 1) : min(c0 + doc, ncand - 1);
+            const float* src = (isq ? qbox : cbox) + (size_t)gdoc * 2 * kD + (arr & 1) * kD + ch * 64 + f4 * 4;
+            *reinterpret_cast<float4*>(&s[arr][doc][f4 * 4]) = ld4(src);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int f4 = 0; f4 < 16; ++f4) {
+            float4 qn[2], qx[2], cn[2], cx[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                qn[u] = *reinterpret_cast<const float4*>(&s[0][2 * tq + u][f4 * 4]);
+                qx[u] = *reinterpret_cast<const float4*>(&s[1][2 * tq + u][f4 * 4]);
+                cn[u] = *reinterpret_cast<const float4*>(&s[2][2 * tc + u][f4 * 4]);
+                cx[u] = *reinterpret_cast<const float4*>(&s[3][2 * tc + u][f4 * 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const float dx = fmaxf(qx[u].x, cx[v].x) - fminf(qn[u].x, cn[v].x);
+                    const float dy = fmaxf(qx[u].y, cx[v].y) - fminf(qn[u].y, cn[v].y);
+                    const float dz = fmaxf(qx[u].z, cx[v].z) - fminf(qn[u].z, cn[v].z);
+                    const float dw = fmaxf(qx[u].w, cx[v].w) - fminf(qn[u].w, cn[v].w);
+                    acc[u][v] = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, acc[u][v]))));
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const uint32_t q = q0 + 2 * tq + u, c = c0 + 2 * tc + v;
+            if (q < nq && c < ncand) diam2[(size_t)q * ncand + c] = acc[u][v];
+        }
+}
+
+int slot_rows(int max_len) {
+    const int r = (max_len + 3) / 4 * 4;
+    return r < 8 ? 8 : r;
+}
+
+int fill_geometry(GramArgs& g, const ScoreArgs& a, int mr_q, int mr_c, int& bn) {
+    g.q = a.q;
+    g.c = a.c;
+    g.cand0 = a.cand0;
+    g.ncand = (uint32_t)(a.cand1 - a.cand0);
+    g.nq = (uint32_t)a.q.n;
+    g.mr_q = slot_rows(mr_q);
+    g.mr_c = slot_rows(mr_c);
+    const int64_t qrows = (int64_t)g.nq * g.mr_q;
+    bn = qrows <= 32 ? 32 : qrows <= 64 ? 64 : 128;
+    g.dpt_c = kBM / g.mr_c;
+    g.dpt_q = bn / g.mr_q;
+    g.n_ct = (int)((g.ncand + g.dpt_c - 1) / g.dpt_c);
+    g.n_qt = (int)((g.nq + g.dpt_q - 1) / g.dpt_q);
+    g.cdist_mode = a.cdist_mode;
+    ASPIRE_REQUIRE((int64_t)g.n_ct * g.n_qt < ((int64_t)1 << 31), ASPIRE_ERR_UNSUPPORTED, "too many tiles in one launch");
+    return ASPIRE_OK;
+}
+
+template <bool L2MAX>
+int launch_gram(const GramArgs& g, int bn, hipStream_t stream) {
+    const dim3 grid((unsigned)(g.n_ct * g.n_qt));
+    if (bn == 32) {
+        hipLaunchKernelGGL((pair_gram_kernel<32, L2MAX>), grid, dim3(256), 0, stream, g);
+    } else if (bn == 64) {
+        hipLaunchKernelGGL((pair_gram_kernel<64, L2MAX>), grid, dim3(256), 0, stream, g);
+    } else {
+        hipLaunchKernelGGL((pair_gram_kernel<128, L2MAX>), grid, dim3(256), 0, stream, g);
+    }
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+}  // namespace
+
+// The matrix-core form serves CSR inputs (no padded extents) scored all-against-all, once the query side fills
+// a useful part of an MFMA tile or documents are longer than the 8-row VALU tile.
+bool gram_path_wanted(const aspire_repset* q, const aspire_repset* c, int pairing) {
+    if (pairing != ASPIRE_PAIR_CROSS || q->ext != 0 || c->ext != 0) return false;
+    if (q->max_len <= 0 || c->max_len <= 0 || q->max_len > 32 || c->max_len > 32) return false;
+    // ASPIRE_HIP_COST_PATH=mfma|valu pins the choice (parity tests compare the two forms); default: by shape
+    if (const char* e = getenv("ASPIRE_HIP_COST_PATH")) {
+        if (!strcmp(e, "mfma")) return true;
+        if (!strcmp(e, "valu")) return false;
+    }
+    const int max_rows = q->max_len > c->max_len ? q->max_len : c->max_len;
+    const int64_t qrows = q->n * (int64_t)slot_rows(q->max_len);
+    const int64_t tiles = (c->n + kBM / slot_rows(c->max_len) - 1) / (kBM / slot_rows(c->max_len));
+    if (tiles < 128) return false;          // small pools are latency bound: the per-pair kernels start faster
+    return max_rows > 8 || qrows >= 24;
+}
+
+size_t gram_extra_bytes_per_cand(void) { return (size_t)2 * kD * sizeof(float); }   // the candidate's box
+
+int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* cost, float* neg, float* diam2, float* qbox,
+                        float* cbox, hipStream_t stream) {
+    GramArgs g{};
+    int bn = 128;
+    if (int rc = fill_geometry(g, a, mr_q, mr_c, bn)) return rc;
+    g.E = 64 * T * T;
+    g.ld = 8 * T;
+    g.cost = cost;
+    g.neg = neg;
+    if (int rc = launch_gram<false>(g, bn, stream)) return rc;
+    if (diam2) {
+        if (a.cand0 == 0) {
+            hipLaunchKernelGGL(doc_box_range_kernel, dim3((unsigned)g.nq), dim3(192), 0, stream, a.q, (int64_t)0, qbox);
+            ASPIRE_LAUNCH_OK();
+        }
+        hipLaunchKernelGGL(doc_box_range_kernel, dim3(g.ncand), dim3(192), 0, stream, a.c, a.cand0, cbox);
+        ASPIRE_LAUNCH_OK();
+        hipLaunchKernelGGL(pair_box_kernel, dim3((g.ncand + 31) / 32, (g.nq + 31) / 32), dim3(256), 0, stream, qbox, cbox,
+                           g.nq, g.ncand, diam2);
+        ASPIRE_LAUNCH_OK();
+    }
+    return ASPIRE_OK;
+}
+
+int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t stream) {
+    GramArgs g{};
+    int bn = 128;
+    ScoreArgs b = a;
+    b.cand0 = 0;
+    b.cand1 = a.c.n;
+    if (int rc = fill_geometry(g, b, mr_q, mr_c, bn)) return rc;
+    g.scores = a.scores;
+    return launch_gram<true>(g, bn, stream);
+}
+
+}  // namespace aspire

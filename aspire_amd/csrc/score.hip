@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "score_types.h"
 
 namespace aspire {
 namespace {
@@ -26,36 +27,6 @@ namespace {
 constexpr int kWaves = 3;
 constexpr int kBlock = 64 * kWaves;
 constexpr int kMaxT = 4;  // sentence rows per document <= 8 * kMaxT
-
-struct RepSet {
-    const float* rows;
-    const int32_t* start;
-    const int32_t* len;
-    int64_t n;
-    int32_t ext;
-};
-
-struct ScoreArgs {
-    RepSet q, c;
-    int pairing;     // ASPIRE_PAIR_*
-    int cdist_mode;  // ASPIRE_CDIST_*
-    int q_per_block; // CROSS: queries handled by one block (grid.y chunks)
-    int64_t cand0, cand1;  // otAspire: the chunk of candidates this launch covers
-    // OT
-    double blur, scaling, temp;
-    const float* diameter;
-    int64_t diam_group;
-    int64_t n_groups;
-    int want;
-    float* scores;
-    float* out_qdistr;
-    float* out_cdistr;
-    float* out_pairsims;
-    float* out_plan;
-    long long* dbg;  // phase cycle stamps (only with -DASPIRE_PHASE_CLOCK)
-};
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // LDS carve (floats): red[kWaves][T*T][128] | rednorm[kWaves][T][16] | reddiam[4] | xpose[kWaves][32][68]
 constexpr int kXpLd = 68;                 // row stride of the transpose scratch: 64 lanes + 4 (keeps b128 reads
@@ -159,11 +130,6 @@ __device__ __forceinline__ float div_r(float x, float e, float r) {
 __device__ __forceinline__ float rcp_refined(float e) {
     float r = __builtin_amdgcn_rcpf(e);
     return fmaf(fmaf(-e, r, 1.0f), r, r);
-}
-
-__device__ __forceinline__ bool use_mm_formula(int mode, int nq, int nc) {
-    // torch.cdist default: matmul expansion iff either side has more than 25 rows.
-    return mode == ASPIRE_CDIST_MM || (mode == ASPIRE_CDIST_AUTO && (nq > 25 || nc > 25));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -311,16 +277,6 @@ template <int T>
 struct PairState {
     float cost[T][T];  // geomloss cost: sqrt(max(|x|^2 - 2 x.y + |y|^2, 1e-8))
     float neg[T][T];   // -cdist (torch formula)
-};
-
-// Per-pair intermediates between the two kernels of the otAspire path, one slot per pair of the current
-// chunk: cost [8T x 8T] row-major, neg [8T x 8T], diam2 (sum over coordinates of (max-min)^2).
-template <int T>
-struct PairWs {
-    static constexpr int kEntries = 64 * T * T;
-    float* cost;
-    float* neg;
-    float* diam2;
 };
 
 // After the three waves' partial sums of one pair met in LDS: all 192 threads finish the entries
@@ -1513,6 +1469,7 @@ extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_reps
     a.cdist_mode = cdist_mode;
     a.scores = scores;
     a.out_pairsims = pair_sims;
+    if (!pair_sims && gram_path_wanted(q, c, pairing)) return launch_pair_gram_l2max(a, q->max_len, c->max_len, (hipStream_t)stream);
     dim3 grid;
     grid = dim3((unsigned)a.c.n, (unsigned)query_chunks(a), 1);
     return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
@@ -1531,14 +1488,20 @@ size_t slot_bytes(int max_rows) {
 }
 size_t qbox_bytes(const aspire_repset* q) { return (size_t)q->n * 2 * kD * sizeof(float); }
 constexpr size_t kWsCap = (size_t)1 << 30;  // suggested workspace is capped at 1 GiB; larger jobs run in chunks
+constexpr size_t kWsSlack = 48;             // alignment of the box tables behind the pair slots
+// workspace bytes one candidate of a chunk needs: its pair slots (+ its bounding box on the matrix-core path)
+size_t per_cand_bytes(const aspire_repset* q, const aspire_repset* c, int pairing) {
+    return slot_bytes(max_rows_of(q, c)) * (pairing == ASPIRE_PAIR_PAIRED ? 1 : (size_t)q->n) +
+           (gram_path_wanted(q, c, pairing) ? gram_extra_bytes_per_cand() : 0);
+}
 }  // namespace
 
 extern "C" size_t aspire_ot_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int pairing) {
     if (!q || !c || q->n <= 0 || c->n <= 0) return 0;
-    const size_t per_cand = slot_bytes(max_rows_of(q, c)) * (pairing == ASPIRE_PAIR_PAIRED ? 1 : (size_t)q->n);
+    const size_t per_cand = per_cand_bytes(q, c, pairing);
     const size_t full = per_cand * (size_t)c->n;
-    if (full <= kWsCap) return full + qbox_bytes(q) + 16;
-    return (per_cand > kWsCap ? per_cand : kWsCap / per_cand * per_cand) + qbox_bytes(q) + 16;
+    if (full <= kWsCap) return full + qbox_bytes(q) + kWsSlack;
+    return (per_cand > kWsCap ? per_cand : kWsCap / per_cand * per_cand) + qbox_bytes(q) + kWsSlack;
 }
 
 extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
@@ -1557,8 +1520,9 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
     ASPIRE_REQUIRE(!diameter || diam_group > 0, ASPIRE_ERR_INVALID_ARG, "diam_group must be positive");
     if (q->n == 0 || c->n == 0) return ASPIRE_OK;
     const int max_rows = max_rows_of(q, c);
-    const size_t per_cand = slot_bytes(max_rows) * (pairing == ASPIRE_PAIR_PAIRED ? 1 : (size_t)q->n);
-    ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + 16, ASPIRE_ERR_INVALID_ARG,
+    const size_t per_cand = per_cand_bytes(q, c, pairing);
+    const bool gram = gram_path_wanted(q, c, pairing);
+    ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + kWsSlack, ASPIRE_ERR_INVALID_ARG,
                    "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
                    workspace_bytes, per_cand, aspire_ot_workspace_bytes(q, c, pairing));
     ScoreArgs a{};
@@ -1579,7 +1543,7 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
     a.out_pairsims = out_pairsims;
     a.out_plan = out_plan;
     const int qchunks = query_chunks(a);
-    const int64_t cand_per_chunk = (int64_t)((((workspace_bytes - qbox_bytes(q)) & ~(size_t)15)) / per_cand);
+    const int64_t cand_per_chunk = (int64_t)((((workspace_bytes - qbox_bytes(q)) & ~(size_t)15) - 32) / per_cand);
     const int64_t pairs_per_cand = pairing == ASPIRE_PAIR_PAIRED ? 1 : q->n;
     return dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
@@ -1591,7 +1555,14 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
             ws.cost = (float*)workspace;
             ws.neg = ws.cost + n_slots * PairWs<T>::kEntries;
             ws.diam2 = ws.neg + n_slots * PairWs<T>::kEntries;
-            if (T == 1 && q->ext == 0 && c->ext == 0) {
+            if (gram) {
+                // many queries or long documents: Gram tiles on the matrix cores (gram.hip)
+                float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
+                float* cbox = (float*)(((uintptr_t)(ws.diam2 + n_slots) + 15) & ~(uintptr_t)15);
+                if (int rc = launch_pair_gram_ot(a, T, q->max_len, c->max_len, ws.cost, ws.neg, diameter ? nullptr : ws.diam2,
+                                                 qbox, cbox, (hipStream_t)stream))
+                    return rc;
+            } else if (T == 1 && q->ext == 0 && c->ext == 0) {
                 // tiled form (lanes own finished (i,j) sums): R = 2 packs four candidates of one query into a
                 // wave (fewest LDS reads per FMA) once there are enough of them to fill the chip, R = 1 otherwise.
                 PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};

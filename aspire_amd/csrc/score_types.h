@@ -1,0 +1,60 @@
+// Device-side argument structs shared by the scoring kernels (score.hip, gram.hip).
+#pragma once
+#include "common.h"
+
+namespace aspire {
+
+struct RepSet {
+    const float* rows;
+    const int32_t* start;
+    const int32_t* len;
+    int64_t n;
+    int32_t ext;
+};
+
+struct ScoreArgs {
+    RepSet q, c;
+    int pairing;     // ASPIRE_PAIR_*
+    int cdist_mode;  // ASPIRE_CDIST_*
+    int q_per_block; // CROSS: queries handled by one block (grid.y chunks)
+    int64_t cand0, cand1;  // otAspire: the chunk of candidates this launch covers
+    // OT
+    double blur, scaling, temp;
+    const float* diameter;
+    int64_t diam_group;
+    int64_t n_groups;
+    int want;
+    float* scores;
+    float* out_qdistr;
+    float* out_cdistr;
+    float* out_pairsims;
+    float* out_plan;
+    long long* dbg;  // phase cycle stamps (only with -DASPIRE_PHASE_CLOCK)
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Per-pair intermediates between the two kernels of the otAspire path, one slot per pair of the current
+// chunk: cost [8T x 8T] row-major, neg [8T x 8T], diam2 (sum over coordinates of (max-min)^2).
+template <int T>
+struct PairWs {
+    static constexpr int kEntries = 64 * T * T;
+    float* cost;
+    float* neg;
+    float* diam2;
+};
+
+__device__ __forceinline__ bool use_mm_formula(int mode, int nq, int nc) {
+    // torch.cdist default: matmul expansion iff either side has more than 25 rows.
+    return mode == ASPIRE_CDIST_MM || (mode == ASPIRE_CDIST_AUTO && (nq > 25 || nc > 25));
+}
+
+
+// gram.hip: matrix-core form of the pairwise-cost stage (host launchers; see the file header)
+bool gram_path_wanted(const aspire_repset* q, const aspire_repset* c, int pairing);
+size_t gram_extra_bytes_per_cand(void);
+int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* cost, float* neg, float* diam2, float* qbox,
+                        float* cbox, hipStream_t stream);
+int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t stream);
+
+}  // namespace aspire

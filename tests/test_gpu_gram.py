@@ -1,0 +1,135 @@
+"""Matrix-core cost stage (aspire_amd/csrc/gram.hip) against the oracle and against the VALU kernels.
+
+The library picks the form by shape; ASPIRE_HIP_COST_PATH=mfma|valu pins it so both can be run on the same
+inputs.  Every comparison goes through the C ABI (ops -> libaspire_hip.so)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def amd():
+    from aspire_amd import ops, scorer, pair_distances, _lib
+    assert torch.cuda.is_available()
+    return type('NS', (), dict(ops=ops, scorer=scorer, pd=pair_distances, lib=_lib))
+
+
+class cost_path:
+    def __init__(self, which):
+        self.which = which
+
+    def __enter__(self):
+        self.old = os.environ.get('ASPIRE_HIP_COST_PATH')
+        os.environ['ASPIRE_HIP_COST_PATH'] = self.which
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ['ASPIRE_HIP_COST_PATH']
+        else:
+            os.environ['ASPIRE_HIP_COST_PATH'] = self.old
+
+
+def _docs(seed, lens, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return [scale * torch.randn(int(n), 768, generator=g) for n in lens]
+
+
+def _l2max_oracle(q, c):
+    return -orc.allpair_masked_dist_l2max(orc.RepLen(q[None].permute(0, 2, 1), [len(q)]),
+                                          orc.RepLen(c[None].permute(0, 2, 1), [len(c)])).item()
+
+
+@pytest.mark.parametrize('qlens,clens', [
+    ([8, 8, 8], [8] * 40),                                    # aligned 8-row documents, 32-row query tile
+    ([5, 8, 1, 7, 3], [8, 3, 1, 6, 7, 2, 8, 5] * 5),          # ragged
+    ([12] * 11, [12] * 23),                                   # 12-row slots, 10 per tile, two query tiles
+    ([9, 16, 13], [11, 1, 16, 4] * 6),                        # T = 2 ragged
+    ([20, 3], [17, 24, 2, 9] * 3),                            # T = 3
+    ([32], [32, 1, 30, 26, 25] * 2),                          # T = 4, crosses the cdist 25/26 switch
+])
+def test_gram_ot_and_l2max_match_oracle(amd, qlens, clens):
+    q, c = _docs(11, qlens), _docs(12, clens)
+    with cost_path('mfma'):
+        ot = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+        l2 = amd.scorer.score_pool(q, c, method='l2max').cpu().numpy()
+    want_ot = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
+    want_l2 = np.array([[_l2max_oracle(x, y) for y in c] for x in q], dtype=np.float32)
+    np.testing.assert_allclose(ot, want_ot, atol=TOL, rtol=0)
+    np.testing.assert_allclose(l2, want_l2, atol=TOL, rtol=0)
+
+
+def test_gram_batch_schedule_matches_valu(amd):
+    """caching_score's grouping (one epsilon schedule per 64 candidates, plan-weighted similarity)."""
+    q, c = _docs(21, [8, 6, 8, 7]), _docs(22, np.random.RandomState(0).randint(1, 9, size=200))
+    with cost_path('mfma'):
+        a = amd.scorer.score_pool(q, c, method='ot', schedule='batch').cpu().numpy()
+    with cost_path('valu'):
+        b = amd.scorer.score_pool(q, c, method='ot', schedule='batch').cpu().numpy()
+    # the plan-weighted similarity amplifies fp32 rounding of the costs (see test_gpu_scoring.PLAN_SIM_TOL)
+    np.testing.assert_allclose(a, b, atol=1e-2, rtol=0)
+    assert np.median(np.abs(a - b)) < 1e-3
+
+
+def test_gram_near_duplicate_sentences(amd):
+    """x ~ y: the expansion |x|^2 - 2 x.y + |y|^2 cancels; those entries are recomputed directly, so a candidate
+    that repeats a query sentence (exactly, or up to a 1e-3 perturbation) scores like the reference's direct
+    torch.cdist."""
+    g = torch.Generator().manual_seed(5)
+    q = _docs(31, [8, 8, 8, 8])
+    c = _docs(32, [8] * 24)
+    c[3][2] = q[1][5]                                                # exact copy -> distance 0
+    c[7][0] = q[2][0] + 1e-3 * torch.randn(768, generator=g)         # distance ~0.028
+    c[9][7] = q[0][1] + 1e-2 * torch.randn(768, generator=g)         # distance ~0.28
+    with cost_path('mfma'):
+        l2 = amd.scorer.score_pool(q, c, method='l2max').cpu().numpy()
+        ot = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    want_l2 = np.array([[_l2max_oracle(x, y) for y in c] for x in q], dtype=np.float32)
+    np.testing.assert_allclose(l2, want_l2, atol=2e-5, rtol=0)
+    assert l2[1, 3] == 0.0
+    # The OT COST is the expansion in the reference too (geomloss squared_distances), so for the three coincident
+    # pairs the reference's own value is rounding noise of its summation order (sqrt of a cancelled ~1e-4): only the
+    # other pairs can be held to 1e-4; the coincident ones agree to the size of that noise.
+    want_ot = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
+    noisy = np.zeros_like(want_ot, dtype=bool)
+    noisy[1, 3] = noisy[2, 7] = noisy[0, 9] = True
+    np.testing.assert_allclose(ot[~noisy], want_ot[~noisy], atol=TOL, rtol=0)
+    np.testing.assert_allclose(ot[noisy], want_ot[noisy], atol=5e-2, rtol=0)
+
+
+@pytest.mark.parametrize('nq,nc,s', [(32, 3000, 8), (16, 1500, 12), (3, 2500, 8), (1, 1500, 20)])
+def test_gram_matches_valu_at_size(amd, nq, nc, s):
+    """Bench-sized grids (several tiles per XCD, tail tiles): both forms of the cost stage agree; the default
+    dispatch picks one of them."""
+    g = torch.Generator().manual_seed(nq * 1000 + s)
+    qrows = torch.randn(nq * s, 768, generator=g).cuda()
+    crows = torch.randn(nc * s, 768, generator=g).cuda()
+    mk = lambda rows, n: amd.ops.DeviceRepSet(rows, (torch.arange(n, device='cuda', dtype=torch.int32) * s).contiguous(),
+                                              torch.full((n,), s, device='cuda', dtype=torch.int32), ext=0, max_len=s)
+    q, c = mk(qrows, nq), mk(crows, nc)
+    out = {}
+    for path in ('mfma', 'valu'):
+        with cost_path(path):
+            out[path] = (amd.ops.ot_sinkhorn(q, c).cpu().numpy(), amd.ops.l2max_scores(q, c).cpu().numpy())
+    dflt = (amd.ops.ot_sinkhorn(q, c).cpu().numpy(), amd.ops.l2max_scores(q, c).cpu().numpy())
+    for k in range(2):
+        assert np.isfinite(out['mfma'][k]).all()
+        np.testing.assert_allclose(out['mfma'][k], out['valu'][k], atol=5e-5, rtol=0)
+        assert np.array_equal(dflt[k], out['mfma'][k]) or np.array_equal(dflt[k], out['valu'][k])
+
+
+def test_gram_workspace_chunking(amd):
+    """A workspace smaller than the pool's slots + boxes: candidates run in chunks, results unchanged."""
+    q, c = _docs(41, [8] * 6), _docs(42, [8] * 300)
+    qs, cs = amd.ops.DeviceRepSet.from_list(q), amd.ops.DeviceRepSet.from_list(c)
+    with cost_path('mfma'):
+        full = amd.ops.ot_sinkhorn(qs, cs).cpu().numpy()
+        small = torch.empty(6 * 70 * 516 + 70 * 6144 + 6 * 6144 + 64, dtype=torch.uint8, device='cuda')
+        chunked = amd.ops.ot_sinkhorn(qs, cs, workspace=small).cpu().numpy()
+    np.testing.assert_array_equal(full, chunked)
