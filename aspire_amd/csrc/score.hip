@@ -15,6 +15,8 @@
 //     holding the T x T entries (8a+li, 8b+lj): row log-sum-exps are DPP reductions over lane bits 0-2,
 //     column ones over bits 3-5 (permlane swaps); potentials stay in registers for all ~70 eps-steps.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -1338,6 +1340,281 @@ __global__ void __launch_bounds__(256) sinkhorn4_kernel(ScoreArgs a, PairWs<1> w
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel 2, block form (throughput form for big grids, any T): a pair occupies LD x LD lanes of one DPP row and
+// lane (li, lj) owns the R x R block of entries (R li + x, R lj + y), LD * R = 8 T:
+//     T = 1: LD 2, R 4 (16 solves per wave)      T = 2, 3, 4: LD 4, R 4 / 6 / 8 (4 solves per wave)
+// so most of a reduction is in-register adds and the cross-lane part is 1-2 DPP levels per direction.  The update
+// is written around ONE exponential per entry, K_ij = exp2((f_i + g_j - C_ij) * log2(e)/eps):
+//     sum_j b_j K_ij = exp((f_i - ft_i)/eps)   =>   ft_i = f_i - eps ln2 log2(sum_j b_j K_ij)
+//     sum_i a_i K_ij = exp((g_j - gt_j)/eps)   =>   gt_j = g_j - eps ln2 log2(sum_i a_i K_ij)
+// (the log-sum-exp of sinkhorn_pair::step2 shifted by the previous potential, with the marginal weights a, b as
+// plain factors instead of log-weights inside the exponent), and the averaged update collapses to one FMA,
+// f_i <- f_i - h log2(.), h = eps ln2 / 2 (eps ln2 for the final extrapolation, 0 once a pair has run out of
+// steps while its wave mates have not).  Per step that is R^2 exp2 + 2R log2 per lane against 2 R^2 exp2 before.
+// Every pair follows its own epsilon schedule; the per-step constants are two exp2 of an affine function of the
+// step index (fp32: a relative 1e-7 on an intermediate temperature is far below the tolerance), no table.
+// A sum that leaves fp32 range (extreme scaling) poisons the score with NaN; sinkhorn_repair_kernel then redoes
+// such pairs with the max-shifted solver.
+// ---------------------------------------------------------------------------------------------
+template <int LD>
+__device__ __forceinline__ float blk_sum_j(float v) {   // all-reduce over the LD lanes that share li
+    v += lane_xor<1>(v);
+    if constexpr (LD == 4) v += lane_xor<2>(v);
+    return v;
+}
+template <int LD>
+__device__ __forceinline__ float blk_max_j(float v) {
+    v = fmaxf(v, lane_xor<1>(v));
+    if constexpr (LD == 4) v = fmaxf(v, lane_xor<2>(v));
+    return v;
+}
+template <int LD>
+__device__ __forceinline__ float blk_sum_i(float v) {   // all-reduce over the LD lanes that share lj
+    if constexpr (LD == 2) {
+        return v + lane_xor<2>(v);
+    } else {
+        v += dpp_mov<0x124>(v, v);       // row_ror:4
+        return v + dpp_mov<0x128>(v, v); // row_ror:8
+    }
+}
+template <int LD>
+__device__ __forceinline__ float blk_max_i(float v) {
+    if constexpr (LD == 2) {
+        return fmaxf(v, lane_xor<2>(v));
+    } else {
+        v = fmaxf(v, dpp_mov<0x124>(v, v));
+        return fmaxf(v, dpp_mov<0x128>(v, v));
+    }
+}
+
+template <int T, int LD, int R>
+__global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs<T> ws, int64_t n_slots) {
+    static_assert(LD * R == 8 * T, "block layout must cover the 8T x 8T slot");
+    constexpr int NL = LD * LD, PPW = 64 / NL, E = 64 * T * T, LDS_ = 8 * T;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pp = lane / NL, lp = lane % NL, li = lp / LD, lj = lp % LD;
+    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * PPW;
+    if (slot0 >= n_slots) return;
+    const bool real = slot0 + pp < n_slots;                  // tail wave: surplus groups redo the last pair, store nothing
+    const int64_t slot = real ? slot0 + pp : n_slots - 1;
+    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+    const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
+    const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
+    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
+    const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
+    const int q_len = a.q.len[q_idx], c_len = a.c.len[c_idx];
+
+    float cost[R][R];
+    bool rv[R], cv[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        rv[t] = R * li + t < q_len;
+        cv[t] = R * lj + t < c_len;
+    }
+    auto load_block = [&](const float* base, float (&dst)[R][R]) {
+#pragma unroll
+        for (int x = 0; x < R; ++x) {
+            const float* row = base + slot * E + (R * li + x) * LDS_ + R * lj;
+            if constexpr (R % 4 == 0) {
+#pragma unroll
+                for (int y = 0; y < R; y += 4) {
+                    const float4 v = ld4(row + y);
+                    dst[x][y] = v.x; dst[x][y + 1] = v.y; dst[x][y + 2] = v.z; dst[x][y + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int y = 0; y < R; y += 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(row + y);
+                    dst[x][y] = v.x; dst[x][y + 1] = v.y;
+                }
+            }
+        }
+    };
+    // ---- marginals (pair_distances.py:57-60) from -cdist; only the weights survive this scope -----------------
+    const float temp = (float)a.temp;
+    float wa[R], wb[R];
+    {
+        load_block(ws.neg, cost);   // borrowed: holds -cdist here
+        float qm[R], cm[R];
+#pragma unroll
+        for (int x = 0; x < R; ++x) {
+            float m = kNegBig;
+#pragma unroll
+            for (int y = 0; y < R; ++y) m = fmaxf(m, (rv[x] && cv[y]) ? cost[x][y] : kNegBig);
+            qm[x] = blk_max_j<LD>(m) / temp;
+        }
+#pragma unroll
+        for (int y = 0; y < R; ++y) {
+            float m = kNegBig;
+#pragma unroll
+            for (int x = 0; x < R; ++x) m = fmaxf(m, (rv[x] && cv[y]) ? cost[x][y] : kNegBig);
+            cm[y] = blk_max_i<LD>(m) / temp;
+        }
+        float mq = kNegBig, mc = kNegBig;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            mq = fmaxf(mq, rv[t] ? qm[t] : kNegBig);
+            mc = fmaxf(mc, cv[t] ? cm[t] : kNegBig);
+        }
+        mq = blk_max_i<LD>(mq);
+        mc = blk_max_j<LD>(mc);
+        float sq = 0.f, sc = 0.f;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            sq += rv[t] ? fast_exp(qm[t] - mq) : 0.f;
+            sc += cv[t] ? fast_exp(cm[t] - mc) : 0.f;
+        }
+        const float lsq = fast_log(blk_sum_i<LD>(sq)), lsc = fast_log(blk_sum_j<LD>(sc));
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;   // log_softmax(...).exp(); zero weight == geomloss's
+            wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;   // log-weight -100000
+        }
+    }
+    load_block(ws.cost, cost);
+    float diam;
+    if (a.diameter == nullptr) {
+        diam = sqrtf(ws.diam2[slot]);
+    } else {
+        diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
+    }
+    // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = exp(ld + (k-1) lsc), n_mid+1 = blur, n_mid+2 = blur (final)
+    const double ld = log((double)diam), lbl = log(a.blur), lsc = log(a.scaling);
+    int n_mid = (int)ceil((lbl - ld) / lsc);
+    n_mid = n_mid < 0 ? 0 : n_mid;
+    const int n_steps = n_mid + 3;
+    int max_steps = n_steps;
+#pragma unroll
+    for (int m = NL; m < 64; m <<= 1) max_steps = max(max_steps, __shfl_xor(max_steps, m));
+    const float ldf = (float)(ld * 1.4426950408889634), lscf = (float)(lsc * 1.4426950408889634);
+    const float c_r2 = 0.5287663729448977f - ldf;      // log2(log2 e) - log2(diam):  r2_k = exp2(c_r2 - (k-1) lscf)
+    const float c_h = -1.5287663729448977f + ldf;      // log2(ln2 / 2) + log2(diam): h_k  = exp2(c_h  + (k-1) lscf)
+    const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
+    const float eb = (float)a.blur;
+    const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
+
+    // ---- initialisation at eps = diam: softmin of the bare weights.  No shift is needed: the largest weight of a
+    // probability vector over <= 32 atoms is >= 1/32 and C/diam <= ~1, so the sums stay in range. --------------
+    float f[R], g[R];
+    {
+        float rs[R], cs[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) rs[t] = cs[t] = 0.f;
+#pragma unroll
+        for (int x = 0; x < R; ++x)
+#pragma unroll
+            for (int y = 0; y < R; ++y) {
+                const float k0 = __builtin_amdgcn_exp2f(-cost[x][y] * r2_first);
+                rs[x] = fmaf(wb[y], k0, rs[x]);
+                cs[y] = fmaf(wa[x], k0, cs[y]);
+            }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            f[t] = -2.f * h_first * __builtin_amdgcn_logf(blk_sum_j<LD>(rs[t]));
+            g[t] = -2.f * h_first * __builtin_amdgcn_logf(blk_sum_i<LD>(cs[t]));
+        }
+    }
+    // ---- the annealing loop ---------------------------------------------------------------------------------
+    for (int k = 0; k < max_steps; ++k) {
+        const float kf = (float)(k - 1);
+        float r2 = __builtin_amdgcn_exp2f(fmaf(-kf, lscf, c_r2));
+        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, c_h));
+        if (k == 0) { r2 = r2_first; h = h_first; }
+        if (k > n_mid) { r2 = r2_blur; h = k == n_mid + 1 ? h_blur : (k == n_mid + 2 ? 2.f * h_blur : 0.f); }
+        float f2[R], g2[R], rs[R], cs[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            f2[t] = f[t] * r2;
+            g2[t] = g[t] * r2;
+            rs[t] = cs[t] = 0.f;
+        }
+#pragma unroll
+        for (int x = 0; x < R; ++x)
+#pragma unroll
+            for (int y = 0; y < R; ++y) {
+                const float kxy = __builtin_amdgcn_exp2f(fmaf(-cost[x][y], r2, f2[x] + g2[y]));
+                rs[x] = fmaf(wb[y], kxy, rs[x]);
+                cs[y] = fmaf(wa[x], kxy, cs[y]);
+            }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            f[t] = fmaf(-h, __builtin_amdgcn_logf(blk_sum_j<LD>(rs[t])), f[t]);
+            g[t] = fmaf(-h, __builtin_amdgcn_logf(blk_sum_i<LD>(cs[t])), g[t]);
+        }
+    }
+    // ---- outputs ---------------------------------------------------------------------------------------------
+    float score;
+    if (a.want == ASPIRE_OT_DISTANCE) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
+            acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
+        }
+        score = blk_sum_i<LD>(blk_sum_j<LD>(acc));
+    } else {
+        const float rb = rcp_refined(eb);
+        load_block(ws.neg, cost);
+        float acc = 0.f;
+#pragma unroll
+        for (int x = 0; x < R; ++x)
+#pragma unroll
+            for (int y = 0; y < R; ++y) {
+                const bool valid = rv[x] && cv[y];
+                const float negm = valid ? cost[x][y] : 0.f;
+                const float outer = valid ? f[x] + g[y] : 0.f;
+                acc += fast_exp(div_r(outer + negm, eb, rb)) * (wa[x] * wb[y]) * negm;
+            }
+        score = blk_sum_i<LD>(blk_sum_j<LD>(acc));
+    }
+    // an overflowed / vanished sum sticks to the potentials as inf / nan: poison the pair (repaired afterwards)
+    if (!(fabsf(score) < 1e30f) || q_len > 8 * T || c_len > 8 * T) score = __builtin_nanf("");
+    if (real && lp == 0) a.scores[p] = score;
+}
+
+// Pairs the block form poisoned (NaN score) are solved again, one wave each, by the max-shifted solver.
+template <int T>
+__global__ void __launch_bounds__(256) sinkhorn_repair_kernel(ScoreArgs a, PairWs<T> ws, int64_t n_slots) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (base >= n_slots) return;
+    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+    auto index_of = [&](int64_t slot, int64_t& q_idx, int64_t& c_idx) {
+        const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
+        q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
+        c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
+        return paired ? c_idx : q_idx * a.c.n + c_idx;
+    };
+    bool bad = false;
+    if (base + lane < n_slots) {
+        int64_t qi, ci;
+        const float s = a.scores[index_of(base + lane, qi, ci)];
+        bad = !(fabsf(s) < 1e30f);
+    }
+    unsigned long long todo = __ballot(bad);
+    while (todo) {
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t slot = base + k;
+        int64_t q_idx, c_idx;
+        const int64_t p = index_of(slot, q_idx, c_idx);
+        PairState<T> st;
+        load_pair<T>(st, ws, slot, lane);
+        float diam;
+        if (a.diameter == nullptr) {
+            diam = sqrtf(ws.diam2[slot]);
+        } else {
+            diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
+        }
+        sinkhorn_pair<T>(a, st, a.q.len[q_idx], a.c.len[c_idx], diam, p, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batch bounding-box diameter (geomloss max_diameter over the call's x and y tensors)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) diameter_kernel(ScoreArgs a, int64_t group, float* out) {
@@ -1596,7 +1873,18 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
             // Packed solves (4 per wave) have twice the throughput (1 x 20 000: 233 -> 197 us per call) but ~2x the
             // latency of one solve per wave (26.7 vs 15.4 us per call at 50 pairs): use them once the grid is big
             // enough that throughput is what counts.
-            if (T == 1 && !extra && n_slots >= 4096) {
+            // ASPIRE_HIP_SINKHORN=wave|packed|block pins the form (parity tests, tuning); default: by grid size
+            const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
+            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : 0;
+            const int form = pinned ? pinned : (n_slots >= 4096 ? 3 : 1);
+            if (form == 3 && !extra) {
+                constexpr int LD = T == 1 ? 2 : 4, R = 8 * T / LD, PPB = 4 * 64 / (LD * LD);
+                hipLaunchKernelGGL((sinkhorn_block_kernel<T, LD, R>), dim3((unsigned)((n_slots + PPB - 1) / PPB)), dim3(256), 0,
+                                   (hipStream_t)stream, a, ws, n_slots);
+                ASPIRE_LAUNCH_OK();
+                hipLaunchKernelGGL(sinkhorn_repair_kernel<T>, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0,
+                                   (hipStream_t)stream, a, ws, n_slots);
+            } else if (form == 2 && T == 1 && !extra) {
                 PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
                 hipLaunchKernelGGL(sinkhorn4_kernel, dim3((unsigned)((n_slots + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a,
                                    ws1, n_slots);

@@ -1,0 +1,104 @@
+"""The three forms of the Sinkhorn kernel (one solve per wave / four packed per wave / block form) agree with each
+other and with the oracle.  ASPIRE_HIP_SINKHORN=wave|packed|block pins the form; the default picks by grid size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def amd():
+    from aspire_amd import ops, scorer, _lib
+    assert torch.cuda.is_available()
+    return type('NS', (), dict(ops=ops, scorer=scorer, lib=_lib))
+
+
+class pinned:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def _docs(seed, lens, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return [scale * torch.randn(int(n), 768, generator=g) for n in lens]
+
+
+@pytest.mark.parametrize('qlens,clens', [
+    ([8], [8, 5, 1, 3, 8, 7, 2, 6] * 3),              # T = 1: 16 solves per wave, tail wave
+    ([4, 7], [8, 1] * 9),
+    ([12], [12, 9, 16, 1, 13] * 3),                   # T = 2: 4 solves per wave
+    ([20, 17], [24, 3, 18] * 2),                      # T = 3 (R = 6)
+    ([32], [32, 26, 1, 30, 25]),                      # T = 4 (R = 8)
+])
+@pytest.mark.parametrize('cost', ['valu', 'mfma'])
+def test_block_form_matches_oracle(amd, qlens, clens, cost):
+    q, c = _docs(51, qlens), _docs(52, clens)
+    with pinned(ASPIRE_HIP_SINKHORN='block', ASPIRE_HIP_COST_PATH=cost):
+        got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('hp', [dict(geoml_scaling=0.5), dict(geoml_blur=0.5, geoml_scaling=0.99),
+                                dict(sent_sm_temp=10.0), dict(geoml_scaling=0.01), dict(geoml_blur=1e-3)])
+def test_block_form_hparams_and_repair(amd, hp):
+    """Small scaling makes the shifted sums overflow in the block form: those pairs come back through the
+    repair kernel (max-shifted solver) -- nothing is left NaN."""
+    q, c = _docs(61, [8, 6]), _docs(62, [8, 2, 7, 5] * 4)
+    with pinned(ASPIRE_HIP_SINKHORN='block'):
+        got = amd.scorer.score_pool(q, c, method='ot', schedule='pair', hparams=hp).cpu().numpy()
+    with pinned(ASPIRE_HIP_SINKHORN='wave'):
+        ref = amd.scorer.score_pool(q, c, method='ot', schedule='pair', hparams=hp).cpu().numpy()
+    assert np.isfinite(got).all()
+    want = np.array([[orc.get_similarity(x, y, hp) for y in c] for x in q], dtype=np.float32)
+    np.testing.assert_allclose(ref, want, atol=TOL, rtol=0)
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('scale', [1e-3, 30.0])
+def test_block_form_extreme_diameters(amd, scale):
+    q, c = _docs(71, [8], scale), _docs(72, [8, 4, 6, 1] * 2, scale)
+    with pinned(ASPIRE_HIP_SINKHORN='block'):
+        got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=TOL * max(1.0, scale), rtol=0)
+
+
+@pytest.mark.parametrize('nq,nc,s', [(2, 5000, 8), (1, 4500, 12), (3, 1700, 20)])
+@pytest.mark.parametrize('want', ['distance', 'plan'])
+def test_forms_agree_at_size(amd, nq, nc, s, want):
+    g = torch.Generator().manual_seed(nq * 100 + s)
+    lens_q = torch.randint(1, s + 1, (nq,), generator=g)
+    lens_c = torch.randint(1, s + 1, (nc,), generator=g)
+    lens_q[0] = s
+    q = amd.ops.DeviceRepSet.from_list([torch.randn(int(n), 768, generator=g) for n in lens_q])
+    c = amd.ops.DeviceRepSet.from_list([torch.randn(int(n), 768, generator=g) for n in lens_c])
+    w = amd.lib.OT_DISTANCE if want == 'distance' else amd.lib.OT_PLAN_SIM
+    out = {}
+    forms = ['wave', 'block'] + (['packed'] if s <= 8 else [])
+    for form in forms:
+        with pinned(ASPIRE_HIP_SINKHORN=form):
+            out[form] = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
+    dflt = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
+    tol = 5e-5 if want == 'distance' else 1e-2     # plan-weighted similarity: see test_gpu_scoring.PLAN_SIM_TOL
+    for form in forms[1:]:
+        assert np.isfinite(out[form]).all()
+        np.testing.assert_allclose(out[form], out['wave'], atol=tol, rtol=0)
+    assert np.array_equal(dflt, out['block'])       # >= 4096 pairs: the block form is the default

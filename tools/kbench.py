@@ -43,4 +43,5 @@ def main():
     us = timeit(lambda: None)
     print(f'{"empty loop":36s} {us:9.1f} us')
 
-main()
+if __name__ == "__main__":
+    main()
