@@ -1389,7 +1389,7 @@ __device__ __forceinline__ float blk_max_i(float v) {
 
 template <int T, int LD, int R>
 __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs<T> ws, int64_t n_slots) {
-    static_assert(LD * R == 8 * T, "block layout must cover the 8T x 8T slot");
+    static_assert(LD * R <= 8 * T && LD * R > 8 * (T - 1), "block layout must fit the 8T x 8T slot");
     constexpr int NL = LD * LD, PPW = 64 / NL, E = 64 * T * T, LDS_ = 8 * T;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1413,6 +1413,8 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
         rv[t] = R * li + t < q_len;
         cv[t] = R * lj + t < c_len;
     }
+    // Entries outside the pair's q_len x c_len rectangle are never written by some producers (and are masked by
+    // zero weights here): read them as 0 so that no stale inf / nan can reach a sum through 0 * x.
     auto load_block = [&](const float* base, float (&dst)[R][R]) {
 #pragma unroll
         for (int x = 0; x < R; ++x) {
@@ -1423,13 +1425,18 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
                     const float4 v = ld4(row + y);
                     dst[x][y] = v.x; dst[x][y + 1] = v.y; dst[x][y + 2] = v.z; dst[x][y + 3] = v.w;
                 }
-            } else {
+            } else if constexpr (R % 2 == 0) {
 #pragma unroll
                 for (int y = 0; y < R; y += 2) {
                     const float2 v = *reinterpret_cast<const float2*>(row + y);
                     dst[x][y] = v.x; dst[x][y + 1] = v.y;
                 }
+            } else {
+#pragma unroll
+                for (int y = 0; y < R; ++y) dst[x][y] = row[y];
             }
+#pragma unroll
+            for (int y = 0; y < R; ++y) dst[x][y] = (rv[x] && cv[y]) ? dst[x][y] : 0.f;
         }
     };
     // ---- marginals (pair_distances.py:57-60) from -cdist; only the weights survive this scope -----------------
@@ -1570,7 +1577,7 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
         score = blk_sum_i<LD>(blk_sum_j<LD>(acc));
     }
     // an overflowed / vanished sum sticks to the potentials as inf / nan: poison the pair (repaired afterwards)
-    if (!(fabsf(score) < 1e30f) || q_len > 8 * T || c_len > 8 * T) score = __builtin_nanf("");
+    if (!(fabsf(score) < 1e30f) || q_len > LD * R || c_len > LD * R) score = __builtin_nanf("");
     if (real && lp == 0) a.scores[p] = score;
 }
 
@@ -1875,15 +1882,31 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
             // enough that throughput is what counts.
             // ASPIRE_HIP_SINKHORN=wave|packed|block pins the form (parity tests, tuning); default: by grid size
             const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
-            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : 0;
+            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : 0;
             const int form = pinned ? pinned : (n_slots >= 4096 ? 3 : 1);
-            if (form == 3 && !extra) {
-                constexpr int LD = T == 1 ? 2 : 4, R = 8 * T / LD, PPB = 4 * 64 / (LD * LD);
-                hipLaunchKernelGGL((sinkhorn_block_kernel<T, LD, R>), dim3((unsigned)((n_slots + PPB - 1) / PPB)), dim3(256), 0,
-                                   (hipStream_t)stream, a, ws, n_slots);
+            if (form >= 3 && !extra) {
+                // lanes per pair side LD and entries per lane side R: the smallest block grid that covers max_rows
+                auto launch_block = [&](auto ldc, auto rc) {
+                    constexpr int LD = decltype(ldc)::value, R = decltype(rc)::value, PPB = 4 * 64 / (LD * LD);
+                    if constexpr (LD * R <= 8 * T && LD * R > 8 * (T - 1)) {
+                        hipLaunchKernelGGL((sinkhorn_block_kernel<T, LD, R>), dim3((unsigned)((n_slots + PPB - 1) / PPB)),
+                                           dim3(256), 0, (hipStream_t)stream, a, ws, n_slots);
+                    }
+                };
+                using I2 = std::integral_constant<int, 2>;
+                using I4 = std::integral_constant<int, 4>;
+                const int r4 = (max_rows + 3) / 4;
+                if (T == 1) launch_block(I2{}, I4{});
+                else if (r4 == 3) launch_block(I4{}, std::integral_constant<int, 3>{});
+                else if (r4 == 4) launch_block(I4{}, I4{});
+                else if (r4 == 5) launch_block(I4{}, std::integral_constant<int, 5>{});
+                else if (r4 == 6) launch_block(I4{}, std::integral_constant<int, 6>{});
+                else if (r4 == 7) launch_block(I4{}, std::integral_constant<int, 7>{});
+                else launch_block(I4{}, std::integral_constant<int, 8>{});
                 ASPIRE_LAUNCH_OK();
-                hipLaunchKernelGGL(sinkhorn_repair_kernel<T>, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0,
-                                   (hipStream_t)stream, a, ws, n_slots);
+                if (form == 3)
+                    hipLaunchKernelGGL(sinkhorn_repair_kernel<T>, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0,
+                                       (hipStream_t)stream, a, ws, n_slots);
             } else if (form == 2 && T == 1 && !extra) {
                 PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
                 hipLaunchKernelGGL(sinkhorn4_kernel, dim3((unsigned)((n_slots + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a,
