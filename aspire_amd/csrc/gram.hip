@@ -25,6 +25,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "score_types.h"
 
 namespace aspire {
@@ -58,13 +60,30 @@ __device__ __forceinline__ float unorder_key(uint32_t u) {
     return __builtin_bit_cast(float, (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
 }
 
+// Row addresses travel through LDS tables as integers and come back as GLOBAL-address-space pointers: a plain
+// `const float*` read from LDS is a generic pointer, which the compiler serves with flat_load_dword -- four scalar
+// loads per float4, each bumping lgkmcnt, so that every LDS wait of the MFMA loop also waited for HBM.  Rows that
+// do not exist point at a row of zeros instead of being predicated.
+typedef const float __attribute__((address_space(1)))* gfp;
+__device__ float g_zero_row[kD];
+__device__ __forceinline__ float4 ldg4(unsigned long long addr, int ofs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float __attribute__((ext_vector_type(4))) v4;
+    const v4 v = *reinterpret_cast<const v4 __attribute__((address_space(1)))*>(reinterpret_cast<gfp>(addr) + ofs);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    (void)addr; (void)ofs;
+    return make_float4(0.f, 0.f, 0.f, 0.f);   // host pass of the single-source compile; never called
+#endif
+}
+
 __device__ __forceinline__ float sq4f(const float4& a) { return fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x))); }
 
 // sum_d (x_d - y_d)^2 over the 768 coordinates (rare path: near-coincident sentences)
-__device__ __noinline__ float direct_d2(const float* x, const float* y) {
+__device__ __noinline__ float direct_d2(unsigned long long x, unsigned long long y) {
     float s0 = 0.f, s1 = 0.f;
     for (int k = 0; k < kD; k += 8) {
-        const float4 a = ld4(x + k), b = ld4(y + k), c = ld4(x + k + 4), d = ld4(y + k + 4);
+        const float4 a = ldg4(x, k), b = ldg4(y, k), c = ldg4(x, k + 4), d = ldg4(y, k + 4);
         const float e0 = a.x - b.x, e1 = a.y - b.y, e2 = a.z - b.z, e3 = a.w - b.w;
         const float f0 = c.x - d.x, f1 = c.y - d.y, f2 = c.z - d.z, f3 = c.w - d.w;
         s0 = fmaf(e3, e3, fmaf(e2, e2, fmaf(e1, e1, fmaf(e0, e0, s0))));
@@ -83,8 +102,8 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
     constexpr bool B_ALL = BN * kBK / 4 >= 256;
     __shared__ __attribute__((aligned(16))) float As[2][kBK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK][LDB];
-    __shared__ const float* c_ptr[kBM];
-    __shared__ const float* q_ptr[BN];
+    __shared__ unsigned long long c_ptr[kBM];   // global addresses of the tile's rows (zero row where there is none)
+    __shared__ unsigned long long q_ptr[BN];
     __shared__ long long c_off[kBM];
     __shared__ long long q_off[BN];
     __shared__ __attribute__((aligned(16))) float c_nrm[kBM];
@@ -102,6 +121,7 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
         L = x * q8 + (x < r8 ? x : r8) + (b >> 3);
     }
     const uint32_t ct = L / (uint32_t)g.n_qt, qt = L - ct * (uint32_t)g.n_qt;
+    const unsigned long long zrow = (unsigned long long)(uintptr_t)&g_zero_row[0];
 
     // ---- tile tables -----------------------------------------------------------------------------------
     if (tid < kBM) {
@@ -113,7 +133,7 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
             len = g.c.len[g.cand0 + c_loc];
             start = g.c.start[g.cand0 + c_loc];
         }
-        c_ptr[tid] = (doc_ok && i < len) ? g.c.rows + (size_t)(start + i) * kD : nullptr;
+        c_ptr[tid] = (doc_ok && i < len) ? (unsigned long long)(uintptr_t)(g.c.rows + (size_t)(start + i) * kD) : zrow;
         c_off[tid] = !doc_ok ? -1 : L2MAX ? (long long)d : (long long)c_loc * g.E + i;
         c_mm[tid] = len > 25;
     } else if (tid < kBM + BN) {
@@ -126,7 +146,7 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
             len = g.q.len[q_loc];
             start = g.q.start[q_loc];
         }
-        q_ptr[r] = (doc_ok && i < len) ? g.q.rows + (size_t)(start + i) * kD : nullptr;
+        q_ptr[r] = (doc_ok && i < len) ? (unsigned long long)(uintptr_t)(g.q.rows + (size_t)(start + i) * kD) : zrow;
         q_off[r] = !doc_ok ? -1 : L2MAX ? (long long)d : ((long long)q_loc * g.ncand) * g.E + (long long)i * g.ld;
         q_mm[r] = len > 25;
     }
@@ -135,44 +155,46 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
 
     // ---- operand staging: thread -> (row, 16-byte k chunk) ---------------------------------------------
     const int lrow = tid >> 2, lk4 = tid & 3;
-    const float* pa[A_F4];
-    const float* pb[B_F4];
+    unsigned long long pa[A_F4], pb[B_F4];
 #pragma unroll
     for (int p = 0; p < A_F4; ++p) pa[p] = c_ptr[lrow + 64 * p];
 #pragma unroll
-    for (int p = 0; p < B_F4; ++p) pb[p] = (B_ALL || lrow < BN) ? q_ptr[(lrow + 64 * p) % BN] : nullptr;
-    float4 ra[A_F4], rb[B_F4];
+    for (int p = 0; p < B_F4; ++p) pb[p] = q_ptr[(lrow + 64 * p) % BN];
+    // Two register sets: while tile t is multiplied out of LDS, tile t+1 sits in one set (landed or landing) and
+    // tile t+2's loads go out into the other -- candidate rows come from HBM, and one iteration of MFMAs
+    // (~1 us) does not cover that latency, two do.
+    float4 ra[2][A_F4], rb[2][B_F4];
     float na[A_F4], nb[B_F4];
 #pragma unroll
     for (int p = 0; p < A_F4; ++p) na[p] = 0.f;
 #pragma unroll
     for (int p = 0; p < B_F4; ++p) nb[p] = 0.f;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](auto setc, int k0) {
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
-        for (int p = 0; p < A_F4; ++p) ra[p] = pa[p] ? ld4(pa[p] + k0 + 4 * lk4) : zero4;
+        for (int p = 0; p < A_F4; ++p) ra[S][p] = ldg4(pa[p], k0 + 4 * lk4);
 #pragma unroll
-        for (int p = 0; p < B_F4; ++p) rb[p] = pb[p] ? ld4(pb[p] + k0 + 4 * lk4) : zero4;
+        for (int p = 0; p < B_F4; ++p) rb[S][p] = ldg4(pb[p], k0 + 4 * lk4);
     };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < A_F4; ++p) {
-            const int row = lrow + 64 * p;
-            As[buf][4 * lk4 + 0][row] = ra[p].x;
-            As[buf][4 * lk4 + 1][row] = ra[p].y;
-            As[buf][4 * lk4 + 2][row] = ra[p].z;
-            As[buf][4 * lk4 + 3][row] = ra[p].w;
-            na[p] += sq4f(ra[p]);
-        }
-#pragma unroll
-        for (int p = 0; p < B_F4; ++p) {
+    // one float4 piece (A piece p < A_F4, B piece p - A_F4 otherwise) of a register set -> LDS, k-major
+    auto store_piece = [&](auto setc, int piece, int buf) {
+        constexpr int S = decltype(setc)::value;
+        if (piece < A_F4) {
+            const int p = piece, row = lrow + 64 * p;
+            As[buf][4 * lk4 + 0][row] = ra[S][p].x;
+            As[buf][4 * lk4 + 1][row] = ra[S][p].y;
+            As[buf][4 * lk4 + 2][row] = ra[S][p].z;
+            As[buf][4 * lk4 + 3][row] = ra[S][p].w;
+            na[p] += sq4f(ra[S][p]);
+        } else if (piece < A_F4 + B_F4) {
+            const int p = piece - A_F4;
             if (B_ALL || lrow < BN) {
                 const int row = lrow + 64 * p;
-                Bs[buf][4 * lk4 + 0][row] = rb[p].x;
-                Bs[buf][4 * lk4 + 1][row] = rb[p].y;
-                Bs[buf][4 * lk4 + 2][row] = rb[p].z;
-                Bs[buf][4 * lk4 + 3][row] = rb[p].w;
-                nb[p] += sq4f(rb[p]);
+                Bs[buf][4 * lk4 + 0][row] = rb[S][p].x;
+                Bs[buf][4 * lk4 + 1][row] = rb[S][p].y;
+                Bs[buf][4 * lk4 + 2][row] = rb[S][p].z;
+                Bs[buf][4 * lk4 + 3][row] = rb[S][p].w;
+                nb[p] += sq4f(rb[S][p]);
             }
         }
     };
@@ -185,28 +207,51 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int nk = kD / kBK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nk) load_tiles((t + 1) * kBK);   // in flight under the MFMAs below
+    // One tile's worth of MFMAs out of LDS buffer `buf`, with the iteration's other work threaded between the
+    // eight k-steps (pinned by sched_barrier) instead of bunched before and after them: next-but-one tile's global
+    // loads after step 0, the next tile's register -> LDS stores (into the other buffer, which nobody reads until
+    // the barrier) after steps 2..5.  Bunched, the two workgroups that share a CU fall into step -- both in their
+    // MFMA phase, then both out of it -- and the matrix pipe idles half the time (measured 42 % busy).
+    auto tile_step = [&](auto load_set, auto store_set, int buf, bool do_load, int k_load, bool do_store) {
+        float a[2][TM], b[2][TN];   // operands of k-step kk+1 are read while step kk's MFMAs run
+        auto read_operands = [&](int kk, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[slot][i] = As[buf][2 * kk + lk][wr * WM + 32 * i + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[slot][j] = Bs[buf][2 * kk + lk][wc * WN + 32 * j + lr];
+        };
+        read_operands(0, 0);
 #pragma unroll
         for (int kk = 0; kk < kBK / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kk + lk][wr * WM + 32 * i + lr];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kk + lk][wc * WN + 32 * j + lr];
+            if (kk + 1 < kBK / 2) read_operands(kk + 1, (kk + 1) & 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+            if (kk == 0 && do_load) load_tiles(load_set, k_load);
+            if (kk >= 2 && kk < 6 && do_store) store_piece(store_set, kk - 2, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (t + 1 < nk) store_tiles(buf ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    constexpr int nk = kD / kBK;
+    static_assert(nk % 2 == 0, "the loop below is unrolled by two");
+    static_assert(A_F4 + B_F4 <= 4, "four store slots per tile step");
+    load_tiles(S0{}, 0);
+    load_tiles(S1{}, kBK);
+#pragma unroll
+    for (int piece = 0; piece < A_F4 + B_F4; ++piece) store_piece(S0{}, piece, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < nk; t += 2) {
+        // LDS buffer 0 = tile t, set 1 = tile t+1 (stored into buffer 1 here), set 0 free (tile t+2 loads into it)
+        tile_step(S0{}, S1{}, 0, t + 2 < nk, (t + 2) * kBK, true);
+        __syncthreads();
+        // LDS buffer 1 = tile t+1, set 0 = tile t+2, set 1 free
+        tile_step(S1{}, S0{}, 1, t + 3 < nk, (t + 3) * kBK, t + 2 < nk);
         __syncthreads();
     }
 
@@ -235,7 +280,7 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
             const int n = wc * WN + 32 * j + lr;
             const long long qo = q_off[n];
             const float xx = q_nrm[n];
-            const float* qp = q_ptr[n];
+            const unsigned long long qp = q_ptr[n];
             const bool qmm = q_mm[n];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -252,13 +297,13 @@ __global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
                     cost[k] = sqrtf(fmaxf(sq, 1e-8f));
                     neg[k] = -sqrtf(fmaxf(sq, 0.f));
                     const float ns = xx + yy[k];
-                    if (!mm && sq < kDirectTau * ns * ns && qp && c_ptr[m0 + k]) neg[k] = -sqrtf(direct_d2(qp, c_ptr[m0 + k]));
+                    if (!mm && sq < kDirectTau * ns * ns && qp != zrow && c_ptr[m0 + k] != zrow) neg[k] = -sqrtf(direct_d2(qp, c_ptr[m0 + k]));
                 }
                 if constexpr (L2MAX) {
                     float best = -INFINITY;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (qp && c_ptr[m0 + k]) best = fmaxf(best, neg[k]);
+                        if (qp != zrow && c_ptr[m0 + k] != zrow) best = fmaxf(best, neg[k]);
                     if (best > -INFINITY) atomicMax(&pairmax[(int)co * 16 + (int)qo], order_key(best));
                 } else {
                     *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
