@@ -93,7 +93,7 @@ __device__ __noinline__ float direct_d2(unsigned long long x, unsigned long long
 }
 
 template <int BN, bool L2MAX>
-__global__ void __launch_bounds__(256) pair_gram_kernel(GramArgs g) {
+__global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int WM = kBM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int LDA = kBM + 4, LDB = BN + 4;
