@@ -482,10 +482,14 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
         }
     };
     // The same update with the critical path cut to the bone (the kernel's time at ~1000 pairs IS 75 x this
-    // chain): everything in base 2 so v_exp_f32 / v_log_f32 need no scaling multiplies -- r2 = log2(e)/eps
-    // turns f, g, C into base-2 exponent units in ONE multiply each (r2 is rounded once from float64), the
-    // shift by the previous potential makes the summand exp2((lb2 + g2 - C2) + f2), and the new potential is
-    // (eps*ln2) * (f2 - log2(sum)).  Measured against a float64 evaluation this is as accurate as the fp32 CPU
+    // chain).  Everything is in base 2 (r2 = log2(e)/eps, rounded once from float64, so v_exp_f32 / v_log_f32 need no
+    // scaling multiplies) and the state carried from step to step is phi_ij = f_i + g_j - C_ij itself:
+    //     sum_j b_j 2^(phi_ij r2) = exp((f_i - ft_i)/eps)        sum_i a_i 2^(phi_ij r2) = exp((g_j - gt_j)/eps)
+    // (the log-sum-exps shifted by the previous potentials), so with LR_i, LC_j the log2 of those sums the averaged
+    // update is  f_i -= h LR_i,  g_j -= h LC_j,  phi_ij -= h (LR_i + LC_j),  h = eps ln2 / 2  (eps ln2 for the final
+    // extrapolation).  The dependent chain per step is fma - exp2 - reduce - log2 - add - fma; f and g are updated
+    // off that chain.  phi's rounding matters only where |phi| is small (the transport plan's support), where its
+    // ulp is far below the tolerance.  Measured against a float64 evaluation this is as accurate as the fp32 CPU
     // path (tools/oterr.py).
     float la2[T], lb2[T];
 #pragma unroll
@@ -493,23 +497,23 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
         la2[t] = la[t] * kLog2e;
         lb2[t] = lb[t] * kLog2e;
     }
-    auto step2 = [&](float r2, float eln2, bool averaged) {
-        float f2[T], g2[T], ft[T], gt[T];
+    float phi[T][T];
+    auto phi_init = [&]() {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            f2[t] = f[t] * r2;
-            g2[t] = g[t] * r2;
-        }
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb)
+                phi[ta][tb] = (rv[ta] && cv[tb]) ? (f[ta] + g[tb]) - s.cost[ta][tb] : 0.f;   // masked slots may hold stale bits
+    };
+    auto step2 = [&](float r2, float h) {
+        float lr[T], lc[T];
         if constexpr (T == 1) {
             // One entry per lane.  The column chain (DPP row_ror:8, v_permlane16_swap, v_permlane32_swap) and
             // the row chain (three DPP quad ops) are independent; a single wave issues in order, so they are
             // interleaved level by level here and pinned with sched_barrier -- a cross-lane op costs 17-26
             // cycles of dependent latency (tools: build/dbg/lat.hip), overlapped they cost it once, not twice.
-            const float c2 = s.cost[0][0] * r2;
-            const float uc = ((la2[0] + f2[0]) - c2) + g2[0];
-            const float ur = ((lb2[0] + g2[0]) - c2) + f2[0];
-            float sc = __builtin_amdgcn_exp2f(rv[0] ? uc : kNegBig);
-            float sr = __builtin_amdgcn_exp2f(cv[0] ? ur : kNegBig);
+            float sc = __builtin_amdgcn_exp2f(fmaf(phi[0][0], r2, la2[0]));
+            float sr = __builtin_amdgcn_exp2f(fmaf(phi[0][0], r2, lb2[0]));
             __builtin_amdgcn_sched_barrier(0);
             sc += lane_xor<8>(sc);
             sr += lane_xor<1>(sr);
@@ -520,34 +524,32 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             sc = swap_add<32>(sc, sc);
             sr += dpp_mov<0x141>(sr, sr);
             __builtin_amdgcn_sched_barrier(0);
-            gt[0] = eln2 * (g2[0] - __builtin_amdgcn_logf(sc));
-            ft[0] = eln2 * (f2[0] - __builtin_amdgcn_logf(sr));
+            lc[0] = __builtin_amdgcn_logf(sc);
+            lr[0] = __builtin_amdgcn_logf(sr);
         } else {
 #pragma unroll
-            for (int tb = 0; tb < T; ++tb) {   // columns: g~_j
+            for (int tb = 0; tb < T; ++tb) {   // columns
                 float sum = 0.f;
 #pragma unroll
-                for (int ta = 0; ta < T; ++ta) {
-                    const float u = ((la2[ta] + f2[ta]) - s.cost[ta][tb] * r2) + g2[tb];
-                    sum += __builtin_amdgcn_exp2f(rv[ta] ? u : kNegBig);
-                }
-                gt[tb] = eln2 * (g2[tb] - __builtin_amdgcn_logf(col8_sum(sum)));
+                for (int ta = 0; ta < T; ++ta) sum += __builtin_amdgcn_exp2f(fmaf(phi[ta][tb], r2, la2[ta]));
+                lc[tb] = __builtin_amdgcn_logf(col8_sum(sum));
             }
 #pragma unroll
-            for (int ta = 0; ta < T; ++ta) {   // rows: f~_i
+            for (int ta = 0; ta < T; ++ta) {   // rows
                 float sum = 0.f;
 #pragma unroll
-                for (int tb = 0; tb < T; ++tb) {
-                    const float u = ((lb2[tb] + g2[tb]) - s.cost[ta][tb] * r2) + f2[ta];
-                    sum += __builtin_amdgcn_exp2f(cv[tb] ? u : kNegBig);
-                }
-                ft[ta] = eln2 * (f2[ta] - __builtin_amdgcn_logf(row8_sum(sum)));
+                for (int tb = 0; tb < T; ++tb) sum += __builtin_amdgcn_exp2f(fmaf(phi[ta][tb], r2, lb2[tb]));
+                lr[ta] = __builtin_amdgcn_logf(row8_sum(sum));
             }
         }
 #pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb) phi[ta][tb] = fmaf(-h, lr[ta] + lc[tb], phi[ta][tb]);
+#pragma unroll
         for (int t = 0; t < T; ++t) {
-            g[t] = averaged ? 0.5f * (g[t] + gt[t]) : gt[t];
-            f[t] = averaged ? 0.5f * (f[t] + ft[t]) : ft[t];
+            g[t] = fmaf(-h, lc[t], g[t]);
+            f[t] = fmaf(-h, lr[t], f[t]);
         }
     };
     // The whole annealing loop.  exact = false uses the shifted log-sum-exp; an overflowed / vanished
@@ -585,13 +587,14 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
                 }
             } else {
                 const float my_r2 = (float)(1.4426950408889634 / (double)my_eps);
-                const float my_eln2 = (float)((double)my_eps * 0.6931471805599453);
+                const float my_h = (float)((double)my_eps * (0.5 * 0.6931471805599453));
+                if (base == 0) phi_init();
                 for (int k = 0; k < cnt; ++k) {
                     const float r2 =
                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r2), k));
-                    const float eln2 =
-                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eln2), k));
-                    step2(r2, eln2, true);
+                    const float h =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_h), k));
+                    step2(r2, h);
                 }
             }
         }
@@ -602,11 +605,13 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
         } else {
             const float r2 = (float)(1.4426950408889634 / (double)eps_last);
             const float eln2 = (float)((double)eps_last * 0.6931471805599453);
-            step2(r2, eln2, true);
-            step2(r2, eln2, false);
+            if (n_mid <= 0) phi_init();
+            step2(r2, 0.5f * eln2);
+            step2(r2, eln2);
         }
     };
     PHASE_STAMP(6);
+    bool phi_live = true;
     solve(false);
     {
         bool bad = false;
@@ -617,6 +622,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
         }
         if (__builtin_expect(__any(bad), 0)) {
             solve(true);
+            phi_live = false;
         }
     }
     const float rb = rcp_refined(eps_last);
@@ -644,8 +650,11 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             for (int tb = 0; tb < T; ++tb) {
                 const bool valid = rv[ta] && cv[tb];
                 const float negm = valid ? s.neg[ta][tb] : 0.f;
-                const float outer = valid ? f[ta] + g[tb] : 0.f;
-                const float plan = fast_exp(div_r(outer + negm, eps_last, rb)) * (wa[ta] * wb[tb]);
+                // f_i + g_j - dist_ij: after the fast solve phi = f + g - C is at hand with the rounding of ITS
+                // magnitude (small on the plan's support) rather than of f's and g's, and C - dist is an exact
+                // difference of two nearby floats -- eps = 0.05 amplifies this exponent's error ~20x.
+                const float expo = !valid ? 0.f : phi_live ? phi[ta][tb] + (s.cost[ta][tb] + negm) : (f[ta] + g[tb]) + negm;
+                const float plan = fast_exp(div_r(expo, eps_last, rb)) * (wa[ta] * wb[tb]);
                 acc += plan * negm;
                 const int i = ta * 8 + li, j = tb * 8 + lj;
                 if (dump && i < a.q.ext && j < a.c.ext) {
@@ -1882,7 +1891,7 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
             // enough that throughput is what counts.
             // ASPIRE_HIP_SINKHORN=wave|packed|block pins the form (parity tests, tuning); default: by grid size
             const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
-            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : 0;
+            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : !strcmp(env_form, "block16") ? 5 : 0;
             const int form = pinned ? pinned : (n_slots >= 4096 ? 3 : 1);
             if (form >= 3 && !extra) {
                 // lanes per pair side LD and entries per lane side R: the smallest block grid that covers max_rows
@@ -1896,7 +1905,8 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
                 using I2 = std::integral_constant<int, 2>;
                 using I4 = std::integral_constant<int, 4>;
                 const int r4 = (max_rows + 3) / 4;
-                if (T == 1) launch_block(I2{}, I4{});
+                if (T == 1 && form == 5) launch_block(I4{}, I2{});
+                else if (T == 1) launch_block(I2{}, I4{});
                 else if (r4 == 3) launch_block(I4{}, std::integral_constant<int, 3>{});
                 else if (r4 == 4) launch_block(I4{}, I4{});
                 else if (r4 == 5) launch_block(I4{}, std::integral_constant<int, 5>{});
@@ -1904,7 +1914,7 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
                 else if (r4 == 7) launch_block(I4{}, std::integral_constant<int, 7>{});
                 else launch_block(I4{}, std::integral_constant<int, 8>{});
                 ASPIRE_LAUNCH_OK();
-                if (form == 3)
+                if (form == 3 || form == 5)
                     hipLaunchKernelGGL(sinkhorn_repair_kernel<T>, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0,
                                        (hipStream_t)stream, a, ws, n_slots);
             } else if (form == 2 && T == 1 && !extra) {
