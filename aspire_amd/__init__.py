@@ -6,5 +6,6 @@ this package is the host-side mirror of the reference's Python call surface
 """
 from . import _lib  # noqa: F401  (fails loudly when the HIP library has not been built)
 from .batch_prep import prepare_abstracts, prepare_bert_sentences  # noqa: F401
-from .pair_distances import AllPairMaskedWasserstein, allpair_masked_dist_l2max, rep_len_tup  # noqa: F401
+from .pair_distances import (AllPairMaskedWasserstein, AllPairMaskedAttention, allpair_masked_dist_l2max,  # noqa: F401
+                             allpair_masked_dist_l2topk, rep_len_tup)
 from .consent import AspireConSent  # noqa: F401

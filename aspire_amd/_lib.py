@@ -22,6 +22,7 @@ ASPIRE_OK, ASPIRE_ERR_INVALID_ARG, ASPIRE_ERR_UNSUPPORTED, ASPIRE_ERR_HIP = 0, 1
 CDIST_AUTO, CDIST_DIRECT, CDIST_MM = 0, 1, 2
 PAIR_CROSS, PAIR_PAIRED = 0, 1
 OT_DISTANCE, OT_PLAN_SIM = 0, 1
+AGG_MAX, AGG_TOP2, AGG_ATTENTION = 0, 1, 2
 
 
 class RepSet(ctypes.Structure):
@@ -65,6 +66,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     'aspire_l2max_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
+    'aspire_l2agg_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int, c_int,
+                                        ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     'aspire_ot_sinkhorn_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int,
                                        ctypes.POINTER(OtParams), c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -237,7 +237,8 @@ __global__ void __launch_bounds__(kBlock, 3) l2max_kernel(ScoreArgs a) {
         __syncthreads();
         if (wave == 0) {
             const int64_t p = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx : q_idx * a.c.n + c_idx;
-            float best = -INFINITY;
+            float negv[T][T];
+            bool val[T][T];
 #pragma unroll
             for (int ta = 0; ta < T; ++ta)
 #pragma unroll
@@ -259,14 +260,77 @@ __global__ void __launch_bounds__(kBlock, 3) l2max_kernel(ScoreArgs a) {
 #pragma unroll
                         for (int w = 0; w < kWaves; ++w) d2 += r[w * T * T * 128 + 64 + lane];
                     }
-                    const float neg = -sqrtf(d2);
-                    const bool valid = i < q_len && j < c_len;
-                    if (valid) best = fmaxf(best, neg);
+                    negv[ta][tb] = -sqrtf(d2);
+                    val[ta][tb] = i < q_len && j < c_len;
                     if (a.out_pairsims && i < a.q.ext && j < a.c.ext)
-                        a.out_pairsims[(p * a.q.ext + i) * a.c.ext + j] = neg + (valid ? 0.f : -10e8f);
+                        a.out_pairsims[(p * a.q.ext + i) * a.c.ext + j] =
+                            negv[ta][tb] + ((val[ta][tb] || a.agg == ASPIRE_AGG_ATTENTION) ? 0.f : -10e8f);
                 }
-            best = wave_max(best);
-            if (lane == 0) a.scores[p] = best;
+            float score;
+            if (a.agg == ASPIRE_AGG_MAX) {
+                float best = -INFINITY;
+#pragma unroll
+                for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < T; ++tb)
+                        if (val[ta][tb]) best = fmaxf(best, negv[ta][tb]);
+                score = wave_max(best);
+            } else if (a.agg == ASPIRE_AGG_TOP2) {
+                // torch.topk(k=2) over the padded block: masked entries take part with -cdist - 10e8
+                float m1 = -INFINITY, m2 = -INFINITY;
+                auto push = [&](float v) {
+                    m2 = fmaxf(m2, fminf(m1, v));
+                    m1 = fmaxf(m1, v);
+                };
+#pragma unroll
+                for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < T; ++tb) {
+                        const int i = ta * 8 + li, j = tb * 8 + lj;
+                        if (val[ta][tb]) push(negv[ta][tb]);
+                        else if (i < a.q.ext && j < a.c.ext) push(negv[ta][tb] + -10e8f);
+                    }
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    const float o1 = __shfl_xor(m1, m), o2 = __shfl_xor(m2, m);
+                    m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+                    m1 = fmaxf(m1, o1);
+                }
+                if (m2 == -INFINITY) m2 = -10e8f;   // no padded extent and a 1 x 1 pair
+                score = m1 + m2;
+            } else {
+                // masked 2-D soft-max of -d / temp over the valid block, then sum p * (-d)
+                const float temp = (float)a.temp;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < T; ++tb)
+                        if (val[ta][tb]) mx = fmaxf(mx, negv[ta][tb] / temp);
+                mx = wave_max(mx);
+                float e[T][T], se = 0.f, sn = 0.f;
+#pragma unroll
+                for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < T; ++tb) {
+                        e[ta][tb] = val[ta][tb] ? expf(negv[ta][tb] / temp - mx) : 0.f;
+                        se += e[ta][tb];
+                        sn = fmaf(e[ta][tb], negv[ta][tb], sn);
+                    }
+                se = wave_sum(se);
+                sn = wave_sum(sn);
+                score = sn / se;
+                if (a.out_plan) {
+#pragma unroll
+                    for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < T; ++tb) {
+                            const int i = ta * 8 + li, j = tb * 8 + lj;
+                            if (i < a.q.ext && j < a.c.ext) a.out_plan[(p * a.q.ext + i) * a.c.ext + j] = e[ta][tb] / se;
+                        }
+                }
+            }
+            if (lane == 0) a.scores[p] = score;
         }
         __syncthreads();
     }
@@ -1748,21 +1812,31 @@ extern "C" void aspire_debug_k1_buffer(void* p) {
 
 extern "C" int aspire_max_sents(void) { return 8 * kMaxT; }
 
-extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
-                                       int cdist_mode, float* scores, float* pair_sims, void* stream) {
+extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                       int cdist_mode, int agg, double temp, float* scores, float* pair_sims,
+                                       float* pair_softmax, void* stream) {
     if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    ASPIRE_REQUIRE(agg == ASPIRE_AGG_MAX || agg == ASPIRE_AGG_TOP2 || agg == ASPIRE_AGG_ATTENTION, ASPIRE_ERR_INVALID_ARG,
+                   "bad aggregation %d", agg);
+    ASPIRE_REQUIRE(agg != ASPIRE_AGG_ATTENTION || temp > 0, ASPIRE_ERR_INVALID_ARG, "attention temperature must be positive");
+    ASPIRE_REQUIRE(!pair_softmax || agg == ASPIRE_AGG_ATTENTION, ASPIRE_ERR_INVALID_ARG,
+                   "pair_softmax is an output of the attention aggregation only");
     if (q->n == 0 || c->n == 0) return ASPIRE_OK;   // nothing to score (an empty pool has no buffers either)
     ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "scores is null");
-    ASPIRE_REQUIRE(!pair_sims || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
-                   "pair_sims output needs padded extents (ext > 0)");
+    ASPIRE_REQUIRE((!pair_sims && !pair_softmax) || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
+                   "pair outputs need padded extents (ext > 0)");
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
     a.pairing = pairing;
     a.cdist_mode = cdist_mode;
+    a.agg = agg;
+    a.temp = temp;
     a.scores = scores;
     a.out_pairsims = pair_sims;
-    if (!pair_sims && gram_path_wanted(q, c, pairing)) return launch_pair_gram_l2max(a, q->max_len, c->max_len, (hipStream_t)stream);
+    a.out_plan = pair_softmax;
+    if (agg == ASPIRE_AGG_MAX && !pair_sims && gram_path_wanted(q, c, pairing))
+        return launch_pair_gram_l2max(a, q->max_len, c->max_len, (hipStream_t)stream);
     dim3 grid;
     grid = dim3((unsigned)a.c.n, (unsigned)query_chunks(a), 1);
     return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
@@ -1771,6 +1845,11 @@ extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_reps
         ASPIRE_LAUNCH_OK();
         return (int)ASPIRE_OK;
     });
+}
+
+extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                       int cdist_mode, float* scores, float* pair_sims, void* stream) {
+    return aspire_l2agg_scores_f32(q, c, D, pairing, cdist_mode, ASPIRE_AGG_MAX, 1.0, scores, pair_sims, nullptr, stream);
 }
 
 namespace {

@@ -24,6 +24,7 @@ struct ScoreArgs {
     int64_t diam_group;
     int64_t n_groups;
     int want;
+    int agg;         // ASPIRE_AGG_* (l2 aggregation kernels)
     float* scores;
     float* out_qdistr;
     float* out_cdistr;

@@ -106,6 +106,24 @@ def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want
     return (scores, pair) if want_pair_sims else scores
 
 
+def l2agg_scores(q, c, agg, temp=1.0, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want_pair_sims=False):
+    """Sibling aggregations of the masked -cdist block: agg = _lib.AGG_TOP2 (pair_distances.py:295-345) or
+    _lib.AGG_ATTENTION (pair_distances.py:95-135; temp = cdatt_sm_temp).  Returns sims [P]; with want_pair_sims also
+    pair_sims [P, q.ext, c.ext] and, for attention, pair_softmax [P, q.ext, c.ext]."""
+    p = _npairs(q, c, pairing)
+    dev = q.rows.device
+    scores = torch.empty(p, device=dev, dtype=torch.float32)
+    pair = torch.empty(p, q.ext, c.ext, device=dev, dtype=torch.float32) if want_pair_sims else None
+    soft = torch.empty(p, q.ext, c.ext, device=dev, dtype=torch.float32) \
+        if want_pair_sims and agg == _lib.AGG_ATTENTION else None
+    qs, cs = q.struct(), c.struct()
+    check(lib.aspire_l2agg_scores_f32(ctypes.byref(qs), ctypes.byref(cs), D, pairing, cdist_mode, agg,
+                                      ctypes.c_double(temp), _ptr(scores), _ptr(pair), _ptr(soft), _stream()))
+    if not want_pair_sims:
+        return scores
+    return (scores, pair, soft) if agg == _lib.AGG_ATTENTION else (scores, pair)
+
+
 def group_diameter(q, c, pairing, group):
     ngroups = (c.n + group - 1) // group
     n = ngroups if pairing == _lib.PAIR_PAIRED else q.n * ngroups

@@ -66,3 +66,30 @@ def allpair_masked_dist_l2max(query, cand, return_pair_sims=False):
         sims, pair = ops.l2max_scores(q, c, pairing=_lib.PAIR_PAIRED, want_pair_sims=True)
         return sims.to(out_dev), pair.to(out_dev)
     return (-1 * ops.l2max_scores(q, c, pairing=_lib.PAIR_PAIRED)).to(out_dev)
+
+
+def allpair_masked_dist_l2topk(query, cand, return_pair_sims=False):
+    """pair_distances.py:295-345 (score_agg_type 'l2top2').
+    :return: positive distances [batch_size] (minus the sum of the two largest -cdist entries), or with
+        return_pair_sims (sims [batch_size], pair_sims [batch_size, q_max_sents, c_max_sents])."""
+    q, c, out_dev = _to_repsets(query, cand)
+    if return_pair_sims:
+        sims, pair = ops.l2agg_scores(q, c, _lib.AGG_TOP2, pairing=_lib.PAIR_PAIRED, want_pair_sims=True)
+        return sims.to(out_dev), pair.to(out_dev)
+    return (-1 * ops.l2agg_scores(q, c, _lib.AGG_TOP2, pairing=_lib.PAIR_PAIRED)).to(out_dev)
+
+
+class AllPairMaskedAttention:
+    """pair_distances.py:95-135 (score_agg_type 'l2attention'): -cdist weighted by its masked 2-D soft-max."""
+
+    def __init__(self, model_hparams):
+        self.cdatt_sm_temp = model_hparams.get('cdatt_sm_temp', 1.0)
+
+    def compute_distance(self, query, cand, return_pair_sims=False):
+        """:return: doc_dists [batch_size]; with return_pair_sims (doc_sims, [pair_sims, pair_softmax, masked_sims])."""
+        q, c, out_dev = _to_repsets(query, cand)
+        kw = dict(temp=self.cdatt_sm_temp, pairing=_lib.PAIR_PAIRED)
+        if return_pair_sims:
+            sims, pair, soft = ops.l2agg_scores(q, c, _lib.AGG_ATTENTION, want_pair_sims=True, **kw)
+            return sims.to(out_dev), [t.to(out_dev) for t in (pair, soft, soft * pair)]
+        return (-1 * ops.l2agg_scores(q, c, _lib.AGG_ATTENTION, **kw)).to(out_dev)

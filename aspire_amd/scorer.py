@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .pair_distances import rep_len_tup, AllPairMaskedWasserstein, allpair_masked_dist_l2max
+from .pair_distances import (rep_len_tup, AllPairMaskedWasserstein, AllPairMaskedAttention, allpair_masked_dist_l2max,
+                             allpair_masked_dist_l2topk)
 
 
 class CandidatePool:
@@ -42,6 +43,7 @@ def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None
                       candidates, exactly caching_score with return_pair_sims=True
                       (disent_models.py:297, pp_gen_nearest.py:182-196).
              'l2max'  tsAspire max-sim (caching_score's 'l2lse' branch, disent_models.py:294-295).
+             'l2top2' / 'l2attention'  the sibling aggregations (disent_models.py:238-245); hparams['cdatt_sm_temp'].
     """
     hparams = hparams or {}
     pool = _as_pool(pool)
@@ -50,6 +52,11 @@ def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None
     if method == 'l2max':
         # cdist's formula switch looks at the padded batch extents in the reference; per pair here.
         return ops.l2max_scores(q, c, pairing=_lib.PAIR_CROSS).view(q.n, c.n)
+    if method == 'l2top2':
+        return ops.l2agg_scores(q, c, _lib.AGG_TOP2, pairing=_lib.PAIR_CROSS).view(q.n, c.n)
+    if method == 'l2attention':
+        return ops.l2agg_scores(q, c, _lib.AGG_ATTENTION, temp=hparams.get('cdatt_sm_temp', 1.0),
+                                pairing=_lib.PAIR_CROSS).view(q.n, c.n)
     if method != 'ot':
         raise ValueError(f'Unknown aggregation: {method}')
     kw = dict(blur=hparams.get('geoml_blur', 0.05), scaling=hparams.get('geoml_scaling', 0.9),
@@ -111,6 +118,11 @@ def caching_score(query_encode_ret_dict, cand_encode_ret_dicts, score_agg_type='
     ct = rep_len_tup(embed=padded_cand.permute(0, 2, 1), abs_lens=cand_lens)
     if score_agg_type in {'l2lse', 'l2max'}:
         batch_sent_sims, pair_sims = allpair_masked_dist_l2max(query=qt, cand=ct, return_pair_sims=True)
+    elif score_agg_type == 'l2top2':
+        batch_sent_sims, pair_sims = allpair_masked_dist_l2topk(query=qt, cand=ct, return_pair_sims=True)
+    elif score_agg_type == 'l2attention':
+        batch_sent_sims, pair_sims = AllPairMaskedAttention(hparams or {}).compute_distance(
+            query=qt, cand=ct, return_pair_sims=True)
     elif score_agg_type == 'l2wasserstein':
         batch_sent_sims, pair_sims = AllPairMaskedWasserstein(hparams or {}).compute_distance(
             query=qt, cand=ct, return_pair_sims=True)
@@ -126,6 +138,8 @@ def caching_score(query_encode_ret_dict, cand_encode_ret_dicts, score_agg_type='
         if len(pair_sims) == 5 and isinstance(pair_sims, list):
             upsm = [pair_sims[0][i, :qlen], pair_sims[1][i, :clen], pair_sims[2][i, :qlen, :clen],
                     pair_sims[3][i, :qlen, :clen], pair_sims[4][i, :qlen, :clen]]
+        elif isinstance(pair_sims, list):   # attention distance (disent_models.py:329-332)
+            upsm = [pair_sims[0][i, :qlen, :clen], pair_sims[1][i, :qlen, :clen], pair_sims[2][i, :qlen, :clen]]
         else:
             upsm = pair_sims[i, :qlen, :clen]
         unpadded.append(upsm)

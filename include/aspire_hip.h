@@ -130,6 +130,28 @@ int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int6
                             int cdist_mode, float* scores, float* pair_sims, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Sibling aggregations of the same masked -cdist block (score_agg_type 'l2top2' / 'l2attention',
+ * src/learning/facetid_models/disent_models.py:238-245):
+ *   ASPIRE_AGG_MAX        aspire_l2max_scores_f32 above.
+ *   ASPIRE_AGG_TOP2       allpair_masked_dist_l2topk, pair_distances.py:295-345: sum of the two largest entries of
+ *                         -cdist + pad_mask over the padded [q.ext, c.ext] block (torch.topk k = 2; with fewer than
+ *                         two valid entries a masked one, ~ -1e9, is picked exactly as the reference does; without
+ *                         padded extents the missing entry counts as -10e8).
+ *   ASPIRE_AGG_ATTENTION  AllPairMaskedAttention.compute_distance, pair_distances.py:95-135 with
+ *                         models_common/activations.py:35-61: sum_ij p_ij * (-d_ij), p = soft-max over the valid
+ *                         block of -d_ij / temp (temp = cdatt_sm_temp).
+ *   scores    [P]  out: the similarity (return_pair_sims=True value); the reference's distance is its negation
+ *   pair_sims [P, q.ext, c.ext] out, optional: TOP2: -cdist + pad_mask; ATTENTION: -cdist, unmasked (:125)
+ *   pair_softmax [P, q.ext, c.ext] out, optional, ATTENTION only: p_ij (zero outside the valid block)
+ * ------------------------------------------------------------------------------------------- */
+#define ASPIRE_AGG_MAX 0
+#define ASPIRE_AGG_TOP2 1
+#define ASPIRE_AGG_ATTENTION 2
+int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                            int cdist_mode, int agg, double temp, float* scores, float* pair_sims,
+                            float* pair_softmax, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A5-A8  otAspire.  Replaces AllPairMaskedWasserstein.compute_distance,
  * src/learning/facetid_models/pair_distances.py:21-92 (copy at
  * examples/ex_aspire_consent_multimatch.py:118-189), including the geomloss==0.2.4

@@ -224,6 +224,38 @@ def make_scores():
     np.savez_compressed(os.path.join(HERE, 'scores.npz'), **out)
 
 
+def make_siblings():
+    """Sibling aggregations of the same masked -cdist block: top-2 sum
+    (pair_distances.py:295-345) and the masked 2-D soft-max attention (pair_distances.py:95-135 with
+    models_common/activations.py:35-61).  Both run from the reference itself; no third-party arithmetic."""
+    g = torch.Generator().manual_seed(123)
+    out = {}
+    cases = {
+        's8': (6, 8, 8, [8] * 6, [8, 8, 5, 3, 8, 2]),
+        'rag': (5, 7, 12, [7, 3, 1, 7, 5], [12, 6, 12, 2, 9]),
+        'big': (2, 28, 30, [28, 26], [30, 27]),
+        'dup': (3, 8, 8, [8, 6, 8], [8, 8, 4]),
+    }
+    for name, (b, qmax, cmax, qlens, clens) in cases.items():
+        q, c = _ragged_batch(g, b, qmax, cmax, qlens, clens, dup=(1, 2, 3) if name == 'dup' else None)
+        qt = RepLen(embed=q.permute(0, 2, 1), abs_lens=qlens)
+        ct = RepLen(embed=c.permute(0, 2, 1), abs_lens=clens)
+        out.update({f'{name}_q': q.numpy(), f'{name}_c': c.numpy(),
+                    f'{name}_qlens': np.array(qlens), f'{name}_clens': np.array(clens)})
+        out[f'{name}_top2_dist'] = ref_pd.allpair_masked_dist_l2topk(qt, ct).numpy()
+        sims, pair = ref_pd.allpair_masked_dist_l2topk(qt, ct, return_pair_sims=True)
+        out[f'{name}_top2_sims'], out[f'{name}_top2_pair'] = sims.numpy(), pair.numpy()
+        for temp in (1.0, 0.2):
+            att = ref_pd.AllPairMaskedAttention({'cdatt_sm_temp': temp})
+            t = 't1' if temp == 1.0 else 't02'
+            out[f'{name}_att_{t}_dist'] = att.compute_distance(qt, ct).numpy()
+            ds, (ps, sm, ms) = att.compute_distance(qt, ct, return_pair_sims=True)
+            out.update({f'{name}_att_{t}_sims': ds.numpy(), f'{name}_att_{t}_pair': ps.numpy(),
+                        f'{name}_att_{t}_softmax': sm.numpy(), f'{name}_att_{t}_masked': ms.numpy()})
+        print(name, 'top2', out[f'{name}_top2_dist'][:3], 'att', out[f'{name}_att_t1_dist'][:3])
+    np.savez_compressed(os.path.join(HERE, 'siblings.npz'), **out)
+
+
 def make_metrics():
     # NumPy 2 removed np.asfarray, which the reference's dcg_at_k calls (metrics.py:179); supply the NumPy 1
     # behaviour so that compute_metrics can run here at all.  Environment shim only -- no arithmetic of ours.
@@ -257,7 +289,7 @@ def make_metrics():
 
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    make_pool()
-    make_prep()
-    make_scores()
-    make_metrics()
+    which = sys.argv[1:] or ['pool', 'prep', 'scores', 'siblings', 'metrics']
+    for name in which:
+        {'pool': make_pool, 'prep': make_prep, 'scores': make_scores, 'siblings': make_siblings,
+         'metrics': make_metrics}[name]()

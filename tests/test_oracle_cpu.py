@@ -124,3 +124,30 @@ def test_epsilon_schedule_shape():
     eps = orc.epsilon_schedule(1, 30.0, 0.05, 0.9)
     assert eps[0] == 30.0 and eps[-1] == 0.05 and eps[1] == pytest.approx(30.0)
     assert all(e > 0.05 for e in eps[1:-1]) and len(eps) == 2 + int(np.ceil(np.log(0.05 / 30.0) / np.log(0.9)))
+
+
+@pytest.fixture(scope='module')
+def siblings(golden_dir):
+    return np.load(os.path.join(golden_dir, 'siblings.npz'))
+
+
+@pytest.mark.parametrize('name', ['s8', 'rag', 'big', 'dup'])
+def test_sibling_aggregations_match_reference(siblings, name):
+    """l2top2 (pair_distances.py:295-345) and l2attention (:95-135) restatements against vectors produced by the
+    reference's own functions (tests/golden/make_golden.py siblings)."""
+    z = siblings
+    q, c = torch.from_numpy(z[f'{name}_q']), torch.from_numpy(z[f'{name}_c'])
+    qt = orc.RepLen(q.permute(0, 2, 1), z[f'{name}_qlens'].tolist())
+    ct = orc.RepLen(c.permute(0, 2, 1), z[f'{name}_clens'].tolist())
+    assert np.array_equal(orc.allpair_masked_dist_l2topk(qt, ct).numpy(), z[f'{name}_top2_dist'])
+    sims, pair = orc.allpair_masked_dist_l2topk(qt, ct, return_pair_sims=True)
+    assert np.array_equal(sims.numpy(), z[f'{name}_top2_sims'])
+    assert np.array_equal(pair.numpy(), z[f'{name}_top2_pair'])
+    for temp, t in ((1.0, 't1'), (0.2, 't02')):
+        att = orc.AllPairMaskedAttention({'cdatt_sm_temp': temp})
+        assert np.array_equal(att.compute_distance(qt, ct).numpy(), z[f'{name}_att_{t}_dist'])
+        ds, (ps, sm, ms) = att.compute_distance(qt, ct, return_pair_sims=True)
+        assert np.array_equal(ds.numpy(), z[f'{name}_att_{t}_sims'])
+        assert np.array_equal(ps.numpy(), z[f'{name}_att_{t}_pair'])
+        assert np.array_equal(sm.numpy(), z[f'{name}_att_{t}_softmax'])
+        assert np.array_equal(ms.numpy(), z[f'{name}_att_{t}_masked'])
