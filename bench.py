@@ -292,7 +292,7 @@ def main():
             # rocprofv3 is in profiles/ (see `breakdown`).
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'pair_cost_kernel<1> + sinkhorn_kernel<1> (one aspire_ot_sinkhorn_f32 call)',
+                         'kernel': 'pair_cost1_kernel + sinkhorn_kernel<1> (one aspire_ot_sinkhorn_f32 call)',
                          'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': bytes_per_launch,
                          'breakdown': breakdown},
         }
