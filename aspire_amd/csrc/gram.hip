@@ -50,6 +50,8 @@ struct GramArgs {
     float* cost;
     float* neg;
     float* scores;       // tsAspire: [nq][c.n]
+    const float* qbox;   // fused diameter (BOX): per-query coordinate boxes [nq][2][768]
+    float* diam2;        //                       out [nq][ncand]
 };
 
 __device__ __forceinline__ uint32_t order_key(float f) {
@@ -92,8 +94,9 @@ __device__ __noinline__ float direct_d2(unsigned long long x, unsigned long long
     return s0 + s1;
 }
 
-template <int BN, bool L2MAX>
-__global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
+template <int BN, bool L2MAX, bool BOX>
+__global__ void __launch_bounds__(256, BN == 128 ? 2 : 3) pair_gram_kernel(GramArgs g) {
+    static_assert(!BOX || (!L2MAX && BN <= 64), "the fused diameter serves the few-query otAspire tiles");
     constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int WM = kBM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int LDA = kBM + 4, LDB = BN + 4;
@@ -110,6 +113,7 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     __shared__ float q_nrm[BN];
     __shared__ unsigned char c_mm[kBM], q_mm[BN];
     __shared__ uint32_t pairmax[L2MAX ? 256 : 1];
+    __shared__ int c_len_s[16];                  // BOX: lengths of the tile's candidate documents (0 = none)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
@@ -149,6 +153,13 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
         q_ptr[r] = (doc_ok && i < len) ? (unsigned long long)(uintptr_t)(g.q.rows + (size_t)(start + i) * kD) : zrow;
         q_off[r] = !doc_ok ? -1 : L2MAX ? (long long)d : ((long long)q_loc * g.ncand) * g.E + (long long)i * g.ld;
         q_mm[r] = len > 25;
+    }
+    if constexpr (BOX) {
+        if (tid >= kBM + BN && tid < kBM + BN + 16) {   // every slot of the table is written (0 = no document)
+            const int d = tid - (kBM + BN);
+            const uint32_t c_loc = ct * g.dpt_c + d;
+            c_len_s[d] = (d < g.dpt_c && c_loc < g.ncand) ? g.c.len[g.cand0 + c_loc] : 0;
+        }
     }
     if constexpr (L2MAX) pairmax[tid] = 0u;
     __syncthreads();
@@ -213,7 +224,19 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     // loads after step 0, the next tile's register -> LDS stores (into the other buffer, which nobody reads until
     // the barrier) after steps 2..5.  Bunched, the two workgroups that share a CU fall into step -- both in their
     // MFMA phase, then both out of it -- and the matrix pipe idles half the time (measured 42 % busy).
-    auto tile_step = [&](auto load_set, auto store_set, int buf, bool do_load, int k_load, bool do_store) {
+    // BOX: geomloss's per-pair diameter formed beside the MFMAs.  Thread (cd, bk) = (tid >> 4, tid & 15) scans
+    // coordinate bk of the staged tile over candidate document cd's rows (min / max), widens it with each query
+    // document's precomputed box for that coordinate, and accumulates the squared extent per query document; the 16
+    // lanes of a document (one DPP row) add up at the end.  Replaces a second pass over every candidate row
+    // (doc_box_range_kernel + pair_box_kernel: 276 us beside a 217 us Gram kernel at 1 x 20 000 x 12).
+    constexpr int kBoxQ = 8;                       // query documents a BN <= 64 tile can hold
+    const int cd = tid >> 4, bk = tid & 15;
+    const int nq_tile = BOX ? (int)min((uint32_t)g.dpt_q, g.nq) : 0;
+    float bacc[kBoxQ];
+#pragma unroll
+    for (int u = 0; u < kBoxQ; ++u) bacc[u] = 0.f;
+    auto tile_step = [&](auto load_set, auto store_set, int buf, bool do_load, int k_load, bool do_store, int k_cur) {
+        float qmn[kBoxQ], qmx[kBoxQ];
         float a[2][TM], b[2][TN];   // operands of k-step kk+1 are read while step kk's MFMAs run
         auto read_operands = [&](int kk, int slot) {
 #pragma unroll
@@ -230,7 +253,41 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+            if constexpr (BOX) {
+                // issued BEFORE the tile loads: vmcnt retires in order, so waiting for these (at step 6) must not
+                // imply waiting for the next-but-one tile's rows
+                if (kk == 0) {
+#pragma unroll
+                    for (int u = 0; u < kBoxQ; ++u)
+                        if (u < nq_tile) {
+                            qmn[u] = g.qbox[(size_t)u * 2 * kD + k_cur + bk];
+                            qmx[u] = g.qbox[(size_t)u * 2 * kD + kD + k_cur + bk];
+                        }
+                }
+            }
             if (kk == 0 && do_load) load_tiles(load_set, k_load);
+            if constexpr (BOX) {
+                if (kk == 6) {
+                    const int len = min(c_len_s[cd], g.mr_c);
+                    if (len > 0) {
+                        float mn = INFINITY, mx = -INFINITY;
+                        const float* col = &As[buf][bk][cd * g.mr_c];
+                        for (int r4 = 0; r4 < len; r4 += 4) {
+                            const float4 v = *reinterpret_cast<const float4*>(col + r4);
+                            mn = fminf(mn, v.x); mx = fmaxf(mx, v.x);
+                            if (r4 + 1 < len) { mn = fminf(mn, v.y); mx = fmaxf(mx, v.y); }
+                            if (r4 + 2 < len) { mn = fminf(mn, v.z); mx = fmaxf(mx, v.z); }
+                            if (r4 + 3 < len) { mn = fminf(mn, v.w); mx = fmaxf(mx, v.w); }
+                        }
+#pragma unroll
+                        for (int u = 0; u < kBoxQ; ++u)
+                            if (u < nq_tile) {
+                                const float ext = fmaxf(mx, qmx[u]) - fminf(mn, qmn[u]);
+                                bacc[u] = fmaf(ext, ext, bacc[u]);
+                            }
+                    }
+                }
+            }
             if (kk >= 2 && kk < 6 && do_store) store_piece(store_set, kk - 2, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -248,13 +305,25 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
 #pragma unroll 1
     for (int t = 0; t < nk; t += 2) {
         // LDS buffer 0 = tile t, set 1 = tile t+1 (stored into buffer 1 here), set 0 free (tile t+2 loads into it)
-        tile_step(S0{}, S1{}, 0, t + 2 < nk, (t + 2) * kBK, true);
+        tile_step(S0{}, S1{}, 0, t + 2 < nk, (t + 2) * kBK, true, t * kBK);
         __syncthreads();
         // LDS buffer 1 = tile t+1, set 0 = tile t+2, set 1 free
-        tile_step(S1{}, S0{}, 1, t + 3 < nk, (t + 3) * kBK, t + 2 < nk);
+        tile_step(S1{}, S0{}, 1, t + 3 < nk, (t + 3) * kBK, t + 2 < nk, (t + 1) * kBK);
         __syncthreads();
     }
 
+    if constexpr (BOX) {
+        const uint32_t c_loc = ct * g.dpt_c + cd;
+#pragma unroll
+        for (int u = 0; u < kBoxQ; ++u) {
+            float sacc = bacc[u];
+            sacc += lane_xor<1>(sacc);
+            sacc += lane_xor<2>(sacc);
+            sacc += lane_xor<4>(sacc);
+            sacc += lane_xor<8>(sacc);
+            if (bk == 0 && u < nq_tile && cd < g.dpt_c && c_loc < g.ncand) g.diam2[(size_t)u * g.ncand + c_loc] = sacc;
+        }
+    }
     // ---- squared norms: the 4 threads of a row hold its 4 interleaved k-chunk partial sums ----------------
 #pragma unroll
     for (int p = 0; p < A_F4; ++p) {
@@ -418,12 +487,17 @@ int fill_geometry(GramArgs& g, const ScoreArgs& a, int mr_q, int mr_c, int& bn) 
 template <bool L2MAX>
 int launch_gram(const GramArgs& g, int bn, hipStream_t stream) {
     const dim3 grid((unsigned)(g.n_ct * g.n_qt));
-    if (bn == 32) {
-        hipLaunchKernelGGL((pair_gram_kernel<32, L2MAX>), grid, dim3(256), 0, stream, g);
-    } else if (bn == 64) {
-        hipLaunchKernelGGL((pair_gram_kernel<64, L2MAX>), grid, dim3(256), 0, stream, g);
+    const bool box = g.diam2 != nullptr;
+    if constexpr (L2MAX) {
+        if (bn == 32) hipLaunchKernelGGL((pair_gram_kernel<32, true, false>), grid, dim3(256), 0, stream, g);
+        else if (bn == 64) hipLaunchKernelGGL((pair_gram_kernel<64, true, false>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((pair_gram_kernel<128, true, false>), grid, dim3(256), 0, stream, g);
     } else {
-        hipLaunchKernelGGL((pair_gram_kernel<128, L2MAX>), grid, dim3(256), 0, stream, g);
+        if (bn == 32 && box) hipLaunchKernelGGL((pair_gram_kernel<32, false, true>), grid, dim3(256), 0, stream, g);
+        else if (bn == 32) hipLaunchKernelGGL((pair_gram_kernel<32, false, false>), grid, dim3(256), 0, stream, g);
+        else if (bn == 64 && box) hipLaunchKernelGGL((pair_gram_kernel<64, false, true>), grid, dim3(256), 0, stream, g);
+        else if (bn == 64) hipLaunchKernelGGL((pair_gram_kernel<64, false, false>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((pair_gram_kernel<128, false, false>), grid, dim3(256), 0, stream, g);
     }
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
@@ -459,12 +533,17 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
     g.ld = 8 * T;
     g.cost = cost;
     g.neg = neg;
+    if (diam2 && a.cand0 == 0) {   // per-coordinate boxes of the queries, once per call
+        hipLaunchKernelGGL(doc_box_range_kernel, dim3((unsigned)g.nq), dim3(192), 0, stream, a.q, (int64_t)0, qbox);
+        ASPIRE_LAUNCH_OK();
+    }
+    if (diam2 && bn <= 64) {       // few queries: the diameter is formed inside the Gram kernel
+        g.qbox = qbox;
+        g.diam2 = diam2;
+        return launch_gram<false>(g, bn, stream);
+    }
     if (int rc = launch_gram<false>(g, bn, stream)) return rc;
     if (diam2) {
-        if (a.cand0 == 0) {
-            hipLaunchKernelGGL(doc_box_range_kernel, dim3((unsigned)g.nq), dim3(192), 0, stream, a.q, (int64_t)0, qbox);
-            ASPIRE_LAUNCH_OK();
-        }
         hipLaunchKernelGGL(doc_box_range_kernel, dim3(g.ncand), dim3(192), 0, stream, a.c, a.cand0, cbox);
         ASPIRE_LAUNCH_OK();
         hipLaunchKernelGGL(pair_box_kernel, dim3((g.ncand + 31) / 32, (g.nq + 31) / 32), dim3(256), 0, stream, qbox, cbox,
