@@ -77,6 +77,8 @@ SIGNATURES = {
     'aspire_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64]),
     'aspire_topk_desc_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    'aspire_topk_keys_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'aspire_topk_merge_keys': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'aspire_selftest_xlane': (c_int, [ctypes.POINTER(c_int)]),
 }
 

@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
                                                              const uint64_t* __restrict__ keys_in, int64_t n_in,
                                                              int64_t in_stride, int64_t kk, uint64_t* __restrict__ keys_out,
                                                              int64_t out_stride, int64_t idx_base, int64_t k_final,
-                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx) {
+                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
+                                                             uint64_t* __restrict__ keys_final, int64_t in_k) {
     constexpr int N = E * kThreads;
     __shared__ uint64_t lds[N];
     const int tid = threadIdx.x;
@@ -111,6 +112,10 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
         if (i < n_in) {
             if (scores) {
                 kv = ((uint64_t)order_bits(scores[q * in_stride + i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+            } else if (in_k > 0) {
+                // keys gathered from R ranks, laid out [rank][query][in_k]: element i of query q = (i / in_k, i % in_k)
+                const int64_t r = i / in_k;
+                kv = keys_in[(r * gridDim.x + q) * in_k + (i - r * in_k)];
             } else {
                 kv = keys_in[q * in_stride + i];
             }
@@ -122,7 +127,15 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
     for (int r = 0; r < E; ++r) {
         const int t = tid * E + r;
         const uint64_t kv = key[r];
-        if (top_scores == nullptr) {
+        if (keys_final != nullptr) {
+            // final pass, key output: the low word carries the GLOBAL index (idx_base + position), so keys of
+            // different shards compare like (score desc, global index asc); 0 = padding (C < k)
+            if (t < k_final) {
+                const uint32_t low = (uint32_t)kv;
+                const uint32_t gl = in_k > 0 ? low : 0xFFFFFFFFu - (uint32_t)(idx_base + (int64_t)(0xFFFFFFFFu - low));
+                keys_final[q * k_final + t] = kv != 0 ? ((kv & 0xFFFFFFFF00000000ull) | gl) : 0ull;
+            }
+        } else if (top_scores == nullptr) {
             if (t < kk) keys_out[q * out_stride + chunk * kk + t] = kv;
         } else if (t < k_final) {
             const bool real = kv != 0;
@@ -130,7 +143,9 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
             top_idx[q * k_final + t] = real ? idx_base + (int64_t)(0xFFFFFFFFu - (uint32_t)kv) : -1;
         }
     }
-    if (top_scores != nullptr) {
+    if (keys_final != nullptr) {
+        for (int64_t t = N + tid; t < k_final; t += kThreads) keys_final[q * k_final + t] = 0ull;
+    } else if (top_scores != nullptr) {
         // k_final beyond the chunk (C < k): the tail is (-inf, -1)
         for (int64_t t = N + tid; t < k_final; t += kThreads) {
             top_scores[q * k_final + t] = -INFINITY;
@@ -155,13 +170,15 @@ extern "C" size_t aspire_topk_workspace_bytes(int64_t Q, int64_t C, int64_t k) {
     return (size_t)(Q * (n1 + n2)) * sizeof(uint64_t);
 }
 
-extern "C" int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
-                                    float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+namespace {
+int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base, float* top_scores, int64_t* top_idx,
+             uint64_t* keys_final, void* workspace, size_t workspace_bytes, void* stream) {
     ASPIRE_REQUIRE(Q >= 0 && C >= 0 && k > 0, ASPIRE_ERR_INVALID_ARG, "bad shape Q=%lld C=%lld k=%lld", (long long)Q,
                    (long long)C, (long long)k);
-    ASPIRE_REQUIRE(scores && top_scores && top_idx, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    ASPIRE_REQUIRE(scores && ((top_scores && top_idx) || keys_final), ASPIRE_ERR_INVALID_ARG, "null pointer");
     ASPIRE_REQUIRE(C < (int64_t)0xFFFFFFFF, ASPIRE_ERR_UNSUPPORTED, "C too large for 32-bit local indices");
+    ASPIRE_REQUIRE(!keys_final || (idx_base >= 0 && idx_base + C < (int64_t)0xFFFFFFFF), ASPIRE_ERR_UNSUPPORTED,
+                   "global candidate indices must fit 32 bits in key form");
     ASPIRE_REQUIRE(C <= kMaxChunk || k < 1024, ASPIRE_ERR_UNSUPPORTED,
                    "k=%lld >= 1024 with C=%lld > %d: full sorts beyond one chunk are not built", (long long)k,
                    (long long)C, kMaxChunk);
@@ -182,14 +199,16 @@ extern "C" int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, i
         const bool final_pass = nch == 1;
         const int64_t out_stride = nch * kk;
         dim3 grid((unsigned)Q, (unsigned)nch);
+        float* ts = final_pass && !keys_final ? top_scores : nullptr;
+        int64_t* ti = final_pass && !keys_final ? top_idx : nullptr;
+        uint64_t* kf = final_pass ? keys_final : nullptr;
+        uint64_t* ko = final_pass ? nullptr : bufs[which];
         if (chunk == 1024) {
-            hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk,
-                               final_pass ? nullptr : bufs[which], out_stride, idx_base, k, final_pass ? top_scores : nullptr,
-                               final_pass ? top_idx : nullptr);
+            hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk, ko,
+                               out_stride, idx_base, k, ts, ti, kf, (int64_t)0);
         } else {
-            hipLaunchKernelGGL(topk_pass_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk,
-                               final_pass ? nullptr : bufs[which], out_stride, idx_base, k, final_pass ? top_scores : nullptr,
-                               final_pass ? top_idx : nullptr);
+            hipLaunchKernelGGL(topk_pass_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk, ko,
+                               out_stride, idx_base, k, ts, ti, kf, (int64_t)0);
         }
         ASPIRE_LAUNCH_OK();
         if (final_pass) break;
@@ -199,5 +218,40 @@ extern "C" int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, i
         in_stride = out_stride;
         which ^= 1;
     }
+    return ASPIRE_OK;
+}
+}  // namespace
+
+extern "C" int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
+                                    float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    ASPIRE_REQUIRE(top_scores && top_idx, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    return topk_run(scores, Q, C, k, idx_base, top_scores, top_idx, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int aspire_topk_keys_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
+                                    uint64_t* keys, void* workspace, size_t workspace_bytes, void* stream) {
+    ASPIRE_REQUIRE(keys, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    return topk_run(scores, Q, C, k, idx_base, nullptr, nullptr, keys, workspace, workspace_bytes, stream);
+}
+
+extern "C" int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k_in, int64_t k, float* top_scores,
+                                      int64_t* top_idx, void* stream) {
+    ASPIRE_REQUIRE(R > 0 && Q >= 0 && k_in > 0 && k > 0, ASPIRE_ERR_INVALID_ARG, "bad shape R=%lld Q=%lld k_in=%lld k=%lld",
+                   (long long)R, (long long)Q, (long long)k_in, (long long)k);
+    ASPIRE_REQUIRE(keys && top_scores && top_idx, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    ASPIRE_REQUIRE(R * k_in <= kMaxChunk, ASPIRE_ERR_UNSUPPORTED, "R * k_in = %lld keys per query exceed one %d-key chunk",
+                   (long long)(R * k_in), kMaxChunk);
+    if (Q == 0) return ASPIRE_OK;
+    const int64_t n = R * k_in;
+    dim3 grid((unsigned)Q, 1);
+    if (n <= 1024) {
+        hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, (const float*)nullptr, keys, n, n, k,
+                           (uint64_t*)nullptr, k, (int64_t)0, k, top_scores, top_idx, (uint64_t*)nullptr, k_in);
+    } else {
+        hipLaunchKernelGGL(topk_pass_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, (const float*)nullptr, keys, n, n, k,
+                           (uint64_t*)nullptr, k, (int64_t)0, k, top_scores, top_idx, (uint64_t*)nullptr, k_in);
+    }
+    ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

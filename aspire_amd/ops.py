@@ -168,6 +168,29 @@ def topk_desc(scores, k, idx_base=0):
     return top_s, top_i
 
 
+def topk_keys(scores, k, idx_base=0, out=None):
+    """Per-query local top-k of scores [Q, C] as sortable int64 keys [Q, k] that carry the GLOBAL candidate index
+    (include/aspire_hip.h: aspire_topk_keys_f32) -- what a shard contributes to the all-gather of section 8(e)."""
+    _f32(scores, 'scores')
+    qn, cn = scores.shape
+    keys = out if out is not None else torch.empty(qn, k, device=scores.device, dtype=torch.int64)
+    nbytes = lib.aspire_topk_workspace_bytes(qn, cn, k)
+    ws = torch.empty(max(nbytes, 8), device=scores.device, dtype=torch.uint8)
+    check(lib.aspire_topk_keys_f32(_ptr(scores), qn, cn, k, idx_base, _ptr(keys), _ptr(ws), nbytes, _stream()))
+    return keys
+
+
+def topk_merge_keys(keys, k):
+    """keys [R, Q, k_in] (R shards' blocks as an all-gather leaves them) -> (top_scores [Q, k], top_idx [Q, k])."""
+    require_gpu()
+    assert keys.dtype == torch.int64 and keys.dim() == 3 and keys.is_contiguous() and keys.is_cuda, 'keys: int64 [R, Q, k_in]'
+    r, qn, k_in = keys.shape
+    top_s = torch.empty(qn, k, device=keys.device, dtype=torch.float32)
+    top_i = torch.empty(qn, k, device=keys.device, dtype=torch.int64)
+    check(lib.aspire_topk_merge_keys(_ptr(keys), r, qn, k_in, k, _ptr(top_s), _ptr(top_i), _stream()))
+    return top_s, top_i
+
+
 def selftest_xlane():
     require_gpu()
     n = (ctypes.c_int * 16)()

@@ -57,6 +57,20 @@ def all_gather_topk(local_scores, local_idx, k, group=None):
     return merge_topk(scores, out[..., 1].contiguous(), k)
 
 
+def all_gather_topk_keys(local_keys, k, group=None):
+    """GPU form of the exchange: every rank contributes its local top-k as sortable keys that already carry global
+    candidate indices (ops.topk_keys); ONE all-gather, then one merge kernel (ops.topk_merge_keys).
+    local_keys int64 [Q, k_local] on the GPU -> (top scores [Q, k], top idx [Q, k])."""
+    from . import ops
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        gathered = torch.empty((world,) + tuple(local_keys.shape), dtype=local_keys.dtype, device=local_keys.device)
+        dist.all_gather_into_tensor(gathered.view(-1), local_keys.contiguous().view(-1), group=group)
+    else:
+        gathered = local_keys.contiguous().unsqueeze(0)
+    return ops.topk_merge_keys(gathered, k)
+
+
 class ShardedPoolRanker:
     """Holds this rank's block of a candidate pool resident in HBM and ranks queries against the whole
     pool.  `pool_reps` is the FULL pool (list of [S_i, 768] arrays) or, with `presharded=True`, only this
@@ -78,11 +92,16 @@ class ShardedPoolRanker:
     def rank_queries(self, query_reps_list, k, **score_kw):
         from . import ops
         from .scorer import score_pool
+        key_form = self.world * k <= 4096      # one chunk of the merge kernel holds every rank's k keys
         if len(self.pool) > 0:
-            scores = score_pool(query_reps_list, self.pool, **score_kw)
-            ls, li = ops.topk_desc(scores.contiguous(), k, idx_base=self.lo)
+            scores = score_pool(query_reps_list, self.pool, **score_kw).contiguous()
+            if key_form:
+                return all_gather_topk_keys(ops.topk_keys(scores, k, idx_base=self.lo), k, self.group)
+            ls, li = ops.topk_desc(scores, k, idx_base=self.lo)
         else:
             dev = ops.require_gpu()
+            if key_form:   # an empty shard contributes padding keys
+                return all_gather_topk_keys(torch.zeros(len(query_reps_list), k, dtype=torch.int64, device=dev), k, self.group)
             ls = torch.full((len(query_reps_list), k), float('-inf'), device=dev)
             li = torch.full((len(query_reps_list), k), -1, dtype=torch.int64, device=dev)
         return all_gather_topk(ls, li, k, self.group)

@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--graph-unroll', type=int, default=24, help='steps per captured graph')
     ap.add_argument('--streams', type=int, default=4, help='HIP streams that independent steps alternate over')
+    ap.add_argument('--shard-path', action='store_true',
+                    help='run the N > 1 code path (key-form top-k, gather, merge kernel) on one GPU, for testing')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -119,7 +121,7 @@ def main():
     if world > 1:
         dist.barrier()
     from aspire_amd import _lib, ops
-    from aspire_amd.parallel import all_gather_topk
+    shard_path = world > 1 or args.shard_path
 
     # ---- inputs resident in HBM (rank r owns global candidates [r*C, (r+1)*C)) ------------------
     query, cands = make_inputs(0, device)
@@ -158,26 +160,48 @@ def main():
             if rc:
                 _lib.check(rc)
 
-        def step(self):
+        def step(self, keys_out=None):
+            """One step: score the resident pool for the query and rank it.  Sharded job: the rank is left in KEY
+            form (global candidate index inside the key) in `keys_out` for the exchange that follows."""
             self.score()
-            rc = lib.aspire_topk_desc_f32(self.p[0], Q, C, TOPK, rank * C, self.p[1], self.p[2], null, 0, stream())
+            if keys_out is not None:
+                rc = lib.aspire_topk_keys_f32(self.p[0], Q, C, TOPK, rank * C, ctypes.c_void_p(keys_out.data_ptr()), null, 0,
+                                              stream())
+            else:
+                rc = lib.aspire_topk_desc_f32(self.p[0], Q, C, TOPK, rank * C, self.p[1], self.p[2], null, 0, stream())
             if rc:
                 _lib.check(rc)
-            if world > 1:
-                return all_gather_topk(self.top_s, self.top_i, TOPK)
-            return self.top_s, self.top_i
-
-    # N > 1: one stream, eager launches: the per-step RCCL all-gather orders the steps anyway, and a capture-time
-    # hang on a multi-GPU node would cost the whole scaling run.
-    use_graph = not args.no_graph and world == 1
-    n_streams = max(1, args.streams) if use_graph else 1
-    lanes = [Lane() for _ in range(n_streams)]
-    scores = lanes[0].scores
 
     # ---- the step loop is launch bound (three 8-13 us kernels per step): capture it in hipGraphs, `unroll`
     # steps per replay, step i on stream i % n_streams so that independent steps overlap (one step's top-k and
     # latency-bound Sinkhorn kernel run beside the next step's HBM-bound cost kernel).
+    # Multi-GPU (SURVEY.md 8e): every rank ranks ITS block of the pool for each query; the only exchange is the
+    # per-query local top-k.  The steps of one graph replay are `unroll` independent queries, so their keys are
+    # exchanged together: ONE RCCL all-gather of unroll * Q * k keys per rank per replay, then ONE merge kernel --
+    # the batch-of-queries form of the merge (config 5 ranks 128 queries per exchange).  The collective stays
+    # outside the captured graph.
+    use_graph = not args.no_graph
+    n_streams = max(1, args.streams) if use_graph else 1
+    lanes = [Lane() for _ in range(n_streams)]
+    scores = lanes[0].scores
     unroll = max(n_streams, min(args.graph_unroll, args.steps)) // n_streams * n_streams
+    keybuf = torch.zeros(unroll, Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
+    gathered = torch.empty(world * unroll * Q * TOPK, device=device, dtype=torch.int64) if shard_path else None
+    merged_s = torch.empty(unroll * Q, TOPK, device=device, dtype=torch.float32) if shard_path else None
+    merged_i = torch.empty(unroll * Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
+
+    def exchange(n_steps):
+        """keys of the last n_steps steps (keybuf[:n_steps]) -> global top-k of each of them on every rank."""
+        n = n_steps * Q * TOPK
+        if world > 1:
+            dist.all_gather_into_tensor(gathered[:world * n], keybuf.view(-1)[:n])     # -> [world][n_steps][Q][k]
+            src = gathered
+        else:
+            src = keybuf
+        rc = lib.aspire_topk_merge_keys(ctypes.c_void_p(src.data_ptr()), world, n_steps * Q, TOPK, TOPK,
+                                        ctypes.c_void_p(merged_s.data_ptr()), ctypes.c_void_p(merged_i.data_ptr()), stream())
+        if rc:
+            _lib.check(rc)
 
     def capture_steps(n, use_lanes):
         g = torch.cuda.CUDAGraph()
@@ -188,11 +212,12 @@ def main():
                 st.wait_stream(main)               # fork
             for i in range(n):
                 k = i % len(use_lanes)
+                ko = keybuf[i] if shard_path else None
                 if k == 0:
-                    use_lanes[0].step()
+                    use_lanes[0].step(ko)
                 else:
                     with torch.cuda.stream(side[k - 1]):
-                        use_lanes[k].step()
+                        use_lanes[k].step(ko)
             for st in side:
                 main.wait_stream(st)               # join
         return g
@@ -206,9 +231,13 @@ def main():
         if graph is not None:
             while done + per_replay <= args.steps:
                 graph.replay()
+                if shard_path:
+                    exchange(per_replay)
                 done += per_replay
         while done < args.steps:
-            eager_lane.step()
+            eager_lane.step(keybuf[0] if shard_path else None)
+            if shard_path:
+                exchange(1)
             done += 1
         if world > 1:
             dist.barrier()
@@ -222,12 +251,21 @@ def main():
 
     for _ in range(max(args.warmup, 3)):
         for ln in lanes:
-            ln.step()
+            ln.step(keybuf[0] if shard_path else None)
+            if shard_path:
+                exchange(1)
     torch.cuda.synchronize()
     g_step = capture_steps(unroll, lanes) if use_graph else None
     if g_step is not None:
         g_step.replay()
+        if shard_path:
+            exchange(unroll)
     elapsed = timed(g_step, unroll, lanes[0])
+    if shard_path:
+        # the merged ranking of the last exchanged step must be a valid descending ranking of global indices
+        torch.cuda.synchronize()
+        assert (merged_i[0] >= 0).all() and (merged_i[0] < world * C).all(), 'merge produced out-of-range indices'
+        assert (merged_s[0, 1:] <= merged_s[0, :-1]).all(), 'merge output is not descending'
     # the same K steps strictly one after the other on ONE stream, for reference
     serial_elapsed = None
     if use_graph and n_streams > 1:
@@ -281,7 +319,8 @@ def main():
             'serial_value': (world * Q * C * args.steps / serial_elapsed) if serial_elapsed else None,
             'config': {'workload': f'otAspire compsci: {Q} query x {C} candidates per GPU, {S} sents x {D}d, '
                                    f'Sinkhorn OT (blur 0.05, scaling 0.9, one eps schedule per pair) + per-query '
-                                   f'top-{TOPK} rank' + (', RCCL all-gather top-k merge' if world > 1 else ''),
+                                   f'top-{TOPK} rank' + (f', one RCCL all-gather of the top-{TOPK} keys of {unroll} queries '
+                                                         f'per replay + merge kernel' if shard_path else ''),
                        'queries': Q, 'candidates_per_gpu': C, 'sents': S, 'dim': D, 'topk': TOPK,
                        'parallelism': f'candidate-pool shards x{world}',
                        'launch': (f'hipGraph replay, {unroll} steps per graph, independent steps alternate over '

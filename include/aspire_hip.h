@@ -218,6 +218,22 @@ int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, i
                          float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SURVEY.md 8(e)  shard merge.  The same rank in KEY form for the candidate-pool shards of a multi-GPU job:
+ *   aspire_topk_keys_f32    per-query local top-k as sortable 64-bit keys [Q, k]:
+ *                           (order-preserving score bits << 32) | (0xFFFFFFFF - global index), 0 = padding.
+ *                           One unsigned descending sort of keys from ANY set of shards is the order of Python's
+ *                           stable sorted(..., reverse=True) over the un-sharded pool (evaluate.py:76).
+ *                           Needs idx_base + C < 2^32 - 1.  Workspace as aspire_topk_desc_f32.
+ *   aspire_topk_merge_keys  keys [R, Q, k_in] as an all-gather of R ranks' [Q, k_in] blocks leaves them ->
+ *                           top_scores [Q, k], top_idx [Q, k] (global indices; (-inf, -1) padding).
+ *                           Limit: R * k_in <= 4096.
+ * ------------------------------------------------------------------------------------------- */
+int aspire_topk_keys_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
+                         uint64_t* keys, void* workspace, size_t workspace_bytes, void* stream);
+int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k_in, int64_t k,
+                           float* top_scores, int64_t* top_idx, void* stream);
+
 /* Cross-lane primitive self test (DPP / permlane forms vs ds_bpermute); out_mismatch_host[16] receives
  * the number of mismatching lanes per check (all 0 = ok; order: xor 1,2,4,8,16,32, row sum, col sum,
  * row max, col max, butterfly 64, butterfly 16).  Synchronous. */

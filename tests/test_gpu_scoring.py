@@ -257,3 +257,33 @@ def test_packed_tile_kernel_matches_single(amd):
     idx = [0, 1, 2, 3, 4097, 8200, 8201, 8202]
     want = np.array([[orc.get_similarity(q, cands[i]) for i in idx] for q in queries], dtype=np.float32)
     np.testing.assert_allclose(big.numpy()[:, idx], want, atol=TOL, rtol=0)
+
+
+def test_topk_keys_and_shard_merge(amd):
+    """Section 8(e): local top-k in key form per shard, keys laid out as an all-gather leaves them, one merge kernel ==
+    the stable descending sort of the un-sharded pool (ties by ascending global index), padding when a shard is short."""
+    import ctypes
+    g = torch.Generator().manual_seed(77)
+    qn, k = 3, 50
+    sizes = [700, 1, 37, 1200, 0, 5000]          # shard sizes (one empty, one shorter than k, one multi-chunk)
+    full = torch.randn(qn, sum(sizes), generator=g)
+    full[:, 5] = full[:, 900] = full[:, 1939] = 3.25      # ties across shards
+    full[1, :30] = float('-inf')
+    keys, lo = [], 0
+    for n in sizes:
+        if n:
+            keys.append(amd.ops.topk_keys(full[:, lo:lo + n].contiguous().cuda(), k, idx_base=lo))
+        else:
+            keys.append(torch.zeros(qn, k, dtype=torch.int64, device='cuda'))
+        lo += n
+    top_s, top_i = amd.ops.topk_merge_keys(torch.stack(keys).contiguous(), k)
+    for qi in range(qn):
+        order = orc.rank_descending(full[qi].tolist())[:k]
+        assert top_i[qi].tolist() == order
+        assert torch.equal(top_s[qi].cpu(), full[qi][order])
+    # a pool smaller than k: (-inf, -1) tail
+    s2, i2 = amd.ops.topk_merge_keys(torch.stack([amd.ops.topk_keys(full[:, :7].contiguous().cuda(), k)]).contiguous(), k)
+    assert i2[0, :7].tolist() == orc.rank_descending(full[0, :7].tolist()) and (i2[:, 7:] == -1).all()
+    assert torch.isinf(s2[:, 7:]).all()
+    with pytest.raises(NotImplementedError):
+        amd.ops.topk_merge_keys(torch.zeros(50, 1, 100, dtype=torch.int64, device='cuda'), 10)
