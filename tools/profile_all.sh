@@ -18,7 +18,8 @@ for shape in "32 50000 8" "128 8192 12" "1 20000 8" "1 20000 12"; do
   run ot_$n rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ot_$n -o ot -- python $R/tools/otprof.py $shape 5
 done
 run pmc_gram rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES --output-format csv -d $OUT/pmc_gram -o pmc -- python $R/tools/otprof.py 32 50000 8 1
-# 3. the encoder
+# 3. the encoder and the pooling kernel
+run pool rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pool -o pool -- python $R/tools/poolbench.py 256 512 12
 run enc rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/enc -o enc -- python $R/tools/encbench.py 32 256
 find $OUT -name "*.csv" | grep -v "kernel_stats\|counter_collection" | xargs rm -f
 find $OUT -name "*kernel_trace*" | xargs rm -f
