@@ -1,0 +1,85 @@
+"""The two steps either side of scoring in the reference's evaluation driver:
+
+  score     src/evaluation/evaluate.py:36-82     for every query of a test pool: similarity of every candidate,
+                                                  stable descending sort, `scores[-facet].json` =
+                                                  {query_id: [[cand_id, -similarity], ...]}
+  evaluate  src/evaluation/evaluate.py:85-160 +   scores json + gold grades -> per-query metric rows
+            utils/utils.py:59-82                  (`query-evaluations[-facet].csv`) and their means per (facet, split)
+                                                  (`aggregated-evaluations[-facet].csv`)
+
+The per-pair Python loop of the reference (one get_similarity call per candidate) becomes one rank_pool call per query
+against sentence reps resident in HBM.  File names and layouts are the reference's, so its own `evaluate` step can read
+what `score` writes here and vice versa.
+"""
+import codecs
+import csv
+import json
+import os
+
+import numpy as np
+
+from . import metrics as _metrics
+
+
+def get_scores_filename(results_dir, facet):           # utils/utils.py:59-61
+    return os.path.join(results_dir, 'scores.json' if facet is None else f'scores-{facet}.json')
+
+
+def get_evaluations_filename(results_dir, facet, aggregated):   # utils/utils.py:66-69
+    kind = 'aggregated' if aggregated else 'query'
+    return os.path.join(results_dir, f'{kind}-evaluations.csv' if facet is None else f'{kind}-evaluations-{facet}.csv')
+
+
+def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, method='ot', schedule='pair', hparams=None):
+    """evaluate.py:36-82.  test_pool: {query_id: {'cands': [cand_id, ...]}} (the dataset's test-pid json);
+    rep_store: aspire_amd.repstore.RepStore of sentence reps.  A faceted query keeps only the sentence rows whose
+    predicted label matches the facet (models.py:127-163; pred_labels: {paper_id: [label per sentence]}).
+    Writes and returns {query_id: [(cand_id, -sim), ...]}."""
+    from . import scorer
+    results = {}
+    for query_id, pool in test_pool.items():
+        cand_ids = list(pool['cands'])
+        q = rep_store.faceted(query_id, facet, pred_labels[query_id]) if facet is not None else rep_store.get(query_id)
+        ranked = scorer.rank_pool([q], rep_store.pool(cand_ids), method=method, schedule=schedule, hparams=hparams)[0]
+        results[query_id] = [(cid, -1 * sim) for cid, sim in ranked]     # evaluate.py:77
+    os.makedirs(results_dir, exist_ok=True)
+    with codecs.open(get_scores_filename(results_dir, facet), 'w', 'utf-8') as fp:
+        json.dump(results, fp)
+    return results
+
+
+def load_score_results(results_dir, gold, facet):
+    """utils/utils.py:71-82: relevance of every candidate in the order the model ranked them."""
+    with codecs.open(get_scores_filename(results_dir, facet), 'r', 'utf-8') as fp:
+        model_scores = json.load(fp)
+    return {qid: [gold[qid][pid] for pid, _ in cand_scores] for qid, cand_scores in model_scores.items()}
+
+
+def evaluate(results_dir, gold, facet=None, threshold_grade=2, split=None):
+    """evaluate.py:85-160.  gold: {query_id: {cand_id: grade}}; split: optional {query_id: 'dev' | 'test'}.
+    Writes the per-query and the aggregated csv; returns (rows, aggregated rows)."""
+    facet_key = 'unfaceted' if facet is None else facet
+    rows = []
+    for query_id, rels in load_score_results(results_dir, gold, facet).items():
+        m = _metrics.compute_metrics(rels, pr_atks=[5, 10, 20], threshold_grade=threshold_grade)
+        m['facet'] = facet_key
+        m['split'] = 'test' if split is None else split[query_id]
+        m['paper_id'] = query_id
+        rows.append(m)
+    metric_cols = [k for k in rows[0] if k not in ('facet', 'split', 'paper_id')] if rows else []
+    with open(get_evaluations_filename(results_dir, facet, aggregated=False), 'w', newline='') as fp:
+        w = csv.DictWriter(fp, fieldnames=metric_cols + ['facet', 'split', 'paper_id'])
+        w.writeheader()
+        w.writerows(rows)
+    agg = []
+    for f in sorted({r['facet'] for r in rows}):
+        for sp in sorted({r['split'] for r in rows}):
+            sel = [r for r in rows if r['facet'] == f and r['split'] == sp]
+            a = {k: round(float(np.mean([r[k] for r in sel])), 4) for k in metric_cols}     # evaluate.py:141 (.round(4))
+            a['facet'], a['split'] = f, sp
+            agg.append(a)
+    with open(get_evaluations_filename(results_dir, facet, aggregated=True), 'w', newline='') as fp:
+        w = csv.DictWriter(fp, fieldnames=metric_cols + ['facet', 'split'])
+        w.writeheader()
+        w.writerows(agg)
+    return rows, agg

@@ -130,3 +130,28 @@ def test_csfcube_style_ragged_rerank(amd):
     dist = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
     want_d = np.array([orc.get_similarity(query, c) for c in cands[:40]], dtype=np.float32)
     np.testing.assert_allclose(dist[:40], want_d, atol=TOL, rtol=0)
+
+
+def test_score_and_evaluate_steps_close_the_map_loop(amd, tmp_path):
+    """evaluate.py score -> scores.json -> evaluate -> MAP, on a synthetic faceted pool: the ranking written to disk is
+    the oracle's (stable descending by similarity), and MAP is what the metrics give for it."""
+    from aspire_amd import evaluate as ev
+    from aspire_amd.repstore import RepStore
+    g = torch.Generator().manual_seed(61)
+    pids = [f'p{i}' for i in range(30)]
+    store = RepStore({p: torch.randn(int(n), 768, generator=g).numpy()
+                      for p, n in zip(pids, torch.randint(2, 10, (30,), generator=g))})
+    test_pool = {'p0': {'cands': pids[1:26]}, 'p1': {'cands': pids[5:30]}}
+    labels = {p: (['background_label', 'method_label'] * 5)[:store.get(p).shape[0]] for p in pids}
+    gold = {q: {c: (i * 7) % 4 for i, c in enumerate(d['cands'])} for q, d in test_pool.items()}
+    res = ev.score(str(tmp_path), test_pool, store, facet='method', pred_labels=labels, method='ot', schedule='pair')
+    for q, d in test_pool.items():
+        qrep = torch.from_numpy(store.faceted(q, 'method', labels[q]))
+        want = [orc.get_similarity(qrep, torch.from_numpy(store.get(c))) for c in d['cands']]
+        order = [d['cands'][i] for i in orc.rank_descending(want)]
+        assert [c for c, _ in res[q]] == order
+        np.testing.assert_allclose([-s for _, s in res[q]], sorted(want, reverse=True), atol=TOL)
+    rows, agg = ev.evaluate(str(tmp_path), gold, facet='method')
+    assert len(rows) == 2 and agg[0]['facet'] == 'method'
+    want_map = np.mean([orc.average_precision([1 if gold[q][c] >= 2 else 0 for c, _ in res[q]]) for q in test_pool])
+    assert agg[0]['av_precision'] == pytest.approx(round(float(want_map), 4))

@@ -71,3 +71,28 @@ def test_repstore_roundtrip_and_facets(tmp_path):
     assert rs.faceted('p2', 'all', labels).shape == (5, 768)
     with pytest.raises(ImportError):
         RepStore.from_h5(tmp_path / 'missing.h5')
+
+
+def test_evaluate_step_reads_scores_json(tmp_path):
+    """evaluate.py:85-160 on a scores.json in the reference's layout: per-query rows + aggregated means, csv files
+    under the reference's names (no GPU: the score step is covered by the -m gpu suite)."""
+    import json
+    from aspire_amd import evaluate as ev
+    from aspire_amd import metrics as mt
+    rng = np.random.RandomState(0)
+    cands = [f'c{i}' for i in range(25)]           # the reference's precision@20 needs pools of >= 20 (metrics.py:141)
+    gold = {q: {c: int(g) for c, g in zip(cands, rng.randint(0, 4, size=25))} for q in ('q1', 'q2')}
+    ranked = {q: [[c, -float(i)] for i, c in enumerate(rng.permutation(cands))] for q in ('q1', 'q2')}
+    with open(ev.get_scores_filename(str(tmp_path), None), 'w') as f:
+        json.dump(ranked, f)
+    rows, agg = ev.evaluate(str(tmp_path), gold, facet=None, threshold_grade=2, split={'q1': 'test', 'q2': 'dev'})
+    assert [r['paper_id'] for r in rows] == ['q1', 'q2']
+    for row, q in zip(rows, ('q1', 'q2')):
+        rels = [gold[q][c] for c, _ in ranked[q]]
+        assert row['av_precision'] == pytest.approx(mt.average_precision([1 if r >= 2 else 0 for r in rels]))
+        assert row['ndcg'] == pytest.approx(mt.ndcg_at_k(rels, len(rels)))
+    assert {(a['facet'], a['split']) for a in agg} == {('unfaceted', 'test'), ('unfaceted', 'dev')}
+    assert os.path.exists(os.path.join(tmp_path, 'query-evaluations.csv'))
+    assert os.path.exists(os.path.join(tmp_path, 'aggregated-evaluations.csv'))
+    assert ev.get_scores_filename('r', 'background') == os.path.join('r', 'scores-background.json')
+    assert ev.get_evaluations_filename('r', 'method', True) == os.path.join('r', 'aggregated-evaluations-method.csv')
