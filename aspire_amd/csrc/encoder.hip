@@ -54,8 +54,21 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int z1 = blockIdx.z / g.nz2, z2 = blockIdx.z % g.nz2;
+    // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs; remap so that
+    // each XCD walks a CONTIGUOUS run of tiles (n fastest) -- the column tiles that share an A row-tile then hit
+    // that XCD's L2 instead of eight different ones.
+    uint32_t bx, by, bz;
+    {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+        const uint32_t b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t x = b & 7, q8 = nb >> 3, r8 = nb & 7;
+        const uint32_t L = x * q8 + (x < r8 ? x : r8) + (b >> 3);
+        bx = L % gx;
+        by = (L / gx) % gy;
+        bz = L / (gx * gy);
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int z1 = bz / g.nz2, z2 = bz % g.nz2;
     const float* A = g.A + z1 * g.sa1 + z2 * g.sa2;
     const float* B = g.B + z1 * g.sb1 + z2 * g.sb2;
     float* C = g.C + z1 * g.sc1 + z2 * g.sc2;
@@ -129,12 +142,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
         const int buf = t & 1;
         if (t + 1 < nk) load_tiles((t + 1) * kBK);  // in flight under the MFMAs below
 #pragma unroll
+        // k-step kk multiplies k rows kk (lanes 0-31) and kk + 8 (lanes 32-63): any pairing of the 16 rows sums
+        // to the same product, and this one puts the two half-waves on opposite halves of the 64 LDS banks
+        // (8 rows x 132 floats = 32 mod 64), so the operand reads are conflict free.
         for (int kk = 0; kk < kBK / 2; ++kk) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kk + lk][wr * WM + 32 * i + lr];
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + (kBK / 2) * lk][wr * WM + 32 * i + lr];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kk + lk][wc * WN + 32 * j + lr];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + (kBK / 2) * lk][wc * WN + 32 * j + lr];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -396,4 +412,18 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         x = out;
     }
     return ASPIRE_OK;
+}
+
+// Tuning hook (not part of include/aspire_hip.h): one plain C = A . B^T (+bias) GEMM through the encoder's tile
+// dispatch, for tools/gemmbench.py.  A [M,K], B [N,K], C [M,N], all row-major fp32 device pointers.
+extern "C" int aspire_debug_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                                     void* stream) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = nullptr;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N; g.ldr = 0;
+    g.nz2 = 1;
+    g.alpha = 1.0f;
+    g.gelu = 0;
+    return launch_gemm<false>(g, 1, (hipStream_t)stream);
 }

@@ -1,0 +1,34 @@
+"""fp32-MFMA GEMM throughput of the encoder's GEMM kernel at given shapes (GPU box).
+usage: python tools/gemmbench.py [M N K ...]   (triples)"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aspire_amd import _lib
+
+def main():
+    v = [int(x) for x in sys.argv[1:]]
+    shapes = [tuple(v[i:i + 3]) for i in range(0, len(v), 3)] or [(8192, 2304, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 768, 768), (4096, 4096, 4096)]
+    f = _lib.lib.aspire_debug_gemm_f32
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    w = torch.randn(4096, 4096, device='cuda')
+    for _ in range(200): w @ w          # clocks up before the first measurement
+    torch.cuda.synchronize()
+    for M, N, K in shapes:
+        A = torch.randn(M, K, device='cuda'); B = torch.randn(N, K, device='cuda'); C = torch.empty(M, N, device='cuda')
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        run = lambda: f(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, st)
+        for _ in range(3): assert run() == 0
+        torch.cuda.synchronize()
+        n, us = 20, 1e30
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n): run()
+            b.record(); torch.cuda.synchronize()
+            us = min(us, a.elapsed_time(b) / n * 1e3)
+        err = (C[:64] - A[:64] @ B.T).abs().max().item()
+        print(f'M={M} N={N} K={K}: {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}%)  max|err| vs torch {err:.2e}')
+
+if __name__ == '__main__':
+    main()

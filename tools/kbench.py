@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aspire_amd import _lib, ops
 
-def timeit(fn, n=200, warm=20):
+def timeit(fn, n=int(os.environ.get("KBENCH_N", "200")), warm=int(os.environ.get("KBENCH_WARM", "20"))):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
