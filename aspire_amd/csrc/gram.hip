@@ -240,9 +240,9 @@ __global__ void __launch_bounds__(256, BN == 128 ? 2 : 3) pair_gram_kernel(GramA
         float a[2][TM], b[2][TN];   // operands of k-step kk+1 are read while step kk's MFMAs run
         auto read_operands = [&](int kk, int slot) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[slot][i] = As[buf][2 * kk + lk][wr * WM + 32 * i + lr];
+            for (int i = 0; i < TM; ++i) a[slot][i] = As[buf][kk + (kBK / 2) * lk][wr * WM + 32 * i + lr];   // k rows kk | kk+8: half-waves on opposite bank halves
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[slot][j] = Bs[buf][2 * kk + lk][wc * WN + 32 * j + lr];
+            for (int j = 0; j < TN; ++j) b[slot][j] = Bs[buf][kk + (kBK / 2) * lk][wc * WN + 32 * j + lr];
         };
         read_operands(0, 0);
 #pragma unroll
