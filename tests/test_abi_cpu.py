@@ -94,3 +94,29 @@ def test_spans_to_csr():
     assert tok.tolist() == [1, 2, 3, 5, 6, 7]
     assert off.tolist() == [0, 2, 3, 3, 6, 6, 6]
     assert tok.dtype == torch.int32 and off.dtype == torch.int32
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/aspire_hip.h is what a C caller (or a cgo / JNI stub) binds: it must compile as C99 with nothing but
+    the standard headers, and a program that references every entry point must link against the library.  The
+    program only takes addresses and calls the two host-only queries (no GPU here)."""
+    import subprocess
+    from aspire_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = _header_functions(root)
+    src = tmp_path / 'abi_check.c'
+    src.write_text('#include <stdio.h>\n#include "aspire_hip.h"\n'
+                   'typedef void (*fn_t)(void);\n'
+                   'int main(void) {\n  fn_t fns[] = {' + ', '.join(f'(fn_t){n}' for n in names) + '};\n'
+                   '  aspire_repset r; aspire_ot_params p; (void)r; (void)p;\n'
+                   '  if (aspire_abi_version() != 1 || aspire_max_sents() != 32) return 1;\n'
+                   '  if (aspire_ot_workspace_bytes(0, 0, ASPIRE_PAIR_CROSS) != 0) return 2;\n'
+                   '  if (aspire_topk_desc_f32(0, 1, 1, 0, 0, 0, 0, 0, 0, 0) != ASPIRE_ERR_INVALID_ARG) return 3;\n'
+                   '  printf("%d %s\\n", (int)(sizeof(fns) / sizeof(fns[0])), aspire_last_error());\n  return 0;\n}\n')
+    exe = tmp_path / 'abi_check'
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', f'-I{root}/include', str(src), '-o', str(exe),
+                           f'-L{libdir}', '-laspire_hip', f'-Wl,-rpath,{libdir}', '-Wl,-rpath,/opt/rocm/lib'])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.split()[0] == str(len(names)) and len(out.stdout.split()) > 1      # count + the error text
