@@ -17,6 +17,8 @@
 //   softmax_mask_kernel      rows of scores: x*scale + key-padding bias, softmax in place (one wave per row)
 //   layernorm_kernel         y = LN(x) * gamma + beta, eps 1e-12                       (one wave per token)
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -42,18 +44,20 @@ struct GemmArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int kBK, bool B_KN>
+template <int BM, int BN, int kBK, bool B_KN, int WAVES_N = 2>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
     constexpr int LDA = BM + 4, LDB = BN + 4;  // k-major LDS rows; +4 keeps float4 alignment and staggers banks
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * kBK / 4 / 256;  // float4 loads per thread per tile
-    constexpr int B_F4 = BN * kBK / 4 / 256;
-    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
+    constexpr int B_F4 = (BN * kBK / 4 + 255) / 256;
+    constexpr bool B_EXACT = BN * kBK / 4 % 256 == 0;   // 96-column tiles: 1.5 float4 per thread, the tail is guarded
+    static_assert(A_F4 >= 1 && B_F4 >= 1 && WM % 32 == 0 && WN % 32 == 0, "tile / wave layout");
     __shared__ __attribute__((aligned(16))) float As[2][kBK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK][LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs; remap so that
     // each XCD walks a CONTIGUOUS run of tiles (n fastest) -- the column tiles that share an A row-tile then hit
     // that XCD's L2 instead of eight different ones.
@@ -94,8 +98,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
             } else {
                 const int row = idx / (kBK / 4), k4 = idx % (kBK / 4);
                 const int n = n0 + row, k = k0 + 4 * k4;
-                rb[p] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(B + (size_t)n * g.ldb + k)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[p] = ((B_EXACT || row < BN) && n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(B + (size_t)n * g.ldb + k)
+                                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -117,10 +121,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
                 *reinterpret_cast<float4*>(&Bs[buf][kr][4 * n4]) = rb[p];
             } else {
                 const int row = idx / (kBK / 4), k4 = idx % (kBK / 4);
-                Bs[buf][4 * k4 + 0][row] = rb[p].x;
-                Bs[buf][4 * k4 + 1][row] = rb[p].y;
-                Bs[buf][4 * k4 + 2][row] = rb[p].z;
-                Bs[buf][4 * k4 + 3][row] = rb[p].w;
+                if (B_EXACT || row < BN) {
+                    Bs[buf][4 * k4 + 0][row] = rb[p].x;
+                    Bs[buf][4 * k4 + 1][row] = rb[p].y;
+                    Bs[buf][4 * k4 + 2][row] = rb[p].z;
+                    Bs[buf][4 * k4 + 3][row] = rb[p].w;
+                }
             }
         }
     };
@@ -281,6 +287,13 @@ __global__ void __launch_bounds__(256) softmax_mask_kernel(float* __restrict__ s
     }
 }
 
+// fraction of the last round of workgroups that runs empty, at 3 resident workgroups per CU
+double gemm_rounds_waste(long long blocks) {
+    const double rounds = (double)blocks / 768.0;
+    const double full = (double)((blocks + 767) / 768);
+    return (full - rounds) / full;
+}
+
 template <bool B_KN>
 int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     // Tile choice: the largest tile that still gives >= ~2 blocks per CU; small-N GEMMs (N = 768 on 8192 rows is
@@ -289,7 +302,15 @@ int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     const long long b12864 = (long long)((g.M + 127) / 128) * ((g.N + 63) / 64) * batch;
     // BK = 16 with double-buffered LDS (34 KB / block, 3 blocks per CU) measured 96 TFLOP/s end to end against
     // 85 for BK = 32 (67 KB, 2 blocks per CU): occupancy matters more than halving the barrier count here.
-    if (b128 >= 512 && g.N >= 128) {
+    // 96-column tiles (4 waves stacked on M, 32 x 96 each) when they divide N and fill whole rounds of the 768
+    // resident workgroups where 128-column tiles leave half a round idle (QKV, N = 2304: 1152 -> 1536 workgroups).
+    const long long b12896 = (long long)((g.M + 127) / 128) * (g.N / 96) * batch;
+    const char* force = getenv("ASPIRE_HIP_GEMM_TILE");   // tuning only
+    const bool force96 = force && !strcmp(force, "96") && g.N % 96 == 0;
+    if (!B_KN && g.N % 96 == 0 && (force96 || (b12896 >= 768 && gemm_rounds_waste(b12896) + 0.05 < gemm_rounds_waste(b128)))) {
+        dim3 grid(g.N / 96, (g.M + 127) / 128, batch);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 96, 16, false, 1>), grid, dim3(256), 0, st, g);
+    } else if (b128 >= 512 && g.N >= 128) {
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
         hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, B_KN>), grid, dim3(256), 0, st, g);
     } else if (b12864 >= 512) {
