@@ -287,6 +287,149 @@ __global__ void __launch_bounds__(256) softmax_mask_kernel(float* __restrict__ s
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused attention for one (document, head, 128 queries): softmax(Q K^T / 8 + mask) V without the [L, L] score
+// matrix ever leaving the chip (the three-kernel form writes it, reads and rewrites it in the softmax, and reads it
+// again: 400 MB per layer at B = 32, L = 256).  Everything is computed TRANSPOSED so that probabilities never change
+// layout between the two products:
+//   S^T = K Q^T   : keys are the MFMA M side, queries the N side -> in the 32x32 C layout lane n = lane & 31 is a
+//                   QUERY and its 16 accumulator registers (x 4 row blocks) are KEYS.  The soft-max over keys is
+//                   therefore in-register per lane, plus ONE exchange with lane ^ 32 (the other half of the keys).
+//   O^T = V^T P^T : P^T is the B operand [k = key][n = query] -- lane n = query again, and the MFMA's k pair is
+//                   (lanes < 32, lanes >= 32) = exactly the two key halves the C layout left in those lanes.  So
+//                   accumulator register t of S^T goes straight back in as the B operand of step t.
+// A wave owns 32 queries (their Q rows live in 32 registers for the whole kernel) and all keys; the 4 waves of a
+// workgroup share the K tile (staged k-major, dims paired (d, d+8) so the half-waves read opposite LDS bank
+// halves) and the V tile (row-major, 72-float rows: keys 4 apart land 32 banks apart).  Keys are walked in
+// tiles of 128 with the usual running max / sum rescaling (flash attention), all in fp32 with exp2.
+// HF semantics kept: scores / sqrt(64) + (1 - mask) * finfo.min, soft-max over keys (modeling_bert.py).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFaLdK = 132, kFaLdV = 72;
+__global__ void __launch_bounds__(256, 2) flash_attn_f32_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                                float* __restrict__ ctx, int L, int H) {
+    __shared__ __attribute__((aligned(16))) float Ks[64][kFaLdK];     // [dim][key]
+    __shared__ __attribute__((aligned(16))) float Vs[128][kFaLdV];    // [key][dim]
+    __shared__ float kbias[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lk = lane >> 5;
+    const int qblocks = (L + 127) / 128;
+    const int qb = blockIdx.x % qblocks, h = (blockIdx.x / qblocks) % H, b = blockIdx.x / (qblocks * H);
+    const size_t ld = 3 * kD;
+    const float* base = qkv + (size_t)b * L * ld + h * 64;
+    const int q_row = qb * 128 + wave * 32 + lr;                      // this lane's query
+    const bool q_ok = q_row < L;
+    // Q^T operand registers: step t = 8 G + j multiplies dims (16 G + j | 16 G + 8 + j) in lanes (< 32 | >= 32)
+    float qreg[32];
+    {
+        const float* qp = base + (size_t)min(q_row, L - 1) * ld;
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const float4 u = *reinterpret_cast<const float4*>(qp + 16 * G + 8 * lk);
+            const float4 v = *reinterpret_cast<const float4*>(qp + 16 * G + 8 * lk + 4);
+            qreg[8 * G + 0] = u.x; qreg[8 * G + 1] = u.y; qreg[8 * G + 2] = u.z; qreg[8 * G + 3] = u.w;
+            qreg[8 * G + 4] = v.x; qreg[8 * G + 5] = v.y; qreg[8 * G + 6] = v.z; qreg[8 * G + 7] = v.w;
+        }
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mb][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                              // l_run: this half-wave's share of the sum
+    constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) folded with log2(e)
+
+    for (int k0 = 0; k0 < L; k0 += 128) {
+        __syncthreads();                                               // previous tile fully consumed
+        // ---- stage K (transposed) and V: thread -> key tid >> 1, 32 dims (tid & 1) * 32 .. -------------------
+        {
+            const int key = tid >> 1, d0 = (tid & 1) * 32;
+            const bool ok = k0 + key < L;
+            const float* kp = base + kD + (size_t)min(k0 + key, L - 1) * ld + d0;
+            const float* vp = kp + kD;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float4 kv = *reinterpret_cast<const float4*>(kp + 4 * c);
+                float4 vv = *reinterpret_cast<const float4*>(vp + 4 * c);
+                if (!ok) kv = vv = make_float4(0.f, 0.f, 0.f, 0.f);
+                Ks[d0 + 4 * c + 0][key] = kv.x;
+                Ks[d0 + 4 * c + 1][key] = kv.y;
+                Ks[d0 + 4 * c + 2][key] = kv.z;
+                Ks[d0 + 4 * c + 3][key] = kv.w;
+                *reinterpret_cast<float4*>(&Vs[key][d0 + 4 * c]) = vv;
+            }
+            if (tid < 128) {
+                const int kk = k0 + tid;
+                // additive mask in log2 units; keys past L are tile padding and must weigh exactly 0
+                kbias[tid] = kk >= L ? -INFINITY : (mask[(size_t)b * L + kk] != 0 ? 0.f : -3.4028234663852886e38f);
+            }
+        }
+        __syncthreads();
+        // ---- S^T tile: 4 blocks of 32 keys x this wave's 32 queries -------------------------------------------
+        f32x16 sacc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[rb][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int d = 16 * (t >> 3) + (t & 7) + 8 * lk;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[d][32 * rb + lr], qreg[t], sacc[rb], 0, 0, 0);
+        }
+        // ---- online soft-max over this tile's keys (registers of this lane + the other half-wave) -------------
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * rb + 8 * (r >> 2) + 4 * lk + (r & 3);
+                // scores * (1/8) + mask, then to log2 units; the mask constant times log2(e) overflows to -inf, which
+                // exp2 maps to the same 0 that exp(-3.4e38 - max) gives
+                sacc[rb][r] = fmaf(sacc[rb][r], kScaleLog2, kbias[key] * 1.44269504088896340736f);
+                tmax = fmaxf(tmax, sacc[rb][r]);
+            }
+        tmax = fmaxf(tmax, lane_xor<32>(tmax));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // exp2(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[rb][r] = __builtin_amdgcn_exp2f(sacc[rb][r] - m_new);
+                psum += sacc[rb][r];
+            }
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[mb][r] *= alpha;
+        // ---- O^T += V^T P^T: accumulator register t of S^T is the B operand of step t -------------------------
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = 32 * rb + 8 * (t >> 2) + 4 * lk + (t & 3);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    o[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key][32 * mb + lr], sacc[rb][t], o[mb], 0, 0, 0);
+            }
+    }
+    // ---- normalise and store: lane = query, registers = head dims (4 consecutive per group) --------------------
+    const float l_tot = l_run + lane_xor<32>(l_run);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        float* op = ctx + ((size_t)b * L + q_row) * kD + h * 64;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4*>(op + 32 * mb + 8 * g4 + 4 * lk) =
+                    make_float4(o[mb][4 * g4 + 0] * inv, o[mb][4 * g4 + 1] * inv, o[mb][4 * g4 + 2] * inv, o[mb][4 * g4 + 3] * inv);
+    }
+}
+
 // fraction of the last round of workgroups that runs empty, at 3 resident workgroups per CU
 double gemm_rounds_waste(long long blocks) {
     const double rounds = (double)blocks / 768.0;
@@ -393,25 +536,35 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         g.A = x; g.B = ly.w_qkv; g.C = ws.qkv; g.bias = ly.b_qkv;
         g.M = (int)M; g.N = 3 * kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = 3 * kD; g.nz2 = 1; g.alpha = 1.f;
         if (int rc = launch_gemm<false>(g, 1, st)) return rc;
-        // 2. scores[b,h] = Q_bh . K_bh^T   (scale and mask are applied by the softmax kernel)
-        g = GemmArgs{};
-        g.A = ws.qkv; g.B = ws.qkv + kD; g.C = ws.scores;
-        g.M = (int)L; g.N = (int)L; g.K = dh; g.lda = 3 * kD; g.ldb = 3 * kD; g.ldc = Lp; g.nz2 = H; g.alpha = 1.f;
-        g.sa1 = (long long)L * 3 * kD; g.sa2 = dh; g.sb1 = g.sa1; g.sb2 = dh;
-        g.sc1 = (long long)H * L * Lp; g.sc2 = (long long)L * Lp;
-        if (int rc = launch_gemm<false>(g, (int)(B * H), st)) return rc;
-        // 3. masked softmax over keys
-        const int64_t srows = B * H * L;
-        hipLaunchKernelGGL(softmax_mask_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, st, ws.scores, attn_mask, srows,
-                           (int)L, Lp, (int)(H * L), 1.0f / sqrtf((float)dh));
-        ASPIRE_LAUNCH_OK();
-        // 4. ctx[b, :, h*64:(h+1)*64] = P_bh . V_bh        (V is [K = L keys, N = 64] n-contiguous)
-        g = GemmArgs{};
-        g.A = ws.scores; g.B = ws.qkv + 2 * kD; g.C = ws.ctx;
-        g.M = (int)L; g.N = dh; g.K = (int)L; g.lda = Lp; g.ldb = 3 * kD; g.ldc = kD; g.nz2 = H; g.alpha = 1.f;
-        g.sa1 = (long long)H * L * Lp; g.sa2 = (long long)L * Lp; g.sb1 = (long long)L * 3 * kD; g.sb2 = dh;
-        g.sc1 = (long long)L * kD; g.sc2 = dh;
-        if (int rc = launch_gemm<true>(g, (int)(B * H), st)) return rc;
+        // 2-4. attention.  Fused kernel (scores never leave the chip) unless ASPIRE_HIP_ATTN=gemm pins the
+        // three-kernel form (QK^T GEMM, masked soft-max, PV GEMM) that the fused one is tested against.
+        const char* attn_env = getenv("ASPIRE_HIP_ATTN");
+        if (dh == 64 && !(attn_env && !strcmp(attn_env, "gemm"))) {
+            const unsigned qblocks = (unsigned)((L + 127) / 128);
+            hipLaunchKernelGGL(flash_attn_f32_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkv, attn_mask, ws.ctx,
+                               (int)L, H);
+            ASPIRE_LAUNCH_OK();
+        } else {
+            // 2. scores[b,h] = Q_bh . K_bh^T   (scale and mask are applied by the softmax kernel)
+            g = GemmArgs{};
+            g.A = ws.qkv; g.B = ws.qkv + kD; g.C = ws.scores;
+            g.M = (int)L; g.N = (int)L; g.K = dh; g.lda = 3 * kD; g.ldb = 3 * kD; g.ldc = Lp; g.nz2 = H; g.alpha = 1.f;
+            g.sa1 = (long long)L * 3 * kD; g.sa2 = dh; g.sb1 = g.sa1; g.sb2 = dh;
+            g.sc1 = (long long)H * L * Lp; g.sc2 = (long long)L * Lp;
+            if (int rc = launch_gemm<false>(g, (int)(B * H), st)) return rc;
+            // 3. masked softmax over keys
+            const int64_t srows = B * H * L;
+            hipLaunchKernelGGL(softmax_mask_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, st, ws.scores, attn_mask, srows,
+                               (int)L, Lp, (int)(H * L), 1.0f / sqrtf((float)dh));
+            ASPIRE_LAUNCH_OK();
+            // 4. ctx[b, :, h*64:(h+1)*64] = P_bh . V_bh        (V is [K = L keys, N = 64] n-contiguous)
+            g = GemmArgs{};
+            g.A = ws.scores; g.B = ws.qkv + 2 * kD; g.C = ws.ctx;
+            g.M = (int)L; g.N = dh; g.K = (int)L; g.lda = Lp; g.ldb = 3 * kD; g.ldc = kD; g.nz2 = H; g.alpha = 1.f;
+            g.sa1 = (long long)H * L * Lp; g.sa2 = (long long)L * Lp; g.sb1 = (long long)L * 3 * kD; g.sb2 = dh;
+            g.sc1 = (long long)L * kD; g.sc2 = dh;
+            if (int rc = launch_gemm<true>(g, (int)(B * H), st)) return rc;
+        }
         // 5. attention output projection + residual, LayerNorm
         g = GemmArgs{};
         g.A = ws.ctx; g.B = ly.w_o; g.C = ws.tmp; g.bias = ly.b_o; g.res = x; g.ldr = kD;
