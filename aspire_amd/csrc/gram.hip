@@ -342,6 +342,16 @@ __global__ void __launch_bounds__(256, BN == 128 ? 2 : 3) pair_gram_kernel(GramA
     __syncthreads();
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // Entries whose expansion cancelled (d^2 tiny against the norms; only where torch.cdist would use the direct
+    // formula) are not finished here: they go on a work list in LDS (the operand buffers are free now) and are
+    // recomputed afterwards by WHOLE WAVES, one entry at a time, 12 coordinates per lane.  A lane-local recompute
+    // would serialise 768 coordinates per flagged entry while its 63 wave mates wait: with real sentence vectors,
+    // where a few percent of the pairs are that close, that was several times the cost of the tile's MFMAs.
+    uint32_t* wlist = reinterpret_cast<uint32_t*>(&As[0][0][0]);
+    constexpr int kCap = 2 * kBK * LDA;                                 // (row << 16 | column) entries in As's footprint
+    __shared__ uint32_t wl_count;
+    if (tid == 0) wl_count = 0;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -360,26 +370,74 @@ __global__ void __launch_bounds__(256, BN == 128 ? 2 : 3) pair_gram_kernel(GramA
                 const float4 yy4 = *reinterpret_cast<const float4*>(&c_nrm[m0]);
                 const float yy[4] = {yy4.x, yy4.y, yy4.z, yy4.w};
                 float cost[4], neg[4];
+                bool redo[4];
+                bool any_redo = false;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float sq = fmaf(-2.f, acc[i][j][4 * g4 + k], xx) + yy[k];
                     cost[k] = sqrtf(fmaxf(sq, 1e-8f));
                     neg[k] = -sqrtf(fmaxf(sq, 0.f));
                     const float ns = xx + yy[k];
-                    if (!mm && sq < kDirectTau * ns * ns && qp != zrow && c_ptr[m0 + k] != zrow) neg[k] = -sqrtf(direct_d2(qp, c_ptr[m0 + k]));
+                    redo[k] = !mm && sq < kDirectTau * ns * ns && qp != zrow && c_ptr[m0 + k] != zrow;
+                    if (redo[k]) {
+                        const uint32_t slot = atomicAdd(&wl_count, 1u);
+                        if (slot < (uint32_t)kCap) wlist[slot] = ((uint32_t)(m0 + k) << 16) | (uint32_t)n;
+                        else { neg[k] = -sqrtf(direct_d2(qp, c_ptr[m0 + k])); redo[k] = false; }   // list full: lane-local
+                    }
+                    any_redo |= redo[k];
                 }
                 if constexpr (L2MAX) {
                     float best = -INFINITY;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (qp != zrow && c_ptr[m0 + k] != zrow) best = fmaxf(best, neg[k]);
+                        if (!redo[k] && qp != zrow && c_ptr[m0 + k] != zrow) best = fmaxf(best, neg[k]);
                     if (best > -INFINITY) atomicMax(&pairmax[(int)co * 16 + (int)qo], order_key(best));
                 } else {
                     *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
-                    *reinterpret_cast<float4*>(g.neg + qo + co) = make_float4(neg[0], neg[1], neg[2], neg[3]);
+                    if (!any_redo) {
+                        *reinterpret_cast<float4*>(g.neg + qo + co) = make_float4(neg[0], neg[1], neg[2], neg[3]);
+                    } else {   // the work-list pass writes the flagged ones: no address is stored twice
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (!redo[k]) g.neg[qo + co + k] = neg[k];
+                    }
                 }
             }
         }
+    __syncthreads();
+    {
+        // 16 lanes (one DPP row) per entry, 48 coordinates per lane: 16 entries per workgroup in flight, 24
+        // independent 16-byte loads per lane, and a 4-step in-row reduction
+        const uint32_t n_redo = min(wl_count, (uint32_t)kCap);
+        const int grp = tid >> 4, l16 = tid & 15;
+        for (uint32_t e0 = 0; e0 < n_redo; e0 += 16) {
+            const uint32_t e = e0 + grp;
+            const bool live = e < n_redo;
+            const uint32_t mn = wlist[live ? e : 0];
+            const int m = (int)(mn >> 16), n = (int)(mn & 0xFFFFu);
+            const unsigned long long xp = q_ptr[n], yp = c_ptr[m];
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; c += 2) {
+                const float4 u0 = ldg4(xp, 4 * l16 + 64 * c), v0 = ldg4(yp, 4 * l16 + 64 * c);
+                const float4 u1 = ldg4(xp, 4 * l16 + 64 * c + 64), v1 = ldg4(yp, 4 * l16 + 64 * c + 64);
+                const float a0 = u0.x - v0.x, a1 = u0.y - v0.y, a2 = u0.z - v0.z, a3 = u0.w - v0.w;
+                const float b0 = u1.x - v1.x, b1 = u1.y - v1.y, b2 = u1.z - v1.z, b3 = u1.w - v1.w;
+                p0 = fmaf(a3, a3, fmaf(a2, a2, fmaf(a1, a1, fmaf(a0, a0, p0))));
+                p1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, p1))));
+            }
+            float part = p0 + p1;
+            part += lane_xor<1>(part);
+            part += lane_xor<2>(part);
+            part += lane_xor<4>(part);
+            part += lane_xor<8>(part);
+            const float negd = -sqrtf(part);
+            if (live && l16 == 0) {
+                if constexpr (L2MAX) atomicMax(&pairmax[(int)c_off[m] * 16 + (int)q_off[n]], order_key(negd));
+                else g.neg[q_off[n] + c_off[m]] = negd;
+            }
+        }
+    }
     if constexpr (L2MAX) {
         __syncthreads();
         const int cd = tid >> 4, qd = tid & 15;

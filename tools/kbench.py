@@ -16,7 +16,14 @@ def timeit(fn, n=int(os.environ.get("KBENCH_N", "200")), warm=int(os.environ.get
 
 def mk(n, s, seed):
     g = torch.Generator().manual_seed(seed)
-    rows = torch.randn(n * s, 768, generator=g).cuda()
+    rows = torch.randn(n * s, 768, generator=g)
+    if os.environ.get('KBENCH_CLUSTER'):
+        # sentence vectors around one common direction with row-specific spread: a few percent of the sentence pairs
+        # are close enough for the matmul expansion to cancel (exercises the direct-formula work list of gram.hip)
+        base = torch.randn(768, generator=torch.Generator().manual_seed(123)) * (15.0 / 768 ** 0.5)
+        spread = 0.05 + 0.25 * torch.rand(n * s, 1, generator=g)
+        rows = base[None, :] + spread * rows
+    rows = rows.cuda()
     ar = torch.arange(n, device='cuda', dtype=torch.int32)
     return ops.DeviceRepSet(rows, (ar * s).contiguous(), torch.full((n,), s, device='cuda', dtype=torch.int32), ext=0, max_len=s)
 
