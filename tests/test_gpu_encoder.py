@@ -36,7 +36,7 @@ def _batch(b, l, vocab, seed, ragged=True):
     return tok, torch.zeros_like(tok), mask, lens.tolist()
 
 
-@pytest.mark.parametrize('n_layers,b,l', [(0, 2, 16), (1, 3, 37), (2, 4, 128), (12, 2, 64)])
+@pytest.mark.parametrize('n_layers,b,l', [(0, 2, 16), (1, 3, 37), (2, 4, 128), (12, 2, 64), (1, 3, 129), (1, 2, 300)])
 def test_bert_forward_matches_transformers(n_layers, b, l):
     from aspire_amd.encoder import HipBertEncoder
     m = _bert(n_layers)
@@ -49,6 +49,24 @@ def test_bert_forward_matches_transformers(n_layers, b, l):
     assert err < TOL, err
     # padded query rows still attend to the real keys in BertModel; they agree too
     assert (got - want).abs().max().item() < TOL
+
+
+def test_fused_attention_matches_three_kernel_form():
+    """ASPIRE_HIP_ATTN=gemm runs attention as QK^T GEMM + masked soft-max + PV GEMM; the fused kernel (default) must
+    give the same hidden states (key tiles of 128: lengths on, just past and between tile edges, ragged masks)."""
+    import os
+    from aspire_amd.encoder import HipBertEncoder
+    m = _bert(2, seed=5)
+    enc = HipBertEncoder(m)
+    for l in (128, 131, 257):
+        tok, seg, mask, _ = _batch(3, l, 3000, seed=100 + l)
+        fused = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+        os.environ['ASPIRE_HIP_ATTN'] = 'gemm'
+        try:
+            ref = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+        finally:
+            del os.environ['ASPIRE_HIP_ATTN']
+        assert (fused - ref).abs().max().item() < 2e-5, l
 
 
 def test_bert_full_length_512():
