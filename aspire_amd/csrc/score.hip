@@ -786,10 +786,10 @@ struct RowSet {
 };
 #ifdef ASPIRE_PHASE_CLOCK
 static __device__ long long* g_k1dbg = nullptr;
-// stamps of workgroup 7, wave 1, its 10th item
+// stamps of workgroup 7, wave 1, its second item
 #define K1_STAMP(k)                                                                                         \
     do {                                                                                                    \
-        if (g_k1dbg && blockIdx.x == 7 && wave == 1 && lane == 0 && item == 7 + 10 * gridDim.x)      \
+        if (g_k1dbg && blockIdx.x == 7 && wave == 1 && lane == 0 && item == 7 + gridDim.x)      \
             g_k1dbg[k] = (long long)__builtin_readcyclecounter();                                           \
     } while (0)
 #else
@@ -859,11 +859,16 @@ __global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, Pair
     for (; item < n_items; item += gridDim.x) {
         const uint32_t next = item + gridDim.x;
         if (next < n_items) load_item(nxt, a, next, nq, paired, dofs, nq_len, nc_len);
-        // ---- accumulate + reduce the current item (register operands only) ----
+        // ---- accumulate + reduce the current item (register operands only).  Only the x.y sums are accumulated:
+        // geomloss's cost is the expansion anyway, and torch.cdist's direct (x - y)^2 form (the marginals' -cdist)
+        // is met by the same expansion to a few 1e-5 except where it cancels -- those entries (d^2 below 1e-4 of the
+        // squared norm sum; none on unrelated vectors) are redone coordinate by coordinate below.  Dropping the
+        // second set of 32 accumulators and its cross-lane reduction is 2/3 of this kernel's VALU work, which at
+        // ~1000 pairs is what the kernel's time is made of.
         K1_STAMP(0);
-        half_tile_partials<true, true>(cur.x0, cur.y, red, xp, lane);
+        half_tile_partials<true, false>(cur.x0, cur.y, red, xp, lane);
         K1_STAMP(1);
-        half_tile_partials<true, true>(cur.x1, cur.y, red + 32, xp, lane);
+        half_tile_partials<true, false>(cur.x1, cur.y, red + 32, xp, lane);
         K1_STAMP(2);
         {
             float nrm[16];
@@ -887,10 +892,55 @@ __global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, Pair
         const uint32_t c_loc = nq == 1 ? item : item / nq;
         const uint32_t q_loc = nq == 1 ? 0 : item - c_loc * nq;
         const int64_t slot = paired ? (int64_t)c_loc : (int64_t)q_loc * ncand + c_loc;
-        finish_pair<1>(lds, use_mm_formula(a.cdist_mode, q_len, c_len), own_diam, ws, slot);
-        K1_STAMP(5);
+        unsigned long long* redo_mask = reinterpret_cast<unsigned long long*>(lds + Lds<1>::kXp);   // wave 0's scratch, idle now
+        if (wave == 0) {
+            const int li = lane >> 3, lj = lane & 7;
+            float gsum = 0.f, xx = 0.f, yy = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                gsum += lds[w * 128 + lane];
+                xx += lds[Lds<1>::kRed + w * 16 + li];
+                yy += lds[Lds<1>::kRed + w * 16 + 8 + lj];
+            }
+            const float sq = fmaf(-2.f, gsum, xx) + yy;
+            const float ns = xx + yy;
+            const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+            const bool redo = !mm && li < q_len && lj < c_len && sq < 1e-4f * ns * ns;
+            ws.cost[slot * 64 + lane] = sqrtf(fmaxf(sq, 1e-8f));
+            if (!redo) ws.neg[slot * 64 + lane] = -sqrtf(fmaxf(sq, 0.f));
+            const unsigned long long m = __ballot(redo);
+            if (lane == 0) {
+                *redo_mask = m;
+                if (own_diam) {
+                    const float* dd = lds + Lds<1>::kRed + Lds<1>::kNorm;
+                    ws.diam2[slot] = dd[0] + dd[1] + dd[2];
+                }
+            }
+        }
         __syncthreads();
-        K1_STAMP(6);
+        {
+            unsigned long long todo = *redo_mask;     // workgroup-uniform
+            if (__builtin_expect(todo != 0, 0)) {
+                const int64_t c_idx = a.cand0 + c_loc;
+                const int64_t q_idx = paired ? c_idx : (int64_t)q_loc;
+                const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
+                const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
+                float* part = lds + Lds<1>::kXp + 8;
+                while (todo) {
+                    const int e = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const float4 u = ld4(qdoc + (size_t)(e >> 3) * kD), v = ld4(cdoc + (size_t)(e & 7) * kD);
+                    const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+                    const float sp = wave_sum(fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0))));
+                    if (lane == 0) part[wave] = sp;
+                    __syncthreads();
+                    if (threadIdx.x == 0) ws.neg[slot * 64 + e] = -sqrtf(part[0] + part[1] + part[2]);
+                    __syncthreads();
+                }
+            }
+        }
+        K1_STAMP(5);
+        K1_STAMP(6);   // (the barrier that used to sit here is the one before the redo-mask read above)
         if (next < n_items) {
             cur = nxt;
             q_len = nq_len;

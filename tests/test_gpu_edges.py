@@ -155,3 +155,25 @@ def test_score_and_evaluate_steps_close_the_map_loop(amd, tmp_path):
     assert len(rows) == 2 and agg[0]['facet'] == 'method'
     want_map = np.mean([orc.average_precision([1 if gold[q][c] >= 2 else 0 for c, _ in res[q]]) for q in test_pool])
     assert agg[0]['av_precision'] == pytest.approx(round(float(want_map), 4))
+
+
+def test_small_pool_with_coincident_sentences(amd):
+    """The small-pool cost kernel accumulates only x.y and takes -cdist from the expansion; entries where that
+    cancels (a candidate sentence equal, or nearly equal, to a query sentence) are redone with the direct formula,
+    so marginals -- and with them the OT value -- follow the reference's torch.cdist."""
+    g = torch.Generator().manual_seed(15)
+    q = _docs(91, [8])[0]
+    cands = _docs(92, [8, 5, 8, 3, 7, 8])
+    cands[0][3] = q[2]                                              # exact copy
+    cands[2][0] = q[7] + 1e-3 * torch.randn(768, generator=g)       # distance ~0.03
+    cands[4][6] = q[0] + 3e-2 * torch.randn(768, generator=g)       # distance ~0.8
+    got = amd.scorer.score_pool([q], cands, method='ot', schedule='pair').cpu().numpy()[0]
+    want = np.array([orc.get_similarity(q, c) for c in cands], dtype=np.float32)
+    noisy = np.array([True, False, True, False, False, False])     # the solver's own cost cancels there (see test_gpu_gram)
+    np.testing.assert_allclose(got[~noisy], want[~noisy], atol=TOL, rtol=0)
+    np.testing.assert_allclose(got[noisy], want[noisy], atol=5e-2, rtol=0)
+    # plan-weighted similarity reads -cdist directly: the exact copy contributes exactly 0 * plan
+    sims = amd.scorer.score_pool([q], cands, method='ot', schedule='batch').cpu().numpy()[0]
+    want_s = np.array(orc.rank_pool_caching(q.numpy(), [c.numpy() for c in cands]), dtype=np.float32)
+    np.testing.assert_allclose(sims[~noisy], want_s[~noisy], atol=1e-2, rtol=0)
+    assert np.isfinite(sims).all()

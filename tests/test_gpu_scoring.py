@@ -252,8 +252,9 @@ def test_packed_tile_kernel_matches_single(amd):
     big = amd.scorer.score_pool(queries, cands, method='ot', schedule='pair').cpu()
     for lo in (0, 4000, 8100):
         small = amd.scorer.score_pool(queries, cands[lo:lo + 103], method='ot', schedule='pair').cpu()
-        # same arithmetic per entry, but the row norms are summed over 16-lane vs 32-lane partitions: last-bit noise
-        np.testing.assert_allclose(big[:, lo:lo + 103].numpy(), small.numpy(), atol=2e-5, rtol=0)
+        # the tile kernel forms -cdist with the direct (x - y)^2 sums, the small-pool kernel from the expansion
+        # (fix-up only where it cancels): the marginals differ in the last digits, the OT value by a few 1e-5
+        np.testing.assert_allclose(big[:, lo:lo + 103].numpy(), small.numpy(), atol=5e-5, rtol=0)
     idx = [0, 1, 2, 3, 4097, 8200, 8201, 8202]
     want = np.array([[orc.get_similarity(q, cands[i]) for i in idx] for q in queries], dtype=np.float32)
     np.testing.assert_allclose(big.numpy()[:, idx], want, atol=TOL, rtol=0)

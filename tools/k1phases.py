@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aspire_amd import _lib, ops
 from tools_common import mk
-q, c = mk(1, 8, 0), mk(20000, 8, 1)
+q, c = mk(1, 8, 0), mk(1000, 8, 1)
 buf = torch.zeros(16, dtype=torch.int64, device='cuda')
 _lib.lib.aspire_debug_k1_buffer.argtypes = [ctypes.c_void_p]
 _lib.lib.aspire_debug_k1_buffer(ctypes.c_void_p(buf.data_ptr()))
