@@ -852,13 +852,9 @@ __global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, Pair
     float* rednorm = lds + Lds<1>::kRed + wave * 16;
     float* xp = lds + Lds<1>::kXp + wave * kXpWave;
 
-    RowSet cur, nxt;
-    int q_len = 0, c_len = 0, nq_len = 0, nc_len = 0;
-    uint32_t item = blockIdx.x;
-    if (item < n_items) load_item(cur, a, item, nq, paired, dofs, q_len, c_len);
-    for (; item < n_items; item += gridDim.x) {
-        const uint32_t next = item + gridDim.x;
-        if (next < n_items) load_item(nxt, a, next, nq, paired, dofs, nq_len, nc_len);
+    // One item: accumulate, reduce, finish, hand over.  `r` is one of two register sets that take turns (the loop
+    // below is unrolled by two so that the set being prefetched into is never copied).
+    auto process = [&](const RowSet& rs, int q_len, int c_len, uint32_t item) {
         // ---- accumulate + reduce the current item (register operands only).  Only the x.y sums are accumulated:
         // geomloss's cost is the expansion anyway, and torch.cdist's direct (x - y)^2 form (the marginals' -cdist)
         // is met by the same expansion to a few 1e-5 except where it cancels -- those entries (d^2 below 1e-4 of the
@@ -866,24 +862,24 @@ __global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, Pair
         // second set of 32 accumulators and its cross-lane reduction is 2/3 of this kernel's VALU work, which at
         // ~1000 pairs is what the kernel's time is made of.
         K1_STAMP(0);
-        half_tile_partials<true, false>(cur.x0, cur.y, red, xp, lane);
+        half_tile_partials<true, false>(rs.x0, rs.y, red, xp, lane);
         K1_STAMP(1);
-        half_tile_partials<true, false>(cur.x1, cur.y, red + 32, xp, lane);
+        half_tile_partials<true, false>(rs.x1, rs.y, red + 32, xp, lane);
         K1_STAMP(2);
         {
             float nrm[16];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                nrm[i] = sq4(cur.x0[i]);
-                nrm[4 + i] = sq4(cur.x1[i]);
-                nrm[8 + i] = sq4(cur.y[i]);
-                nrm[12 + i] = sq4(cur.y[4 + i]);
+                nrm[i] = sq4(rs.x0[i]);
+                nrm[4 + i] = sq4(rs.x1[i]);
+                nrm[8 + i] = sq4(rs.y[i]);
+                nrm[12 + i] = sq4(rs.y[4 + i]);
             }
             const float r = lds_wave_reduce<16>(nrm, xp, lane);
             if ((lane & 3) == 0) rednorm[lane >> 2] = r;
         }
         if (own_diam) {
-            const float sbox = wave_sum(box_partial(cur));
+            const float sbox = wave_sum(box_partial(rs));
             if (lane == 0) lds[Lds<1>::kRed + Lds<1>::kNorm + wave] = sbox;
         }
         K1_STAMP(3);
@@ -940,13 +936,21 @@ __global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, Pair
             }
         }
         K1_STAMP(5);
-        K1_STAMP(6);   // (the barrier that used to sit here is the one before the redo-mask read above)
-        if (next < n_items) {
-            cur = nxt;
-            q_len = nq_len;
-            c_len = nc_len;
-        }
-        K1_STAMP(7);
+    };
+    RowSet ra, rb;
+    int qa = 0, ca = 0, qb = 0, cb = 0;
+    const uint32_t stride = gridDim.x;
+    uint32_t item = blockIdx.x;
+    if (item < n_items) load_item(ra, a, item, nq, paired, dofs, qa, ca);
+    while (item < n_items) {
+        const uint32_t n1 = item + stride;
+        if (n1 < n_items) load_item(rb, a, n1, nq, paired, dofs, qb, cb);     // in flight under this item's arithmetic
+        process(ra, qa, ca, item);
+        if (n1 >= n_items) break;
+        const uint32_t n2 = n1 + stride;
+        if (n2 < n_items) load_item(ra, a, n2, nq, paired, dofs, qa, ca);
+        process(rb, qb, cb, n1);
+        item = n2;
     }
 }
 
