@@ -371,9 +371,66 @@ __device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want
     }
 }
 
+// Lane <-> entry map of the one-solve-per-wave kernel.  T > 1: (li, lj) = (lane >> 3, lane & 7).  T == 1 spreads the
+// two cross-row lane bits over BOTH index directions -- lj = lane bits {0, 1, 4}, li = lane bits {2, 3, 5} -- so that
+// each of the two reductions of a Sinkhorn step is two DPP levels plus ONE v_permlane*_swap, instead of three DPP
+// levels for the rows and one DPP level plus two swaps (mov + swap + add each, the longest links of the dependent
+// chain) for the columns.
+template <int T>
+__device__ __forceinline__ void lane_ij(int lane, int& li, int& lj) {
+    if constexpr (T == 1) {
+        lj = (lane & 3) | ((lane >> 2) & 4);
+        li = ((lane >> 2) & 3) | ((lane >> 3) & 4);
+    } else {
+        li = lane >> 3;
+        lj = lane & 7;
+    }
+}
+template <int T>
+__device__ __forceinline__ float rsum8(float v) {   // all-reduce over the 8 lanes that share li
+    if constexpr (T == 1) {
+        v += lane_xor<1>(v);
+        v += lane_xor<2>(v);
+        return swap_add<16>(v, v);
+    } else {
+        return row8_sum(v);
+    }
+}
+template <int T>
+__device__ __forceinline__ float csum8(float v) {   // all-reduce over the 8 lanes that share lj
+    if constexpr (T == 1) {
+        v += dpp_mov<0x124>(v, v);   // row_ror:4
+        v += dpp_mov<0x128>(v, v);   // row_ror:8
+        return swap_add<32>(v, v);
+    } else {
+        return col8_sum(v);
+    }
+}
+template <int T>
+__device__ __forceinline__ float rmax8(float v) {
+    if constexpr (T == 1) {
+        v = fmaxf(v, lane_xor<1>(v));
+        v = fmaxf(v, lane_xor<2>(v));
+        return fmaxf(v, lane_xor<16>(v));
+    } else {
+        return row8_max(v);
+    }
+}
+template <int T>
+__device__ __forceinline__ float cmax8(float v) {
+    if constexpr (T == 1) {
+        v = fmaxf(v, dpp_mov<0x124>(v, v));
+        v = fmaxf(v, dpp_mov<0x128>(v, v));
+        return fmaxf(v, lane_xor<32>(v));
+    } else {
+        return col8_max(v);
+    }
+}
+
 template <int T>
 __device__ __forceinline__ void load_pair(PairState<T>& s, const PairWs<T>& ws, int64_t slot, int lane) {
-    const int li = lane >> 3, lj = lane & 7;
+    int li, lj;
+    lane_ij<T>(lane, li, lj);
 #pragma unroll
     for (int ta = 0; ta < T; ++ta)
 #pragma unroll
@@ -395,14 +452,12 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
 
 #ifdef ASPIRE_PHASE_CLOCK
-#define PHASE_STAMP(k)                                                             \
-    do {                                                                           \
-        if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_ok) { \
-            a.dbg[(k)] = (long long)__builtin_readcyclecounter();                  \
-            a.dbg[16 + (k)] = (long long)wall_clock64();                           \
-        }                                                                          \
-        if (a.dbg && blockIdx.x < 1000 && blockIdx.y == 0 && lane == 0 && stamp_ok)  \
-            a.dbg[4096 + 16 * blockIdx.x + (k)] = (long long)wall_clock64();       \
+// debug build only (tools/k1phases.py): cycle stamps of one wave into the buffer set by aspire_debug_k1_buffer
+static __device__ long long* g_k1dbg = nullptr;
+#define PHASE_STAMP(k)                                                                              \
+    do {                                                                                            \
+        if (g_k1dbg && blockIdx.x == 3 && (threadIdx.x >> 6) == 1 && lane == 0 && stamp_ok)        \
+            g_k1dbg[32 + (k)] = (long long)__builtin_readcyclecounter();                            \
     } while (0)
 #else
 #define PHASE_STAMP(k) \
@@ -413,9 +468,11 @@ __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_log
 template <int T>
 __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_len, int c_len, float diam, int64_t p,
                               int lane) {
-    const int li = lane >> 3, lj = lane & 7;
+    int li, lj;
+    lane_ij<T>(lane, li, lj);
     const bool stamp_ok = true;
     (void)stamp_ok;
+    PHASE_STAMP(3);
     bool rv[T], cv[T];  // row / column validity
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -432,14 +489,14 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             float m = kNegBig;
 #pragma unroll
             for (int tb = 0; tb < T; ++tb) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : kNegBig);
-            qm[ta] = row8_max(m) / temp;
+            qm[ta] = rmax8<T>(m) / temp;
         }
 #pragma unroll
         for (int tb = 0; tb < T; ++tb) {
             float m = kNegBig;
 #pragma unroll
             for (int ta = 0; ta < T; ++ta) m = fmaxf(m, (rv[ta] && cv[tb]) ? s.neg[ta][tb] : kNegBig);
-            cm[tb] = col8_max(m) / temp;
+            cm[tb] = cmax8<T>(m) / temp;
         }
         float mq = kNegBig, mc = kNegBig;
 #pragma unroll
@@ -447,15 +504,15 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             mq = fmaxf(mq, rv[t] ? qm[t] : kNegBig);
             mc = fmaxf(mc, cv[t] ? cm[t] : kNegBig);
         }
-        mq = col8_max(mq);  // rows are spread over lane bits 3-5
-        mc = row8_max(mc);  // columns over lane bits 0-2
+        mq = cmax8<T>(mq);  // rows are spread over lane bits 3-5
+        mc = rmax8<T>(mc);  // columns over lane bits 0-2
         float sq = 0.f, sc = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             sq += rv[t] ? fast_exp(qm[t] - mq) : 0.f;
             sc += cv[t] ? fast_exp(cm[t] - mc) : 0.f;
         }
-        const float lsq = fast_log(col8_sum(sq)), lsc = fast_log(row8_sum(sc));
+        const float lsq = fast_log(csum8<T>(sq)), lsc = fast_log(rsum8<T>(sc));
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             // log_softmax(...).exp(), then geomloss log_weights: log(a), a <= 0 -> -100000
@@ -472,6 +529,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     int n_mid = (int)ceil((lbl - ld) / lsc);
     if (n_mid < 0) n_mid = 0;
     const float eps_last = (float)a.blur;
+    const float ldf = (float)(ld * 1.4426950408889634), lscf = (float)(lsc * 1.4426950408889634);   // log2 units
     PHASE_STAMP(5);
 
     float f[T], g[T];
@@ -489,12 +547,12 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
                 m = tv[0];
 #pragma unroll
                 for (int tb = 1; tb < T; ++tb) m = fmaxf(m, tv[tb]);
-                m = row8_max(m);
+                m = rmax8<T>(m);
             }
             float sum = 0.f;
 #pragma unroll
             for (int tb = 0; tb < T; ++tb) sum += fast_exp(tv[tb] - m);
-            out[ta] = -eps * (m + fast_log(row8_sum(sum)));
+            out[ta] = -eps * (m + fast_log(rsum8<T>(sum)));
         }
     };
     auto lse_cols = [&](float eps, const float (&qc)[T][T], const float (&h)[T], const float (&shift)[T], bool exact,
@@ -509,12 +567,12 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
                 m = tv[0];
 #pragma unroll
                 for (int ta = 1; ta < T; ++ta) m = fmaxf(m, tv[ta]);
-                m = col8_max(m);
+                m = cmax8<T>(m);
             }
             float sum = 0.f;
 #pragma unroll
             for (int ta = 0; ta < T; ++ta) sum += fast_exp(tv[ta] - m);
-            out[tb] = -eps * (m + fast_log(col8_sum(sum)));
+            out[tb] = -eps * (m + fast_log(csum8<T>(sum)));
         }
     };
     // One symmetric Sinkhorn update at `eps` (reps = 1/eps):
@@ -572,21 +630,21 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     auto step2 = [&](float r2, float h) {
         float lr[T], lc[T];
         if constexpr (T == 1) {
-            // One entry per lane.  The column chain (DPP row_ror:8, v_permlane16_swap, v_permlane32_swap) and
-            // the row chain (three DPP quad ops) are independent; a single wave issues in order, so they are
-            // interleaved level by level here and pinned with sched_barrier -- a cross-lane op costs 17-26
-            // cycles of dependent latency (tools: build/dbg/lat.hip), overlapped they cost it once, not twice.
+            // One entry per lane.  The column chain and the row chain (two DPP levels and one v_permlane*_swap each,
+            // see lane_ij) are independent; a single wave issues in order, so they are interleaved level by level
+            // here and pinned with sched_barrier -- a cross-lane op costs 17-26 cycles of dependent latency
+            // (tools: build/dbg/lat.hip), overlapped they cost it once, not twice.
             float sc = __builtin_amdgcn_exp2f(fmaf(phi[0][0], r2, la2[0]));
             float sr = __builtin_amdgcn_exp2f(fmaf(phi[0][0], r2, lb2[0]));
             __builtin_amdgcn_sched_barrier(0);
-            sc += lane_xor<8>(sc);
-            sr += lane_xor<1>(sr);
+            sc += dpp_mov<0x124>(sc, sc);     // columns: lane bits 2, 3 (row_ror:4, row_ror:8), then bit 5
+            sr += lane_xor<1>(sr);            // rows:    lane bits 0, 1 (quad_perm), then bit 4
             __builtin_amdgcn_sched_barrier(0);
-            sc = swap_add<16>(sc, sc);
+            sc += dpp_mov<0x128>(sc, sc);
             sr += lane_xor<2>(sr);
             __builtin_amdgcn_sched_barrier(0);
             sc = swap_add<32>(sc, sc);
-            sr += dpp_mov<0x141>(sr, sr);
+            sr = swap_add<16>(sr, sr);
             __builtin_amdgcn_sched_barrier(0);
             lc[0] = __builtin_amdgcn_logf(sc);
             lr[0] = __builtin_amdgcn_logf(sr);
@@ -596,14 +654,14 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
                 float sum = 0.f;
 #pragma unroll
                 for (int ta = 0; ta < T; ++ta) sum += __builtin_amdgcn_exp2f(fmaf(phi[ta][tb], r2, la2[ta]));
-                lc[tb] = __builtin_amdgcn_logf(col8_sum(sum));
+                lc[tb] = __builtin_amdgcn_logf(csum8<T>(sum));
             }
 #pragma unroll
             for (int ta = 0; ta < T; ++ta) {   // rows
                 float sum = 0.f;
 #pragma unroll
                 for (int tb = 0; tb < T; ++tb) sum += __builtin_amdgcn_exp2f(fmaf(phi[ta][tb], r2, lb2[tb]));
-                lr[ta] = __builtin_amdgcn_logf(row8_sum(sum));
+                lr[ta] = __builtin_amdgcn_logf(rsum8<T>(sum));
             }
         }
 #pragma unroll
@@ -621,7 +679,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     // (instead of a compare + branch on every step's critical path) decides whether the solve has to be
     // repeated with exact maxima.
     auto solve = [&](bool exact) {
-        {   // initialisation at eps_s[0] = diam: softmin of the bare log-weights (always exact maximum)
+        if (exact) {   // initialisation at eps_s[0] = diam: softmin of the bare log-weights, exact maximum
             const float reps = rcp_refined(diam);
             float qc[T][T], zero[T];
 #pragma unroll
@@ -633,12 +691,38 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             lse_cols(diam, qc, la, zero, true, g);
             lse_rows(diam, qc, lb, zero, true, f);
             step(diam, reps, true, true);
+        } else {
+            // the same initialisation without a max shift (the largest weight of a probability vector over <= 32
+            // atoms is >= 1/32 and C/diam <= ~1, so the sums stay in range), weights as plain factors, then the
+            // first averaged step at eps = diam in the phi form like all the others
+            const float r2d = kLog2e * rcp_refined(diam), eln2d = diam * kLn2;
+            float rs[T], cs[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) rs[t] = cs[t] = 0.f;
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < T; ++tb) {
+                    const float k0 = (rv[ta] && cv[tb]) ? __builtin_amdgcn_exp2f(-s.cost[ta][tb] * r2d) : 0.f;
+                    rs[ta] = fmaf(wb[tb], k0, rs[ta]);
+                    cs[tb] = fmaf(wa[ta], k0, cs[tb]);
+                }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f[t] = -eln2d * __builtin_amdgcn_logf(rsum8<T>(rs[t]));
+                g[t] = -eln2d * __builtin_amdgcn_logf(csum8<T>(cs[t]));
+            }
+            phi_init();
+            step2(r2d, 0.5f * eln2d);
         }
         for (int base = 0; base < n_mid; base += 64) {
             // lane k of this chunk evaluates eps_{base+k} in double exactly as numpy does and rounds to fp32;
             // the per-step constants derived from it are broadcast with v_readlane inside the loop.
-            const double eps_d = exp(ld + (double)(base + lane) * lsc);
-            const float my_eps = (float)eps_d;
+            // (exact path: float64 exactly as numpy builds geomloss's schedule; fast path: fp32 exp2 of the same
+            // affine function -- a relative 1e-7 on an intermediate temperature moves the result by far less than
+            // the tolerance, and the float64 exp cost as much as ten annealing steps)
+            const float my_eps = exact ? (float)exp(ld + (double)(base + lane) * lsc)
+                                       : __builtin_amdgcn_exp2f(fmaf((float)(base + lane), lscf, ldf));
             const int cnt = min(64, n_mid - base);
             if (exact) {
                 const float my_reps = rcp_refined(my_eps);
@@ -650,16 +734,24 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
                     step(eps, reps, true, true);
                 }
             } else {
-                const float my_r2 = (float)(1.4426950408889634 / (double)my_eps);
-                const float my_h = (float)((double)my_eps * (0.5 * 0.6931471805599453));
-                if (base == 0) phi_init();
-                for (int k = 0; k < cnt; ++k) {
-                    const float r2 =
-                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_r2), k));
-                    const float h =
-                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_h), k));
-                    step2(r2, h);
+                const float my_r2 = kLog2e * rcp_refined(my_eps);
+                const float my_h = my_eps * (0.5f * kLn2);
+                // cnt is wave-uniform: keep the loop control on the scalar unit and unroll so that the branch and
+                // the two v_readlane broadcasts are not on every step's dependent chain
+                const int cnt_s = __builtin_amdgcn_readfirstlane(cnt);
+                auto bcast = [&](float v, int k) {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+                };
+                int k = 0;
+                for (; k + 4 <= cnt_s; k += 4) {      // unrolled by hand (the pinned schedule inside step2 defeats #pragma unroll)
+                    const float r0 = bcast(my_r2, k), h0 = bcast(my_h, k), r1 = bcast(my_r2, k + 1), h1 = bcast(my_h, k + 1);
+                    const float r2_ = bcast(my_r2, k + 2), h2 = bcast(my_h, k + 2), r3 = bcast(my_r2, k + 3), h3 = bcast(my_h, k + 3);
+                    step2(r0, h0);
+                    step2(r1, h1);
+                    step2(r2_, h2);
+                    step2(r3, h3);
                 }
+                for (; k < cnt_s; ++k) step2(bcast(my_r2, k), bcast(my_h, k));
             }
         }
         if (exact) {
@@ -667,9 +759,8 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             step(eps_last, rb, true, true);
             step(eps_last, rb, false, true);  // last extrapolation: simultaneous, not averaged
         } else {
-            const float r2 = (float)(1.4426950408889634 / (double)eps_last);
-            const float eln2 = (float)((double)eps_last * 0.6931471805599453);
-            if (n_mid <= 0) phi_init();
+            const float r2 = kLog2e * rcp_refined(eps_last);
+            const float eln2 = eps_last * kLn2;
             step2(r2, 0.5f * eln2);
             step2(r2, eln2);
         }
@@ -785,7 +876,6 @@ struct RowSet {
     float4 x0[4], x1[4], y[8];
 };
 #ifdef ASPIRE_PHASE_CLOCK
-static __device__ long long* g_k1dbg = nullptr;
 // stamps of workgroup 7, wave 1, its second item
 #define K1_STAMP(k)                                                                                         \
     do {                                                                                                    \
