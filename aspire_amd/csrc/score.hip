@@ -1005,23 +1005,38 @@ __global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, Pair
         }
         __syncthreads();
         {
-            unsigned long long todo = *redo_mask;     // workgroup-uniform
+            const unsigned long long todo = *redo_mask;     // workgroup-uniform
             if (__builtin_expect(todo != 0, 0)) {
+                // 16 lanes (one DPP row) per flagged entry, 48 coordinates per lane, twelve entries at a time over
+                // the three waves, no barriers: with real sentence vectors a few entries per pair can be this close
                 const int64_t c_idx = a.cand0 + c_loc;
                 const int64_t q_idx = paired ? c_idx : (int64_t)q_loc;
-                const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
-                const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
-                float* part = lds + Lds<1>::kXp + 8;
-                while (todo) {
-                    const int e = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const float4 u = ld4(qdoc + (size_t)(e >> 3) * kD), v = ld4(cdoc + (size_t)(e & 7) * kD);
-                    const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
-                    const float sp = wave_sum(fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0))));
-                    if (lane == 0) part[wave] = sp;
-                    __syncthreads();
-                    if (threadIdx.x == 0) ws.neg[slot * 64 + e] = -sqrtf(part[0] + part[1] + part[2]);
-                    __syncthreads();
+                const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
+                const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
+                const int n_flag = __builtin_popcountll(todo), l16 = lane & 15;
+                for (int base = wave * 4; base < n_flag; base += 4 * kWaves) {
+                    const int my = base + (lane >> 4);
+                    const bool live = my < n_flag;
+                    unsigned long long m = todo;
+                    for (int t = 0; t < (live ? my : 0); ++t) m &= m - 1;      // drop the first `my` set bits
+                    const int e = __builtin_ctzll(m);
+                    const float* xr = qdoc + (size_t)(e >> 3) * kD + 4 * l16;
+                    const float* yr = cdoc + (size_t)(e & 7) * kD + 4 * l16;
+                    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 12; c += 2) {
+                        const float4 u0 = ld4(xr + 64 * c), v0 = ld4(yr + 64 * c), u1 = ld4(xr + 64 * c + 64), v1 = ld4(yr + 64 * c + 64);
+                        const float a0 = u0.x - v0.x, a1 = u0.y - v0.y, a2 = u0.z - v0.z, a3 = u0.w - v0.w;
+                        const float b0 = u1.x - v1.x, b1 = u1.y - v1.y, b2 = u1.z - v1.z, b3 = u1.w - v1.w;
+                        p0 = fmaf(a3, a3, fmaf(a2, a2, fmaf(a1, a1, fmaf(a0, a0, p0))));
+                        p1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, p1))));
+                    }
+                    float part = p0 + p1;
+                    part += lane_xor<1>(part);
+                    part += lane_xor<2>(part);
+                    part += lane_xor<4>(part);
+                    part += lane_xor<8>(part);
+                    if (live && l16 == 0) ws.neg[slot * 64 + e] = -sqrtf(part);
                 }
             }
         }

@@ -177,3 +177,23 @@ def test_small_pool_with_coincident_sentences(amd):
     want_s = np.array(orc.rank_pool_caching(q.numpy(), [c.numpy() for c in cands]), dtype=np.float32)
     np.testing.assert_allclose(sims[~noisy], want_s[~noisy], atol=1e-2, rtol=0)
     assert np.isfinite(sims).all()
+
+
+def test_small_pool_clustered_vectors(amd):
+    """Sentence vectors around one common direction: many entries of the small-pool cost kernel take the
+    direct-formula redo (16 lanes each); OT distances and max-sim still meet the oracle."""
+    g = torch.Generator().manual_seed(18)
+    base = torch.randn(768, generator=g) * (15.0 / 768 ** 0.5)
+
+    def doc(n):
+        return base[None, :] + (0.05 + 0.25 * torch.rand(n, 1, generator=g)) * torch.randn(n, 768, generator=g)
+    q = doc(8)
+    cands = [doc(int(n)) for n in torch.randint(1, 9, (60,), generator=g)]
+    got = amd.scorer.score_pool([q], cands, method='ot', schedule='pair').cpu().numpy()[0]
+    want = np.array([orc.get_similarity(q, c) for c in cands], dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    l2 = amd.scorer.score_pool([q], cands, method='l2max').cpu().numpy()[0]
+    want_l2 = np.array([-orc.allpair_masked_dist_l2max(orc.RepLen(q[None].permute(0, 2, 1), [8]),
+                                                        orc.RepLen(c[None].permute(0, 2, 1), [len(c)])).item() for c in cands],
+                       dtype=np.float32)
+    np.testing.assert_allclose(l2, want_l2, atol=1e-5, rtol=0)
