@@ -98,7 +98,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    ap.add_argument('--graph-unroll', type=int, default=24, help='steps per captured graph')
+    ap.add_argument('--graph-unroll', type=int, default=0,
+                    help='steps per captured graph (0 = pick a divisor of --steps near 64: a replay has a fixed host cost)')
     ap.add_argument('--streams', type=int, default=4, help='HIP streams that independent steps alternate over')
     ap.add_argument('--shard-path', action='store_true',
                     help='run the N > 1 code path (key-form top-k, gather, merge kernel) on one GPU, for testing')
@@ -167,6 +168,8 @@ def main():
             if keys_out is not None:
                 rc = lib.aspire_topk_keys_f32(self.p[0], Q, C, TOPK, rank * C, ctypes.c_void_p(keys_out.data_ptr()), null, 0,
                                               stream())
+            elif os.environ.get('ASPIRE_BENCH_EXPERIMENT') == 'no-topk':     # tuning experiment only (invalid as a result)
+                rc = 0
             else:
                 rc = lib.aspire_topk_desc_f32(self.p[0], Q, C, TOPK, rank * C, self.p[1], self.p[2], null, 0, stream())
             if rc:
@@ -184,7 +187,15 @@ def main():
     n_streams = max(1, args.streams) if use_graph else 1
     lanes = [Lane() for _ in range(n_streams)]
     scores = lanes[0].scores
-    unroll = max(n_streams, min(args.graph_unroll, args.steps)) // n_streams * n_streams
+    def pick_unroll(k, ns):
+        # one graph replay costs tens of microseconds on the host whatever its size: 24-step graphs spent a quarter of
+        # the time there.  Take a divisor of K that is a multiple of the stream count, as close to 64 steps as possible
+        # (a 300-step graph replayed once was slower again); no such divisor -> 64 and a tail graph for the remainder.
+        cands = [d for d in range(ns, min(k, 128) + 1, ns) if k % d == 0 and d >= min(k, 32)]
+        return min(cands, key=lambda d: abs(d - 64)) if cands else max(ns, min(64, k) // ns * ns)
+
+    unroll = (max(n_streams, min(args.graph_unroll, args.steps)) // n_streams * n_streams) if args.graph_unroll > 0 \
+        else pick_unroll(args.steps, n_streams)
     keybuf = torch.zeros(unroll, Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
     gathered = torch.empty(world * unroll * Q * TOPK, device=device, dtype=torch.int64) if shard_path else None
     merged_s = torch.empty(unroll * Q, TOPK, device=device, dtype=torch.float32) if shard_path else None
@@ -234,6 +245,12 @@ def main():
                 if shard_path:
                     exchange(per_replay)
                 done += per_replay
+            tail = tail_graphs.get(id(graph))
+            if tail is not None and done + tail[1] <= args.steps:
+                tail[0].replay()
+                if shard_path:
+                    exchange(tail[1])
+                done += tail[1]
         while done < args.steps:
             eager_lane.step(keybuf[0] if shard_path else None)
             if shard_path:
@@ -256,6 +273,11 @@ def main():
                 exchange(1)
     torch.cuda.synchronize()
     g_step = capture_steps(unroll, lanes) if use_graph else None
+    tail_graphs = {}      # id(main graph) -> (graph of the K % unroll remainder, its step count)
+    rem = (args.steps % unroll) // n_streams * n_streams if use_graph else 0
+    if rem:
+        tail_graphs[id(g_step)] = (capture_steps(rem, lanes), rem)
+        tail_graphs[id(g_step)][0].replay()
     if g_step is not None:
         # untimed: let clocks and caches settle on the captured graph itself (~0.25 s), beyond the W warm-up steps
         t_settle = time.perf_counter()
@@ -276,6 +298,8 @@ def main():
     serial_elapsed = None
     if use_graph and n_streams > 1:
         g_serial = capture_steps(unroll, lanes[:1])
+        if args.steps % unroll:
+            tail_graphs[id(g_serial)] = (capture_steps(args.steps % unroll, lanes[:1]), args.steps % unroll)
         g_serial.replay()
         serial_elapsed = timed(g_serial, unroll, lanes[0])
 
