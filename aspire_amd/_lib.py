@@ -21,7 +21,7 @@ c_void_p, c_int, c_int32, c_int64, c_double, c_size_t = (ctypes.c_void_p, ctypes
 ASPIRE_OK, ASPIRE_ERR_INVALID_ARG, ASPIRE_ERR_UNSUPPORTED, ASPIRE_ERR_HIP = 0, 1, 2, 3
 CDIST_AUTO, CDIST_DIRECT, CDIST_MM = 0, 1, 2
 PAIR_CROSS, PAIR_PAIRED = 0, 1
-OT_DISTANCE, OT_PLAN_SIM = 0, 1
+OT_DISTANCE, OT_PLAN_SIM, OT_SIMILARITY = 0, 1, 2
 AGG_MAX, AGG_TOP2, AGG_ATTENTION = 0, 1, 2
 
 
@@ -77,6 +77,10 @@ SIGNATURES = {
     'aspire_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64]),
     'aspire_topk_desc_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    'aspire_ot_rank_workspace_bytes': (c_size_t, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64]),
+    'aspire_ot_rank_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, ctypes.POINTER(OtParams), c_void_p,
+                                   c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
     'aspire_topk_keys_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'aspire_topk_merge_keys': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'aspire_selftest_xlane': (c_int, [ctypes.POINTER(c_int)]),

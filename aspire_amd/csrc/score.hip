@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "score_types.h"
+#include "topk_device.h"
 
 namespace aspire {
 namespace {
@@ -785,7 +786,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
 
     // ---- outputs ------------------------------------------------------------------------------
     float score;
-    if (a.want == ASPIRE_OT_DISTANCE) {
+    if (a.want != ASPIRE_OT_PLAN_SIM) {
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -793,6 +794,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
         }
         score = wave_sum(acc);
+        if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
     } else {
         score = 0.f;
     }
@@ -1347,22 +1349,23 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
-    if (slot >= n_slots) return;
-    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
-    const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
-    const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
-    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
-    const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
-    PairState<T> st;
-    load_pair<T>(st, ws, slot, lane);
-    float diam;
-    if (a.diameter == nullptr) {
-        diam = sqrtf(ws.diam2[slot]);
-    } else {
-        diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
+    if (slot < n_slots) {
+        const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+        const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+        const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
+        const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
+        const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
+        const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
+        PairState<T> st;
+        load_pair<T>(st, ws, slot, lane);
+        float diam;
+        if (a.diameter == nullptr) {
+            diam = sqrtf(ws.diam2[slot]);
+        } else {
+            diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
+        }
+        sinkhorn_pair<T>(a, st, a.q.len[q_idx], a.c.len[c_idx], diam, p, lane);
     }
-    sinkhorn_pair<T>(a, st, a.q.len[q_idx], a.c.len[c_idx], diam, p, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1543,7 +1546,7 @@ __global__ void __launch_bounds__(256) sinkhorn4_kernel(ScoreArgs a, PairWs<1> w
     }
     // ---- outputs ---------------------------------------------------------------------------------------------
     float score;
-    if (a.want == ASPIRE_OT_DISTANCE) {
+    if (a.want != ASPIRE_OT_PLAN_SIM) {
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -1551,6 +1554,7 @@ __global__ void __launch_bounds__(256) sinkhorn4_kernel(ScoreArgs a, PairWs<1> w
             acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
         }
         score = row16_sum_i(quad_sum_j(acc));
+        if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
     } else {
         const float eb = (float)a.blur, rb = rcp_refined(eb);
         float acc = 0.f;
@@ -1785,7 +1789,7 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
     }
     // ---- outputs ---------------------------------------------------------------------------------------------
     float score;
-    if (a.want == ASPIRE_OT_DISTANCE) {
+    if (a.want != ASPIRE_OT_PLAN_SIM) {
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < R; ++t) {
@@ -1793,6 +1797,7 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
             acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
         }
         score = blk_sum_i<LD>(blk_sum_j<LD>(acc));
+        if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
     } else {
         const float rb = rcp_refined(eb);
         load_block(ws.neg, cost);
@@ -2035,14 +2040,23 @@ extern "C" size_t aspire_ot_workspace_bytes(const aspire_repset* q, const aspire
     return (per_cand > kWsCap ? per_cand : kWsCap / per_cand * per_cand) + qbox_bytes(q) + kWsSlack;
 }
 
-extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
-                                      const aspire_ot_params* prm, const float* diameter, int64_t diam_group, int want,
-                                      float* scores, float* out_qdistr, float* out_cdistr, float* out_pairsims,
-                                      float* out_plan, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// rank request of aspire_ot_rank_f32 (k == 0: scores only)
+struct RankReq {
+    int64_t k, idx_base;
+    float* top_scores;
+    int64_t* top_idx;
+    uint64_t* keys;
+};
+
+int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing, const aspire_ot_params* prm,
+           const float* diameter, int64_t diam_group, int want, float* scores, float* out_qdistr, float* out_cdistr,
+           float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes, void* stream, const RankReq& rank) {
     if (int rc = check_repsets(q, c, D, pairing)) return rc;
     if (q->n == 0 || c->n == 0) return ASPIRE_OK;   // nothing to score (an empty pool has no buffers either)
     ASPIRE_REQUIRE(prm && scores, ASPIRE_ERR_INVALID_ARG, "null params/scores");
-    ASPIRE_REQUIRE(want == ASPIRE_OT_DISTANCE || want == ASPIRE_OT_PLAN_SIM, ASPIRE_ERR_INVALID_ARG, "bad want %d", want);
+    ASPIRE_REQUIRE(want == ASPIRE_OT_DISTANCE || want == ASPIRE_OT_PLAN_SIM || want == ASPIRE_OT_SIMILARITY, ASPIRE_ERR_INVALID_ARG,
+                   "bad want %d", want);
     ASPIRE_REQUIRE(prm->blur > 0 && prm->scaling > 0 && prm->scaling < 1 && prm->sent_sm_temp > 0,
                    ASPIRE_ERR_INVALID_ARG, "need blur > 0, 0 < scaling < 1, temp > 0");
     const bool extra = out_qdistr || out_cdistr || out_pairsims || out_plan;
@@ -2076,7 +2090,9 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
     const int qchunks = query_chunks(a);
     const int64_t cand_per_chunk = (int64_t)((((workspace_bytes - qbox_bytes(q)) & ~(size_t)15) - 32) / per_cand);
     const int64_t pairs_per_cand = pairing == ASPIRE_PAIR_PAIRED ? 1 : q->n;
-    return dispatch_T(max_rows, [&](auto tc) -> int {
+    const int64_t pairs_q = pairing == ASPIRE_PAIR_PAIRED ? 1 : q->n;
+    const size_t ot_bytes = workspace_bytes;
+    const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         for (int64_t c0 = 0; c0 < c->n; c0 += cand_per_chunk) {
             a.cand0 = c0;
@@ -2086,6 +2102,10 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
             ws.cost = (float*)workspace;
             ws.neg = ws.cost + n_slots * PairWs<T>::kEntries;
             ws.diam2 = ws.neg + n_slots * PairWs<T>::kEntries;
+            // ASPIRE_HIP_SINKHORN=wave|packed|block pins the form (parity tests, tuning); default: by grid size
+            const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
+            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : !strcmp(env_form, "block16") ? 5 : 0;
+            const int form = pinned ? pinned : (n_slots >= 4096 ? 3 : 1);
             if (gram) {
                 // many queries or long documents: Gram tiles on the matrix cores (gram.hip)
                 float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
@@ -2127,10 +2147,6 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
             // Packed solves (4 per wave) have twice the throughput (1 x 20 000: 233 -> 197 us per call) but ~2x the
             // latency of one solve per wave (26.7 vs 15.4 us per call at 50 pairs): use them once the grid is big
             // enough that throughput is what counts.
-            // ASPIRE_HIP_SINKHORN=wave|packed|block pins the form (parity tests, tuning); default: by grid size
-            const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
-            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : !strcmp(env_form, "block16") ? 5 : 0;
-            const int form = pinned ? pinned : (n_slots >= 4096 ? 3 : 1);
             if (form >= 3 && !extra) {
                 // lanes per pair side LD and entries per lane side R: the smallest block grid that covers max_rows
                 auto launch_block = [&](auto ldc, auto rc) {
@@ -2167,6 +2183,41 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
         }
         return (int)ASPIRE_OK;
     });
+    if (rc_run) return rc_run;
+    if (rank.k > 0) {
+        // the rank kernels follow the scores on the same stream (their scratch sits behind the OT workspace proper)
+        const size_t need = aspire_topk_workspace_bytes(pairs_q, c->n, rank.k);
+        void* tws = need ? (char*)workspace + ot_bytes : nullptr;
+        return topk_run(scores, pairs_q, c->n, rank.k, rank.idx_base, rank.top_scores, rank.top_idx, rank.keys, tws, need, stream);
+    }
+    return ASPIRE_OK;
+}
+}  // namespace
+
+extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                      const aspire_ot_params* prm, const float* diameter, int64_t diam_group, int want,
+                                      float* scores, float* out_qdistr, float* out_cdistr, float* out_pairsims,
+                                      float* out_plan, void* workspace, size_t workspace_bytes, void* stream) {
+    return ot_run(q, c, D, pairing, prm, diameter, diam_group, want, scores, out_qdistr, out_cdistr, out_pairsims, out_plan,
+                  workspace, workspace_bytes, stream, RankReq{0, 0, nullptr, nullptr, nullptr});
+}
+
+extern "C" size_t aspire_ot_rank_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t k) {
+    if (!q || !c || q->n <= 0 || c->n <= 0) return 0;
+    return aspire_ot_workspace_bytes(q, c, ASPIRE_PAIR_CROSS) + aspire_topk_workspace_bytes(q->n, c->n, k);
+}
+
+extern "C" int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const aspire_ot_params* prm,
+                                  const float* diameter, int64_t diam_group, int want, float* scores, int64_t k,
+                                  int64_t idx_base, float* top_scores, int64_t* top_idx, uint64_t* keys, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    ASPIRE_REQUIRE(k > 0, ASPIRE_ERR_INVALID_ARG, "k must be positive");
+    ASPIRE_REQUIRE((top_scores && top_idx) || keys, ASPIRE_ERR_INVALID_ARG, "need (top_scores, top_idx) or keys");
+    ASPIRE_REQUIRE(q && c, ASPIRE_ERR_INVALID_ARG, "null repset");
+    const size_t tneed = aspire_topk_workspace_bytes(q->n, c->n, k);
+    ASPIRE_REQUIRE(workspace_bytes >= tneed, ASPIRE_ERR_INVALID_ARG, "workspace too small for the rank scratch");
+    return ot_run(q, c, D, ASPIRE_PAIR_CROSS, prm, diameter, diam_group, want, scores, nullptr, nullptr, nullptr, nullptr, workspace,
+                  workspace_bytes - tneed, stream, RankReq{k, idx_base, top_scores, top_idx, keys});
 }
 
 extern "C" int aspire_group_diameter_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,

@@ -155,6 +155,29 @@ def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_t
     return (scores, extras) if want_extras else scores
 
 
+def ot_rank(q, c, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.CDIST_AUTO, diameter=None, diam_group=0,
+            want=_lib.OT_DISTANCE, idx_base=0, key_form=False):
+    """The ranking step in one call (include/aspire_hip.h: aspire_ot_rank_f32): otAspire scores [Q, C] of every
+    query against every candidate and their per-query stable descending rank.  Returns (scores [Q, C], top_scores
+    [Q, k], top_idx [Q, k]) -- `scores` holds the raw kernel output (positive distances for OT_DISTANCE, so the rank
+    is of the OUTPUT; pass want=OT_PLAN_SIM for similarities) -- or (scores, keys [Q, k]) with key_form."""
+    dev = q.rows.device
+    scores = torch.empty(q.n, c.n, device=dev, dtype=torch.float32)
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode)
+    qs, cs = q.struct(), c.struct()
+    nbytes = lib.aspire_ot_rank_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), k)
+    ws = torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
+    top_s = top_i = keys = None
+    if key_form:
+        keys = torch.empty(q.n, k, device=dev, dtype=torch.int64)
+    else:
+        top_s = torch.empty(q.n, k, device=dev, dtype=torch.float32)
+        top_i = torch.empty(q.n, k, device=dev, dtype=torch.int64)
+    check(lib.aspire_ot_rank_f32(ctypes.byref(qs), ctypes.byref(cs), D, ctypes.byref(prm), _ptr(diameter), diam_group, want,
+                                 _ptr(scores), k, idx_base, _ptr(top_s), _ptr(top_i), _ptr(keys), _ptr(ws), ws.numel(), _stream()))
+    return (scores, keys) if key_form else (scores, top_s, top_i)
+
+
 def topk_desc(scores, k, idx_base=0):
     """A12 (evaluate.py:76): scores [Q, C] -> (top_scores [Q,k], top_idx [Q,k] int64), stable descending."""
     _f32(scores, 'scores')

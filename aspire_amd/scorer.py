@@ -74,14 +74,30 @@ def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None
     raise ValueError(f'Unknown schedule: {schedule}')
 
 
-def rank_pool(query_reps_list, pool, k=None, **kw):
-    """Per query: [(pid, score), ...] best first, ties in pool order (evaluate.py:76)."""
+def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hparams=None, score_batch_size=64):
+    """Per query: [(pid, score), ...] best first, ties in pool order (evaluate.py:76).  otAspire goes through ONE
+    C-ABI call that scores and ranks (aspire_ot_rank_f32)."""
     pool = _as_pool(pool)
     if len(pool) == 0:
         return [[] for _ in query_reps_list]
-    scores = score_pool(query_reps_list, pool, **kw)
     k = len(pool) if k is None else min(k, len(pool))
-    top_s, top_i = ops.topk_desc(scores.contiguous(), k)
+    if method == 'ot' and schedule in ('pair', 'batch') and (len(pool) <= 4096 or k < 1024):
+        hparams = hparams or {}
+        if hparams.get('geoml_reach', None) is not None:
+            raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
+        q = ops.DeviceRepSet.from_list(query_reps_list)
+        kw = dict(blur=hparams.get('geoml_blur', 0.05), scaling=hparams.get('geoml_scaling', 0.9),
+                  sent_sm_temp=hparams.get('sent_sm_temp', 1.0))
+        if schedule == 'pair':
+            _, top_s, top_i = ops.ot_rank(q, pool.repset, k, want=_lib.OT_SIMILARITY, **kw)
+        else:
+            diam = ops.group_diameter(q, pool.repset, _lib.PAIR_CROSS, group=score_batch_size)
+            _, top_s, top_i = ops.ot_rank(q, pool.repset, k, want=_lib.OT_PLAN_SIM, diameter=diam,
+                                          diam_group=score_batch_size, **kw)
+    else:
+        scores = score_pool(query_reps_list, pool, method=method, schedule=schedule, hparams=hparams,
+                            score_batch_size=score_batch_size)
+        top_s, top_i = ops.topk_desc(scores.contiguous(), k)
     top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
     return [[(pool.pids[i], float(s)) for s, i in zip(rs, ri) if i >= 0] for rs, ri in zip(top_s, top_i)]
 

@@ -150,34 +150,35 @@ def main():
             self.scores = torch.empty(Q, C, device=device, dtype=torch.float32)
             self.top_s = torch.empty(Q, TOPK, device=device, dtype=torch.float32)
             self.top_i = torch.empty(Q, TOPK, device=device, dtype=torch.int64)
-            self.ws = torch.empty(lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), _lib.PAIR_CROSS),
+            self.ws = torch.empty(lib.aspire_ot_rank_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), TOPK),
                                   device=device, dtype=torch.uint8)
             self.p = [ctypes.c_void_p(t.data_ptr()) for t in (self.scores, self.top_s, self.top_i, self.ws)]
 
         def score(self):
+            """The scoring pass alone (cost + Sinkhorn kernels), for the roofline's kernel duration."""
             rc = lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, _lib.PAIR_CROSS, ctypes.byref(prm),
-                                            null, 0, _lib.OT_DISTANCE, self.p[0], null, null, null, null, self.p[3],
+                                            null, 0, _lib.OT_SIMILARITY, self.p[0], null, null, null, null, self.p[3],
                                             self.ws.numel(), stream())
             if rc:
                 _lib.check(rc)
 
         def step(self, keys_out=None):
-            """One step: score the resident pool for the query and rank it.  Sharded job: the rank is left in KEY
-            form (global candidate index inside the key) in `keys_out` for the exchange that follows."""
-            self.score()
-            if keys_out is not None:
-                rc = lib.aspire_topk_keys_f32(self.p[0], Q, C, TOPK, rank * C, ctypes.c_void_p(keys_out.data_ptr()), null, 0,
-                                              stream())
-            elif os.environ.get('ASPIRE_BENCH_EXPERIMENT') == 'no-topk':     # tuning experiment only (invalid as a result)
-                rc = 0
-            else:
-                rc = lib.aspire_topk_desc_f32(self.p[0], Q, C, TOPK, rank * C, self.p[1], self.p[2], null, 0, stream())
+            """One step = one query ranked against the resident pool: similarities (-OT distance, models.py:197) of
+            all candidates and their stable descending top-k, ONE C-ABI call (aspire_ot_rank_f32: cost kernel,
+            Sinkhorn kernel, rank kernel).  Sharded job: the rank is left in KEY form (global
+            candidate index inside the key) in `keys_out` for the exchange that follows."""
+            if os.environ.get('ASPIRE_BENCH_EXPERIMENT') == 'no-topk':     # tuning experiment only (invalid as a result)
+                return self.score()
+            ko = ctypes.c_void_p(keys_out.data_ptr()) if keys_out is not None else null
+            rc = lib.aspire_ot_rank_f32(ctypes.byref(qs), ctypes.byref(cs), D, ctypes.byref(prm), null, 0, _lib.OT_SIMILARITY,
+                                        self.p[0], TOPK, rank * C, null if keys_out is not None else self.p[1],
+                                        null if keys_out is not None else self.p[2], ko, self.p[3], self.ws.numel(), stream())
             if rc:
                 _lib.check(rc)
 
-    # ---- the step loop is launch bound (three 8-13 us kernels per step): capture it in hipGraphs, `unroll`
-    # steps per replay, step i on stream i % n_streams so that independent steps overlap (one step's top-k and
-    # latency-bound Sinkhorn kernel run beside the next step's HBM-bound cost kernel).
+    # ---- the step loop is launch bound (three 8-9 us kernels per step): capture it in hipGraphs, `unroll`
+    # steps per replay, step i on stream i % n_streams so that independent steps overlap (one step's
+    # latency-bound Sinkhorn and rank kernels run beside the next step's HBM-bound cost kernel).
     # Multi-GPU (SURVEY.md 8e): every rank ranks ITS block of the pool for each query; the only exchange is the
     # per-query local top-k.  The steps of one graph replay are `unroll` independent queries, so their keys are
     # exchanged together: ONE RCCL all-gather of unroll * Q * k keys per rank per replay, then ONE merge kernel --
@@ -361,7 +362,7 @@ def main():
             # rocprofv3 is in profiles/ (see `breakdown`).
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'pair_cost1_kernel + sinkhorn_kernel<1> (one aspire_ot_sinkhorn_f32 call)',
+                         'kernel': 'pair_cost1_kernel + sinkhorn_kernel<1> (the scoring pass of a step)',
                          'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': bytes_per_launch,
                          'breakdown': breakdown},
         }

@@ -168,6 +168,7 @@ typedef struct {
 
 #define ASPIRE_OT_DISTANCE 0 /* return_pair_sims=False: OT_eps = <a,f> + <b,g>  (positive)          */
 #define ASPIRE_OT_PLAN_SIM 1 /* return_pair_sims=True : sum_ij P_ij * neg_ij     (negative)         */
+#define ASPIRE_OT_SIMILARITY 2 /* -OT_eps: what AspireModel.get_similarity returns (models.py:197), the ranking key */
 
 /*   diameter   NULL: each pair uses the bounding-box diameter of its own valid rows (what the
  *              reference computes when called with B = 1, src/evaluation/utils/models.py:190-197).
@@ -217,6 +218,20 @@ size_t aspire_topk_workspace_bytes(int64_t Q, int64_t C, int64_t k);
 int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
                          float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A5-A8 + A12 in one call: the ranking step of evaluate.py:58-76 / pp_gen_nearest.py:131-204 for a pool --
+ * scores [Q, C] exactly as aspire_ot_sinkhorn_f32 (pairing = ASPIRE_PAIR_CROSS, no pair outputs) followed by the
+ * per-query rank exactly as aspire_topk_desc_f32 (top_scores, top_idx) or aspire_topk_keys_f32 (keys != NULL).
+ * One host call, the kernels queued back to back on `stream`.  (A variant with the rank fused into the Sinkhorn
+ * kernel's last workgroup was measured slower than the separate rank kernel -- DESIGN.md -- and is not kept.)
+ * Workspace: aspire_ot_rank_workspace_bytes(q, c, k).
+ * ------------------------------------------------------------------------------------------- */
+size_t aspire_ot_rank_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t k);
+int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const aspire_ot_params* prm,
+                       const float* diameter, int64_t diam_group, int want, float* scores, int64_t k,
+                       int64_t idx_base, float* top_scores, int64_t* top_idx, uint64_t* keys, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SURVEY.md 8(e)  shard merge.  The same rank in KEY form for the candidate-pool shards of a multi-GPU job:

@@ -29,9 +29,9 @@ CASES = ['s8', 'rag', 'one', 'big']
 @pytest.fixture(scope='module')
 def amd():
     import aspire_amd
-    from aspire_amd import ops, scorer, pair_distances
+    from aspire_amd import ops, scorer, pair_distances, _lib
     assert torch.cuda.is_available(), 'these tests need the GPU'
-    return type('NS', (), dict(ops=ops, scorer=scorer, pd=pair_distances, pkg=aspire_amd))
+    return type('NS', (), dict(ops=ops, scorer=scorer, pd=pair_distances, pkg=aspire_amd, lib=_lib))
 
 
 @pytest.fixture(scope='module')
@@ -288,3 +288,29 @@ def test_topk_keys_and_shard_merge(amd):
     assert torch.isinf(s2[:, 7:]).all()
     with pytest.raises(NotImplementedError):
         amd.ops.topk_merge_keys(torch.zeros(50, 1, 100, dtype=torch.int64, device='cuda'), 10)
+
+
+@pytest.mark.parametrize('nq,lens', [(1, [8] * 1000), (1, [8, 3, 5, 1] * 64 + [2]), (3, [6] * 300), (2, [12, 9] * 100),
+                                     (1, [8] * 7), (1, [8] * 1500)])
+@pytest.mark.parametrize('want', ['similarity', 'plan'])
+def test_score_and_rank_in_one_call(amd, nq, lens, want):
+    """aspire_ot_rank_f32 (scores + per-query rank, one host call) against the separate calls, bit for bit, in both
+    output forms; OT_SIMILARITY is exactly the negated distance."""
+    g = torch.Generator().manual_seed(len(lens) * 7 + nq)
+    q = amd.ops.DeviceRepSet.from_list([torch.randn(8 if i == 0 else 5, 768, generator=g) for i in range(nq)])
+    cands = [torch.randn(n, 768, generator=g) for n in lens]
+    cands[5 % len(cands)] = cands[3 % len(cands)].clone()           # a tie between two candidates
+    c = amd.ops.DeviceRepSet.from_list(cands)
+    w = amd.lib.OT_SIMILARITY if want == 'similarity' else amd.lib.OT_PLAN_SIM
+    k = 100
+    ref_scores = amd.ops.ot_sinkhorn(q, c, want=w).view(nq, len(lens))
+    ref_s, ref_i = amd.ops.topk_desc(ref_scores.contiguous(), k)
+    for _ in range(3):
+        scores, top_s, top_i = amd.ops.ot_rank(q, c, k, want=w)
+        assert torch.equal(scores, ref_scores) and torch.equal(top_s, ref_s) and torch.equal(top_i, ref_i)
+        _, keys = amd.ops.ot_rank(q, c, k, want=w, idx_base=50_000, key_form=True)
+        ms, mi = amd.ops.topk_merge_keys(keys.unsqueeze(0).contiguous(), k)
+        assert torch.equal(ms, ref_s) and torch.equal(mi, torch.where(ref_i >= 0, ref_i + 50_000, ref_i))
+    if want == 'similarity':
+        dist = amd.ops.ot_sinkhorn(q, c, want=amd.lib.OT_DISTANCE).view(nq, len(lens))
+        assert torch.equal(-dist, ref_scores)
