@@ -29,6 +29,93 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
                        k_final, top_scores, top_idx, keys_final, in_k);
 }
 
+// Small pools (n <= 1024) ranked for a short list (k <= 128): select, then sort only the survivors.  The scores' order
+// bits are bucketed monotonically into 256 bins between their minimum and maximum, a suffix count finds the bin that
+// holds the k-th largest, every key in that bin or above survives (usually k plus a handful), and a 256-key network
+// (one key per thread, 36 levels) replaces the 1024-key one (four keys per thread, 55 levels).  Exact: the bucket map
+// is monotone, ties and order are decided by the full 64-bit keys of the survivors.  Falls back to the full sort in
+// the same launch when the boundary bin is crowded (more than 256 survivors, e.g. all scores equal).
+__global__ void __launch_bounds__(kThreads) topk_select_kernel(const float* __restrict__ scores, int64_t n_in, int64_t in_stride,
+                                                               int64_t idx_base, int64_t k_final, float* __restrict__ top_scores,
+                                                               int64_t* __restrict__ top_idx, uint64_t* __restrict__ keys_final) {
+    __shared__ uint64_t lds[4 * kThreads];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sm[16];      // [0..3] wave minima, [4..7] wave maxima, [8] boundary bin, [9] survivors, [10] cursor
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.x;
+    uint64_t key[4];
+    unsigned mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = tid * 4 + r;
+        uint64_t kv = 0;
+        if (i < n_in) {
+            kv = ((uint64_t)order_bits(scores[q * in_stride + i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+            const unsigned hi = (unsigned)(kv >> 32);
+            mn = min(mn, hi);
+            mx = max(mx, hi);
+        }
+        key[r] = kv;
+    }
+    hist[tid] = 0;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        mn = min(mn, (unsigned)__shfl_xor((int)mn, m));
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, m));
+    }
+    if (lane == 0) { sm[wave] = mn; sm[4 + wave] = mx; }
+    if (tid == 0) { sm[8] = 0; sm[9] = 0xFFFFFFFFu; sm[10] = 0; }
+    __syncthreads();
+    mn = min(min(sm[0], sm[1]), min(sm[2], sm[3]));
+    mx = max(max(sm[4], sm[5]), max(sm[6], sm[7]));
+    const float scale = 255.0f / (float)(mx - mn);            // mx == mn: inf -> every bucket NaN/0 -> handled below
+    auto bucket_of = [&](uint64_t kv) {
+        const float t = (float)((unsigned)(kv >> 32) - mn) * scale;
+        return (int)fminf(t, 255.0f);
+    };
+    const bool spread = mx > mn;
+    if (spread) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (key[r] != 0) atomicAdd(&hist[bucket_of(key[r])], 1u);
+    }
+    __syncthreads();
+    if (spread && wave == 0) {
+        // lane l owns bins 4l .. 4l+3; suffix counts from the top bin down
+        unsigned h[4] = {hist[4 * lane], hist[4 * lane + 1], hist[4 * lane + 2], hist[4 * lane + 3]};
+        unsigned incl = h[0] + h[1] + h[2] + h[3];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {                     // inclusive suffix sum over lanes (lane 63 first)
+            const unsigned o = (unsigned)__shfl_down((int)incl, m);
+            if (lane + m < 64) incl += o;
+        }
+        unsigned above = incl - (h[0] + h[1] + h[2] + h[3]);  // keys in bins of higher lanes
+        const unsigned kk = (unsigned)k_final;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            if (above < kk && above + h[j] >= kk) { sm[8] = 4 * lane + j; sm[9] = above + h[j]; }
+            above += h[j];
+        }
+        if (lane == 0 && above < kk) { sm[8] = 0; sm[9] = above; }   // fewer than k keys in all: everything survives
+    }
+    __syncthreads();
+    const unsigned n_surv = sm[9];
+    if (spread && n_surv <= (unsigned)kThreads) {
+        const int bmin = (int)sm[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (key[r] != 0 && bucket_of(key[r]) >= bmin) lds[atomicAdd(&sm[10], 1u)] = key[r];
+        __syncthreads();
+        uint64_t one[1] = {tid < (int)n_surv ? lds[tid] : 0ull};
+        __syncthreads();                                      // the sort's exchanges reuse lds
+        bitonic_sort<1, kThreads>(one, lds, tid);
+        topk_emit<1>(one, q, 0, k_final, nullptr, k_final, idx_base, k_final, top_scores, top_idx, keys_final, 0);
+    } else {
+        block_bitonic_desc<4>(key, lds, tid);
+        topk_emit<4>(key, q, 0, k_final, nullptr, k_final, idx_base, k_final, top_scores, top_idx, keys_final, 0);
+    }
+}
+
 int chunk_for(int64_t n) { return n <= 1024 ? 1024 : kMaxChunk; }
 
 }  // namespace
@@ -78,7 +165,10 @@ int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_b
         int64_t* ti = final_pass && !keys_final ? top_idx : nullptr;
         uint64_t* kf = final_pass ? keys_final : nullptr;
         uint64_t* ko = final_pass ? nullptr : bufs[which];
-        if (chunk == 1024) {
+        if (chunk == 1024 && final_pass && sc != nullptr && k <= 128 && n > 256) {
+            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Q), dim3(kThreads), 0, (hipStream_t)stream, sc, n, in_stride, idx_base,
+                               k, ts, ti, kf);
+        } else if (chunk == 1024) {
             hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk, ko,
                                out_stride, idx_base, k, ts, ti, kf, (int64_t)0);
         } else {

@@ -9,7 +9,8 @@ constexpr int kTopkThreads = 256;
 constexpr int kTopkMaxChunk = 4096;
 
 __device__ __forceinline__ uint32_t order_bits(float f) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    // -0.0 and +0.0 compare equal in the reference's sort (a tie, decided by pool order): give them one key
+    const uint32_t u = __builtin_bit_cast(uint32_t, f + 0.0f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float unorder_bits(uint32_t u) {
@@ -82,37 +83,14 @@ __device__ __forceinline__ void block_bitonic_desc(uint64_t (&key)[E], uint64_t*
     bitonic_sort<E, E * kTopkThreads>(key, lds, tid);
 }
 
-// in: either scores (first pass; index = position) or keys.  n_in per query; chunk c covers
-// [c*N, (c+1)*N).  Writes kk = min(k, N) keys per chunk, or the final outputs.
+// Output of a sorted block (thread t holds ranks t*E .. t*E+E-1): chunk winners as keys, or the final
+// (top_scores, top_idx) / key-form outputs.
 template <int E>
-__device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_t n_queries, uint64_t* lds, const float* __restrict__ scores,
-                                                             const uint64_t* __restrict__ keys_in, int64_t n_in,
-                                                             int64_t in_stride, int64_t kk, uint64_t* __restrict__ keys_out,
-                                                             int64_t out_stride, int64_t idx_base, int64_t k_final,
-                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
-                                                             uint64_t* __restrict__ keys_final, int64_t in_k) {
+__device__ __forceinline__ void topk_emit(const uint64_t (&key)[E], int64_t q, int64_t chunk, int64_t kk, uint64_t* __restrict__ keys_out,
+                                          int64_t out_stride, int64_t idx_base, int64_t k_final, float* __restrict__ top_scores,
+                                          int64_t* __restrict__ top_idx, uint64_t* __restrict__ keys_final, int64_t in_k) {
     constexpr int N = E * kTopkThreads;
     const int tid = threadIdx.x;
-    const int64_t base = chunk * N;
-    uint64_t key[E];
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-        const int64_t i = base + tid * E + r;
-        uint64_t kv = 0;  // pad: below every real key
-        if (i < n_in) {
-            if (scores) {
-                kv = ((uint64_t)order_bits(scores[q * in_stride + i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
-            } else if (in_k > 0) {
-                // keys gathered from R ranks, laid out [rank][query][in_k]: element i of query q = (i / in_k, i % in_k)
-                const int64_t r = i / in_k;
-                kv = keys_in[(r * n_queries + q) * in_k + (i - r * in_k)];
-            } else {
-                kv = keys_in[q * in_stride + i];
-            }
-        }
-        key[r] = kv;
-    }
-    block_bitonic_desc<E>(key, lds, tid);
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const int t = tid * E + r;
@@ -144,6 +122,39 @@ __device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_
     }
 }
 
+// in: either scores (first pass; index = position) or keys.  n_in per query; chunk c covers
+// [c*N, (c+1)*N).  Writes kk = min(k, N) keys per chunk, or the final outputs.
+template <int E>
+__device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_t n_queries, uint64_t* lds, const float* __restrict__ scores,
+                                                             const uint64_t* __restrict__ keys_in, int64_t n_in,
+                                                             int64_t in_stride, int64_t kk, uint64_t* __restrict__ keys_out,
+                                                             int64_t out_stride, int64_t idx_base, int64_t k_final,
+                                                             float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
+                                                             uint64_t* __restrict__ keys_final, int64_t in_k) {
+    constexpr int N = E * kTopkThreads;
+    const int tid = threadIdx.x;
+    const int64_t base = chunk * N;
+    uint64_t key[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int64_t i = base + tid * E + r;
+        uint64_t kv = 0;  // pad: below every real key
+        if (i < n_in) {
+            if (scores) {
+                kv = ((uint64_t)order_bits(scores[q * in_stride + i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+            } else if (in_k > 0) {
+                // keys gathered from R ranks, laid out [rank][query][in_k]: element i of query q = (i / in_k, i % in_k)
+                const int64_t r = i / in_k;
+                kv = keys_in[(r * n_queries + q) * in_k + (i - r * in_k)];
+            } else {
+                kv = keys_in[q * in_stride + i];
+            }
+        }
+        key[r] = kv;
+    }
+    block_bitonic_desc<E>(key, lds, tid);
+    topk_emit<E>(key, q, chunk, kk, keys_out, out_stride, idx_base, k_final, top_scores, top_idx, keys_final, in_k);
+}
 
 // host driver of the multi-pass rank (topk.hip); exactly one of (top_scores, top_idx) / keys_final is produced
 int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base, float* top_scores, int64_t* top_idx,

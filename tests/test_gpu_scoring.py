@@ -314,3 +314,27 @@ def test_score_and_rank_in_one_call(amd, nq, lens, want):
     if want == 'similarity':
         dist = amd.ops.ot_sinkhorn(q, c, want=amd.lib.OT_DISTANCE).view(nq, len(lens))
         assert torch.equal(-dist, ref_scores)
+
+
+@pytest.mark.parametrize('n', [257, 300, 1000, 1024])
+@pytest.mark.parametrize('k', [1, 7, 100, 128])
+def test_topk_select_path(amd, n, k):
+    """Pools of 257..1024 candidates ranked for k <= 128 go through select-then-sort (bucket the scores, keep the bins
+    that hold the top k, sort the survivors); crowded boundary bins fall back to the full sort.  Same order as
+    Python's stable descending sort in every regime."""
+    g = torch.Generator().manual_seed(n * 131 + k)
+    rows = [torch.randn(n, generator=g) - 38.0,                                  # like OT similarities
+            torch.round(torch.randn(n, generator=g) * 2) / 2,                    # many exact ties
+            torch.cat([torch.full((n - 5,), -40.0), torch.randn(5, generator=g)]),   # one crowded bin -> fallback
+            torch.full((n,), 3.25),                                              # all equal -> fallback
+            torch.where(torch.rand(n, generator=g) < 0.3, torch.tensor(float('-inf')), torch.randn(n, generator=g)),
+            torch.cat([torch.randn(n - 3, generator=g) * 1e-6, torch.tensor([1e30, -1e30, 0.0])])]   # huge spread
+    scores = torch.stack(rows).contiguous()
+    top_s, top_i = amd.ops.topk_desc(scores.cuda(), k, idx_base=7)
+    keys = amd.ops.topk_keys(scores.cuda(), k, idx_base=7)
+    ms, mi = amd.ops.topk_merge_keys(keys.unsqueeze(0).contiguous(), k)
+    for r in range(scores.shape[0]):
+        order = orc.rank_descending(scores[r].tolist())[:k]
+        assert [i - 7 for i in top_i[r].tolist()] == order, (r, n, k)
+        assert torch.equal(top_s[r].cpu(), scores[r][order])
+    assert torch.equal(mi, top_i) and torch.equal(ms, top_s)
