@@ -94,8 +94,8 @@ def cpu_baseline(query, cands, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=300)
-    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=6000)   # ~70 ms timed: a 300-step region (3 ms) was at the mercy of host jitter
+    ap.add_argument('--warmup', type=int, default=60)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--graph-unroll', type=int, default=0,

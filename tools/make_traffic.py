@@ -13,7 +13,7 @@ m = {k: sum(v) / len(v) for k, v in agg.items()}
 stats = {}
 for r in csv.DictReader(open('profiles/r01_bench_ot1x1000_kernel_stats.csv')):
     n = r['Name']
-    k = 'pair_cost' if 'pair_cost' in n else 'sinkhorn' if 'sinkhorn_kernel' in n else 'topk' if 'topk' in n else None
+    k = 'pair_cost' if 'pair_cost' in n else 'sinkhorn' if 'sinkhorn_kernel' in n else 'topk' if 'topk' in n else None  # topk_select_kernel or topk_pass_kernel
     if k: stats[k] = (float(r['AverageNs']), int(r['Calls']), n.split('(anonymous namespace)::')[1].split('(')[0] if '(anonymous namespace)::' in n else n)
 fetch = {k: m[(k, 'FETCH_SIZE')] for k in ('pair_cost', 'sinkhorn')}
 write = {k: m[(k, 'WRITE_SIZE')] for k in ('pair_cost', 'sinkhorn')}
