@@ -100,7 +100,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--graph-unroll', type=int, default=0,
                     help='steps per captured graph (0 = pick a divisor of --steps near 64: a replay has a fixed host cost)')
-    ap.add_argument('--streams', type=int, default=4, help='HIP streams that independent steps alternate over')
+    ap.add_argument('--streams', type=int, default=0,
+                    help='lanes = HIP streams with their own graphs (0 = 15, 11, 7 or 3, whichever divides --steps)')
     ap.add_argument('--shard-path', action='store_true',
                     help='run the N > 1 code path (key-form top-k, gather, merge kernel) on one GPU, for testing')
     args = ap.parse_args()
@@ -176,87 +177,150 @@ def main():
             if rc:
                 _lib.check(rc)
 
-    # ---- the step loop is launch bound (three 8-9 us kernels per step): capture it in hipGraphs, `unroll`
-    # steps per replay, step i on stream i % n_streams so that independent steps overlap (one step's
-    # latency-bound Sinkhorn and rank kernels run beside the next step's HBM-bound cost kernel).
+    # ---- the step loop is launch bound (three 5-9 us kernels per step), so steps are captured in hipGraphs; and a
+    # step is latency bound (1000 pairs are one round of workgroups), so independent steps run side by side: the K
+    # steps are dealt to NL lanes, every lane has its own HIP stream, buffers and a graph of PER consecutive steps,
+    # and the lanes' graphs replay concurrently (one step's Sinkhorn and rank kernels run beside another step's cost
+    # kernel).  Measured on MI355X / ROCm 7: 94 M alignments/s with 3 lanes, 105 with 7, 108 with 11, 110 with 15, but
+    # 73 with 4 and 89 with 8 -- lane counts of the form 4n + 3 spread over the four hardware queues best -- and the
+    # same number from run to run, which one graph with four branches did not give (78 or 100 M, depending on how
+    # the runtime mapped its branches; tools/mg_experiment.py, tools/benchdist.sh).
     # Multi-GPU: every rank ranks ITS block of the pool for each query; the only exchange is the
-    # per-query local top-k.  The steps of one graph replay are `unroll` independent queries, so their keys are
-    # exchanged together: ONE RCCL all-gather of unroll * Q * k keys per rank per replay, then ONE merge kernel --
+    # per-query local top-k.  The NL * PER steps of one round of replays are independent queries, so their keys are
+    # exchanged together: ONE RCCL all-gather of NL * PER * Q * k keys per rank per round, then ONE merge kernel --
     # the batch-of-queries form of the merge (config 5 ranks 128 queries per exchange).  The collective stays
-    # outside the captured graph.
+    # outside the captured graphs.
     use_graph = not args.no_graph
-    n_streams = max(1, args.streams) if use_graph else 1
-    lanes = [Lane() for _ in range(n_streams)]
+
+    def pick_lanes(k):
+        for nl in (15, 11, 7, 3):
+            if k % nl == 0 and k // nl >= 4:
+                return nl
+        return 7 if k >= 28 else 3 if k >= 6 else 1
+
+    NL = (max(1, args.streams) if args.streams > 0 else pick_lanes(args.steps)) if use_graph else 1
+    n_lane = [args.steps // NL + (1 if k < args.steps % NL else 0) for k in range(NL)]     # steps of each lane
+
+    def pick_per(n):
+        # a graph replay costs tens of microseconds on the host whatever its size: keep graphs at 20-64 steps
+        if args.graph_unroll > 0:
+            return max(1, min(args.graph_unroll, n))
+        cands = [d for d in range(1, min(n, 64) + 1) if n % d == 0 and d >= min(n, 20)]
+        return min(cands, key=lambda d: abs(d - 40)) if cands else max(1, min(40, n))
+
+    PER = pick_per(min(n_lane)) if use_graph else 1
+    lanes = [Lane() for _ in range(NL)]
+    lane_stream = [torch.cuda.Stream() for _ in range(NL)]
     scores = lanes[0].scores
-    def pick_unroll(k, ns):
-        # one graph replay costs tens of microseconds on the host whatever its size: 24-step graphs spent a quarter of
-        # the time there.  Take a divisor of K that is a multiple of the stream count, as close to 64 steps as possible
-        # (a 300-step graph replayed once was slower again); no such divisor -> 64 and a tail graph for the remainder.
-        cands = [d for d in range(ns, min(k, 128) + 1, ns) if k % d == 0 and d >= min(k, 32)]
-        return min(cands, key=lambda d: abs(d - 64)) if cands else max(ns, min(64, k) // ns * ns)
+    n_streams, unroll = NL, PER                       # names used in the report below
+    keybuf = torch.zeros(NL, PER, Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
+    gathered = torch.empty(world * NL * PER * Q * TOPK, device=device, dtype=torch.int64) if shard_path else None
+    merged_s = torch.empty(NL * PER * Q, TOPK, device=device, dtype=torch.float32) if shard_path else None
+    merged_i = torch.empty(NL * PER * Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
 
-    unroll = (max(n_streams, min(args.graph_unroll, args.steps)) // n_streams * n_streams) if args.graph_unroll > 0 \
-        else pick_unroll(args.steps, n_streams)
-    keybuf = torch.zeros(unroll, Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
-    gathered = torch.empty(world * unroll * Q * TOPK, device=device, dtype=torch.int64) if shard_path else None
-    merged_s = torch.empty(unroll * Q, TOPK, device=device, dtype=torch.float32) if shard_path else None
-    merged_i = torch.empty(unroll * Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
-
-    def exchange(n_steps):
-        """keys of the last n_steps steps (keybuf[:n_steps]) -> global top-k of each of them on every rank."""
+    def exchange(keys, n_steps):
+        """keys [n_steps, Q, k] (contiguous) of n_steps steps -> global top-k of each of them on every rank."""
         n = n_steps * Q * TOPK
         if world > 1:
-            dist.all_gather_into_tensor(gathered[:world * n], keybuf.view(-1)[:n])     # -> [world][n_steps][Q][k]
+            dist.all_gather_into_tensor(gathered[:world * n], keys.view(-1)[:n])     # -> [world][n_steps][Q][k]
             src = gathered
         else:
-            src = keybuf
+            src = keys
         rc = lib.aspire_topk_merge_keys(ctypes.c_void_p(src.data_ptr()), world, n_steps * Q, TOPK, TOPK,
                                         ctypes.c_void_p(merged_s.data_ptr()), ctypes.c_void_p(merged_i.data_ptr()), stream())
         if rc:
             _lib.check(rc)
 
-    def capture_steps(n, use_lanes):
+    def capture_lane(k, n, keys=None):
+        """n consecutive steps of lane k, captured on the lane's own stream."""
         g = torch.cuda.CUDAGraph()
-        side = [torch.cuda.Stream() for _ in range(len(use_lanes) - 1)]
-        with torch.cuda.graph(g):
-            main = torch.cuda.current_stream()
-            for st in side:
-                st.wait_stream(main)               # fork
+        with torch.cuda.graph(g, stream=lane_stream[k]):
             for i in range(n):
-                k = i % len(use_lanes)
-                ko = keybuf[i] if shard_path else None
-                if k == 0:
-                    use_lanes[0].step(ko)
-                else:
-                    with torch.cuda.stream(side[k - 1]):
-                        use_lanes[k].step(ko)
-            for st in side:
-                main.wait_stream(st)               # join
+                lanes[k].step(keys[i] if keys is not None else None)
         return g
 
-    def timed(graph, per_replay, eager_lane):
+    # ---- graphs: a PER-step graph per lane, plus a tail graph where a lane's share is not a multiple of PER --------
+    full = [n // PER for n in n_lane]
+    rem = [n % PER for n in n_lane]
+    g_lane = g_tail = None
+    keytail = None
+    if use_graph:
+        g_lane = [capture_lane(k, PER, keybuf[k] if shard_path else None) for k in range(NL)]
+        if shard_path and any(rem):
+            keytail = torch.zeros(NL, max(rem), Q, TOPK, device=device, dtype=torch.int64)
+        g_tail = [capture_lane(k, rem[k], keytail[k] if shard_path else None) if rem[k] else None for k in range(NL)]
+
+    def run_steps(which):
+        """Enqueue this rank's K steps (which = lanes to use: all of them, or [0] for the serial reference)."""
+        main = torch.cuda.current_stream()
+        if not use_graph:
+            kb = keybuf[0, 0] if shard_path else None
+            for _ in range(args.steps):
+                lanes[0].step(kb)
+                if shard_path:
+                    exchange(keybuf[0, :1], 1)
+            return
+        if which == [0] and NL > 1:                 # serial reference: every step on lane 0, one after the other
+            ser = serial_graphs
+            for _ in range(args.steps // PER):
+                ser[0].replay()
+            if ser[1] is not None:
+                ser[1].replay()
+            return
+        for st in lane_stream:
+            st.wait_stream(main)
+        if not shard_path:
+            for r in range(max(full)):
+                for k in range(NL):
+                    if r < full[k]:
+                        with torch.cuda.stream(lane_stream[k]):
+                            g_lane[k].replay()
+            for k in range(NL):
+                if g_tail[k] is not None:
+                    with torch.cuda.stream(lane_stream[k]):
+                        g_tail[k].replay()
+        else:
+            # rounds: every lane replays once, then the round's keys are exchanged and merged on the main stream
+            for r in range(min(full)):
+                for k in range(NL):
+                    with torch.cuda.stream(lane_stream[k]):
+                        g_lane[k].replay()
+                for st in lane_stream:
+                    main.wait_stream(st)
+                exchange(keybuf, NL * PER)
+                for st in lane_stream:
+                    st.wait_stream(main)            # the next round overwrites keybuf
+            for k in range(NL):                      # a lane whose share holds one more whole graph (PER = 1 only)
+                if full[k] > min(full):
+                    with torch.cuda.stream(lane_stream[k]):
+                        g_lane[k].replay()
+                    main.wait_stream(lane_stream[k])
+                    exchange(keybuf[k], PER)
+                    lane_stream[k].wait_stream(main)
+            if any(rem):
+                m = min(rem)
+                for k in range(NL):
+                    if g_tail[k] is not None:
+                        with torch.cuda.stream(lane_stream[k]):
+                            g_tail[k].replay()
+                for st in lane_stream:
+                    main.wait_stream(st)
+                if m > 0:
+                    exchange(keytail[:, :m].contiguous(), NL * m)
+                for k in range(NL):                  # lanes that carry one step more: its keys go alone
+                    if rem[k] > m:
+                        exchange(keytail[k, m:m + 1], 1)
+        for st in lane_stream:
+            main.wait_stream(st)
+
+    serial_graphs = None
+
+    def timed(which):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        done = 0
-        if graph is not None:
-            while done + per_replay <= args.steps:
-                graph.replay()
-                if shard_path:
-                    exchange(per_replay)
-                done += per_replay
-            tail = tail_graphs.get(id(graph))
-            if tail is not None and done + tail[1] <= args.steps:
-                tail[0].replay()
-                if shard_path:
-                    exchange(tail[1])
-                done += tail[1]
-        while done < args.steps:
-            eager_lane.step(keybuf[0] if shard_path else None)
-            if shard_path:
-                exchange(1)
-            done += 1
+        run_steps(which)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -267,29 +331,23 @@ def main():
             el = t.item()
         return el
 
-    for _ in range(max(args.warmup, 3)):
-        for ln in lanes:
-            ln.step(keybuf[0] if shard_path else None)
-            if shard_path:
-                exchange(1)
+    for _ in range(max(args.warmup // NL, 1)):       # W untimed warm-up steps, spread over the lanes
+        for k in range(NL):
+            with torch.cuda.stream(lane_stream[k]):
+                lanes[k].step(keybuf[k, 0] if shard_path else None)
     torch.cuda.synchronize()
-    g_step = capture_steps(unroll, lanes) if use_graph else None
-    tail_graphs = {}      # id(main graph) -> (graph of the K % unroll remainder, its step count)
-    rem = (args.steps % unroll) // n_streams * n_streams if use_graph else 0
-    if rem:
-        tail_graphs[id(g_step)] = (capture_steps(rem, lanes), rem)
-        tail_graphs[id(g_step)][0].replay()
-    if g_step is not None:
-        # untimed: let clocks and caches settle on the captured graph itself (~0.25 s), beyond the W warm-up steps
+    if shard_path:
+        exchange(keybuf, NL * PER)
+        torch.cuda.synchronize()
+    if use_graph and world == 1:
+        # untimed: let clocks and caches settle on the captured graphs themselves (~0.25 s), beyond the W warm-up steps
         t_settle = time.perf_counter()
-        while True:
-            g_step.replay()
-            if shard_path:
-                exchange(unroll)
+        while time.perf_counter() - t_settle < 0.25:
+            for k in range(NL):
+                with torch.cuda.stream(lane_stream[k]):
+                    g_lane[k].replay()
             torch.cuda.synchronize()
-            if world > 1 or time.perf_counter() - t_settle > 0.25:      # multi-GPU: one replay (ranks stay in step)
-                break
-    elapsed = timed(g_step, unroll, lanes[0])
+    elapsed = timed(list(range(NL)))
     if shard_path:
         # the merged ranking of the last exchanged step must be a valid descending ranking of global indices
         torch.cuda.synchronize()
@@ -297,12 +355,17 @@ def main():
         assert (merged_s[0, 1:] <= merged_s[0, :-1]).all(), 'merge output is not descending'
     # the same K steps strictly one after the other on ONE stream, for reference
     serial_elapsed = None
-    if use_graph and n_streams > 1:
-        g_serial = capture_steps(unroll, lanes[:1])
-        if args.steps % unroll:
-            tail_graphs[id(g_serial)] = (capture_steps(args.steps % unroll, lanes[:1]), args.steps % unroll)
-        g_serial.replay()
-        serial_elapsed = timed(g_serial, unroll, lanes[0])
+    if use_graph and NL > 1 and not shard_path:
+        tail_n = args.steps % PER
+        serial_graphs = (capture_lane(0, PER), capture_lane(0, tail_n) if tail_n else None)
+        with torch.cuda.stream(lane_stream[0]):
+            serial_graphs[0].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(lane_stream[0]):
+            run_steps([0])
+        torch.cuda.synchronize()
+        serial_elapsed = time.perf_counter() - t0
 
     def capture(fn, n):
         g = torch.cuda.CUDAGraph()
@@ -350,12 +413,12 @@ def main():
             'serial_value': (world * Q * C * args.steps / serial_elapsed) if serial_elapsed else None,
             'config': {'workload': f'otAspire compsci: {Q} query x {C} candidates per GPU, {S} sents x {D}d, '
                                    f'Sinkhorn OT (blur 0.05, scaling 0.9, one eps schedule per pair) + per-query '
-                                   f'top-{TOPK} rank' + (f', one RCCL all-gather of the top-{TOPK} keys of {unroll} queries '
-                                                         f'per replay + merge kernel' if shard_path else ''),
+                                   f'top-{TOPK} rank' + (f', one RCCL all-gather of the top-{TOPK} keys of {n_streams * unroll} queries '
+                                                         f'per round + merge kernel' if shard_path else ''),
                        'queries': Q, 'candidates_per_gpu': C, 'sents': S, 'dim': D, 'topk': TOPK,
                        'parallelism': f'candidate-pool shards x{world}',
-                       'launch': (f'hipGraph replay, {unroll} steps per graph, independent steps alternate over '
-                                  f'{n_streams} HIP streams') if use_graph else 'eager, 1 stream'},
+                       'launch': (f'{n_streams} lanes (HIP streams) x hipGraphs of {unroll} steps replayed concurrently, '
+                                  f'independent steps dealt to the lanes') if use_graph else 'eager, 1 stream'},
             # The scoring pass is two back-to-back kernels: pair_cost_kernel streams every rep once (the HBM side)
             # and sinkhorn_kernel solves from a 0.5 MB cost buffer (dependent-chain latency bound).  The
             # roofline prices BOTH durations against the algorithmic bytes; the per-kernel split measured by
