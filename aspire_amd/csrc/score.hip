@@ -2135,7 +2135,11 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     // small grids are latency bound: three waves per pair (a third of the coordinates each),
                     // persistent and software pipelined (measured 15.6 us per launch at 50-250 pairs against
                     // 20-23 us for the tiled form with its stages split over three or four waves)
-                    const int64_t blocks = n_slots < 512 ? n_slots : 512;
+                    const char* env_blocks = getenv("ASPIRE_HIP_COST1_BLOCKS");   // tuning only
+                    // 1024: at ~1000 pairs one pair per workgroup beats 512 persistent workgroups with two each, both
+                    // alone (44.9 vs 43.6 M pairs/s) and beside other launches (111 vs 106 M in bench.py)
+                    const int64_t cap = env_blocks ? atoi(env_blocks) : 1024;
+                    const int64_t blocks = n_slots < cap ? n_slots : cap;
                     hipLaunchKernelGGL(pair_cost1_kernel, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
                                        (hipStream_t)stream, a, ws1);
                 }
