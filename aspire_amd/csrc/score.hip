@@ -928,7 +928,11 @@ __device__ __forceinline__ float box_partial(const RowSet& r) {
     return fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
 }
 
-__global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws) {
+// PREFETCH: the persistent form (next item's rows in a second register set).  !PREFETCH: one register set, for
+// launches with (about) one item per workgroup -- half the registers, so twice the workgroups are resident and every
+// pair's loads are in flight from the start.
+template <bool PREFETCH>
+__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1044,6 +1048,15 @@ __global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, Pair
         }
         K1_STAMP(5);
     };
+    if constexpr (!PREFETCH) {
+        for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+            RowSet r1;
+            int q1 = 0, c1 = 0;
+            load_item(r1, a, item, nq, paired, dofs, q1, c1);
+            process(r1, q1, c1, item);
+        }
+        return;
+    }
     RowSet ra, rb;
     int qa = 0, ca = 0, qb = 0, cb = 0;
     const uint32_t stride = gridDim.x;
@@ -1346,6 +1359,9 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
 // latencies.
 template <int T>
 __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws, int64_t n_slots) {
+    // this kernel is ONE long dependent chain per wave: when it shares a SIMD with throughput work of another launch
+    // (a cost kernel of the next query), its instructions should issue first
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
@@ -2140,8 +2156,16 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     // alone (44.9 vs 43.6 M pairs/s) and beside other launches (111 vs 106 M in bench.py)
                     const int64_t cap = env_blocks ? atoi(env_blocks) : 1024;
                     const int64_t blocks = n_slots < cap ? n_slots : cap;
-                    hipLaunchKernelGGL(pair_cost1_kernel, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
-                                       (hipStream_t)stream, a, ws1);
+                    // ASPIRE_HIP_COST1=single picks the one-register-set form: 8 % faster for a lone call (15.6 vs
+                    // 17.4 us cost + Sinkhorn at 1000 pairs), 10 % slower when many queries' launches overlap (bench.py:
+                    // 101 vs 111 M alignments/s) -- the default serves the throughput case
+                    const char* env_c1 = getenv("ASPIRE_HIP_COST1");
+                    if (env_c1 && !strcmp(env_c1, "single") && blocks >= n_slots)
+                        hipLaunchKernelGGL(pair_cost1_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
+                                           (hipStream_t)stream, a, ws1);
+                    else
+                        hipLaunchKernelGGL(pair_cost1_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
+                                           (hipStream_t)stream, a, ws1);
                 }
             } else {
                 hipLaunchKernelGGL(pair_cost_kernel<T>, dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
 __global__ void __launch_bounds__(kThreads) topk_select_kernel(const float* __restrict__ scores, int64_t n_in, int64_t in_stride,
                                                                int64_t idx_base, int64_t k_final, float* __restrict__ top_scores,
                                                                int64_t* __restrict__ top_idx, uint64_t* __restrict__ keys_final) {
+    __builtin_amdgcn_s_setprio(3);     // one workgroup, latency only: issue ahead of co-resident throughput kernels
     __shared__ uint64_t lds[4 * kThreads];
     __shared__ unsigned hist[256];
     __shared__ unsigned sm[16];      // [0..3] wave minima, [4..7] wave maxima, [8] boundary bin, [9] survivors, [10] cursor
