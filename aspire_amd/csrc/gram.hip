@@ -272,12 +272,17 @@ __global__ void __launch_bounds__(256, BN == 128 ? 2 : 3) pair_gram_kernel(GramA
                     if (len > 0) {
                         float mn = INFINITY, mx = -INFINITY;
                         const float* col = &As[buf][bk][cd * g.mr_c];
-                        for (int r4 = 0; r4 < len; r4 += 4) {
+                        int r4 = 0;
+                        for (; r4 + 4 <= len; r4 += 4) {          // whole groups of four rows: no predicates, min3 / max3
+                            const float4 v = *reinterpret_cast<const float4*>(col + r4);
+                            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+                            mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+                        }
+                        if (r4 < len) {                            // ragged tail (rows past len are zero rows: masked)
                             const float4 v = *reinterpret_cast<const float4*>(col + r4);
                             mn = fminf(mn, v.x); mx = fmaxf(mx, v.x);
                             if (r4 + 1 < len) { mn = fminf(mn, v.y); mx = fmaxf(mx, v.y); }
                             if (r4 + 2 < len) { mn = fminf(mn, v.z); mx = fmaxf(mx, v.z); }
-                            if (r4 + 3 < len) { mn = fminf(mn, v.w); mx = fmaxf(mx, v.w); }
                         }
 #pragma unroll
                         for (int u = 0; u < kBoxQ; ++u)
