@@ -157,3 +157,65 @@ def test_gram_clustered_sentence_vectors(amd):
     np.testing.assert_allclose(l2, want_l2, atol=6e-5, rtol=0)
     np.testing.assert_allclose(l2v, want_l2, atol=1e-5, rtol=0)
     np.testing.assert_allclose(ot, want_ot, atol=TOL, rtol=0)
+
+
+def test_baseline_config3_full_size_properties(amd):
+    """BASELINE config 3 at full size (32 queries x 50 000 candidates, 8 x 768, tsAspire max-sim): the oracle cannot
+    score 1.6 M pairs in seconds, so parity is pinned through size-independent properties -- any subset of the pool
+    scored on its own gives the same numbers (each pair is independent), the two kernel families agree on a sample,
+    and the oracle agrees on a handful of pairs."""
+    g = torch.Generator().manual_seed(1)
+    nq, nc, s = 32, 50_000, 8
+    qrows = torch.randn(nq * s, 768, generator=g).cuda()
+    crows = torch.randn(nc * s, 768, generator=g).cuda()
+    mk = lambda rows, n: amd.ops.DeviceRepSet(rows, (torch.arange(n, device='cuda', dtype=torch.int32) * s).contiguous(),
+                                              torch.full((n,), s, device='cuda', dtype=torch.int32), ext=0, max_len=s)
+    q, c = mk(qrows, nq), mk(crows, nc)
+    full = amd.ops.l2max_scores(q, c).view(nq, nc)
+    assert torch.isfinite(full).all() and (full < 0).all()
+    pick = torch.randperm(nc, generator=g)[:3000].sort().values
+    sub_rows = crows.view(nc, s, 768)[pick.cuda()].reshape(-1, 768).contiguous()
+    sub = amd.ops.l2max_scores(q, mk(sub_rows, len(pick))).view(nq, len(pick))
+    np.testing.assert_allclose(full[:, pick.cuda()].cpu().numpy(), sub.cpu().numpy(), atol=1e-6, rtol=0)
+    with cost_path('valu'):
+        valu = amd.ops.l2max_scores(q, mk(sub_rows, len(pick))).view(nq, len(pick))
+    np.testing.assert_allclose(sub.cpu().numpy(), valu.cpu().numpy(), atol=2e-5, rtol=0)
+    for qi, ci in [(0, 0), (31, 49_999), (7, 12_345), (19, 33_333)]:
+        want = _l2max_oracle(qrows[qi * s:(qi + 1) * s].cpu(), crows[ci * s:(ci + 1) * s].cpu())
+        assert full[qi, ci].item() == pytest.approx(want, abs=TOL)
+    # per-query top-100 of the full matrix == stable descending sort of that row
+    top_s, top_i = amd.ops.topk_desc(full.contiguous(), 100)
+    for qi in (0, 17):
+        order = orc.rank_descending(full[qi].cpu().tolist())[:100]
+        assert top_i[qi].cpu().tolist() == order
+
+
+def test_baseline_config5_slice_properties(amd):
+    """BASELINE config 5 shape (128 queries, 12 x 768 sentences) on a slice of one GPU's shard (8192 candidates): subset
+    consistency of the otAspire similarities, agreement of the kernel families, and the oracle on a few pairs."""
+    g = torch.Generator().manual_seed(2)
+    nq, nc, s = 128, 8192, 12
+    qrows = torch.randn(nq * s, 768, generator=g).cuda()
+    crows = torch.randn(nc * s, 768, generator=g).cuda()
+    mk = lambda rows, n: amd.ops.DeviceRepSet(rows, (torch.arange(n, device='cuda', dtype=torch.int32) * s).contiguous(),
+                                              torch.full((n,), s, device='cuda', dtype=torch.int32), ext=0, max_len=s)
+    q, c = mk(qrows, nq), mk(crows, nc)
+    full = amd.ops.ot_sinkhorn(q, c, want=amd.lib.OT_SIMILARITY).view(nq, nc)
+    assert torch.isfinite(full).all()
+    pick = torch.arange(100, 1124)                      # 1024 candidates: several Gram tiles, block Sinkhorn
+    sub_rows = crows.view(nc, s, 768)[pick.cuda()].reshape(-1, 768).contiguous()
+    with cost_path('mfma'):        # the same kernel family as the full pool (1024 candidates alone would take the VALU one)
+        sub = amd.ops.ot_sinkhorn(q, mk(sub_rows, len(pick)), want=amd.lib.OT_SIMILARITY).view(nq, len(pick))
+    assert torch.equal(full[:, pick.cuda()], sub)
+    # The two kernel families agree to a few 1e-6 -- except where geomloss's schedule length, ceil(log(diam/blur) /
+    # -log(scaling)), flips: the diameter is summed in a different order, and a pair whose diameter sits on a
+    # boundary gains or loses one annealing step (5e-4 on the result; the reference flips the same way under any
+    # change of its own rounding).  1 pair in 131 072 here.
+    with cost_path('valu'):
+        with_valu = amd.ops.ot_sinkhorn(q, mk(sub_rows, len(pick)), want=amd.lib.OT_SIMILARITY).view(nq, len(pick))
+    diff = (sub - with_valu).abs()
+    assert diff.median().item() < 1e-5
+    assert int((diff > 5e-5).sum()) <= 8 and diff.max().item() < 2e-3
+    for qi, ci in [(0, 100), (127, 1123), (64, 600)]:
+        want = orc.get_similarity(qrows[qi * s:(qi + 1) * s].cpu(), crows[ci * s:(ci + 1) * s].cpu())
+        assert full[qi, ci].item() == pytest.approx(want, abs=TOL)
