@@ -2122,6 +2122,9 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
             const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
             const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : !strcmp(env_form, "block16") ? 5 : 0;
             const int form = pinned ? pinned : (n_slots >= 4096 ? 3 : 1);
+            // ASPIRE_HIP_STAGE=cost: launch the cost stage only (bench.py times the dominant kernel alone this way)
+            const char* env_stage = getenv("ASPIRE_HIP_STAGE");
+            const bool cost_only = env_stage && !strcmp(env_stage, "cost");
             if (gram) {
                 // many queries or long documents: Gram tiles on the matrix cores (gram.hip)
                 float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
@@ -2172,6 +2175,7 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                                    Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
             }
             ASPIRE_LAUNCH_OK();
+            if (cost_only) continue;
             // Packed solves (4 per wave) have twice the throughput (1 x 20 000: 233 -> 197 us per call) but ~2x the
             // latency of one solve per wave (26.7 vs 15.4 us per call at 50 pairs): use them once the grid is big
             // enough that throughput is what counts.

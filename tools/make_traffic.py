@@ -21,10 +21,11 @@ traffic = int(sum(2 * fetch[k] * 1024 + write[k] * 1024 for k in fetch))
 json.dump({
     'round': 1,
     'command': 'rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python bench.py --steps 50 --no-graph --no-cpu-baseline',
-    'workload': '1 query x 1000 candidates x 8 sents x 768 d; one aspire_ot_sinkhorn_f32 call = cost kernel + sinkhorn_kernel<1>',
+    'workload': '1 query x 1000 candidates x 8 sents x 768 d; one aspire_ot_sinkhorn_f32 call = cost kernel + sinkhorn_kernel<1>; hbm_bytes_per_launch = both kernels, cost_kernel_hbm_bytes_per_launch = the cost kernel alone',
     'FETCH_SIZE_mean_KB': fetch, 'WRITE_SIZE_mean_KB': write,
     'correction': 'MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced (16 B/lane) read stream -> doubled; WRITE_SIZE uncalibrated, taken as is',
-    'hbm_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': 24604576,
+    'hbm_bytes_per_launch': traffic, 'cost_kernel_hbm_bytes_per_launch': int(2 * fetch['pair_cost'] * 1024 + write['pair_cost'] * 1024),
+    'algorithmic_bytes_per_launch': 24604576,
     'breakdown': {'source': 'profiles/r01_bench_ot1x1000_kernel_stats.csv (rocprofv3 --kernel-trace --stats on bench.py --steps 480 --streams 1)',
                   'cost_kernel': stats['pair_cost'][2], 'cost_kernel_us': stats['pair_cost'][0] / 1e3,
                   'sinkhorn_kernel_us': stats['sinkhorn'][0] / 1e3, 'topk_pass_kernel_us': stats['topk'][0] / 1e3,
