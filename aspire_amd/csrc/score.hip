@@ -1166,11 +1166,11 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
         const int sy_len = a.c.len[sy_idx];
         const float* sy_doc = a.c.rows + (size_t)a.c.start[sy_idx] * kD;
 
-        float accg[R][R], accd[R][R];
+        float accg[R][R];
 #pragma unroll
         for (int x = 0; x < R; ++x)
 #pragma unroll
-            for (int y = 0; y < R; ++y) accg[x][y] = accd[x][y] = 0.f;
+            for (int y = 0; y < R; ++y) accg[x][y] = 0.f;
         float ny[8], nx[C::kXRows], dsq = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) ny[k] = 0.f;
@@ -1246,8 +1246,6 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
                 for (int x = 0; x < R; ++x)
 #pragma unroll
                     for (int y = 0; y < R; ++y) {
-                        const float dx = xv[x].x - yv[y].x, dy = xv[x].y - yv[y].y, dz = xv[x].z - yv[y].z, dw = xv[x].w - yv[y].w;
-                        accd[x][y] = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, accd[x][y]))));
                         accg[x][y] = fmaf(xv[x].w, yv[y].w, fmaf(xv[x].z, yv[y].z, fmaf(xv[x].y, yv[y].y, fmaf(xv[x].x, yv[y].x, accg[x][y]))));
                     }
               }
@@ -1273,7 +1271,6 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
 #pragma unroll
                 for (int y = 0; y < R; ++y) {
                     lds[((x * R + y) * 2 + 0) * 64 + lane] = accg[x][y];
-                    lds[((x * R + y) * 2 + 1) * 64 + lane] = accd[x][y];
                 }
             lds[kAcc * 64 + lane] = dsq;
             __syncthreads();
@@ -1289,7 +1286,6 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
 #pragma unroll
                     for (int y = 0; y < R; ++y) {
                         accg[x][y] += o[((x * R + y) * 2 + 0) * 64 + lane];
-                        accd[x][y] += o[((x * R + y) * 2 + 1) * 64 + lane];
                     }
                 dsq += o[kAcc * 64 + lane];
             }
@@ -1331,19 +1327,73 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
         }
 
         // ---- finish the entries and hand them to the Sinkhorn kernel -----------------------------------------
-        if (my_c_real) {
-            const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
-            const int64_t slot = paired ? (int64_t)my_c_loc : (int64_t)q_loc * ncand + my_c_loc;
+        // Only x.y was accumulated: -cdist comes from the same expansion as the cost, and the entries where it cancels
+        // (torch.cdist's direct formula differs there) are redone below.  See pair_cost1_kernel.
+        const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+        const int64_t slot = paired ? (int64_t)my_c_loc : (int64_t)q_loc * ncand + my_c_loc;
+        bool redo[R][R];
+#pragma unroll
+        for (int x = 0; x < R; ++x)
+#pragma unroll
+            for (int y = 0; y < R; ++y) {
+                const int i = R * li + x, j = R * lj + y;
+                const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
+                const float ns = xx[x] + yy[y];
+                redo[x][y] = my_c_real && !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
+                if (my_c_real) {
+                    ws.cost[slot * 64 + i * 8 + j] = sqrtf(fmaxf(sq, 1e-8f));
+                    if (!redo[x][y]) ws.neg[slot * 64 + i * 8 + j] = -sqrtf(fmaxf(sq, 0.f));
+                }
+            }
+        if (my_c_real && own_diam && lp == 0) ws.diam2[slot] = diam2;
+        if constexpr (R == 2 && DS == 1) {
+            // direct-formula redo, the 16 lanes of a candidate together: 48 coordinates per lane, 4-step DPP-row sum
+            const float* crow = a.c.rows + (size_t)a.c.start[c_idx] * kD + 4 * lp;
+            const float* qrow = qdoc + 4 * lp;
 #pragma unroll
             for (int x = 0; x < R; ++x)
 #pragma unroll
                 for (int y = 0; y < R; ++y) {
-                    const int i = R * li + x, j = R * lj + y;
-                    const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
-                    ws.cost[slot * 64 + i * 8 + j] = sqrtf(fmaxf(sq, 1e-8f));
-                    ws.neg[slot * 64 + i * 8 + j] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(accd[x][y]);
+                    unsigned long long wm = __ballot(redo[x][y]);
+                    unsigned gm = (unsigned)(wm >> (16 * p)) & 0xFFFFu;        // flagged lanes of this candidate's group
+                    while (__any(gm != 0)) {
+                        const bool act = gm != 0;
+                        const int b16 = act ? __builtin_ctz(gm) : 0;
+                        gm &= gm - 1;
+                        const int i = R * (b16 >> 2) + x, j = R * (b16 & 3) + y;
+                        float p0 = 0.f;
+                        if (act) {
+#pragma unroll
+                            for (int cc = 0; cc < 12; ++cc) {
+                                const float4 u = ld4(qrow + (size_t)i * kD + 64 * cc), v = ld4(crow + (size_t)j * kD + 64 * cc);
+                                const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+                                p0 = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, p0))));
+                            }
+                        }
+                        p0 += lane_xor<1>(p0);
+                        p0 += lane_xor<2>(p0);
+                        p0 += lane_xor<4>(p0);
+                        p0 += lane_xor<8>(p0);
+                        if (act && lp == b16) ws.neg[slot * 64 + i * 8 + j] = -sqrtf(p0);
+                    }
                 }
-            if (own_diam && lp == 0) ws.diam2[slot] = diam2;
+        } else {
+#pragma unroll
+            for (int x = 0; x < R; ++x)
+#pragma unroll
+                for (int y = 0; y < R; ++y)
+                    if (redo[x][y]) {   // other layouts (not instantiated for production): lane-local direct sum
+                        const int i = R * li + x, j = R * lj + y;
+                        const float* xr = qdoc + (size_t)i * kD;
+                        const float* yr = a.c.rows + ((size_t)a.c.start[c_idx] + j) * kD;
+                        float d2s = 0.f;
+                        for (int d = 0; d < kD; d += 4) {
+                            const float4 u = ld4(xr + d), v = ld4(yr + d);
+                            const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+                            d2s = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, d2s))));
+                        }
+                        ws.neg[slot * 64 + i * 8 + j] = -sqrtf(d2s);
+                    }
         }
         if constexpr (DS == 1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // scratch and stage buffers are reused by the next item

@@ -197,3 +197,23 @@ def test_small_pool_clustered_vectors(amd):
                                                         orc.RepLen(c[None].permute(0, 2, 1), [len(c)])).item() for c in cands],
                        dtype=np.float32)
     np.testing.assert_allclose(l2, want_l2, atol=1e-5, rtol=0)
+
+
+def test_big_pool_clustered_vectors(amd):
+    """The big-pool tile kernel (4 candidates per wave) also takes -cdist from the expansion and redoes the entries
+    where it cancels, 16 lanes per entry: clustered vectors, ragged lengths, against the small-pool path and the oracle."""
+    g = torch.Generator().manual_seed(23)
+    base = torch.randn(768, generator=g) * (15.0 / 768 ** 0.5)
+
+    def doc(n):
+        return base[None, :] + (0.05 + 0.25 * torch.rand(n, 1, generator=g)) * torch.randn(n, 768, generator=g)
+    q = doc(8)
+    cands = [doc(int(n)) for n in torch.randint(1, 9, (8203,), generator=g)]
+    big = amd.scorer.score_pool([q], cands, method='ot', schedule='pair').cpu().numpy()[0]
+    assert np.isfinite(big).all()
+    for lo in (0, 5000, 8100):
+        small = amd.scorer.score_pool([q], cands[lo:lo + 103], method='ot', schedule='pair').cpu().numpy()[0]
+        np.testing.assert_allclose(big[lo:lo + 103], small, atol=5e-5, rtol=0)
+    idx = [0, 1, 4097, 8202]
+    want = np.array([orc.get_similarity(q, cands[i]) for i in idx], dtype=np.float32)
+    np.testing.assert_allclose(big[idx], want, atol=TOL, rtol=0)
