@@ -348,8 +348,9 @@ struct PairState {
 
 // After the three waves' partial sums of one pair met in LDS: all 192 threads finish the entries
 // (sum of partials, both L2 formulas) and store them to the pair's workspace slot.
-template <int T>
-__device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want_diam, const PairWs<T>& ws, int64_t slot) {
+template <int T, bool DIRECT = true>
+__device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want_diam, const PairWs<T>& ws, int64_t slot,
+                                            const float* qdoc = nullptr, const float* cdoc = nullptr, int q_len = 0, int c_len = 0) {
     for (int e = threadIdx.x; e < 64 * T * T; e += kBlock) {
         const int tile = e >> 6, l = e & 63, ta = tile / T, tb = tile % T, li = l >> 3, lj = l & 7;
         const float* r = lds + tile * 128;
@@ -357,14 +358,35 @@ __device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
             g += r[w * T * T * 128 + l];
-            d2 += r[w * T * T * 128 + 64 + l];
+            if (DIRECT) d2 += r[w * T * T * 128 + 64 + l];
             xx += lds[Lds<T>::kRed + w * T * 16 + ta * 16 + li];
             yy += lds[Lds<T>::kRed + w * T * 16 + tb * 16 + 8 + lj];
         }
         const float sq = fmaf(-2.f, g, xx) + yy;
         const int64_t o = slot * (64 * T * T) + (ta * 8 + li) * (8 * T) + tb * 8 + lj;
         ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
-        ws.neg[o] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);
+        if constexpr (DIRECT) {
+            ws.neg[o] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);
+        } else {
+            // only x.y was accumulated (see pair_cost1_kernel): -cdist from the expansion, except where it cancels
+            const int i = ta * 8 + li, j = tb * 8 + lj;
+            const float ns = xx + yy;
+            float negv = -sqrtf(fmaxf(sq, 0.f));
+            if (!mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns) {   // rare: this thread walks the two rows itself
+                const float* xr = qdoc + (size_t)i * kD;
+                const float* yr = cdoc + (size_t)j * kD;
+                float s0 = 0.f, s1 = 0.f;
+                for (int d = 0; d < kD; d += 8) {
+                    const float4 u0 = ld4(xr + d), v0 = ld4(yr + d), u1 = ld4(xr + d + 4), v1 = ld4(yr + d + 4);
+                    const float a0 = u0.x - v0.x, a1 = u0.y - v0.y, a2 = u0.z - v0.z, a3 = u0.w - v0.w;
+                    const float b0 = u1.x - v1.x, b1 = u1.y - v1.y, b2 = u1.z - v1.z, b3 = u1.w - v1.w;
+                    s0 = fmaf(a3, a3, fmaf(a2, a2, fmaf(a1, a1, fmaf(a0, a0, s0))));
+                    s1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, s1))));
+                }
+                negv = -sqrtf(s0 + s1);
+            }
+            ws.neg[o] = negv;
+        }
     }
     if (want_diam && threadIdx.x == 0) {
         const float* dd = lds + Lds<T>::kRed + Lds<T>::kNorm;
@@ -840,7 +862,10 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
 
 // Kernel 1 of the otAspire path: pairwise sentence costs of the pairs of one chunk of candidates
 // [a.cand0, a.cand1) -> workspace.  Streams every candidate row once; HBM bound for few queries.
-template <int T>
+// DIRECT: both L2 formulas accumulated (padded reference tensors: their pair matrices are compared at 1e-5).  !DIRECT
+// (CSR inputs): x.y only, -cdist from the expansion with the cancelled entries redone -- half the arithmetic and
+// half the cross-lane reductions of the T x T tile loop.
+template <int T, bool DIRECT>
 __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairWs<T> ws) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -859,13 +884,13 @@ __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairW
         const int q_avail = a.q.ext > 0 ? a.q.ext : q_len;
         const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
         if (own_diam) {
-            pair_partials<T, true, true, true>(qdoc, q_avail, q_len, cdoc, c_avail, c_len, lds, wave, lane);
+            pair_partials<T, true, DIRECT, true>(qdoc, q_avail, q_len, cdoc, c_avail, c_len, lds, wave, lane);
         } else {
-            pair_partials<T, true, true, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
+            pair_partials<T, true, DIRECT, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
         }
         __syncthreads();
         const int64_t slot = paired ? (c_idx - a.cand0) : q_idx * ncand + (c_idx - a.cand0);
-        finish_pair<T>(lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), own_diam, ws, slot);
+        finish_pair<T, DIRECT>(lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), own_diam, ws, slot, qdoc, cdoc, q_len, c_len);
         __syncthreads();
     }
 }
@@ -2221,8 +2246,12 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                                            (hipStream_t)stream, a, ws1);
                 }
             } else {
-                hipLaunchKernelGGL(pair_cost_kernel<T>, dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
-                                   Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
+                if (q->ext == 0 && c->ext == 0)
+                    hipLaunchKernelGGL((pair_cost_kernel<T, false>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
+                                       Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
+                else
+                    hipLaunchKernelGGL((pair_cost_kernel<T, true>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
+                                       Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
             }
             ASPIRE_LAUNCH_OK();
             if (cost_only) continue;
