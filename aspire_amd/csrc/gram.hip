@@ -581,8 +581,15 @@ bool gram_path_wanted(const aspire_repset* q, const aspire_repset* c, int pairin
     const int max_rows = q->max_len > c->max_len ? q->max_len : c->max_len;
     const int64_t qrows = q->n * (int64_t)slot_rows(q->max_len);
     const int64_t tiles = (c->n + kBM / slot_rows(c->max_len) - 1) / (kBM / slot_rows(c->max_len));
+    if (max_rows > 8) {
+        // long documents: the VALU tile-loop kernel costs ~5 ns per (pair x 8x8 tile), the Gram kernel ~75 us of
+        // latency (48 dependent K stages) before its throughput counts: 1 x 3000 x 12 is 82 vs 88 us, 1 x 4000 x 20
+        // 194 vs 120 us
+        const int64_t T = (max_rows + 7) / 8;
+        return tiles >= 32 && q->n * c->n * T * T >= 16000;
+    }
     if (tiles < 128) return false;          // small pools are latency bound: the per-pair kernels start faster
-    return max_rows > 8 || qrows >= 24;
+    return qrows >= 24;
 }
 
 size_t gram_extra_bytes_per_cand(void) { return (size_t)2 * kD * sizeof(float); }   // the candidate's box
