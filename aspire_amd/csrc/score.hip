@@ -918,22 +918,28 @@ struct RowSet {
 // Rows beyond a document's length are loaded as COPIES OF ITS LAST ROW (row index clamped): entries that involve
 // them are masked downstream, and duplicates leave the bounding box unchanged, so the box needs no per-row
 // predicate.  (Only used when ext == 0; padded tensors take the general kernel, which reads the real pad rows.)
+// `item` = (sub-tile, pair): T * T sub-tiles of 8 x 8 entries per pair (1 for documents of <= 8 rows), the pair index
+// fastest.  Sub-tile (ta, tb) takes query rows 8 ta .. and candidate rows 8 tb ...
 __device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_t item, uint32_t nq, bool paired, int dofs,
-                                          int& q_len, int& c_len) {
-    const uint32_t c_loc = nq == 1 ? item : item / nq;
+                                          int& q_len, int& c_len, uint32_t T) {
+    const uint32_t npairs = (uint32_t)(a.cand1 - a.cand0) * nq;
+    const uint32_t tile = T == 1 ? 0 : item / npairs;        // pair index fastest: a pair's sub-tiles go to different workgroups
+    const uint32_t pair = item - tile * npairs, ta = tile / T, tb = tile - ta * T;
+    const uint32_t c_loc = nq == 1 ? pair : pair / nq;
     const int64_t c_idx = a.cand0 + c_loc;
-    const int64_t q_idx = paired ? c_idx : (nq == 1 ? 0 : item - c_loc * nq);
+    const int64_t q_idx = paired ? c_idx : (nq == 1 ? 0 : pair - c_loc * nq);
     c_len = a.c.len[c_idx];
     q_len = a.q.len[q_idx];
     const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
     const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
+    const int i0 = 8 * ta, j0 = 8 * tb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        r.x0[i] = ld4(qdoc + (size_t)min(i, q_len - 1) * kD);
-        r.x1[i] = ld4(qdoc + (size_t)min(4 + i, q_len - 1) * kD);
+        r.x0[i] = ld4(qdoc + (size_t)min(i0 + i, q_len - 1) * kD);
+        r.x1[i] = ld4(qdoc + (size_t)min(i0 + 4 + i, q_len - 1) * kD);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j, c_len - 1) * kD);
+    for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j0 + j, c_len - 1) * kD);
 }
 
 __device__ __forceinline__ float box_partial(const RowSet& r) {
@@ -957,7 +963,7 @@ __device__ __forceinline__ float box_partial(const RowSet& r) {
 // launches with (about) one item per workgroup -- half the registers, so twice the workgroups are resident and every
 // pair's loads are in flight from the start.
 template <bool PREFETCH>
-__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws) {
+__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -967,7 +973,8 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
     // hundreds of cycles per item on this hardware.
     const uint32_t nq = paired ? 1u : (uint32_t)a.q.n;
     const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
-    const uint32_t n_items = ncand * nq;
+    const uint32_t tt = T * T, ld_e = 8 * T, n_ent = 64 * tt;      // sub-tiles per pair, row stride and entries of a pair's slot
+    const uint32_t n_items = ncand * nq * tt;
     const bool own_diam = a.diameter == nullptr;
     float* red = lds + wave * 128;
     float* rednorm = lds + Lds<1>::kRed + wave * 16;
@@ -999,15 +1006,45 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
             const float r = lds_wave_reduce<16>(nrm, xp, lane);
             if ((lane & 3) == 0) rednorm[lane >> 2] = r;
         }
-        if (own_diam) {
-            const float sbox = wave_sum(box_partial(rs));
+        const uint32_t npairs = ncand * nq;
+        const uint32_t tile = tt == 1 ? 0 : item / npairs;
+        const uint32_t pair = item - tile * npairs, ta = tile / T, tb = tile - ta * T;
+        const uint32_t c_loc = nq == 1 ? pair : pair / nq;
+        const uint32_t q_loc = nq == 1 ? 0 : pair - c_loc * nq;
+        if (own_diam && tile == 0) {
+            float sbox;
+            if (tt == 1) {
+                sbox = wave_sum(box_partial(rs));
+            } else {
+                // long documents: the bounding box spans ALL rows of both documents; the pair's first sub-tile walks them
+                const int64_t c_idx = a.cand0 + c_loc;
+                const int64_t q_idx = paired ? c_idx : (int64_t)q_loc;
+                const float* qd = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
+                const float* cd = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
+                float4 mn = ld4(qd), mx = mn;
+                auto upd = [&](const float4& v) {
+                    mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+                    mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+                };
+                auto walk = [&](const float* doc, int n) {     // eight independent loads in flight (rows clamp: idempotent)
+                    for (int r0 = 0; r0 < n; r0 += 8) {
+                        float4 v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = ld4(doc + (size_t)min(r0 + k, n - 1) * kD);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) upd(v[k]);
+                    }
+                };
+                walk(qd, q_len);
+                walk(cd, c_len);
+                const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
+                sbox = wave_sum(fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx))));
+            }
             if (lane == 0) lds[Lds<1>::kRed + Lds<1>::kNorm + wave] = sbox;
         }
         K1_STAMP(3);
         __syncthreads();
         K1_STAMP(4);
-        const uint32_t c_loc = nq == 1 ? item : item / nq;
-        const uint32_t q_loc = nq == 1 ? 0 : item - c_loc * nq;
         const int64_t slot = paired ? (int64_t)c_loc : (int64_t)q_loc * ncand + c_loc;
         unsigned long long* redo_mask = reinterpret_cast<unsigned long long*>(lds + Lds<1>::kXp);   // wave 0's scratch, idle now
         if (wave == 0) {
@@ -1022,13 +1059,15 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
             const float sq = fmaf(-2.f, gsum, xx) + yy;
             const float ns = xx + yy;
             const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
-            const bool redo = !mm && li < q_len && lj < c_len && sq < 1e-4f * ns * ns;
-            ws.cost[slot * 64 + lane] = sqrtf(fmaxf(sq, 1e-8f));
-            if (!redo) ws.neg[slot * 64 + lane] = -sqrtf(fmaxf(sq, 0.f));
+            const int gi = 8 * ta + li, gj = 8 * tb + lj;                  // entry of the pair's 8T x 8T slot
+            const bool redo = !mm && gi < q_len && gj < c_len && sq < 1e-4f * ns * ns;
+            const int64_t o = slot * n_ent + gi * ld_e + gj;
+            ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
+            if (!redo) ws.neg[o] = -sqrtf(fmaxf(sq, 0.f));
             const unsigned long long m = __ballot(redo);
             if (lane == 0) {
                 *redo_mask = m;
-                if (own_diam) {
+                if (own_diam && tile == 0) {
                     const float* dd = lds + Lds<1>::kRed + Lds<1>::kNorm;
                     ws.diam2[slot] = dd[0] + dd[1] + dd[2];
                 }
@@ -1051,8 +1090,9 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
                     unsigned long long m = todo;
                     for (int t = 0; t < (live ? my : 0); ++t) m &= m - 1;      // drop the first `my` set bits
                     const int e = __builtin_ctzll(m);
-                    const float* xr = qdoc + (size_t)(e >> 3) * kD + 4 * l16;
-                    const float* yr = cdoc + (size_t)(e & 7) * kD + 4 * l16;
+                    const int gi = 8 * ta + (e >> 3), gj = 8 * tb + (e & 7);
+                    const float* xr = qdoc + (size_t)gi * kD + 4 * l16;
+                    const float* yr = cdoc + (size_t)gj * kD + 4 * l16;
                     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
                     for (int c = 0; c < 12; c += 2) {
@@ -1067,7 +1107,7 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
                     part += lane_xor<2>(part);
                     part += lane_xor<4>(part);
                     part += lane_xor<8>(part);
-                    if (live && l16 == 0) ws.neg[slot * 64 + e] = -sqrtf(part);
+                    if (live && l16 == 0) ws.neg[slot * n_ent + gi * ld_e + gj] = -sqrtf(part);
                 }
             }
         }
@@ -1077,7 +1117,7 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
         for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
             RowSet r1;
             int q1 = 0, c1 = 0;
-            load_item(r1, a, item, nq, paired, dofs, q1, c1);
+            load_item(r1, a, item, nq, paired, dofs, q1, c1, T);
             process(r1, q1, c1, item);
         }
         return;
@@ -1086,14 +1126,14 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
     int qa = 0, ca = 0, qb = 0, cb = 0;
     const uint32_t stride = gridDim.x;
     uint32_t item = blockIdx.x;
-    if (item < n_items) load_item(ra, a, item, nq, paired, dofs, qa, ca);
+    if (item < n_items) load_item(ra, a, item, nq, paired, dofs, qa, ca, T);
     while (item < n_items) {
         const uint32_t n1 = item + stride;
-        if (n1 < n_items) load_item(rb, a, n1, nq, paired, dofs, qb, cb);     // in flight under this item's arithmetic
+        if (n1 < n_items) load_item(rb, a, n1, nq, paired, dofs, qb, cb, T);     // in flight under this item's arithmetic
         process(ra, qa, ca, item);
         if (n1 >= n_items) break;
         const uint32_t n2 = n1 + stride;
-        if (n2 < n_items) load_item(ra, a, n2, nq, paired, dofs, qa, ca);
+        if (n2 < n_items) load_item(ra, a, n2, nq, paired, dofs, qa, ca, T);
         process(rb, qb, cb, n1);
         item = n2;
     }
@@ -2240,13 +2280,21 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     const char* env_c1 = getenv("ASPIRE_HIP_COST1");
                     if (env_c1 && !strcmp(env_c1, "single") && blocks >= n_slots)
                         hipLaunchKernelGGL(pair_cost1_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
-                                           (hipStream_t)stream, a, ws1);
+                                           (hipStream_t)stream, a, ws1, 1u);
                     else
                         hipLaunchKernelGGL(pair_cost1_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
-                                           (hipStream_t)stream, a, ws1);
+                                           (hipStream_t)stream, a, ws1, 1u);
                 }
             } else {
-                if (q->ext == 0 && c->ext == 0)
+                if (q->ext == 0 && c->ext == 0 && n_slots < 512) {
+                    // CSR documents of more than 8 rows: every 8 x 8 sub-tile of every pair is an item of the
+                    // small-pool kernel while the pairs alone would not fill the chip (1 x 125 x 20: 125 workgroups walking 9
+                    // tiles each -> 1024 side by side, 54 -> 36 us; from ~1000 pairs the per-pair kernel is ahead again)
+                    PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
+                    const int64_t items = n_slots * T * T;
+                    hipLaunchKernelGGL(pair_cost1_kernel<true>, dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
+                                       Lds<1>::kTotal * sizeof(float), (hipStream_t)stream, a, ws1, (uint32_t)T);
+                } else if (q->ext == 0 && c->ext == 0)
                     hipLaunchKernelGGL((pair_cost_kernel<T, false>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
                                        Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
                 else
