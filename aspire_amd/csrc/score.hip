@@ -962,8 +962,12 @@ __device__ __forceinline__ float box_partial(const RowSet& r) {
 // PREFETCH: the persistent form (next item's rows in a second register set).  !PREFETCH: one register set, for
 // launches with (about) one item per workgroup -- half the registers, so twice the workgroups are resident and every
 // pair's loads are in flight from the start.
-template <bool PREFETCH>
-__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T) {
+// SUB: documents of more than 8 rows, (sub-tile, pair) items; !SUB keeps the one-tile case free of the sub-tile
+// arithmetic (199 instead of 256 registers per lane: at 256 the two resident waves own the whole register file of a
+// SIMD and no other launch's waves fit beside them -- bench.py's overlapped lanes fell from 110 to 67 M alignments/s).
+template <bool PREFETCH, bool SUB = false>
+__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
+    const uint32_t T = SUB ? T_rt : 1u;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2292,7 +2296,7 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     // tiles each -> 1024 side by side, 54 -> 36 us; from ~1000 pairs the per-pair kernel is ahead again)
                     PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
                     const int64_t items = n_slots * T * T;
-                    hipLaunchKernelGGL(pair_cost1_kernel<true>, dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
+                    hipLaunchKernelGGL((pair_cost1_kernel<true, true>), dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
                                        Lds<1>::kTotal * sizeof(float), (hipStream_t)stream, a, ws1, (uint32_t)T);
                 } else if (q->ext == 0 && c->ext == 0)
                     hipLaunchKernelGGL((pair_cost_kernel<T, false>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
