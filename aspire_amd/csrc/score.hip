@@ -648,17 +648,30 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
         for (int ta = 0; ta < T; ++ta)
 #pragma unroll
             for (int tb = 0; tb < T; ++tb)
-                phi[ta][tb] = (rv[ta] && cv[tb]) ? (f[ta] + g[tb]) - s.cost[ta][tb] : 0.f;   // masked slots may hold stale bits
+                phi[ta][tb] = (rv[ta] && cv[tb]) ? (f[ta] + g[tb]) - s.cost[ta][tb] : -__builtin_inff();   // masked slots may hold stale bits
     };
+    float pad1[T][T];
+#pragma unroll
+    for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < T; ++tb) pad1[ta][tb] = (rv[ta] && cv[tb]) ? 0.f : 1.f;
+    // One exponential per entry and no potentials in the loop: E_ij = 2^(phi_ij r2) serves both sums with the marginal
+    // weights as plain factors (sum_j b_j E_ij, sum_i a_i E_ij), and since sum a = sum b = 1 the result
+    //     <a, f> + <b, g> = sum_ij a_i b_j (f_i + g_j) = sum_ij a_i b_j (phi_ij + C_ij)
+    // needs phi alone -- f and g are never formed on this path.  With one entry per lane (T == 1) the update
+    // h (LR_i + LC_j) = h log2(rowsum_i * colsum_j) is ONE logarithm: two transcendentals per entry and step instead
+    // of four (they issue at quarter rate: the lone launch's dependent chain is unchanged, but overlapped queries share
+    // the SIMDs' issue slots -- bench.py 110 -> 115 M alignments/s; 1 x 125 x 20 35.6 -> 31.4 us).  Masked entries carry phi = -inf (E = 0, out of every sum)
+    // and a +1 on their own (empty) sums keeps their logarithm at 0.
     auto step2 = [&](float r2, float h) {
-        float lr[T], lc[T];
         if constexpr (T == 1) {
             // One entry per lane.  The column chain and the row chain (two DPP levels and one v_permlane*_swap each,
             // see lane_ij) are independent; a single wave issues in order, so they are interleaved level by level
             // here and pinned with sched_barrier -- a cross-lane op costs 17-26 cycles of dependent latency
             // (tools: build/dbg/lat.hip), overlapped they cost it once, not twice.
-            float sc = __builtin_amdgcn_exp2f(fmaf(phi[0][0], r2, la2[0]));
-            float sr = __builtin_amdgcn_exp2f(fmaf(phi[0][0], r2, lb2[0]));
+            const float e = __builtin_amdgcn_exp2f(phi[0][0] * r2);
+            float sc = wa[0] * e;
+            float sr = wb[0] * e;
             __builtin_amdgcn_sched_barrier(0);
             sc += dpp_mov<0x124>(sc, sc);     // columns: lane bits 2, 3 (row_ror:4, row_ror:8), then bit 5
             sr += lane_xor<1>(sr);            // rows:    lane bits 0, 1 (quad_perm), then bit 4
@@ -669,32 +682,31 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             sc = swap_add<32>(sc, sc);
             sr = swap_add<16>(sr, sr);
             __builtin_amdgcn_sched_barrier(0);
-            lc[0] = __builtin_amdgcn_logf(sc);
-            lr[0] = __builtin_amdgcn_logf(sr);
+            phi[0][0] = fmaf(-h, __builtin_amdgcn_logf(fmaf(sc, sr, pad1[0][0])), phi[0][0]);
         } else {
+            float e[T][T], lr[T], lc[T];
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < T; ++tb) e[ta][tb] = __builtin_amdgcn_exp2f(phi[ta][tb] * r2);
 #pragma unroll
             for (int tb = 0; tb < T; ++tb) {   // columns
                 float sum = 0.f;
 #pragma unroll
-                for (int ta = 0; ta < T; ++ta) sum += __builtin_amdgcn_exp2f(fmaf(phi[ta][tb], r2, la2[ta]));
-                lc[tb] = __builtin_amdgcn_logf(csum8<T>(sum));
+                for (int ta = 0; ta < T; ++ta) sum = fmaf(wa[ta], e[ta][tb], sum);
+                lc[tb] = __builtin_amdgcn_logf(csum8<T>(sum) + (cv[tb] ? 0.f : 1.f));
             }
 #pragma unroll
             for (int ta = 0; ta < T; ++ta) {   // rows
                 float sum = 0.f;
 #pragma unroll
-                for (int tb = 0; tb < T; ++tb) sum += __builtin_amdgcn_exp2f(fmaf(phi[ta][tb], r2, lb2[tb]));
-                lr[ta] = __builtin_amdgcn_logf(rsum8<T>(sum));
+                for (int tb = 0; tb < T; ++tb) sum = fmaf(wb[tb], e[ta][tb], sum);
+                lr[ta] = __builtin_amdgcn_logf(rsum8<T>(sum) + (rv[ta] ? 0.f : 1.f));
             }
-        }
 #pragma unroll
-        for (int ta = 0; ta < T; ++ta)
+            for (int ta = 0; ta < T; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < T; ++tb) phi[ta][tb] = fmaf(-h, lr[ta] + lc[tb], phi[ta][tb]);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            g[t] = fmaf(-h, lc[t], g[t]);
-            f[t] = fmaf(-h, lr[t], f[t]);
+                for (int tb = 0; tb < T; ++tb) phi[ta][tb] = fmaf(-h, lr[ta] + lc[tb], phi[ta][tb]);
         }
     };
     // The whole annealing loop.  exact = false uses the shifted log-sum-exp; an overflowed / vanished
@@ -791,14 +803,18 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     PHASE_STAMP(6);
     bool phi_live = true;
     solve(false);
+    // <a, f> + <b, g> from phi alone (see step2); an overflowed / vanished sum anywhere has turned into inf / nan that
+    // reaches this total, so its finiteness is the one test that decides whether the solve is repeated exactly.
+    float fast_total;
     {
-        bool bad = false;
+        float acc = 0.f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            bad |= rv[t] && !(fabsf(f[t]) < 1e30f);
-            bad |= cv[t] && !(fabsf(g[t]) < 1e30f);
-        }
-        if (__builtin_expect(__any(bad), 0)) {
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb)
+                acc += (rv[ta] && cv[tb]) ? (wa[ta] * wb[tb]) * (phi[ta][tb] + s.cost[ta][tb]) : 0.f;
+        fast_total = wave_sum(acc);
+        if (__builtin_expect(!(fabsf(fast_total) < 1e30f), 0)) {
             solve(true);
             phi_live = false;
         }
@@ -809,13 +825,17 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     // ---- outputs ------------------------------------------------------------------------------
     float score;
     if (a.want != ASPIRE_OT_PLAN_SIM) {
-        float acc = 0.f;
+        if (phi_live) {
+            score = fast_total;
+        } else {
+            float acc = 0.f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
-            acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
+            for (int t = 0; t < T; ++t) {
+                acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
+                acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
+            }
+            score = wave_sum(acc);
         }
-        score = wave_sum(acc);
         if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
     } else {
         score = 0.f;
