@@ -24,6 +24,11 @@
 #include "score_types.h"
 #include "topk_device.h"
 
+// The buffer-load intrinsic bound by name (see doc_rsrc below).
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ v4f_t raw_buffer_load_v4f32(rsrc_t srsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
 namespace aspire {
 namespace {
 
@@ -88,7 +93,12 @@ __device__ __forceinline__ void load_rows(float4 (&r)[N], const float* doc, int 
     }
 }
 
-__device__ __forceinline__ float sq4(const float4& a) { return fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x))); }
+// (v_pk_mul_f32 + v_pk_fma_f32 + add -- three issue slots instead of four -- measured no faster than this chain, alone
+// or overlapped: 104-105 vs 106-108 M alignments/s in bench.py.)
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ float sq4(const float4& a) { return dot4(a, a); }
 
 // Per-wave partial sums of half an 8x8 tile (4 query rows x 8 candidate rows) -> LDS.
 // red layout: [tile][2][64] (0: x.y dot, 1: sum (x-y)^2), element 8*i + j.  Only 32 accumulators, 4 query
@@ -117,7 +127,7 @@ __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const f
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                acc[i * 8 + j] = fmaf(x[i].w, y[j].w, fmaf(x[i].z, y[j].z, fmaf(x[i].y, y[j].y, x[i].x * y[j].x)));
+                acc[i * 8 + j] = dot4(x[i], y[j]);
         const float r = lds_wave_reduce<32>(acc, xp, lane);
         if ((lane & 1) == 0) red_half[(lane >> 1)] = r;
     }
@@ -922,6 +932,18 @@ __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairW
 struct RowSet {
     float4 x0[4], x1[4], y[8];
 };
+// Buffer descriptor over one document's rows (wave-uniform by construction: the compiler must be able to prove it).
+// A document is at most 32 rows x 3072 B; the range check is left wide open (rows are clamped by the callers).
+// (The intrinsic is bound by name: this toolchain's __builtin_amdgcn_raw_buffer_load_b128 lowers to a one-dword load.)
+__device__ __forceinline__ rsrc_t doc_rsrc(const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return rsrc_t{(int)lo, (int)(hi & 0xffffu), 0x7fffffff, 0x00020000};
+}
+__device__ __forceinline__ float4 ld_row(rsrc_t rs, int lane_bytes, int row) {
+    const v4f_t t = raw_buffer_load_v4f32(rs, lane_bytes, row * (kD * 4), 0);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 #ifdef ASPIRE_PHASE_CLOCK
 // stamps of workgroup 7, wave 1, its second item
 #define K1_STAMP(k)                                                                                         \
@@ -948,18 +970,23 @@ __device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_
     const uint32_t c_loc = nq == 1 ? pair : pair / nq;
     const int64_t c_idx = a.cand0 + c_loc;
     const int64_t q_idx = paired ? c_idx : (nq == 1 ? 0 : pair - c_loc * nq);
-    c_len = a.c.len[c_idx];
-    q_len = a.q.len[q_idx];
-    const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
-    const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
+    c_len = __builtin_amdgcn_readfirstlane(a.c.len[c_idx]);
+    q_len = __builtin_amdgcn_readfirstlane(a.q.len[q_idx]);
+    // Row addresses are wave-uniform: one buffer descriptor per document (built from readfirstlane'd scalars), the
+    // row's byte offset in the scalar offset operand and the lane's 16 B slice in the 32-bit vector offset -- no
+    // per-row 64-bit vector multiply-add (16 quarter-rate VALU ops per item on a kernel whose overlapped throughput
+    // is VALU-bound) and no address register pairs held while the loads are in flight.
+    const auto crs = doc_rsrc(a.c.rows + (size_t)a.c.start[c_idx] * kD);
+    const auto qrs = doc_rsrc(a.q.rows + (size_t)a.q.start[q_idx] * kD);
+    const int lofs = dofs * 4;
     const int i0 = 8 * ta, j0 = 8 * tb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        r.x0[i] = ld4(qdoc + (size_t)min(i0 + i, q_len - 1) * kD);
-        r.x1[i] = ld4(qdoc + (size_t)min(i0 + 4 + i, q_len - 1) * kD);
+        r.x0[i] = ld_row(qrs, lofs, min(i0 + i, q_len - 1));
+        r.x1[i] = ld_row(qrs, lofs, min(i0 + 4 + i, q_len - 1));
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j0 + j, c_len - 1) * kD);
+    for (int j = 0; j < 8; ++j) r.y[j] = ld_row(crs, lofs, min(j0 + j, c_len - 1));
 }
 
 __device__ __forceinline__ float box_partial(const RowSet& r) {
@@ -983,8 +1010,14 @@ __device__ __forceinline__ float box_partial(const RowSet& r) {
 // launches with (about) one item per workgroup -- half the registers, so twice the workgroups are resident and every
 // pair's loads are in flight from the start.
 // SUB: documents of more than 8 rows, (sub-tile, pair) items; !SUB keeps the one-tile case free of the sub-tile
-// arithmetic (199 instead of 256 registers per lane: at 256 the two resident waves own the whole register file of a
-// SIMD and no other launch's waves fit beside them -- bench.py's overlapped lanes fell from 110 to 67 M alignments/s).
+// arithmetic.  Register budgets decide how these kernels share a SIMD with OTHER queries' launches (bench.py overlaps
+// many): the one-register-set form sits at 128 registers per lane (three of its waves + two Sinkhorn waves per SIMD);
+// at 256 nothing fits beside two resident waves and overlapped throughput falls from ~110 to ~70 M alignments/s with
+// every kernel's own time unchanged.  tests/test_abi_cpu.py pins the budgets.
+// (A fused form -- wave 0 going straight on to the pair's Sinkhorn solve, entries through LDS -- was built and dropped:
+// all workgroups of a <= 1024-pair launch are resident at once and move through the two phases in lock step, so a
+// lone call gains nothing (45 vs 48.5 M pairs/s), and the union of the two phases' live scalars spills, which costs
+// the overlapped case its co-residency: 86 vs 112 M alignments/s.)
 template <bool PREFETCH, bool SUB = false>
 __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
     const uint32_t T = SUB ? T_rt : 1u;
@@ -2295,18 +2328,25 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     // 20-23 us for the tiled form with its stages split over three or four waves)
                     const char* env_blocks = getenv("ASPIRE_HIP_COST1_BLOCKS");   // tuning only
                     // 1024: at ~1000 pairs one pair per workgroup beats 512 persistent workgroups with two each, both
-                    // alone (44.9 vs 43.6 M pairs/s) and beside other launches (111 vs 106 M in bench.py)
+                    // alone and beside other launches
                     const int64_t cap = env_blocks ? atoi(env_blocks) : 1024;
                     const int64_t blocks = n_slots < cap ? n_slots : cap;
-                    // ASPIRE_HIP_COST1=single picks the one-register-set form: 8 % faster for a lone call (15.6 vs
-                    // 17.4 us cost + Sinkhorn at 1000 pairs), 10 % slower when many queries' launches overlap (bench.py:
-                    // 101 vs 111 M alignments/s) -- the default serves the throughput case
+                    // One item per workgroup (every launch of <= 1024 pairs): the one-register-set form, 128 registers
+                    // per lane.  It claims 40 KB of LDS (it uses 28): four workgroups per CU = three waves per SIMD,
+                    // which leaves registers and wave slots for the Sinkhorn / top-k waves of OTHER queries' launches --
+                    // bench.py's overlapped lanes measure 112.8 M alignments/s at 40 KB, 101.8 at 28 KB (five per CU), 110
+                    // at 53-64 KB; a lone call does not care (48.4-49.2 M/s).  The two-register-set (prefetching) form
+                    // serves the persistent case; ASPIRE_HIP_COST1=prefetch forces it (diagnostic).
                     const char* env_c1 = getenv("ASPIRE_HIP_COST1");
-                    if (env_c1 && !strcmp(env_c1, "single") && blocks >= n_slots)
-                        hipLaunchKernelGGL(pair_cost1_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
+                    const char* env_lds = getenv("ASPIRE_HIP_COST1_LDS");      // tuning only: KB of LDS claimed per workgroup
+                    const bool single = blocks >= n_slots && !(env_c1 && !strcmp(env_c1, "prefetch"));
+                    const size_t lds1_bytes = env_lds ? (size_t)atoi(env_lds) * 1024
+                                                      : single ? (size_t)40 * 1024 : Lds<1>::kTotal * sizeof(float);
+                    if (single)
+                        hipLaunchKernelGGL(pair_cost1_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds1_bytes,
                                            (hipStream_t)stream, a, ws1, 1u);
                     else
-                        hipLaunchKernelGGL(pair_cost1_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float),
+                        hipLaunchKernelGGL(pair_cost1_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds1_bytes,
                                            (hipStream_t)stream, a, ws1, 1u);
                 }
             } else {

@@ -125,8 +125,8 @@ def test_header_is_plain_c_and_links(tmp_path):
 def test_kernel_register_budgets():
     """Co-residency budgets, read from the built code objects' metadata (tools/kernel_resources.py).  A SIMD has 512
     registers per lane: the headline workload overlaps many queries' launches, which only works while the small-pool
-    cost kernel's two resident waves leave room for the Sinkhorn / top-k waves of other queries (at 256 registers
-    bench.py fell from 110 to 67 M alignments/s with every kernel's own time unchanged)."""
+    cost kernel's resident waves leave room for the Sinkhorn / top-k waves of other queries (with a 256-register cost
+    kernel bench.py fell from ~110 to ~70 M alignments/s, every kernel's own time unchanged)."""
     import sys
     from aspire_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -143,15 +143,15 @@ def test_kernel_register_budgets():
         assert len(hits) == 1, (pattern, len(hits))
         return hits[0]
 
-    cost = one(r'pair_cost1_kernelILb1ELb0E')
+    cost = one(r'pair_cost1_kernelILb0ELb0E')       # one register set: the form every launch of <= 1024 pairs takes
     sink = one(r'sinkhorn_kernelILi1E')
     topk = one(r'topk_select_kernel')
-    assert cost['vgpr'] <= 200 and cost['scratch'] == 0
+    assert cost['vgpr'] <= 128 and cost['scratch'] == 0
     assert sink['vgpr'] <= 56 and sink['scratch'] == 0
     assert topk['vgpr'] <= 56 and topk['scratch'] == 0
-    # two cost waves + two Sinkhorn (or top-k) waves per SIMD fit together
+    # three cost waves (four workgroups of three waves per CU, see the 40 KB LDS claim) + two Sinkhorn waves per SIMD
     granule = lambda v: (v + 7) // 8 * 8
-    assert 2 * granule(cost['vgpr']) + 2 * granule(sink['vgpr']) <= 512
+    assert 3 * granule(cost['vgpr']) + 2 * granule(sink['vgpr']) <= 512
     # no hot-path kernel of the headline workload spills
     for name, r in res.items():
         if re.search(r'pair_cost1|sinkhorn_kernel|sinkhorn_block|topk_|l2max_kernel|pair_tile', name):
