@@ -962,6 +962,10 @@ __device__ __forceinline__ float4 ld_row(rsrc_t rs, int lane_bytes, int row) {
 // predicate.  (Only used when ext == 0; padded tensors take the general kernel, which reads the real pad rows.)
 // `item` = (sub-tile, pair): T * T sub-tiles of 8 x 8 entries per pair (1 for documents of <= 8 rows), the pair index
 // fastest.  Sub-tile (ta, tb) takes query rows 8 ta .. and candidate rows 8 tb ...
+// BUF: buffer loads (below); !BUF: plain global loads with per-row vector addresses -- the two-register-set form keeps
+// those: with buffer loads the scheduler spreads it over all 256 registers of its budget (197 with global loads),
+// and a 256-register kernel shares a SIMD with nothing.
+template <bool BUF>
 __device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_t item, uint32_t nq, bool paired, int dofs,
                                           int& q_len, int& c_len, uint32_t T) {
     const uint32_t npairs = (uint32_t)(a.cand1 - a.cand0) * nq;
@@ -970,6 +974,21 @@ __device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_
     const uint32_t c_loc = nq == 1 ? pair : pair / nq;
     const int64_t c_idx = a.cand0 + c_loc;
     const int64_t q_idx = paired ? c_idx : (nq == 1 ? 0 : pair - c_loc * nq);
+    const int i0 = 8 * ta, j0 = 8 * tb;
+    if constexpr (!BUF) {
+        c_len = a.c.len[c_idx];
+        q_len = a.q.len[q_idx];
+        const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
+        const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r.x0[i] = ld4(qdoc + (size_t)min(i0 + i, q_len - 1) * kD);
+            r.x1[i] = ld4(qdoc + (size_t)min(i0 + 4 + i, q_len - 1) * kD);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j0 + j, c_len - 1) * kD);
+        return;
+    }
     c_len = __builtin_amdgcn_readfirstlane(a.c.len[c_idx]);
     q_len = __builtin_amdgcn_readfirstlane(a.q.len[q_idx]);
     // Row addresses are wave-uniform: one buffer descriptor per document (built from readfirstlane'd scalars), the
@@ -979,7 +998,6 @@ __device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_
     const auto crs = doc_rsrc(a.c.rows + (size_t)a.c.start[c_idx] * kD);
     const auto qrs = doc_rsrc(a.q.rows + (size_t)a.q.start[q_idx] * kD);
     const int lofs = dofs * 4;
-    const int i0 = 8 * ta, j0 = 8 * tb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         r.x0[i] = ld_row(qrs, lofs, min(i0 + i, q_len - 1));
@@ -1174,7 +1192,7 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
         for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
             RowSet r1;
             int q1 = 0, c1 = 0;
-            load_item(r1, a, item, nq, paired, dofs, q1, c1, T);
+            load_item<true>(r1, a, item, nq, paired, dofs, q1, c1, T);
             process(r1, q1, c1, item);
         }
         return;
@@ -1183,14 +1201,14 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
     int qa = 0, ca = 0, qb = 0, cb = 0;
     const uint32_t stride = gridDim.x;
     uint32_t item = blockIdx.x;
-    if (item < n_items) load_item(ra, a, item, nq, paired, dofs, qa, ca, T);
+    if (item < n_items) load_item<false>(ra, a, item, nq, paired, dofs, qa, ca, T);
     while (item < n_items) {
         const uint32_t n1 = item + stride;
-        if (n1 < n_items) load_item(rb, a, n1, nq, paired, dofs, qb, cb, T);     // in flight under this item's arithmetic
+        if (n1 < n_items) load_item<false>(rb, a, n1, nq, paired, dofs, qb, cb, T);     // in flight under this item's arithmetic
         process(ra, qa, ca, item);
         if (n1 >= n_items) break;
         const uint32_t n2 = n1 + stride;
-        if (n2 < n_items) load_item(ra, a, n2, nq, paired, dofs, qa, ca, T);
+        if (n2 < n_items) load_item<false>(ra, a, n2, nq, paired, dofs, qa, ca, T);
         process(rb, qb, cb, n1);
         item = n2;
     }
@@ -2331,15 +2349,17 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     // alone and beside other launches
                     const int64_t cap = env_blocks ? atoi(env_blocks) : 1024;
                     const int64_t blocks = n_slots < cap ? n_slots : cap;
-                    // One item per workgroup (every launch of <= 1024 pairs): the one-register-set form, 128 registers
-                    // per lane.  It claims 40 KB of LDS (it uses 28): four workgroups per CU = three waves per SIMD,
-                    // which leaves registers and wave slots for the Sinkhorn / top-k waves of OTHER queries' launches --
-                    // bench.py's overlapped lanes measure 112.8 M alignments/s at 40 KB, 101.8 at 28 KB (five per CU), 110
-                    // at 53-64 KB; a lone call does not care (48.4-49.2 M/s).  The two-register-set (prefetching) form
-                    // serves the persistent case; ASPIRE_HIP_COST1=prefetch forces it (diagnostic).
+                    // Two forms of the kernel for one item per workgroup (every launch of <= 1024 pairs), both kept
+                    // because they win different cases on the same box (bench.py, 1 x 1000 x 8, three runs each):
+                    //   two register sets, global loads, 197 registers: overlapped lanes 115 M alignments/s, lone 45 M
+                    //   one register set, buffer loads, 128 registers, 40 KB LDS claim (four workgroups per CU,
+                    //   28 KB used): overlapped 111 M, lone 47-49 M (17.1 vs 18.2 us per 1000-pair call)
+                    // The default serves throughput; ASPIRE_HIP_COST1=single picks the other.  Either way the budget
+                    // that matters is what the resident cost waves leave on a SIMD for OTHER queries' Sinkhorn /
+                    // top-k waves: at 256 registers (nothing fits beside two waves) the same kernels give ~70 M.
                     const char* env_c1 = getenv("ASPIRE_HIP_COST1");
                     const char* env_lds = getenv("ASPIRE_HIP_COST1_LDS");      // tuning only: KB of LDS claimed per workgroup
-                    const bool single = blocks >= n_slots && !(env_c1 && !strcmp(env_c1, "prefetch"));
+                    const bool single = blocks >= n_slots && env_c1 && !strcmp(env_c1, "single");
                     const size_t lds1_bytes = env_lds ? (size_t)atoi(env_lds) * 1024
                                                       : single ? (size_t)40 * 1024 : Lds<1>::kTotal * sizeof(float);
                     if (single)

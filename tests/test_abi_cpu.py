@@ -143,15 +143,18 @@ def test_kernel_register_budgets():
         assert len(hits) == 1, (pattern, len(hits))
         return hits[0]
 
-    cost = one(r'pair_cost1_kernelILb0ELb0E')       # one register set: the form every launch of <= 1024 pairs takes
+    cost = one(r'pair_cost1_kernelILb1ELb0E')       # two register sets (default form of every launch of <= 1024 pairs)
+    single = one(r'pair_cost1_kernelILb0ELb0E')     # one register set (ASPIRE_HIP_COST1=single: the lone-call form)
     sink = one(r'sinkhorn_kernelILi1E')
     topk = one(r'topk_select_kernel')
-    assert cost['vgpr'] <= 128 and cost['scratch'] == 0
+    assert cost['vgpr'] <= 200 and cost['scratch'] == 0
+    assert single['vgpr'] <= 128 and single['scratch'] == 0
     assert sink['vgpr'] <= 56 and sink['scratch'] == 0
     assert topk['vgpr'] <= 56 and topk['scratch'] == 0
-    # three cost waves (four workgroups of three waves per CU, see the 40 KB LDS claim) + two Sinkhorn waves per SIMD
+    # two (three) cost waves + two Sinkhorn / top-k waves per SIMD fit together
     granule = lambda v: (v + 7) // 8 * 8
-    assert 3 * granule(cost['vgpr']) + 2 * granule(sink['vgpr']) <= 512
+    assert 2 * granule(cost['vgpr']) + 2 * granule(sink['vgpr']) <= 512
+    assert 3 * granule(single['vgpr']) + 2 * granule(sink['vgpr']) <= 512
     # no hot-path kernel of the headline workload spills
     for name, r in res.items():
         if re.search(r'pair_cost1|sinkhorn_kernel|sinkhorn_block|topk_|l2max_kernel|pair_tile', name):
