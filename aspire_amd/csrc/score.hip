@@ -498,6 +498,23 @@ static __device__ long long* g_k1dbg = nullptr;
     } while (0)
 #endif
 
+// Length of geomloss's annealing schedule, n_mid = ceil((log blur - log diam) / log scaling) in float64 (numpy's
+// arange) -- a discontinuous function of the diameter, so it has to be the float64 value.  The float64 logarithm of
+// the diameter cost ~0.5 us of every solve's prologue: here the quotient is formed in fp32 (v_log_f32; the logs of blur
+// and scaling come from the host) with a bound on its error, and only a quotient that close to an integer (a few
+// pairs in 10^4) is redone in float64.
+__device__ __forceinline__ int schedule_mid_steps(const ScoreArgs& a, float diam, float& log2_diam) {
+    log2_diam = __builtin_amdgcn_logf(diam);
+    const float x = (a.log2_blur - log2_diam) / a.log2_scaling;
+    const float err = (fabsf(a.log2_blur) + fabsf(log2_diam) + 1.f) * 3e-7f / fabsf(a.log2_scaling) + fabsf(x) * 2e-7f;
+    int n_mid;
+    if (__builtin_expect(fabsf(x - rintf(x)) < 8.f * err, 0))
+        n_mid = (int)ceil((a.log_blur - log((double)diam)) / a.log_scaling);
+    else
+        n_mid = (int)ceilf(x);
+    return n_mid < 0 ? 0 : n_mid;
+}
+
 template <int T>
 __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_len, int c_len, float diam, int64_t p,
                               int lane) {
@@ -558,11 +575,10 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     PHASE_STAMP(4);
     // ---- epsilon schedule (geomloss epsilon_schedule, p = 1) --------------------------------------
     //   [diam] + [exp(e) for e in arange(log diam, log blur, log scaling)] + [blur]
-    const double ld = log((double)diam), lbl = log(a.blur), lsc = log(a.scaling);
-    int n_mid = (int)ceil((lbl - ld) / lsc);
-    if (n_mid < 0) n_mid = 0;
+    float ldf;                                    // log2 units
+    const int n_mid = schedule_mid_steps(a, diam, ldf);
+    const float lscf = a.log2_scaling;
     const float eps_last = (float)a.blur;
-    const float ldf = (float)(ld * 1.4426950408889634), lscf = (float)(lsc * 1.4426950408889634);   // log2 units
     PHASE_STAMP(5);
 
     float f[T], g[T];
@@ -766,7 +782,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             // (exact path: float64 exactly as numpy builds geomloss's schedule; fast path: fp32 exp2 of the same
             // affine function -- a relative 1e-7 on an intermediate temperature moves the result by far less than
             // the tolerance, and the float64 exp cost as much as ten annealing steps)
-            const float my_eps = exact ? (float)exp(ld + (double)(base + lane) * lsc)
+            const float my_eps = exact ? (float)exp(log((double)diam) + (double)(base + lane) * a.log_scaling)
                                        : __builtin_amdgcn_exp2f(fmaf((float)(base + lane), lscf, ldf));
             const int cnt = min(64, n_mid - base);
             if (exact) {
@@ -1669,16 +1685,15 @@ __global__ void __launch_bounds__(256) sinkhorn4_kernel(ScoreArgs a, PairWs<1> w
         }
     }
     // ---- this pair's epsilon schedule -> LDS ---------------------------------------------------------------
-    const double ld = log((double)diam), lbl = log(a.blur), lsc = log(a.scaling);
-    int n_mid = (int)ceil((lbl - ld) / lsc);
-    n_mid = n_mid < 0 ? 0 : n_mid;
+    float ldf;
+    int n_mid = schedule_mid_steps(a, diam, ldf);
+    const float lscf = a.log2_scaling;
     const bool overflow = n_mid + 3 > kMaxSteps4;             // schedule longer than the table: poison the score
     if (overflow) n_mid = kMaxSteps4 - 3;
     // table rows: 0 = diam (the first loop step), 1 .. n_mid = the annealed values, n_mid+1, n_mid+2 = blur
     float2* tab = sched[wave][pp];
     // The annealed values exp(ld + k*lsc) are formed in fp32 here (5 per lane; in float64 they cost more than the
     // whole annealing loop): a relative 1e-6 on an intermediate temperature moves the final potentials by < 1e-7.
-    const float ldf = (float)(ld * 1.4426950408889634), lscf = (float)(lsc * 1.4426950408889634);
     for (int k = l16; k < n_mid + 3; k += 16) {
         float e;
         if (k == 0) e = diam;
@@ -1930,14 +1945,13 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
         diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
     }
     // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = exp(ld + (k-1) lsc), n_mid+1 = blur, n_mid+2 = blur (final)
-    const double ld = log((double)diam), lbl = log(a.blur), lsc = log(a.scaling);
-    int n_mid = (int)ceil((lbl - ld) / lsc);
-    n_mid = n_mid < 0 ? 0 : n_mid;
+    float ldf;
+    const int n_mid = schedule_mid_steps(a, diam, ldf);
+    const float lscf = a.log2_scaling;
     const int n_steps = n_mid + 3;
     int max_steps = n_steps;
 #pragma unroll
     for (int m = NL; m < 64; m <<= 1) max_steps = max(max_steps, __shfl_xor(max_steps, m));
-    const float ldf = (float)(ld * 1.4426950408889634), lscf = (float)(lsc * 1.4426950408889634);
     const float c_r2 = 0.5287663729448977f - ldf;      // log2(log2 e) - log2(diam):  r2_k = exp2(c_r2 - (k-1) lscf)
     const float c_h = -1.5287663729448977f + ldf;      // log2(ln2 / 2) + log2(diam): h_k  = exp2(c_h  + (k-1) lscf)
     const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
@@ -2284,6 +2298,10 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
     a.blur = prm->blur;
     a.scaling = prm->scaling;
     a.temp = prm->sent_sm_temp;
+    a.log_blur = std::log(prm->blur);
+    a.log_scaling = std::log(prm->scaling);
+    a.log2_blur = (float)(a.log_blur * 1.4426950408889634);
+    a.log2_scaling = (float)(a.log_scaling * 1.4426950408889634);
     a.diameter = diameter;
     a.diam_group = diameter ? diam_group : 1;
     a.n_groups = diameter ? (c->n + diam_group - 1) / diam_group : 0;

@@ -20,6 +20,8 @@ struct ScoreArgs {
     int64_t cand0, cand1;  // otAspire: the chunk of candidates this launch covers
     // OT
     double blur, scaling, temp;
+    double log_blur, log_scaling;        // natural logs, float64, formed on the host (schedule lengths)
+    float log2_blur, log2_scaling;       // the same in log2 units, fp32
     const float* diameter;
     int64_t diam_group;
     int64_t n_groups;

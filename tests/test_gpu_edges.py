@@ -217,3 +217,42 @@ def test_big_pool_clustered_vectors(amd):
     idx = [0, 1, 4097, 8202]
     want = np.array([orc.get_similarity(q, cands[i]) for i in idx], dtype=np.float32)
     np.testing.assert_allclose(big[idx], want, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('form', ['wave', 'packed', 'block'])
+def test_schedule_length_at_its_discontinuities(amd, form):
+    """geomloss's schedule has ceil((log blur - log diam) / log scaling) annealed steps -- float64, and discontinuous in
+    the diameter.  The kernels form the quotient in fp32 and redo it in float64 only when it is close to an integer:
+    given diameters sitting exactly on, and a few ulps either side of, those integers must give the oracle's schedule
+    (one step more or less moves the distance by several 1e-4)."""
+    import os
+    blur, scaling = 0.05, 0.9
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(6, 768, generator=g)
+    c = torch.randn(7, 768, generator=g)
+    diams = []
+    for k in (60, 68, 72, 80):      # diameters 28 .. 230 around the clouds' own (~95)
+        d0 = blur * scaling ** (-k)
+        for rel in (0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-3, -1e-3):
+            diams.append(np.float32(d0 * (1.0 + rel)))
+    diams = np.array(diams, dtype=np.float32)
+    n = len(diams)
+    qs = amd.ops.DeviceRepSet.from_list([q])
+    cs = amd.ops.DeviceRepSet.from_list([c] * n)
+    old = os.environ.get('ASPIRE_HIP_SINKHORN')
+    os.environ['ASPIRE_HIP_SINKHORN'] = form
+    try:
+        got = amd.ops.ot_sinkhorn(qs, cs, blur=blur, scaling=scaling, diameter=torch.from_numpy(diams).cuda(),
+                                  diam_group=1).cpu().numpy()
+    finally:
+        if old is None:
+            del os.environ['ASPIRE_HIP_SINKHORN']
+        else:
+            os.environ['ASPIRE_HIP_SINKHORN'] = old
+    w = orc.AllPairMaskedWasserstein({'geoml_blur': blur, 'geoml_scaling': scaling})
+    qt = orc.RepLen(q[None].permute(0, 2, 1), [6])
+    ct = orc.RepLen(c[None].permute(0, 2, 1), [7])
+    want = np.array([w.compute_distance(qt, ct, diameter=float(d)).item() for d in diams], dtype=np.float32)
+    lens = np.array([len(orc.epsilon_schedule(1, float(d), blur, scaling)) for d in diams])
+    assert len(set(lens)) >= 8          # the diameters do straddle schedule lengths
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
