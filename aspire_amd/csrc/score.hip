@@ -689,15 +689,25 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
     // of four (they issue at quarter rate: the lone launch's dependent chain is unchanged, but overlapped queries share
     // the SIMDs' issue slots -- bench.py 110 -> 115 M alignments/s; 1 x 125 x 20 35.6 -> 31.4 us).  Masked entries carry phi = -inf (E = 0, out of every sum)
     // and a +1 on their own (empty) sums keeps their logarithm at 0.
-    auto step2 = [&](float r2, float h) {
+    // A step at temperature eps:  E = 2^(phi r2),  phi -= h log2(rowsum colsum),  r2 = log2(e)/eps,  h = eps ln2 / 2
+    // (eps ln2 for the final, un-averaged step).  Through the geometric part of the schedule the constants of the next
+    // step follow from this one's by the factor scaling (r2 /= scaling, h *= scaling): two multiplies off the dependent
+    // chain instead of two v_readlane broadcasts of a per-lane table, and nothing for the loop to index, so it
+    // unrolls freely.  (Carrying psi = phi r2 instead saves one more multiply per step but rescales the state 77 times:
+    // mean error against float64 8.6e-6 instead of 5.4e-6.)
+    float r2v = 0.f, hv = 0.f;       // wave-uniform, kept in vector registers: gfx950 has no scalar float multiply
+    auto step2 = [&](float r2_mul, float h_mul) {
         if constexpr (T == 1) {
             // One entry per lane.  The column chain and the row chain (two DPP levels and one v_permlane*_swap each,
             // see lane_ij) are independent; a single wave issues in order, so they are interleaved level by level
             // here and pinned with sched_barrier -- a cross-lane op costs 17-26 cycles of dependent latency
             // (tools: build/dbg/lat.hip), overlapped they cost it once, not twice.
-            const float e = __builtin_amdgcn_exp2f(phi[0][0] * r2);
+            const float e = __builtin_amdgcn_exp2f(phi[0][0] * r2v);
             float sc = wa[0] * e;
             float sr = wb[0] * e;
+            // opaque to the optimizer: left alone it contracts a * b + dpp(a * b) into mov_dpp + fma, two issue slots
+            // per step more than mul + add_dpp
+            asm volatile("" : "+v"(sc), "+v"(sr));
             __builtin_amdgcn_sched_barrier(0);
             sc += dpp_mov<0x124>(sc, sc);     // columns: lane bits 2, 3 (row_ror:4, row_ror:8), then bit 5
             sr += lane_xor<1>(sr);            // rows:    lane bits 0, 1 (quad_perm), then bit 4
@@ -708,13 +718,13 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
             sc = swap_add<32>(sc, sc);
             sr = swap_add<16>(sr, sr);
             __builtin_amdgcn_sched_barrier(0);
-            phi[0][0] = fmaf(-h, __builtin_amdgcn_logf(fmaf(sc, sr, pad1[0][0])), phi[0][0]);
+            phi[0][0] = fmaf(-hv, __builtin_amdgcn_logf(fmaf(sc, sr, pad1[0][0])), phi[0][0]);
         } else {
             float e[T][T], lr[T], lc[T];
 #pragma unroll
             for (int ta = 0; ta < T; ++ta)
 #pragma unroll
-                for (int tb = 0; tb < T; ++tb) e[ta][tb] = __builtin_amdgcn_exp2f(phi[ta][tb] * r2);
+                for (int tb = 0; tb < T; ++tb) e[ta][tb] = __builtin_amdgcn_exp2f(phi[ta][tb] * r2v);
 #pragma unroll
             for (int tb = 0; tb < T; ++tb) {   // columns
                 float sum = 0.f;
@@ -732,8 +742,10 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
 #pragma unroll
             for (int ta = 0; ta < T; ++ta)
 #pragma unroll
-                for (int tb = 0; tb < T; ++tb) phi[ta][tb] = fmaf(-h, lr[ta] + lc[tb], phi[ta][tb]);
+                for (int tb = 0; tb < T; ++tb) phi[ta][tb] = fmaf(-hv, lr[ta] + lc[tb], phi[ta][tb]);
         }
+        r2v *= r2_mul;      // the next step's constants
+        hv *= h_mul;
     };
     // The whole annealing loop.  exact = false uses the shifted log-sum-exp; an overflowed / vanished
     // sum turns into inf / nan that then sticks to the potentials, so ONE finiteness test at the end
@@ -774,57 +786,49 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
                 g[t] = -eln2d * __builtin_amdgcn_logf(csum8<T>(cs[t]));
             }
             phi_init();
-            step2(r2d, 0.5f * eln2d);
+            // steps: eps = diam, then the n_mid annealed values diam scaling^k (k = 0 .. n_mid - 1; fp32 -- a relative
+            // 1e-6 on an intermediate temperature moves the result by far less than the tolerance, and the float64 exp
+            // cost as much as ten annealing steps), then blur, then the final un-averaged step at blur
+            const float rho_s = __builtin_amdgcn_exp2f(-lscf), scal = __builtin_amdgcn_exp2f(lscf);     // 1 / scaling, scaling
+            const float last_eps = n_mid > 0 ? __builtin_amdgcn_exp2f(fmaf((float)(n_mid - 1), lscf, ldf)) : diam;
+            const float rho_b = last_eps * rcp_refined(eps_last), inv_rho_b = eps_last * rcp_refined(last_eps);
+            const int n_s = __builtin_amdgcn_readfirstlane(n_mid);                          // wave-uniform: scalar loop control
+            r2v = r2d;
+            hv = 0.5f * eln2d;
+            step2(n_s > 0 ? 1.f : rho_b, n_s > 0 ? 1.f : inv_rho_b);                        // at diam
+            int k = 1;
+            for (; k + 4 <= n_s; k += 4) {      // unrolled by hand (the pinned schedule inside step2 defeats #pragma unroll)
+                step2(rho_s, scal);
+                step2(rho_s, scal);
+                step2(rho_s, scal);
+                step2(rho_s, scal);
+            }
+            for (; k < n_s; ++k) step2(rho_s, scal);
+            if (n_s > 0) step2(rho_b, inv_rho_b);                                            // the last annealed value -> blur
+            // the two steps at blur with exactly rounded constants (drops the drift of the running products)
+            r2v = kLog2e * rcp_refined(eps_last);
+            hv = 0.5f * eps_last * kLn2;
+            step2(1.f, 2.f);                                                                 // at blur, averaged
+            step2(1.f, 1.f);                                                                 // at blur, final (h doubled)
+            return;
         }
+
+        // exact path only from here: float64 schedule exactly as numpy builds geomloss's, lane k of a chunk evaluates
+        // eps_{base+k} and the per-step constants are broadcast with v_readlane
+        const double ld = log((double)diam);
         for (int base = 0; base < n_mid; base += 64) {
-            // lane k of this chunk evaluates eps_{base+k} in double exactly as numpy does and rounds to fp32;
-            // the per-step constants derived from it are broadcast with v_readlane inside the loop.
-            // (exact path: float64 exactly as numpy builds geomloss's schedule; fast path: fp32 exp2 of the same
-            // affine function -- a relative 1e-7 on an intermediate temperature moves the result by far less than
-            // the tolerance, and the float64 exp cost as much as ten annealing steps)
-            const float my_eps = exact ? (float)exp(log((double)diam) + (double)(base + lane) * a.log_scaling)
-                                       : __builtin_amdgcn_exp2f(fmaf((float)(base + lane), lscf, ldf));
+            const float my_eps = (float)exp(ld + (double)(base + lane) * a.log_scaling);
+            const float my_reps = rcp_refined(my_eps);
             const int cnt = min(64, n_mid - base);
-            if (exact) {
-                const float my_reps = rcp_refined(my_eps);
-                for (int k = 0; k < cnt; ++k) {
-                    const float eps =
-                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eps), k));
-                    const float reps =
-                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_reps), k));
-                    step(eps, reps, true, true);
-                }
-            } else {
-                const float my_r2 = kLog2e * rcp_refined(my_eps);
-                const float my_h = my_eps * (0.5f * kLn2);
-                // cnt is wave-uniform: keep the loop control on the scalar unit and unroll so that the branch and
-                // the two v_readlane broadcasts are not on every step's dependent chain
-                const int cnt_s = __builtin_amdgcn_readfirstlane(cnt);
-                auto bcast = [&](float v, int k) {
-                    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-                };
-                int k = 0;
-                for (; k + 4 <= cnt_s; k += 4) {      // unrolled by hand (the pinned schedule inside step2 defeats #pragma unroll)
-                    const float r0 = bcast(my_r2, k), h0 = bcast(my_h, k), r1 = bcast(my_r2, k + 1), h1 = bcast(my_h, k + 1);
-                    const float r2_ = bcast(my_r2, k + 2), h2 = bcast(my_h, k + 2), r3 = bcast(my_r2, k + 3), h3 = bcast(my_h, k + 3);
-                    step2(r0, h0);
-                    step2(r1, h1);
-                    step2(r2_, h2);
-                    step2(r3, h3);
-                }
-                for (; k < cnt_s; ++k) step2(bcast(my_r2, k), bcast(my_h, k));
+            for (int k = 0; k < cnt; ++k) {
+                const float eps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_eps), k));
+                const float reps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_reps), k));
+                step(eps, reps, true, true);
             }
         }
-        if (exact) {
-            const float rb = rcp_refined(eps_last);
-            step(eps_last, rb, true, true);
-            step(eps_last, rb, false, true);  // last extrapolation: simultaneous, not averaged
-        } else {
-            const float r2 = kLog2e * rcp_refined(eps_last);
-            const float eln2 = eps_last * kLn2;
-            step2(r2, 0.5f * eln2);
-            step2(r2, eln2);
-        }
+        const float rb = rcp_refined(eps_last);
+        step(eps_last, rb, true, true);
+        step(eps_last, rb, false, true);  // last extrapolation: simultaneous, not averaged
     };
     PHASE_STAMP(6);
     bool phi_live = true;
