@@ -1235,6 +1235,176 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel 1, matrix-core form for small single-tile pools (T == 1, CSR inputs, all-pairs).
+//
+// The VALU forms above spend ~1800 vector instructions per pair (768 multiply-adds per wave-slice plus the 64-lane
+// reduction of their 64 partial sums, norms, bounding box), and with many queries' launches overlapped the chip is
+// VALU-issue bound.  Here x.y runs on v_mfma_f32_16x16x4_f32 (exact fp32 multiply-adds; the matrix pipe is idle
+// otherwise): a workgroup takes TWO candidates (16 rows = the M side) against the query's 8 rows (N side, columns
+// 8-15 repeat them), its four waves a quarter of the 768 coordinates each.  Lane (r, g) = (l & 15, l >> 4) loads row
+// r's coordinates 16 t + 4 g .. + 3 of its quarter as float4s; component c of chunk t is one K = 4 step for BOTH
+// operands (the K index only has to agree between A and B, and both use the same lane -> coordinate map), so the
+// accumulators are finished sums over the quarter and nothing is reduced across lanes.  Norms: 48 multiply-adds per
+// lane on the same registers + two swaps over g.  The pair's bounding box (own epsilon schedule) wants all rows of a
+// coordinate in one lane: a second, row-per-register view of the same bytes (L1 / L2 hits) feeds v_min3 / v_max3.
+// Measured (bench.py, 1 x 1000 x 8): 829 vector instructions per pair instead of 1825, but 9.8 us per launch against
+// 9.3 and 100 M alignments/s overlapped against 124 -- the second view's load round trip and the 16-row gathers
+// (every load instruction touches 16 half-used cache lines) cost more than the issue slots saved.  Kept behind
+// ASPIRE_HIP_COST1=mfma (parity-tested) as the starting point for few-query pools whose rows fill the N side.
+// ---------------------------------------------------------------------------------------------
+typedef float mfma4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256, 2) pair_cost_mfma1_kernel(ScoreArgs a, PairWs<1> ws) {
+    __shared__ float g_part[4][16][17];      // [wave][candidate row 0..15][query row 0..15 (+1 pad)]
+    __shared__ float yn_s[4][16], xn_s[4][8], box_s[4][2];
+    __shared__ unsigned long long redo_s[2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4, which = r >> 3, rr = r & 7;
+    const uint32_t nq = (uint32_t)a.q.n, ncand = (uint32_t)(a.cand1 - a.cand0);
+    const uint32_t item = blockIdx.x;                    // grid = nq * ceil(ncand / 2)
+    const uint32_t cp = nq == 1 ? item : item / nq, q_loc = nq == 1 ? 0u : item - cp * nq;
+    const uint32_t cl0 = 2 * cp, cl1 = min(2 * cp + 1, ncand - 1);       // odd tail: the last candidate twice
+    const int64_t c_idx0 = a.cand0 + cl0, c_idx1 = a.cand0 + cl1, q_idx = (int64_t)q_loc;
+    const int c_len0 = a.c.len[c_idx0], c_len1 = a.c.len[c_idx1], q_len = a.q.len[q_idx];
+    const float* cdoc0 = a.c.rows + (size_t)a.c.start[c_idx0] * kD;
+    const float* cdoc1 = a.c.rows + (size_t)a.c.start[c_idx1] * kD;
+    const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
+    const bool own_diam = a.diameter == nullptr;
+    const int dbase = wave * 192;
+
+    // ---- operands in the matrix layout (rows beyond a document's length repeat its last row: masked downstream)
+    const float* yptr = (which ? cdoc1 : cdoc0) + (size_t)min(rr, (which ? c_len1 : c_len0) - 1) * kD + dbase + 4 * g;
+    const float* xptr = qdoc + (size_t)min(rr, q_len - 1) * kD + dbase + 4 * g;
+    float4 xb[12], ya[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) xb[t] = ld4(xptr + 16 * t);     // the query first: L2 resident, lands early
+#pragma unroll
+    for (int t = 0; t < 12; ++t) ya[t] = ld4(yptr + 16 * t);
+    __builtin_amdgcn_sched_barrier(0);       // all 24 loads in flight before the first multiply (left alone the scheduler
+                                             // issues them five at a time between the MFMAs: several HBM round trips)
+    mfma4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float yn0 = 0.f, yn1 = 0.f, xn0 = 0.f, xn1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].x, xb[t].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].y, xb[t].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].z, xb[t].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].w, xb[t].w, acc, 0, 0, 0);
+        yn0 = fmaf(ya[t].y, ya[t].y, fmaf(ya[t].x, ya[t].x, yn0));
+        yn1 = fmaf(ya[t].w, ya[t].w, fmaf(ya[t].z, ya[t].z, yn1));
+        xn0 = fmaf(xb[t].y, xb[t].y, fmaf(xb[t].x, xb[t].x, xn0));
+        xn1 = fmaf(xb[t].w, xb[t].w, fmaf(xb[t].z, xb[t].z, xn1));
+    }
+    float yn = yn0 + yn1, xn = xn0 + xn1;
+    yn = swap_add<16>(yn, yn);      // over g (lane bits 4, 5)
+    xn = swap_add<16>(xn, xn);
+    yn = swap_add<32>(yn, yn);
+    xn = swap_add<32>(xn, xn);
+    if (g == 0) {
+        yn_s[wave][r] = yn;
+        if (r < 8) xn_s[wave][r] = xn;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) g_part[wave][4 * g + v][r] = acc[v];    // D[i][j]: lane holds rows 4 g + v of column r
+
+    // ---- bounding boxes of (query + candidate) per coordinate: row-per-register view, 48 lanes x 4 coordinates
+    if (own_diam) {
+        float s0 = 0.f, s1 = 0.f;
+        if (lane < 48) {
+            const int d = dbase + 4 * lane;
+            auto box8 = [&](const float* doc, int len, float4& mn, float4& mx, bool init) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = ld4(doc + (size_t)min(k, len - 1) * kD + d);
+                if (init) mn = mx = v[0];
+#pragma unroll
+                for (int k = init ? 1 : 0; k < 8; ++k) {
+                    mn.x = fminf(mn.x, v[k].x); mn.y = fminf(mn.y, v[k].y); mn.z = fminf(mn.z, v[k].z); mn.w = fminf(mn.w, v[k].w);
+                    mx.x = fmaxf(mx.x, v[k].x); mx.y = fmaxf(mx.y, v[k].y); mx.z = fmaxf(mx.z, v[k].z); mx.w = fmaxf(mx.w, v[k].w);
+                }
+            };
+            float4 qmn, qmx;
+            box8(qdoc, q_len, qmn, qmx, true);
+            auto span2 = [&](const float* doc, int len) {
+                float4 mn = qmn, mx = qmx;
+                box8(doc, len, mn, mx, false);
+                const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
+                return fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            };
+            s0 = span2(cdoc0, c_len0);
+            s1 = span2(cdoc1, c_len1);
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+            box_s[wave][0] = s0;
+            box_s[wave][1] = s1;
+        }
+    }
+    __syncthreads();
+
+    // ---- finish: waves 0 and 1 take a candidate each, lane e = 8 i + j as in pair_cost1_kernel ----
+    if (wave < 2) {
+        const int cand = wave, li = lane >> 3, lj = lane & 7;
+        const int c_len = cand ? c_len1 : c_len0;
+        float gsum = 0.f, xx = 0.f, yy = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            gsum += g_part[w][8 * cand + lj][li];
+            xx += xn_s[w][li];
+            yy += yn_s[w][8 * cand + lj];
+        }
+        const float sq = fmaf(-2.f, gsum, xx) + yy;
+        const float ns = xx + yy;
+        const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+        const bool redo = !mm && li < q_len && lj < c_len && sq < 1e-4f * ns * ns;
+        const int64_t slot = (int64_t)q_loc * ncand + (cand ? cl1 : cl0);
+        const int64_t o = slot * 64 + lane;
+        ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
+        if (!redo) ws.neg[o] = -sqrtf(fmaxf(sq, 0.f));
+        const unsigned long long m = __ballot(redo);
+        if (lane == 0) {
+            redo_s[cand] = m;
+            if (own_diam) ws.diam2[slot] = (box_s[0][cand] + box_s[1][cand]) + (box_s[2][cand] + box_s[3][cand]);
+        }
+    }
+    __syncthreads();
+    // ---- entries whose expansion cancelled: torch.cdist's direct formula, 16 lanes per entry (see pair_cost1_kernel)
+#pragma unroll 1
+    for (int cand = 0; cand < 2; ++cand) {
+        const unsigned long long todo = redo_s[cand];        // workgroup-uniform
+        if (__builtin_expect(todo == 0, 1)) continue;
+        const float* cdoc = cand ? cdoc1 : cdoc0;
+        const int64_t slot = (int64_t)q_loc * ncand + (cand ? cl1 : cl0);
+        const int n_flag = __builtin_popcountll(todo), l16 = lane & 15;
+        for (int base = wave * 4; base < n_flag; base += 16) {
+            const int my = base + (lane >> 4);
+            const bool live = my < n_flag;
+            unsigned long long m = todo;
+            for (int t = 0; t < (live ? my : 0); ++t) m &= m - 1;      // drop the first `my` set bits
+            const int e = __builtin_ctzll(m);
+            const float* xr = qdoc + (size_t)(e >> 3) * kD + 4 * l16;
+            const float* yr = cdoc + (size_t)(e & 7) * kD + 4 * l16;
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; c += 2) {
+                const float4 u0 = ld4(xr + 64 * c), v0 = ld4(yr + 64 * c), u1 = ld4(xr + 64 * c + 64), v1 = ld4(yr + 64 * c + 64);
+                const float a0 = u0.x - v0.x, a1 = u0.y - v0.y, a2 = u0.z - v0.z, a3 = u0.w - v0.w;
+                const float b0 = u1.x - v1.x, b1 = u1.y - v1.y, b2 = u1.z - v1.z, b3 = u1.w - v1.w;
+                p0 = fmaf(a3, a3, fmaf(a2, a2, fmaf(a1, a1, fmaf(a0, a0, p0))));
+                p1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, p1))));
+            }
+            float part = p0 + p1;
+            part += lane_xor<1>(part);
+            part += lane_xor<2>(part);
+            part += lane_xor<4>(part);
+            part += lane_xor<8>(part);
+            if (live && l16 == 0) ws.neg[slot * 64 + e] = -sqrtf(part);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Kernel 1, tiled form for documents of <= 8 sentence rows (T == 1, CSR inputs).
 //
 // The accumulate-then-reduce kernels above give every lane a slice of the 768 coordinates and all 64 (i,j)
@@ -2384,7 +2554,10 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     const bool single = blocks >= n_slots && env_c1 && !strcmp(env_c1, "single");
                     const size_t lds1_bytes = env_lds ? (size_t)atoi(env_lds) * 1024
                                                       : single ? (size_t)40 * 1024 : Lds<1>::kTotal * sizeof(float);
-                    if (single)
+                    if (env_c1 && !strcmp(env_c1, "mfma") && pairing == ASPIRE_PAIR_CROSS && blocks >= n_slots)
+                        hipLaunchKernelGGL(pair_cost_mfma1_kernel, dim3((unsigned)(q->n * ((a.cand1 - a.cand0 + 1) / 2))), dim3(256), 0,
+                                           (hipStream_t)stream, a, ws1);
+                    else if (single)
                         hipLaunchKernelGGL(pair_cost1_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds1_bytes,
                                            (hipStream_t)stream, a, ws1, 1u);
                     else

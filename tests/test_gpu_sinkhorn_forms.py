@@ -111,6 +111,7 @@ def test_forms_agree_at_size(amd, nq, nc, s, want):
 @pytest.mark.parametrize('qlens,clens', [
     ([8], [8, 5, 1, 3, 8, 7, 2, 6] * 5),          # ragged single-tile pool
     ([3, 8], [1, 8, 4] * 7),                      # two queries: items alternate between them
+    ([5], [8, 2, 7] * 5),                         # odd pool: the matrix-core form's last workgroup holds one candidate
 ])
 def test_small_pool_cost_kernel_forms_match_oracle(amd, qlens, clens):
     """Both forms of the small-pool cost kernel (two register sets + global loads, the default; one register set +
@@ -119,8 +120,9 @@ def test_small_pool_cost_kernel_forms_match_oracle(amd, qlens, clens):
     q, c = _docs(61, qlens), _docs(62, clens)
     want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
     got = {}
-    for form in ('prefetch', 'single'):
+    for form in ('prefetch', 'single', 'mfma'):
         with pinned(ASPIRE_HIP_COST1=form):
             got[form] = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
         np.testing.assert_allclose(got[form], want, atol=TOL, rtol=0)
     np.testing.assert_array_equal(got['prefetch'], got['single'])
+    np.testing.assert_allclose(got['mfma'], got['prefetch'], atol=5e-5, rtol=0)      # another summation order
