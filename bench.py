@@ -213,7 +213,9 @@ def main():
     lane_stream = [torch.cuda.Stream() for _ in range(NL)]
     scores = lanes[0].scores
     n_streams, unroll = NL, PER                       # names used in the report below
-    keybuf = torch.zeros(NL, PER, Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
+    # two key buffers: round r's lanes write keybuf[r & 1] while round r-1's keys are exchanged and merged
+    keybuf2 = torch.zeros(2, NL, PER, Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
+    keybuf = keybuf2[0] if shard_path else None
     gathered = torch.empty(world * NL * PER * Q * TOPK, device=device, dtype=torch.int64) if shard_path else None
     merged_s = torch.empty(NL * PER * Q, TOPK, device=device, dtype=torch.float32) if shard_path else None
     merged_i = torch.empty(NL * PER * Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
@@ -246,6 +248,7 @@ def main():
     keytail = None
     if use_graph:
         g_lane = [capture_lane(k, PER, keybuf[k] if shard_path else None) for k in range(NL)]
+        g_lane_b = [g_lane, [capture_lane(k, PER, keybuf2[1, k]) for k in range(NL)]] if shard_path else None
         if shard_path and any(rem):
             keytail = torch.zeros(NL, max(rem), Q, TOPK, device=device, dtype=torch.int64)
         g_tail = [capture_lane(k, rem[k], keytail[k] if shard_path else None) if rem[k] else None for k in range(NL)]
@@ -280,16 +283,28 @@ def main():
                     with torch.cuda.stream(lane_stream[k]):
                         g_tail[k].replay()
         else:
-            # rounds: every lane replays once, then the round's keys are exchanged and merged on the main stream
+            # rounds: every lane replays once, then the round's keys are exchanged (one all-gather) and merged on the
+            # main stream -- while the lanes already run the next round into the other key buffer.  A lane waits only
+            # for the exchange that last read the buffer it is about to overwrite (two rounds back).
+            ev_ex = [None, None]
             for r in range(min(full)):
+                b = r & 1
+                ev_lane = []
                 for k in range(NL):
                     with torch.cuda.stream(lane_stream[k]):
-                        g_lane[k].replay()
-                for st in lane_stream:
-                    main.wait_stream(st)
-                exchange(keybuf, NL * PER)
-                for st in lane_stream:
-                    st.wait_stream(main)            # the next round overwrites keybuf
+                        if ev_ex[b] is not None:
+                            lane_stream[k].wait_event(ev_ex[b])
+                        g_lane_b[b][k].replay()
+                        e = torch.cuda.Event()
+                        e.record(lane_stream[k])
+                        ev_lane.append(e)
+                for e in ev_lane:
+                    main.wait_event(e)
+                exchange(keybuf2[b], NL * PER)
+                ev_ex[b] = torch.cuda.Event()
+                ev_ex[b].record(main)
+            for st in lane_stream:
+                st.wait_stream(main)                # the tail below reuses buffer 0
             for k in range(NL):                      # a lane whose share holds one more whole graph (PER = 1 only)
                 if full[k] > min(full):
                     with torch.cuda.stream(lane_stream[k]):
@@ -353,6 +368,10 @@ def main():
         torch.cuda.synchronize()
         assert (merged_i[0] >= 0).all() and (merged_i[0] < world * C).all(), 'merge produced out-of-range indices'
         assert (merged_s[0, 1:] <= merged_s[0, :-1]).all(), 'merge output is not descending'
+        if world == 1:
+            # one shard: the merged ranking IS the shard's own stable descending ranking of the step's scores
+            ref_s, ref_i = torch.sort(lanes[0].scores[0], descending=True, stable=True)
+            assert torch.equal(merged_i[0], ref_i[:TOPK]) and torch.equal(merged_s[0], ref_s[:TOPK]), 'merged ranking differs'
     # the same K steps strictly one after the other on ONE stream, for reference
     serial_elapsed = None
     if use_graph and NL > 1 and not shard_path:
