@@ -111,11 +111,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    # ASPIRE_BENCH_ONE_GPU=1 (testing only, invalid as a result): every rank on cuda:0 over gloo, so that the N > 1
+    # control flow (sharded indices, all-gather layout, merge, double-buffered exchange) can be exercised on a 1-GPU box
+    one_gpu_test = os.environ.get('ASPIRE_BENCH_ONE_GPU') == '1'
+    if one_gpu_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if one_gpu_test:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     import __graft_entry__
     if rank == 0:
@@ -368,6 +376,13 @@ def main():
         torch.cuda.synchronize()
         assert (merged_i[0] >= 0).all() and (merged_i[0] < world * C).all(), 'merge produced out-of-range indices'
         assert (merged_s[0, 1:] <= merged_s[0, :-1]).all(), 'merge output is not descending'
+        if world > 1:
+            # every rank merged the same gathered keys: identical rankings, drawn from more than one shard
+            mine = merged_i[0].clone()
+            everyone = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(everyone, mine)
+            assert all(torch.equal(everyone[0], e) for e in everyone), 'ranks disagree on the merged ranking'
+            assert len(torch.unique(mine // C)) > 1, 'merged ranking holds candidates of one shard only'
         if world == 1:
             # one shard: the merged ranking IS the shard's own stable descending ranking of the step's scores
             ref_s, ref_i = torch.sort(lanes[0].scores[0], descending=True, stable=True)
