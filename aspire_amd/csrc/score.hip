@@ -2503,7 +2503,11 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
             // ASPIRE_HIP_SINKHORN=wave|packed|block pins the form (parity tests, tuning); default: by grid size
             const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
             const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : !strcmp(env_form, "block16") ? 5 : 0;
-            const int form = pinned ? pinned : (n_slots >= 4096 ? 3 : 1);
+            // measured crossovers (1 x N x 8, cost + solve, us): N = 5000: wave 58 / 16-lane block 64 / 4-lane block 68;
+            // 8000: 88 / 83 / 89; 12000: 119 / 109 / 106
+            const int form = pinned ? pinned
+                             : T == 1 ? (n_slots < 7000 ? 1 : n_slots < 10000 ? 5 : 3)
+                                      : (n_slots >= 4096 ? 3 : 1);
             // ASPIRE_HIP_STAGE=cost: launch the cost stage only (bench.py times the dominant kernel alone this way)
             const char* env_stage = getenv("ASPIRE_HIP_STAGE");
             const bool cost_only = env_stage && !strcmp(env_stage, "cost");
