@@ -2507,7 +2507,7 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
             // 8000: 88 / 83 / 89; 12000: 119 / 109 / 106
             const int form = pinned ? pinned
                              : T == 1 ? (n_slots < 7000 ? 1 : n_slots < 10000 ? 5 : 3)
-                                      : (n_slots >= 4096 ? 3 : 1);
+                                      : (n_slots >= 2500 ? 3 : 1);      // S = 12 / 20: even at 2000 / ~2500, block ahead at 3000
             // ASPIRE_HIP_STAGE=cost: launch the cost stage only (bench.py times the dominant kernel alone this way)
             const char* env_stage = getenv("ASPIRE_HIP_STAGE");
             const bool cost_only = env_stage && !strcmp(env_stage, "cost");
