@@ -1056,10 +1056,9 @@ __device__ __forceinline__ float box_partial(const RowSet& r) {
 // all workgroups of a <= 1024-pair launch are resident at once and move through the two phases in lock step, so a
 // lone call gains nothing (45 vs 48.5 M pairs/s), and the union of the two phases' live scalars spills, which costs
 // the overlapped case its co-residency: 86 vs 112 M alignments/s.)
-template <bool PREFETCH, bool SUB = false>
-__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
+template <bool PREFETCH, bool SUB>
+__device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs<1>& ws, uint32_t T_rt, float* lds) {
     const uint32_t T = SUB ? T_rt : 1u;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dofs = wave * 256 + lane * 4;
@@ -1232,6 +1231,21 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
         process(rb, qb, cb, n1);
         item = n2;
     }
+}
+template <bool PREFETCH>
+__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    pair_cost1_body<PREFETCH, false>(a, ws, T_rt, lds);
+}
+// The sub-tile form, capped at 216 registers (amdgpu_num_vgpr counts HALF registers on gfx950: 108 -> 216; uncapped it
+// takes 256 and no other launch's waves share a SIMD with it).
+#ifndef SUB_CAP
+#define SUB_CAP 108
+#endif
+__global__ void __launch_bounds__(kBlock, 2) __attribute__((amdgpu_num_vgpr(SUB_CAP)))
+pair_cost1_sub_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    pair_cost1_body<true, true>(a, ws, T_rt, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2575,7 +2589,7 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     // tiles each -> 1024 side by side, 54 -> 36 us; from ~1000 pairs the per-pair kernel is ahead again)
                     PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
                     const int64_t items = n_slots * T * T;
-                    hipLaunchKernelGGL((pair_cost1_kernel<true, true>), dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
+                    hipLaunchKernelGGL(pair_cost1_sub_kernel, dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
                                        Lds<1>::kTotal * sizeof(float), (hipStream_t)stream, a, ws1, (uint32_t)T);
                 } else if (q->ext == 0 && c->ext == 0)
                     hipLaunchKernelGGL((pair_cost_kernel<T, false>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),

@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 
 Q, C, S, D = 1, 1000, 8, 768
 TOPK = 100
+if os.environ.get('ASPIRE_BENCH_SHAPE'):      # "C,S": tuning experiments at other pool shapes (invalid as a result)
+    C, S = (int(v) for v in os.environ['ASPIRE_BENCH_SHAPE'].split(','))
+    TOPK = min(TOPK, C)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 

@@ -143,12 +143,14 @@ def test_kernel_register_budgets():
         assert len(hits) == 1, (pattern, len(hits))
         return hits[0]
 
-    cost = one(r'pair_cost1_kernelILb1ELb0E')       # two register sets (default form of every launch of <= 1024 pairs)
-    single = one(r'pair_cost1_kernelILb0ELb0E')     # one register set (ASPIRE_HIP_COST1=single: the lone-call form)
+    cost = one(r'pair_cost1_kernelILb1EE')       # two register sets (default form of every launch of <= 1024 pairs)
+    single = one(r'pair_cost1_kernelILb0EE')     # one register set (ASPIRE_HIP_COST1=single: the lone-call form)
     sink = one(r'sinkhorn_kernelILi1E')
     topk = one(r'topk_select_kernel')
     assert cost['vgpr'] <= 200 and cost['scratch'] == 0
     assert single['vgpr'] <= 128 and single['scratch'] == 0
+    sub = one(r'pair_cost1_sub_kernel')             # sub-tile form (long documents, small pools): capped, see score.hip
+    assert sub['vgpr'] <= 216 and sub['scratch'] == 0
     assert sink['vgpr'] <= 56 and sink['scratch'] == 0
     assert topk['vgpr'] <= 56 and topk['scratch'] == 0
     # two (three) cost waves + two Sinkhorn / top-k waves per SIMD fit together
