@@ -35,20 +35,26 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
 // (one key per thread, 36 levels) replaces the 1024-key one (four keys per thread, 55 levels).  Exact: the bucket map
 // is monotone, ties and order are decided by the full 64-bit keys of the survivors.  Falls back to the full sort in
 // the same launch when the boundary bin is crowded (more than 256 survivors, e.g. all scores equal).
+// E keys per thread: 4 (chunks of 1024) or 16 (chunks of 4096; pools beyond 4096 candidates take one workgroup per chunk
+// and leave k keys each for the next pass -- the full 4096-key network of topk_pass_kernel<16> cost 16-44 us there).
+template <int E>
 __global__ void __launch_bounds__(kThreads) topk_select_kernel(const float* __restrict__ scores, int64_t n_in, int64_t in_stride,
-                                                               int64_t idx_base, int64_t k_final, float* __restrict__ top_scores,
-                                                               int64_t* __restrict__ top_idx, uint64_t* __restrict__ keys_final) {
-    __builtin_amdgcn_s_setprio(3);     // one workgroup, latency only: issue ahead of co-resident throughput kernels
-    __shared__ uint64_t lds[4 * kThreads];
+                                                               int64_t idx_base, int64_t k_final, int64_t kk,
+                                                               uint64_t* __restrict__ keys_out, int64_t out_stride,
+                                                               float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
+                                                               uint64_t* __restrict__ keys_final) {
+    __builtin_amdgcn_s_setprio(3);     // few workgroups, latency only: issue ahead of co-resident throughput kernels
+    __shared__ uint64_t lds[E * kThreads];
     __shared__ unsigned hist[256];
     __shared__ unsigned sm[16];      // [0..3] wave minima, [4..7] wave maxima, [8] boundary bin, [9] survivors, [10] cursor
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q = blockIdx.x;
-    uint64_t key[4];
+    const int64_t q = blockIdx.x, chunk = blockIdx.y;
+    const int64_t base = chunk * (E * kThreads);
+    uint64_t key[E];
     unsigned mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t i = tid * 4 + r;
+    for (int r = 0; r < E; ++r) {
+        const int64_t i = base + tid * E + r;
         uint64_t kv = 0;
         if (i < n_in) {
             kv = ((uint64_t)order_bits(scores[q * in_stride + i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
@@ -77,7 +83,7 @@ __global__ void __launch_bounds__(kThreads) topk_select_kernel(const float* __re
     const bool spread = mx > mn;
     if (spread) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < E; ++r)
             if (key[r] != 0) atomicAdd(&hist[bucket_of(key[r])], 1u);
     }
     __syncthreads();
@@ -91,29 +97,29 @@ __global__ void __launch_bounds__(kThreads) topk_select_kernel(const float* __re
             if (lane + m < 64) incl += o;
         }
         unsigned above = incl - (h[0] + h[1] + h[2] + h[3]);  // keys in bins of higher lanes
-        const unsigned kk = (unsigned)k_final;
+        const unsigned kq = (unsigned)kk;
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
-            if (above < kk && above + h[j] >= kk) { sm[8] = 4 * lane + j; sm[9] = above + h[j]; }
+            if (above < kq && above + h[j] >= kq) { sm[8] = 4 * lane + j; sm[9] = above + h[j]; }
             above += h[j];
         }
-        if (lane == 0 && above < kk) { sm[8] = 0; sm[9] = above; }   // fewer than k keys in all: everything survives
+        if (lane == 0 && above < kq) { sm[8] = 0; sm[9] = above; }   // fewer than k keys in all: everything survives
     }
     __syncthreads();
     const unsigned n_surv = sm[9];
     if (spread && n_surv <= (unsigned)kThreads) {
         const int bmin = (int)sm[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < E; ++r)
             if (key[r] != 0 && bucket_of(key[r]) >= bmin) lds[atomicAdd(&sm[10], 1u)] = key[r];
         __syncthreads();
         uint64_t one[1] = {tid < (int)n_surv ? lds[tid] : 0ull};
         __syncthreads();                                      // the sort's exchanges reuse lds
         bitonic_sort<1, kThreads>(one, lds, tid);
-        topk_emit<1>(one, q, 0, k_final, nullptr, k_final, idx_base, k_final, top_scores, top_idx, keys_final, 0);
+        topk_emit<1>(one, q, chunk, kk, keys_out, out_stride, idx_base, k_final, top_scores, top_idx, keys_final, 0);
     } else {
-        block_bitonic_desc<4>(key, lds, tid);
-        topk_emit<4>(key, q, 0, k_final, nullptr, k_final, idx_base, k_final, top_scores, top_idx, keys_final, 0);
+        block_bitonic_desc<E>(key, lds, tid);
+        topk_emit<E>(key, q, chunk, kk, keys_out, out_stride, idx_base, k_final, top_scores, top_idx, keys_final, 0);
     }
 }
 
@@ -166,9 +172,14 @@ int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_b
         int64_t* ti = final_pass && !keys_final ? top_idx : nullptr;
         uint64_t* kf = final_pass ? keys_final : nullptr;
         uint64_t* ko = final_pass ? nullptr : bufs[which];
-        if (chunk == 1024 && final_pass && sc != nullptr && k <= 128 && n > 256) {
-            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Q), dim3(kThreads), 0, (hipStream_t)stream, sc, n, in_stride, idx_base,
-                               k, ts, ti, kf);
+        if (sc != nullptr && k <= 128 && n > 256) {
+            // first pass over scores, short list: select + 256-key sort per chunk (final outputs if there is one chunk)
+            if (chunk == 1024)
+                hipLaunchKernelGGL(topk_select_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, n, in_stride, idx_base, k, kk,
+                                   ko, out_stride, ts, ti, kf);
+            else
+                hipLaunchKernelGGL(topk_select_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, n, in_stride, idx_base, k, kk,
+                                   ko, out_stride, ts, ti, kf);
         } else if (chunk == 1024) {
             hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, kin, n, in_stride, kk, ko,
                                out_stride, idx_base, k, ts, ti, kf, (int64_t)0);

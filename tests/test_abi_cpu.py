@@ -146,7 +146,7 @@ def test_kernel_register_budgets():
     cost = one(r'pair_cost1_kernelILb1EE')       # two register sets (default form of every launch of <= 1024 pairs)
     single = one(r'pair_cost1_kernelILb0EE')     # one register set (ASPIRE_HIP_COST1=single: the lone-call form)
     sink = one(r'sinkhorn_kernelILi1E')
-    topk = one(r'topk_select_kernel')
+    topk = one(r'topk_select_kernelILi4E')
     assert cost['vgpr'] <= 200 and cost['scratch'] == 0
     assert single['vgpr'] <= 128 and single['scratch'] == 0
     sub = one(r'pair_cost1_sub_kernel')             # sub-tile form (long documents, small pools): capped, see score.hip

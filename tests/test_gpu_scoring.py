@@ -316,10 +316,11 @@ def test_score_and_rank_in_one_call(amd, nq, lens, want):
         assert torch.equal(-dist, ref_scores)
 
 
-@pytest.mark.parametrize('n', [257, 300, 1000, 1024])
+@pytest.mark.parametrize('n', [257, 300, 1000, 1024, 1025, 1300, 4096, 4097, 9000, 20000])
 @pytest.mark.parametrize('k', [1, 7, 100, 128])
 def test_topk_select_path(amd, n, k):
-    """Pools of 257..1024 candidates ranked for k <= 128 go through select-then-sort (bucket the scores, keep the bins
+    """Pools ranked for k <= 128 go through select-then-sort per chunk of 1024 (pools up to 1024) or 4096 keys,
+    chunk winners merged by the sorting passes; the original wording for one chunk: pools of 257..1024 candidates (bucket the scores, keep the bins
     that hold the top k, sort the survivors); crowded boundary bins fall back to the full sort.  Same order as
     Python's stable descending sort in every regime."""
     g = torch.Generator().manual_seed(n * 131 + k)
