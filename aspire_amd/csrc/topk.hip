@@ -106,12 +106,16 @@ __global__ void __launch_bounds__(kThreads) topk_select_kernel(const float* __re
         if (lane == 0 && above < kq) { sm[8] = 0; sm[9] = above; }   // fewer than k keys in all: everything survives
     }
     __syncthreads();
-    const unsigned n_surv = sm[9];
-    if (spread && n_surv <= (unsigned)kThreads) {
+    // a chunk with at most 256 keys (a small pool, or the tail chunk of a big one): every key survives -- without this
+    // a one-key tail chunk (min == max) took the full 4096-key sort: 1 x 4097 cost 40 us more than 1 x 4096
+    const int64_t n_valid = min((int64_t)(E * kThreads), n_in - base);
+    const bool take_all = n_valid <= kThreads;
+    const unsigned n_surv = take_all ? (unsigned)max(n_valid, (int64_t)0) : sm[9];
+    if (take_all || (spread && n_surv <= (unsigned)kThreads)) {
         const int bmin = (int)sm[8];
 #pragma unroll
         for (int r = 0; r < E; ++r)
-            if (key[r] != 0 && bucket_of(key[r]) >= bmin) lds[atomicAdd(&sm[10], 1u)] = key[r];
+            if (key[r] != 0 && (take_all || bucket_of(key[r]) >= bmin)) lds[atomicAdd(&sm[10], 1u)] = key[r];
         __syncthreads();
         uint64_t one[1] = {tid < (int)n_surv ? lds[tid] : 0ull};
         __syncthreads();                                      // the sort's exchanges reuse lds
@@ -163,7 +167,8 @@ int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_b
     bufs[1] = bufs[0] + (workspace ? Q * ((C + kMaxChunk - 1) / kMaxChunk * kk) : 0);
     int which = 0;
     for (;;) {
-        const int chunk = chunk_for(n);
+        const bool select = sc != nullptr && k <= 128;       // first pass over scores, short list: select + 256-key sort per chunk
+        const int chunk = select && n > 1024 && n <= 2048 ? 2048 : chunk_for(n);
         const int64_t nch = n == 0 ? 1 : (n + chunk - 1) / chunk;
         const bool final_pass = nch == 1;
         const int64_t out_stride = nch * kk;
@@ -172,9 +177,12 @@ int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_b
         int64_t* ti = final_pass && !keys_final ? top_idx : nullptr;
         uint64_t* kf = final_pass ? keys_final : nullptr;
         uint64_t* ko = final_pass ? nullptr : bufs[which];
-        if (sc != nullptr && k <= 128 && n > 256) {
-            // first pass over scores, short list: select + 256-key sort per chunk (final outputs if there is one chunk)
-            if (chunk == 1024)
+        if (select) {
+            // (final outputs if there is one chunk)
+            if (chunk == 2048)
+                hipLaunchKernelGGL(topk_select_kernel<8>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, n, in_stride, idx_base, k, kk,
+                                   ko, out_stride, ts, ti, kf);
+            else if (chunk == 1024)
                 hipLaunchKernelGGL(topk_select_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, sc, n, in_stride, idx_base, k, kk,
                                    ko, out_stride, ts, ti, kf);
             else
