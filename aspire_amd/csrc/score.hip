@@ -2555,9 +2555,11 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
                     // persistent and software pipelined (measured 15.6 us per launch at 50-250 pairs against
                     // 20-23 us for the tiled form with its stages split over three or four waves)
                     const char* env_blocks = getenv("ASPIRE_HIP_COST1_BLOCKS");   // tuning only
-                    // 1024: at ~1000 pairs one pair per workgroup beats 512 persistent workgroups with two each, both
-                    // alone and beside other launches
-                    const int64_t cap = env_blocks ? atoi(env_blocks) : 1024;
+                    // One pair per workgroup up to 2048 pairs (at ~1000 pairs it beats 512 persistent workgroups with two
+                    // each, alone and beside other launches; 1300-1500 pairs: 119-121 vs 111-115 M alignments/s overlapped
+                    // against a 1024-workgroup grid with uneven shares); beyond, 512 persistent workgroups = what is
+                    // resident at two per CU (3000 pairs: 109 vs 103 M overlapped with 1024, the same alone)
+                    const int64_t cap = env_blocks ? atoi(env_blocks) : (n_slots <= 2048 ? 2048 : 512);
                     const int64_t blocks = n_slots < cap ? n_slots : cap;
                     // Two forms of the kernel for one item per workgroup (every launch of <= 1024 pairs), both kept
                     // because they win different cases on the same box (bench.py, 1 x 1000 x 8, three runs each):
