@@ -1,0 +1,62 @@
+"""Randomised parity sweep across the dispatch thresholds (pool sizes, document lengths, query counts):
+GPU otAspire / tsAspire scores of sampled pairs against the oracle, and the rank of every query against the stable
+descending sort of its own scores.   python tools/fuzz_parity.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from aspire_amd import ops, scorer, _lib
+from oracle import aspire_oracle as orc
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+sizes = [1, 5, 100, 256, 257, 511, 512, 1000, 1024, 1025, 2047, 2049, 2500, 4096, 4097, 7001, 8192, 10001, 16001]
+worst_ot = worst_l2 = 0.0
+for case in range(n_cases):
+    nq = int(rng.choice([1, 1, 1, 2, 3, 5]))
+    nc = int(rng.choice(sizes))
+    smax = int(rng.choice([8, 8, 8, 12, 20, 32]))
+    if nq * nc * (smax // 8 + (smax % 8 > 0)) ** 2 > 120000:
+        nc = max(1, nc // 8)
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    scale = float(rng.choice([1.0, 1.0, 0.3, 2.0]))
+    mk = lambda n: scale * torch.randn(int(n), 768, generator=g)
+    ragged = rng.random() < 0.7
+    q = [mk(rng.integers(1, smax + 1) if ragged else smax) for _ in range(nq)]
+    c = [mk(rng.integers(1, smax + 1) if ragged else smax) for _ in range(nc)]
+    if rng.random() < 0.3 and nc > 2:          # a candidate sharing sentences with the query
+        c[1] = torch.cat([q[0][:1], c[1]])[:smax]
+    ot = scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    l2 = scorer.score_pool(q, c, method='l2max').cpu().numpy()
+    assert np.isfinite(ot).all() and np.isfinite(l2).all(), (case, nq, nc, smax)
+    for _ in range(12):
+        i, j = int(rng.integers(nq)), int(rng.integers(nc))
+        if nc > 2 and rng.random() < 0.2:
+            j = 1
+        w = orc.get_similarity(q[i], c[j])
+        shared = j == 1 and len(c[1]) and torch.equal(c[1][0], q[0][0]) and i == 0
+        tol = 5e-2 if shared else 1e-4          # coincident sentences: geomloss's own cancellation noise
+        e = abs(float(ot[i, j]) - w)
+        assert e <= tol, (case, nq, nc, smax, i, j, float(ot[i, j]), w, len(q[i]), len(c[j]))
+        if not shared:
+            worst_ot = max(worst_ot, e)
+        wl = -orc.allpair_masked_dist_l2max(orc.RepLen(q[i][None].permute(0, 2, 1), [len(q[i])]),
+                                            orc.RepLen(c[j][None].permute(0, 2, 1), [len(c[j])])).item()
+        el = abs(float(l2[i, j]) - wl)
+        # coincident sentences under torch.cdist's matmul formula (a side beyond 25 rows): the reference's own value is
+        # sqrt(clamp(cancellation noise)), 0 or ~3e-2 by rounding luck
+        tol_l2 = 5e-2 if (shared and max(len(q[i]), len(c[j])) > 25) else 1e-4
+        assert el <= tol_l2, (case, nq, nc, smax, i, j, float(l2[i, j]), wl, len(q[i]), len(c[j]))
+        if tol_l2 == 1e-4:
+            worst_l2 = max(worst_l2, el)
+    k = int(min(nc, rng.choice([1, 10, 100, 128])))
+    qs, cs = ops.DeviceRepSet.from_list(q), ops.DeviceRepSet.from_list(c)
+    sc, ts, ti = ops.ot_rank(qs, cs, k, want=_lib.OT_SIMILARITY)
+    sc, ts, ti = sc.cpu(), ts.cpu(), ti.cpu()
+    np.testing.assert_allclose(sc.numpy(), ot, atol=2e-4, rtol=0)
+    for i in range(nq):
+        order = orc.rank_descending(sc[i].tolist())[:k]
+        assert ti[i].tolist() == order, (case, nq, nc, smax, k, i)
+        assert torch.equal(ts[i], sc[i][order])
+    print(f'case {case}: Q={nq} C={nc} S<={smax} ragged={ragged} k={k} ok', flush=True)
+print(f'{n_cases} cases ok; worst |ot - oracle| {worst_ot:.2e}, worst |l2max - oracle| {worst_l2:.2e}')
