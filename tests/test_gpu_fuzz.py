@@ -15,4 +15,4 @@ def test_fuzz_parity_short():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_parity.py'), '14', '11'], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert '14 cases ok' in out.stdout
+    assert '14 cases ok' in out.stdout and 'caching_score cases ok' in out.stdout

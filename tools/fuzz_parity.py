@@ -60,3 +60,60 @@ for case in range(n_cases):
         assert torch.equal(ts[i], sc[i][order])
     print(f'case {case}: Q={nq} C={nc} S<={smax} ragged={ragged} k={k} ok', flush=True)
 print(f'{n_cases} cases ok; worst |ot - oracle| {worst_ot:.2e}, worst |l2max - oracle| {worst_l2:.2e}')
+
+# ---- part 2: the padded, paired calling pattern of caching_score (disent_models.py:256-342), groups of <= 64 ----------
+worst = {'l2max': 0.0, 'neg': 0.0, 'distr': 0.0, 'plan_sim': 0.0, 'l2top2': 0.0}
+n2 = max(4, n_cases // 2)
+for case in range(n2):
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    smax = int(rng.choice([8, 8, 12, 20, 32]))
+    b = int(rng.choice([1, 2, 7, 33, 64]))
+    qlen = int(rng.integers(1, smax + 1))
+    qrep = torch.randn(qlen, 768, generator=g).numpy()
+    creps = [torch.randn(int(rng.integers(1, smax + 1)), 768, generator=g).numpy() for _ in range(b)]
+    qd, cds = {'sent_reps': qrep}, [{'sent_reps': r} for r in creps]
+    for agg in ('l2max', 'l2top2', 'l2wasserstein'):
+        got = scorer.caching_score(qd, cds, score_agg_type=agg)
+        if agg == 'l2top2':
+            qt = orc.RepLen(torch.stack([torch.nn.functional.pad(torch.as_tensor(qrep), (0, 0, 0, 0))] * b).permute(0, 2, 1), [qlen] * b)
+            cmax = max(len(r) for r in creps)
+            pc = torch.zeros(b, cmax, 768)
+            for i, r in enumerate(creps):
+                pc[i, :len(r)] = torch.as_tensor(r)
+            ct = orc.RepLen(pc.permute(0, 2, 1), [len(r) for r in creps])
+            want_s, _ = orc.allpair_masked_dist_l2topk(qt, ct, return_pair_sims=True)
+            e = float(np.abs(got['batch_scores'] - want_s.numpy()).max())
+            assert e <= 1e-4, (case, agg, b, qlen, e)
+            worst['l2top2'] = max(worst['l2top2'], e)
+            continue
+        want_s, want_p = orc.caching_score(qrep, creps, agg)
+        if agg == 'l2max':
+            e = float(np.abs(got['batch_scores'] - want_s).max())
+            assert e <= 1e-4, (case, agg, b, qlen, e)
+            worst['l2max'] = max(worst['l2max'], e)
+            for gp, wp in zip(got['pair_scores'], want_p):
+                assert np.abs(gp - wp).max() <= 1e-4
+        else:
+            for gp, wp in zip(got['pair_scores'], want_p):
+                worst['distr'] = max(worst['distr'], float(np.abs(gp[0] - wp[0]).max()), float(np.abs(gp[1] - wp[1]).max()))
+                worst['neg'] = max(worst['neg'], float(np.abs(gp[2] - wp[2]).max()))
+            e = float(np.abs(got['batch_scores'] - want_s).max())
+            worst['plan_sim'] = max(worst['plan_sim'], e)
+            assert worst['distr'] <= 1e-4 and worst['neg'] <= 1e-4, (case, b, qlen, worst)
+            if e > 3e-3:
+                # fp32 plan-weighted similarity, exp((f + g - d) / 0.05) with |f|, |g|, |d| ~ 38: the reference's own fp32
+                # value is noisy at this level -- judge both against the float64 evaluation of the same batch
+                cmax = max(len(r) for r in creps)
+                pc = torch.zeros(b, cmax, 768, dtype=torch.float64)
+                for i, r in enumerate(creps):
+                    pc[i, :len(r)] = torch.as_tensor(r, dtype=torch.float64)
+                pq = torch.as_tensor(qrep, dtype=torch.float64)[None].expand(b, -1, -1).contiguous()
+                w64, _ = orc.AllPairMaskedWasserstein({}).compute_distance(
+                    orc.RepLen(pq.permute(0, 2, 1), [qlen] * b), orc.RepLen(pc.permute(0, 2, 1), [len(r) for r in creps]),
+                    return_pair_sims=True)
+                e_gpu = float(np.abs(got['batch_scores'] - w64.numpy()).max())
+                e_cpu = float(np.abs(want_s - w64.numpy()).max())
+                print(f'   plan-sim vs float64: gpu {e_gpu:.2e}, cpu fp32 {e_cpu:.2e}', flush=True)
+                assert e_gpu <= max(3 * e_cpu, 3e-3), (case, b, qlen, e_gpu, e_cpu)
+    print(f'caching case {case}: B={b} qlen={qlen} S<={smax} ok', flush=True)
+print(f'{n2} caching_score cases ok; worst errors {worst}')
