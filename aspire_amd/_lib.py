@@ -83,6 +83,16 @@ SIGNATURES = {
                                    c_void_p]),
     'aspire_topk_keys_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'aspire_topk_merge_keys': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'aspire_ot_rank_batch_workspace_bytes': (c_size_t, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int64]),
+    'aspire_ot_rank_batch_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_void_p, c_int64,
+                                         ctypes.POINTER(OtParams), c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                         c_size_t, c_void_p]),
+    'aspire_debug_set': (c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    'aspire_debug_ot_cost_stage_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int,
+                                               ctypes.POINTER(OtParams), c_void_p, c_void_p, c_size_t, c_void_p]),
+    'aspire_debug_ot_rank_batch_stages_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_void_p, c_int64,
+                                                      ctypes.POINTER(OtParams), c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                                      c_void_p, c_size_t, c_void_p, c_int]),
     'aspire_selftest_xlane': (c_int, [ctypes.POINTER(c_int)]),
 }
 
@@ -112,3 +122,21 @@ def check(status):
         if status == ASPIRE_ERR_UNSUPPORTED:
             raise NotImplementedError(msg)
         raise AspireHipError(msg)
+
+
+class pinned:
+    """Context manager over aspire_debug_set: pin diagnostic switches (kernel forms, grids) for a block of calls, e.g.
+    ``with pinned(SINKHORN='block', COST_PATH='valu'): ...``; the defaults come back on exit."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            check(lib.aspire_debug_set(k.encode(), str(v).encode()))
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            lib.aspire_debug_set(k.encode(), None)
+        return False

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace aspire {
 namespace {
@@ -448,8 +449,7 @@ int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     // 96-column tiles (4 waves stacked on M, 32 x 96 each) when they divide N and fill whole rounds of the 768
     // resident workgroups where 128-column tiles leave half a round idle (QKV, N = 2304: 1152 -> 1536 workgroups).
     const long long b12896 = (long long)((g.M + 127) / 128) * (g.N / 96) * batch;
-    const char* force = getenv("ASPIRE_HIP_GEMM_TILE");   // tuning only
-    const bool force96 = force && !strcmp(force, "96") && g.N % 96 == 0;
+    const bool force96 = tuning().gemm_tile96 && g.N % 96 == 0;   // tuning only
     if (!B_KN && g.N % 96 == 0 && (force96 || (b12896 >= 768 && gemm_rounds_waste(b12896) + 0.05 < gemm_rounds_waste(b128)))) {
         dim3 grid(g.N / 96, (g.M + 127) / 128, batch);
         hipLaunchKernelGGL((gemm_f32_kernel<128, 96, 16, false, 1>), grid, dim3(256), 0, st, g);
@@ -538,8 +538,7 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         if (int rc = launch_gemm<false>(g, 1, st)) return rc;
         // 2-4. attention.  Fused kernel (scores never leave the chip) unless ASPIRE_HIP_ATTN=gemm pins the
         // three-kernel form (QK^T GEMM, masked soft-max, PV GEMM) that the fused one is tested against.
-        const char* attn_env = getenv("ASPIRE_HIP_ATTN");
-        if (dh == 64 && !(attn_env && !strcmp(attn_env, "gemm"))) {
+        if (dh == 64 && !tuning().attn_gemm) {
             const unsigned qblocks = (unsigned)((L + 127) / 128);
             hipLaunchKernelGGL(flash_attn_f32_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkv, attn_mask, ws.ctx,
                                (int)L, H);

@@ -27,6 +27,7 @@
 
 #include <type_traits>
 
+#include "tuning.h"
 #include "score_types.h"
 
 namespace aspire {
@@ -576,10 +577,8 @@ bool gram_path_wanted(const aspire_repset* q, const aspire_repset* c, int pairin
     if (pairing != ASPIRE_PAIR_CROSS || q->ext != 0 || c->ext != 0) return false;
     if (q->max_len <= 0 || c->max_len <= 0 || q->max_len > 32 || c->max_len > 32) return false;
     // ASPIRE_HIP_COST_PATH=mfma|valu pins the choice (parity tests compare the two forms); default: by shape
-    if (const char* e = getenv("ASPIRE_HIP_COST_PATH")) {
-        if (!strcmp(e, "mfma")) return true;
-        if (!strcmp(e, "valu")) return false;
-    }
+    if (tuning().cost_path == 1) return true;
+    if (tuning().cost_path == 2) return false;
     const int max_rows = q->max_len > c->max_len ? q->max_len : c->max_len;
     const int64_t qrows = q->n * (int64_t)slot_rows(q->max_len);
     const int64_t tiles = (c->n + kBM / slot_rows(c->max_len) - 1) / (kBM / slot_rows(c->max_len));

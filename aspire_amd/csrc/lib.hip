@@ -2,11 +2,70 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+
 #include "common.h"
+#include "tuning.h"
 
 namespace aspire {
 namespace {
 thread_local char g_err[512] = "";
+Tuning g_tuning;
+std::once_flag g_tuning_once;
+
+bool apply_tuning(Tuning& t, const char* key, const char* v) {
+    const bool unset = !v || !*v;
+    if (!strcmp(key, "SINKHORN")) {
+        const int f = unset ? 0 : !strcmp(v, "wave") ? 1 : !strcmp(v, "block") ? 3 : !strcmp(v, "block-norepair") ? 4 : !strcmp(v, "block16") ? 5 : -1;
+        if (f < 0) return false;
+        t.sinkhorn_form = f;
+    } else if (!strcmp(key, "COST_PATH")) {
+        const int f = unset ? 0 : !strcmp(v, "mfma") ? 1 : !strcmp(v, "valu") ? 2 : -1;
+        if (f < 0) return false;
+        t.cost_path = f;
+    } else if (!strcmp(key, "COST1_BLOCKS")) {
+        t.cost1_blocks = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "ATTN")) {
+        if (!unset && strcmp(v, "gemm")) return false;
+        t.attn_gemm = unset ? 0 : 1;
+    } else if (!strcmp(key, "GEMM_TILE")) {
+        if (!unset && strcmp(v, "96")) return false;
+        t.gemm_tile96 = unset ? 0 : 1;
+    } else if (!strcmp(key, "BATCH_CHUNKS")) {
+        t.batch_chunks = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "BATCH_FORM")) {
+        const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : -1;
+        if (f < 0) return false;
+        t.batch_form = f;
+    } else {
+        return false;
+    }
+    return true;
+}
+
+void tuning_from_env() {
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "BATCH_CHUNKS", "BATCH_FORM"};
+    for (const char* k : keys) {
+        char name[64];
+        snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);
+        if (const char* v = getenv(name)) apply_tuning(g_tuning, k, v);
+    }
+}
+}  // namespace
+
+const Tuning& tuning() {
+    std::call_once(g_tuning_once, tuning_from_env);
+    return g_tuning;
+}
+bool tuning_set(const char* key, const char* value) {
+    std::call_once(g_tuning_once, tuning_from_env);
+    return apply_tuning(g_tuning, key, value);
+}
+
+namespace {
 }
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -63,6 +122,12 @@ __global__ void xlane_selftest_kernel(int* mismatch) {
 using namespace aspire;
 
 extern "C" int aspire_abi_version(void) { return ASPIRE_ABI_VERSION; }
+
+extern "C" int aspire_debug_set(const char* key, const char* value) {
+    ASPIRE_REQUIRE(key, ASPIRE_ERR_INVALID_ARG, "null key");
+    ASPIRE_REQUIRE(tuning_set(key, value), ASPIRE_ERR_INVALID_ARG, "unknown diagnostic switch %s=%s", key, value ? value : "");
+    return ASPIRE_OK;
+}
 extern "C" const char* aspire_last_error(void) { return g_err; }
 
 extern "C" int aspire_selftest_xlane(int* out_mismatch_host) {

@@ -18,16 +18,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
+#include "tuning.h"
 #include "score_types.h"
 #include "topk_device.h"
-
-// The buffer-load intrinsic bound by name (see doc_rsrc below).
-typedef int rsrc_t __attribute__((ext_vector_type(4)));
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-__device__ v4f_t raw_buffer_load_v4f32(rsrc_t srsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 namespace aspire {
 namespace {
@@ -36,14 +33,15 @@ constexpr int kWaves = 3;
 constexpr int kBlock = 64 * kWaves;
 constexpr int kMaxT = 4;  // sentence rows per document <= 8 * kMaxT
 
-// LDS carve (floats): red[kWaves][T*T][128] | rednorm[kWaves][T][16] | reddiam[4] | xpose[kWaves][32][68]
+// LDS carve (floats): red[kWaves][T*T][128] | rednorm[kWaves][T][16] | reddiam[4] | redo_mask (8 B) + pad | xpose[kWaves][32][68]
 constexpr int kXpLd = 68;                 // row stride of the transpose scratch: 64 lanes + 4 (keeps b128 reads
 constexpr int kXpWave = 32 * kXpLd;       // 16 B aligned and spreads the 16-lane read groups over all bank slots)
 template <int T>
 struct Lds {
     static constexpr int kRed = kWaves * T * T * 128;
     static constexpr int kNorm = kWaves * T * 16;
-    static constexpr int kXp = kRed + kNorm + 4;
+    static constexpr int kRedo = kRed + kNorm + 4;   // 64-bit mask of entries to redo (pair_cost1_body): a word no reduction scratch touches
+    static constexpr int kXp = kRedo + 4;
     static constexpr int kTotal = kXp + kWaves * kXpWave;
 };
 
@@ -920,11 +918,12 @@ __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairW
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const bool paired = a.pairing != ASPIRE_PAIR_CROSS;          // one query per candidate (PAIRED, MAPPED)
     const int64_t c_idx = a.cand0 + blockIdx.x;
     const int64_t ncand = a.cand1 - a.cand0;
-    const int64_t q_begin = paired ? c_idx : (int64_t)blockIdx.y * a.q_per_block;
-    const int64_t q_end = paired ? c_idx + 1 : min(a.q.n, q_begin + a.q_per_block);
+    const int64_t q_own = a.pairing == kPairMapped ? (int64_t)a.qmap[c_idx] : c_idx;
+    const int64_t q_begin = paired ? q_own : (int64_t)blockIdx.y * a.q_per_block;
+    const int64_t q_end = paired ? q_own + 1 : min(a.q.n, q_begin + a.q_per_block);
     const bool own_diam = a.diameter == nullptr;
     const int c_len = a.c.len[c_idx];
     const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
@@ -952,18 +951,6 @@ __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairW
 struct RowSet {
     float4 x0[4], x1[4], y[8];
 };
-// Buffer descriptor over one document's rows (wave-uniform by construction: the compiler must be able to prove it).
-// A document is at most 32 rows x 3072 B; the range check is left wide open (rows are clamped by the callers).
-// (The intrinsic is bound by name: this toolchain's __builtin_amdgcn_raw_buffer_load_b128 lowers to a one-dword load.)
-__device__ __forceinline__ rsrc_t doc_rsrc(const float* p) {
-    const uint64_t v = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return rsrc_t{(int)lo, (int)(hi & 0xffffu), 0x7fffffff, 0x00020000};
-}
-__device__ __forceinline__ float4 ld_row(rsrc_t rs, int lane_bytes, int row) {
-    const v4f_t t = raw_buffer_load_v4f32(rs, lane_bytes, row * (kD * 4), 0);
-    return make_float4(t.x, t.y, t.z, t.w);
-}
 #ifdef ASPIRE_PHASE_CLOCK
 // stamps of workgroup 7, wave 1, its second item
 #define K1_STAMP(k)                                                                                         \
@@ -982,49 +969,30 @@ __device__ __forceinline__ float4 ld_row(rsrc_t rs, int lane_bytes, int row) {
 // predicate.  (Only used when ext == 0; padded tensors take the general kernel, which reads the real pad rows.)
 // `item` = (sub-tile, pair): T * T sub-tiles of 8 x 8 entries per pair (1 for documents of <= 8 rows), the pair index
 // fastest.  Sub-tile (ta, tb) takes query rows 8 ta .. and candidate rows 8 tb ...
-// BUF: buffer loads (below); !BUF: plain global loads with per-row vector addresses -- the two-register-set form keeps
-// those: with buffer loads the scheduler spreads it over all 256 registers of its budget (197 with global loads),
-// and a 256-register kernel shares a SIMD with nothing.
-template <bool BUF>
-__device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_t item, uint32_t nq, bool paired, int dofs,
+// Plain global loads with per-row vector addresses (a buffer-descriptor form was measured: the scheduler spreads it
+// over all 256 registers of its budget -- 197 here -- and a 256-register kernel shares a SIMD with nothing).
+__device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_t item, uint32_t nq, int dofs,
                                           int& q_len, int& c_len, uint32_t T) {
     const uint32_t npairs = (uint32_t)(a.cand1 - a.cand0) * nq;
     const uint32_t tile = T == 1 ? 0 : item / npairs;        // pair index fastest: a pair's sub-tiles go to different workgroups
     const uint32_t pair = item - tile * npairs, ta = tile / T, tb = tile - ta * T;
     const uint32_t c_loc = nq == 1 ? pair : pair / nq;
     const int64_t c_idx = a.cand0 + c_loc;
-    const int64_t q_idx = paired ? c_idx : (nq == 1 ? 0 : pair - c_loc * nq);
+    const int64_t q_idx = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx
+                          : a.pairing == kPairMapped      ? (int64_t)a.qmap[c_idx]
+                                                          : (nq == 1 ? 0 : pair - c_loc * nq);
     const int i0 = 8 * ta, j0 = 8 * tb;
-    if constexpr (!BUF) {
-        c_len = a.c.len[c_idx];
-        q_len = a.q.len[q_idx];
-        const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
-        const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r.x0[i] = ld4(qdoc + (size_t)min(i0 + i, q_len - 1) * kD);
-            r.x1[i] = ld4(qdoc + (size_t)min(i0 + 4 + i, q_len - 1) * kD);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j0 + j, c_len - 1) * kD);
-        return;
-    }
-    c_len = __builtin_amdgcn_readfirstlane(a.c.len[c_idx]);
-    q_len = __builtin_amdgcn_readfirstlane(a.q.len[q_idx]);
-    // Row addresses are wave-uniform: one buffer descriptor per document (built from readfirstlane'd scalars), the
-    // row's byte offset in the scalar offset operand and the lane's 16 B slice in the 32-bit vector offset -- no
-    // per-row 64-bit vector multiply-add (16 quarter-rate VALU ops per item on a kernel whose overlapped throughput
-    // is VALU-bound) and no address register pairs held while the loads are in flight.
-    const auto crs = doc_rsrc(a.c.rows + (size_t)a.c.start[c_idx] * kD);
-    const auto qrs = doc_rsrc(a.q.rows + (size_t)a.q.start[q_idx] * kD);
-    const int lofs = dofs * 4;
+    c_len = a.c.len[c_idx];
+    q_len = a.q.len[q_idx];
+    const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
+    const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        r.x0[i] = ld_row(qrs, lofs, min(i0 + i, q_len - 1));
-        r.x1[i] = ld_row(qrs, lofs, min(i0 + 4 + i, q_len - 1));
+        r.x0[i] = ld4(qdoc + (size_t)min(i0 + i, q_len - 1) * kD);
+        r.x1[i] = ld4(qdoc + (size_t)min(i0 + 4 + i, q_len - 1) * kD);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.y[j] = ld_row(crs, lofs, min(j0 + j, c_len - 1));
+    for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j0 + j, c_len - 1) * kD);
 }
 
 __device__ __forceinline__ float box_partial(const RowSet& r) {
@@ -1044,28 +1012,27 @@ __device__ __forceinline__ float box_partial(const RowSet& r) {
     return fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
 }
 
-// PREFETCH: the persistent form (next item's rows in a second register set).  !PREFETCH: one register set, for
-// launches with (about) one item per workgroup -- half the registers, so twice the workgroups are resident and every
-// pair's loads are in flight from the start.
+// The persistent, software-pipelined form: the next item's rows are in flight in a second register set while the
+// current item is accumulated, reduced and written.
 // SUB: documents of more than 8 rows, (sub-tile, pair) items; !SUB keeps the one-tile case free of the sub-tile
-// arithmetic.  Register budgets decide how these kernels share a SIMD with OTHER queries' launches (bench.py overlaps
-// many): the one-register-set form sits at 128 registers per lane (three of its waves + two Sinkhorn waves per SIMD);
-// at 256 nothing fits beside two resident waves and overlapped throughput falls from ~110 to ~70 M alignments/s with
-// every kernel's own time unchanged.  tests/test_abi_cpu.py pins the budgets.
-// (A fused form -- wave 0 going straight on to the pair's Sinkhorn solve, entries through LDS -- was built and dropped:
-// all workgroups of a <= 1024-pair launch are resident at once and move through the two phases in lock step, so a
-// lone call gains nothing (45 vs 48.5 M pairs/s), and the union of the two phases' live scalars spills, which costs
-// the overlapped case its co-residency: 86 vs 112 M alignments/s.)
-template <bool PREFETCH, bool SUB>
+// arithmetic.  Register budgets decide how these kernels share a SIMD with OTHER launches (independent calls on other
+// streams): at 197 registers two of these waves leave room for two 52-register Sinkhorn waves; at 256 nothing fits beside
+// them and overlapped throughput fell from ~110 to ~70 M alignments/s with every kernel's own time unchanged.
+// tests/test_abi_cpu.py pins the budgets.  (Superseded forms -- one register set with buffer loads, a matrix-core
+// form, cost + solve fused per workgroup -- are described in DESIGN.md "Tried and dropped".)
+template <bool SUB>
 __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs<1>& ws, uint32_t T_rt, float* lds) {
     const uint32_t T = SUB ? T_rt : 1u;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dofs = wave * 256 + lane * 4;
-    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const bool paired = a.pairing != ASPIRE_PAIR_CROSS;          // one query per candidate (PAIRED, MAPPED)
     // 32-bit item arithmetic: a chunk holds at most workspace / 516 B < 2^31 pairs, and 64-bit division costs
     // hundreds of cycles per item on this hardware.
     const uint32_t nq = paired ? 1u : (uint32_t)a.q.n;
+    auto query_of = [&](int64_t c_idx, uint32_t q_loc) -> int64_t {
+        return a.pairing == ASPIRE_PAIR_PAIRED ? c_idx : a.pairing == kPairMapped ? (int64_t)a.qmap[c_idx] : (int64_t)q_loc;
+    };
     const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
     const uint32_t tt = T * T, ld_e = 8 * T, n_ent = 64 * tt;      // sub-tiles per pair, row stride and entries of a pair's slot
     const uint32_t n_items = ncand * nq * tt;
@@ -1112,7 +1079,7 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
             } else {
                 // long documents: the bounding box spans ALL rows of both documents; the pair's first sub-tile walks them
                 const int64_t c_idx = a.cand0 + c_loc;
-                const int64_t q_idx = paired ? c_idx : (int64_t)q_loc;
+                const int64_t q_idx = query_of(c_idx, q_loc);
                 const float* qd = a.q.rows + (size_t)a.q.start[q_idx] * kD + dofs;
                 const float* cd = a.c.rows + (size_t)a.c.start[c_idx] * kD + dofs;
                 float4 mn = ld4(qd), mx = mn;
@@ -1140,7 +1107,10 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
         __syncthreads();
         K1_STAMP(4);
         const int64_t slot = paired ? (int64_t)c_loc : (int64_t)q_loc * ncand + c_loc;
-        unsigned long long* redo_mask = reinterpret_cast<unsigned long long*>(lds + Lds<1>::kXp);   // wave 0's scratch, idle now
+        // A dedicated word: wave 0 rewrites it only after the NEXT item's first barrier, which every wave reaches only
+        // after it has read this item's mask (it used to live in wave 0's reduction scratch, which wave 0 rewrites
+        // at once when a workgroup walks several items).
+        unsigned long long* redo_mask = reinterpret_cast<unsigned long long*>(lds + Lds<1>::kRedo);
         if (wave == 0) {
             const int li = lane >> 3, lj = lane & 7;
             float gsum = 0.f, xx = 0.f, yy = 0.f;
@@ -1174,7 +1144,7 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
                 // 16 lanes (one DPP row) per flagged entry, 48 coordinates per lane, twelve entries at a time over
                 // the three waves, no barriers: with real sentence vectors a few entries per pair can be this close
                 const int64_t c_idx = a.cand0 + c_loc;
-                const int64_t q_idx = paired ? c_idx : (int64_t)q_loc;
+                const int64_t q_idx = query_of(c_idx, q_loc);
                 const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
                 const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
                 const int n_flag = __builtin_popcountll(todo), l16 = lane & 15;
@@ -1207,35 +1177,25 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
         }
         K1_STAMP(5);
     };
-    if constexpr (!PREFETCH) {
-        for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-            RowSet r1;
-            int q1 = 0, c1 = 0;
-            load_item<true>(r1, a, item, nq, paired, dofs, q1, c1, T);
-            process(r1, q1, c1, item);
-        }
-        return;
-    }
     RowSet ra, rb;
     int qa = 0, ca = 0, qb = 0, cb = 0;
     const uint32_t stride = gridDim.x;
     uint32_t item = blockIdx.x;
-    if (item < n_items) load_item<false>(ra, a, item, nq, paired, dofs, qa, ca, T);
+    if (item < n_items) load_item(ra, a, item, nq, dofs, qa, ca, T);
     while (item < n_items) {
         const uint32_t n1 = item + stride;
-        if (n1 < n_items) load_item<false>(rb, a, n1, nq, paired, dofs, qb, cb, T);     // in flight under this item's arithmetic
+        if (n1 < n_items) load_item(rb, a, n1, nq, dofs, qb, cb, T);     // in flight under this item's arithmetic
         process(ra, qa, ca, item);
         if (n1 >= n_items) break;
         const uint32_t n2 = n1 + stride;
-        if (n2 < n_items) load_item<false>(ra, a, n2, nq, paired, dofs, qa, ca, T);
+        if (n2 < n_items) load_item(ra, a, n2, nq, dofs, qa, ca, T);
         process(rb, qb, cb, n1);
         item = n2;
     }
 }
-template <bool PREFETCH>
-__global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
+__global__ void __launch_bounds__(kBlock, 2) pair_cost1_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    pair_cost1_body<PREFETCH, false>(a, ws, T_rt, lds);
+    pair_cost1_body<false>(a, ws, T_rt, lds);
 }
 // The sub-tile form, capped at 216 registers (amdgpu_num_vgpr counts HALF registers on gfx950: 108 -> 216; uncapped it
 // takes 256 and no other launch's waves share a SIMD with it).
@@ -1245,177 +1205,7 @@ __global__ void __launch_bounds__(kBlock, PREFETCH ? 2 : 3) pair_cost1_kernel(Sc
 __global__ void __launch_bounds__(kBlock, 2) __attribute__((amdgpu_num_vgpr(SUB_CAP)))
 pair_cost1_sub_kernel(ScoreArgs a, PairWs<1> ws, uint32_t T_rt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    pair_cost1_body<true, true>(a, ws, T_rt, lds);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Kernel 1, matrix-core form for small single-tile pools (T == 1, CSR inputs, all-pairs).
-//
-// The VALU forms above spend ~1800 vector instructions per pair (768 multiply-adds per wave-slice plus the 64-lane
-// reduction of their 64 partial sums, norms, bounding box), and with many queries' launches overlapped the chip is
-// VALU-issue bound.  Here x.y runs on v_mfma_f32_16x16x4_f32 (exact fp32 multiply-adds; the matrix pipe is idle
-// otherwise): a workgroup takes TWO candidates (16 rows = the M side) against the query's 8 rows (N side, columns
-// 8-15 repeat them), its four waves a quarter of the 768 coordinates each.  Lane (r, g) = (l & 15, l >> 4) loads row
-// r's coordinates 16 t + 4 g .. + 3 of its quarter as float4s; component c of chunk t is one K = 4 step for BOTH
-// operands (the K index only has to agree between A and B, and both use the same lane -> coordinate map), so the
-// accumulators are finished sums over the quarter and nothing is reduced across lanes.  Norms: 48 multiply-adds per
-// lane on the same registers + two swaps over g.  The pair's bounding box (own epsilon schedule) wants all rows of a
-// coordinate in one lane: a second, row-per-register view of the same bytes (L1 / L2 hits) feeds v_min3 / v_max3.
-// Measured (bench.py, 1 x 1000 x 8): 829 vector instructions per pair instead of 1825, but 9.8 us per launch against
-// 9.3 and 100 M alignments/s overlapped against 124 -- the second view's load round trip and the 16-row gathers
-// (every load instruction touches 16 half-used cache lines) cost more than the issue slots saved.  Kept behind
-// ASPIRE_HIP_COST1=mfma (parity-tested) as the starting point for few-query pools whose rows fill the N side.
-// ---------------------------------------------------------------------------------------------
-typedef float mfma4_t __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256, 2) pair_cost_mfma1_kernel(ScoreArgs a, PairWs<1> ws) {
-    __shared__ float g_part[4][16][17];      // [wave][candidate row 0..15][query row 0..15 (+1 pad)]
-    __shared__ float yn_s[4][16], xn_s[4][8], box_s[4][2];
-    __shared__ unsigned long long redo_s[2];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, g = lane >> 4, which = r >> 3, rr = r & 7;
-    const uint32_t nq = (uint32_t)a.q.n, ncand = (uint32_t)(a.cand1 - a.cand0);
-    const uint32_t item = blockIdx.x;                    // grid = nq * ceil(ncand / 2)
-    const uint32_t cp = nq == 1 ? item : item / nq, q_loc = nq == 1 ? 0u : item - cp * nq;
-    const uint32_t cl0 = 2 * cp, cl1 = min(2 * cp + 1, ncand - 1);       // odd tail: the last candidate twice
-    const int64_t c_idx0 = a.cand0 + cl0, c_idx1 = a.cand0 + cl1, q_idx = (int64_t)q_loc;
-    const int c_len0 = a.c.len[c_idx0], c_len1 = a.c.len[c_idx1], q_len = a.q.len[q_idx];
-    const float* cdoc0 = a.c.rows + (size_t)a.c.start[c_idx0] * kD;
-    const float* cdoc1 = a.c.rows + (size_t)a.c.start[c_idx1] * kD;
-    const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
-    const bool own_diam = a.diameter == nullptr;
-    const int dbase = wave * 192;
-
-    // ---- operands in the matrix layout (rows beyond a document's length repeat its last row: masked downstream)
-    const float* yptr = (which ? cdoc1 : cdoc0) + (size_t)min(rr, (which ? c_len1 : c_len0) - 1) * kD + dbase + 4 * g;
-    const float* xptr = qdoc + (size_t)min(rr, q_len - 1) * kD + dbase + 4 * g;
-    float4 xb[12], ya[12];
-#pragma unroll
-    for (int t = 0; t < 12; ++t) xb[t] = ld4(xptr + 16 * t);     // the query first: L2 resident, lands early
-#pragma unroll
-    for (int t = 0; t < 12; ++t) ya[t] = ld4(yptr + 16 * t);
-    __builtin_amdgcn_sched_barrier(0);       // all 24 loads in flight before the first multiply (left alone the scheduler
-                                             // issues them five at a time between the MFMAs: several HBM round trips)
-    mfma4_t acc = {0.f, 0.f, 0.f, 0.f};
-    float yn0 = 0.f, yn1 = 0.f, xn0 = 0.f, xn1 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].x, xb[t].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].y, xb[t].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].z, xb[t].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t].w, xb[t].w, acc, 0, 0, 0);
-        yn0 = fmaf(ya[t].y, ya[t].y, fmaf(ya[t].x, ya[t].x, yn0));
-        yn1 = fmaf(ya[t].w, ya[t].w, fmaf(ya[t].z, ya[t].z, yn1));
-        xn0 = fmaf(xb[t].y, xb[t].y, fmaf(xb[t].x, xb[t].x, xn0));
-        xn1 = fmaf(xb[t].w, xb[t].w, fmaf(xb[t].z, xb[t].z, xn1));
-    }
-    float yn = yn0 + yn1, xn = xn0 + xn1;
-    yn = swap_add<16>(yn, yn);      // over g (lane bits 4, 5)
-    xn = swap_add<16>(xn, xn);
-    yn = swap_add<32>(yn, yn);
-    xn = swap_add<32>(xn, xn);
-    if (g == 0) {
-        yn_s[wave][r] = yn;
-        if (r < 8) xn_s[wave][r] = xn;
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) g_part[wave][4 * g + v][r] = acc[v];    // D[i][j]: lane holds rows 4 g + v of column r
-
-    // ---- bounding boxes of (query + candidate) per coordinate: row-per-register view, 48 lanes x 4 coordinates
-    if (own_diam) {
-        float s0 = 0.f, s1 = 0.f;
-        if (lane < 48) {
-            const int d = dbase + 4 * lane;
-            auto box8 = [&](const float* doc, int len, float4& mn, float4& mx, bool init) {
-                float4 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = ld4(doc + (size_t)min(k, len - 1) * kD + d);
-                if (init) mn = mx = v[0];
-#pragma unroll
-                for (int k = init ? 1 : 0; k < 8; ++k) {
-                    mn.x = fminf(mn.x, v[k].x); mn.y = fminf(mn.y, v[k].y); mn.z = fminf(mn.z, v[k].z); mn.w = fminf(mn.w, v[k].w);
-                    mx.x = fmaxf(mx.x, v[k].x); mx.y = fmaxf(mx.y, v[k].y); mx.z = fmaxf(mx.z, v[k].z); mx.w = fmaxf(mx.w, v[k].w);
-                }
-            };
-            float4 qmn, qmx;
-            box8(qdoc, q_len, qmn, qmx, true);
-            auto span2 = [&](const float* doc, int len) {
-                float4 mn = qmn, mx = qmx;
-                box8(doc, len, mn, mx, false);
-                const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
-                return fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-            };
-            s0 = span2(cdoc0, c_len0);
-            s1 = span2(cdoc1, c_len1);
-        }
-        s0 = wave_sum(s0);
-        s1 = wave_sum(s1);
-        if (lane == 0) {
-            box_s[wave][0] = s0;
-            box_s[wave][1] = s1;
-        }
-    }
-    __syncthreads();
-
-    // ---- finish: waves 0 and 1 take a candidate each, lane e = 8 i + j as in pair_cost1_kernel ----
-    if (wave < 2) {
-        const int cand = wave, li = lane >> 3, lj = lane & 7;
-        const int c_len = cand ? c_len1 : c_len0;
-        float gsum = 0.f, xx = 0.f, yy = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            gsum += g_part[w][8 * cand + lj][li];
-            xx += xn_s[w][li];
-            yy += yn_s[w][8 * cand + lj];
-        }
-        const float sq = fmaf(-2.f, gsum, xx) + yy;
-        const float ns = xx + yy;
-        const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
-        const bool redo = !mm && li < q_len && lj < c_len && sq < 1e-4f * ns * ns;
-        const int64_t slot = (int64_t)q_loc * ncand + (cand ? cl1 : cl0);
-        const int64_t o = slot * 64 + lane;
-        ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
-        if (!redo) ws.neg[o] = -sqrtf(fmaxf(sq, 0.f));
-        const unsigned long long m = __ballot(redo);
-        if (lane == 0) {
-            redo_s[cand] = m;
-            if (own_diam) ws.diam2[slot] = (box_s[0][cand] + box_s[1][cand]) + (box_s[2][cand] + box_s[3][cand]);
-        }
-    }
-    __syncthreads();
-    // ---- entries whose expansion cancelled: torch.cdist's direct formula, 16 lanes per entry (see pair_cost1_kernel)
-#pragma unroll 1
-    for (int cand = 0; cand < 2; ++cand) {
-        const unsigned long long todo = redo_s[cand];        // workgroup-uniform
-        if (__builtin_expect(todo == 0, 1)) continue;
-        const float* cdoc = cand ? cdoc1 : cdoc0;
-        const int64_t slot = (int64_t)q_loc * ncand + (cand ? cl1 : cl0);
-        const int n_flag = __builtin_popcountll(todo), l16 = lane & 15;
-        for (int base = wave * 4; base < n_flag; base += 16) {
-            const int my = base + (lane >> 4);
-            const bool live = my < n_flag;
-            unsigned long long m = todo;
-            for (int t = 0; t < (live ? my : 0); ++t) m &= m - 1;      // drop the first `my` set bits
-            const int e = __builtin_ctzll(m);
-            const float* xr = qdoc + (size_t)(e >> 3) * kD + 4 * l16;
-            const float* yr = cdoc + (size_t)(e & 7) * kD + 4 * l16;
-            float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-            for (int c = 0; c < 12; c += 2) {
-                const float4 u0 = ld4(xr + 64 * c), v0 = ld4(yr + 64 * c), u1 = ld4(xr + 64 * c + 64), v1 = ld4(yr + 64 * c + 64);
-                const float a0 = u0.x - v0.x, a1 = u0.y - v0.y, a2 = u0.z - v0.z, a3 = u0.w - v0.w;
-                const float b0 = u1.x - v1.x, b1 = u1.y - v1.y, b2 = u1.z - v1.z, b3 = u1.w - v1.w;
-                p0 = fmaf(a3, a3, fmaf(a2, a2, fmaf(a1, a1, fmaf(a0, a0, p0))));
-                p1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, p1))));
-            }
-            float part = p0 + p1;
-            part += lane_xor<1>(part);
-            part += lane_xor<2>(part);
-            part += lane_xor<4>(part);
-            part += lane_xor<8>(part);
-            if (live && l16 == 0) ws.neg[slot * 64 + e] = -sqrtf(part);
-        }
-    }
+    pair_cost1_body<true>(a, ws, T_rt, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1477,12 +1267,14 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
     float* lds = lds_all + wave * C::kLdsFloats;
     float* nscr = lds + C::kRows * C::kRowStride;       // [16][kNormLd]: norm partials, then (DS = 4) accumulators
     const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const bool mapped = a.pairing == kPairMapped;                // batched jobs: items are the groups of four of jobs [job0, job1)
     const bool own_diam = a.diameter == nullptr;
-    const uint32_t nq = paired ? 1u : (uint32_t)a.q.n;
+    const uint32_t nq = (paired || mapped) ? 1u : (uint32_t)a.q.n;
     const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
     const uint32_t ngroups = (ncand + C::kNC - 1) / C::kNC;
-    const uint32_t n_items = ngroups * nq;                       // item = (candidate group, query), group-major
-    const uint32_t first = DS == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    const uint32_t item_lo = mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
+    const uint32_t n_items = mapped ? (uint32_t)a.grp_off[a.job1] : ngroups * nq;   // item = (candidate group, query), group-major
+    const uint32_t first = item_lo + (DS == 1 ? blockIdx.x * 4 + wave : blockIdx.x);
     const uint32_t stride = DS == 1 ? gridDim.x * 4 : gridDim.x;
 
     // lane roles ------------------------------------------------------------------------------------------
@@ -1497,16 +1289,22 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
 
     for (uint32_t item = first; item < n_items; item += stride) {
         const uint32_t cg = nq == 1 ? item : item / nq;
-        const uint32_t q_loc = nq == 1 ? 0 : item - cg * nq;
-        const uint32_t c_loc0 = cg * C::kNC;                                   // first candidate of the group
-        const uint32_t my_c_loc = min(c_loc0 + (R == 1 ? 0u : (uint32_t)p), ncand - 1);   // tail groups: clamp (duplicate work, not stored)
-        const bool my_c_real = c_loc0 + (R == 1 ? 0u : (uint32_t)p) < ncand;
+        uint32_t q_loc = nq == 1 ? 0 : item - cg * nq;
+        uint32_t c_loc0 = cg * C::kNC;                                         // first candidate of the group
+        uint32_t c_end = ncand;                                                // candidates of the group stop here
+        if (mapped) {
+            q_loc = (uint32_t)a.grp_job[item];
+            c_loc0 = (uint32_t)a.job_off[q_loc] + (item - (uint32_t)a.grp_off[q_loc]) * C::kNC;
+            c_end = (uint32_t)a.job_off[q_loc + 1];
+        }
+        const uint32_t my_c_loc = min(c_loc0 + (R == 1 ? 0u : (uint32_t)p), c_end - 1);   // tail groups: clamp (duplicate work, not stored)
+        const bool my_c_real = c_loc0 + (R == 1 ? 0u : (uint32_t)p) < c_end;
         const int64_t c_idx = a.cand0 + my_c_loc;
         const int64_t q_idx = paired ? c_idx : (int64_t)q_loc;
         const int c_len = a.c.len[c_idx], q_len = a.q.len[q_idx];
         const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
         // staging source of this lane (pad rows clamp to the last valid row: masked downstream, box-neutral)
-        const int64_t sy_idx = a.cand0 + (R == 1 ? my_c_loc : min(c_loc0 + (uint32_t)sg, ncand - 1));
+        const int64_t sy_idx = a.cand0 + (R == 1 ? my_c_loc : min(c_loc0 + (uint32_t)sg, c_end - 1));
         const int sy_len = a.c.len[sy_idx];
         const float* sy_doc = a.c.rows + (size_t)a.c.start[sy_idx] * kD;
 
@@ -1674,7 +1472,7 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
         // Only x.y was accumulated: -cdist comes from the same expansion as the cost, and the entries where it cancels
         // (torch.cdist's direct formula differs there) are redone below.  See pair_cost1_kernel.
         const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
-        const int64_t slot = paired ? (int64_t)my_c_loc : (int64_t)q_loc * ncand + my_c_loc;
+        const int64_t slot = (paired || mapped) ? (int64_t)my_c_loc : (int64_t)q_loc * ncand + my_c_loc;
         bool redo[R][R];
 #pragma unroll
         for (int x = 0; x < R; ++x)
@@ -1758,230 +1556,18 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+    int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+    if (a.pairing == kPairMapped) {              // the slots of jobs [job0, job1); the grid is sized from an upper bound
+        slot += a.job_off[a.job0];
+        n_slots = a.job_off[a.job1];
+    }
     if (slot < n_slots) {
-        const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-        const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
-        const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
-        const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
-        const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
-        const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
+        const PairIdx ix = pair_of_slot(a, slot);
         PairState<T> st;
         load_pair<T>(st, ws, slot, lane);
-        float diam;
-        if (a.diameter == nullptr) {
-            diam = sqrtf(ws.diam2[slot]);
-        } else {
-            diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
-        }
-        sinkhorn_pair<T>(a, st, a.q.len[q_idx], a.c.len[c_idx], diam, p, lane);
+        const float diam = a.diameter == nullptr ? sqrtf(ws.diam2[slot]) : group_diameter_of(a, ix);
+        sinkhorn_pair<T>(a, st, a.q.len[ix.q_idx], a.c.len[ix.c_idx], diam, ix.p, lane);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Kernel 2, packed form for <= 8 x 8 problems: FOUR Sinkhorn solves per wave.  A pair lives in one DPP row of 16
-// lanes, lane (li, lj) = ((l >> 2) & 3, l & 3) owning the 2 x 2 entries (2 li + a, 2 lj + b).  Both reductions of
-// the update then stay inside a DPP row -- over j: in-register + quad_perm xor 1, xor 2; over i: in-register +
-// row_ror:4, row_ror:8 -- so the 22-cycle v_permlane swaps of the one-pair-per-wave layout disappear and a step
-// costs ~70 issue cycles per pair instead of ~145 (tools: build/dbg/thr.hip for the per-op prices).
-// Every pair follows its own epsilon schedule (own diameter): lane k of a pair evaluates steps k, k+16, ... in
-// float64 and parks the per-step constants {log2(e)/eps, eps*ln2} in an LDS table that its 16 lanes read back
-// (one broadcast ds_read_b64 per step, fetched a step ahead).
-// ---------------------------------------------------------------------------------------------
-constexpr int kMaxSteps4 = 160;   // eps steps per pair the table holds (diam/blur up to ~1e7 at scaling 0.9)
-
-__device__ __forceinline__ float row16_sum_i(float v) {   // all-reduce over lane bits 2,3 (the 4 values of li)
-    v += dpp_mov<0x124>(v, v);                             // row_ror:4
-    return v + dpp_mov<0x128>(v, v);                       // row_ror:8
-}
-__device__ __forceinline__ float row16_max_i(float v) {
-    v = fmaxf(v, dpp_mov<0x124>(v, v));
-    return fmaxf(v, dpp_mov<0x128>(v, v));
-}
-__device__ __forceinline__ float quad_sum_j(float v) {     // all-reduce over lane bits 0,1 (the 4 values of lj)
-    v += lane_xor<1>(v);
-    return v + lane_xor<2>(v);
-}
-__device__ __forceinline__ float quad_max_j(float v) {
-    v = fmaxf(v, lane_xor<1>(v));
-    return fmaxf(v, lane_xor<2>(v));
-}
-
-__global__ void __launch_bounds__(256) sinkhorn4_kernel(ScoreArgs a, PairWs<1> ws, int64_t n_slots) {
-    __shared__ float2 sched[4][4][kMaxSteps4];               // [wave][pair][step] = {r2, eln2}
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pp = lane >> 4, l16 = lane & 15, li = (lane >> 2) & 3, lj = lane & 3;
-    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
-    if (slot0 >= n_slots) return;
-    const bool real = slot0 + pp < n_slots;                  // tail wave: surplus groups redo the last pair, store nothing
-    const int64_t slot = real ? slot0 + pp : n_slots - 1;
-    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
-    const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
-    const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
-    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
-    const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
-    const int q_len = a.q.len[q_idx], c_len = a.c.len[c_idx];
-
-    float cost[2][2], neg[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const float2 cc = *reinterpret_cast<const float2*>(ws.cost + slot * 64 + (2 * li + x) * 8 + 2 * lj);
-        const float2 nn = *reinterpret_cast<const float2*>(ws.neg + slot * 64 + (2 * li + x) * 8 + 2 * lj);
-        cost[x][0] = cc.x; cost[x][1] = cc.y;
-        neg[x][0] = nn.x; neg[x][1] = nn.y;
-    }
-    float diam;
-    if (a.diameter == nullptr) {
-        diam = sqrtf(ws.diam2[slot]);
-    } else {
-        diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
-    }
-    bool rv[2], cv[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        rv[t] = 2 * li + t < q_len;
-        cv[t] = 2 * lj + t < c_len;
-    }
-    // ---- marginals (pair_distances.py:57-60) -------------------------------------------------------------
-    const float temp = (float)a.temp;
-    float la2[2], lb2[2], wa[2], wb[2];
-    {
-        float qm[2], cm[2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            float m = fmaxf((rv[x] && cv[0]) ? neg[x][0] : kNegBig, (rv[x] && cv[1]) ? neg[x][1] : kNegBig);
-            qm[x] = quad_max_j(m) / temp;
-        }
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            float m = fmaxf((rv[0] && cv[y]) ? neg[0][y] : kNegBig, (rv[1] && cv[y]) ? neg[1][y] : kNegBig);
-            cm[y] = row16_max_i(m) / temp;
-        }
-        const float mq = row16_max_i(fmaxf(rv[0] ? qm[0] : kNegBig, rv[1] ? qm[1] : kNegBig));
-        const float mc = quad_max_j(fmaxf(cv[0] ? cm[0] : kNegBig, cv[1] ? cm[1] : kNegBig));
-        const float sq = (rv[0] ? fast_exp(qm[0] - mq) : 0.f) + (rv[1] ? fast_exp(qm[1] - mq) : 0.f);
-        const float sc = (cv[0] ? fast_exp(cm[0] - mc) : 0.f) + (cv[1] ? fast_exp(cm[1] - mc) : 0.f);
-        const float lsq = fast_log(row16_sum_i(sq)), lsc = fast_log(quad_sum_j(sc));
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;
-            wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;
-            la2[t] = (wa[t] > 0.f ? fast_log(wa[t]) : -100000.f) * kLog2e;   // geomloss log_weights, in base-2 units
-            lb2[t] = (wb[t] > 0.f ? fast_log(wb[t]) : -100000.f) * kLog2e;
-        }
-    }
-    // ---- this pair's epsilon schedule -> LDS ---------------------------------------------------------------
-    float ldf;
-    int n_mid = schedule_mid_steps(a, diam, ldf);
-    const float lscf = a.log2_scaling;
-    const bool overflow = n_mid + 3 > kMaxSteps4;             // schedule longer than the table: poison the score
-    if (overflow) n_mid = kMaxSteps4 - 3;
-    // table rows: 0 = diam (the first loop step), 1 .. n_mid = the annealed values, n_mid+1, n_mid+2 = blur
-    float2* tab = sched[wave][pp];
-    // The annealed values exp(ld + k*lsc) are formed in fp32 here (5 per lane; in float64 they cost more than the
-    // whole annealing loop): a relative 1e-6 on an intermediate temperature moves the final potentials by < 1e-7.
-    for (int k = l16; k < n_mid + 3; k += 16) {
-        float e;
-        if (k == 0) e = diam;
-        else if (k <= n_mid) e = __builtin_amdgcn_exp2f(fmaf((float)(k - 1), lscf, ldf));
-        else e = (float)a.blur;
-        tab[k] = make_float2(kLog2e * rcp_refined(e), e * kLn2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int n_steps = n_mid + 3;                            // the last one is the un-averaged extrapolation
-    int max_steps = n_steps;
-    max_steps = max(max_steps, __shfl_xor(max_steps, 16));
-    max_steps = max(max_steps, __shfl_xor(max_steps, 32));
-
-    // ---- initialisation at eps = diam: softmin of the bare log-weights.  No max shift is needed: the largest
-    // weight of a probability vector over <= 8 atoms is >= 1/8 and C/diam <= ~1, so the sum stays in range. ----
-    float f[2], g[2];
-    {
-        const float2 e0 = tab[0];
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            float sum = 0.f;
-#pragma unroll
-            for (int x = 0; x < 2; ++x) sum += __builtin_amdgcn_exp2f(rv[x] ? fmaf(-cost[x][y], e0.x, la2[x]) : kNegBig);
-            g[y] = -e0.y * __builtin_amdgcn_logf(row16_sum_i(sum));
-        }
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            float sum = 0.f;
-#pragma unroll
-            for (int y = 0; y < 2; ++y) sum += __builtin_amdgcn_exp2f(cv[y] ? fmaf(-cost[x][y], e0.x, lb2[y]) : kNegBig);
-            f[x] = -e0.y * __builtin_amdgcn_logf(quad_sum_j(sum));
-        }
-    }
-    // ---- the annealing loop (see step2 of sinkhorn_pair for the derivation of the shifted base-2 update) ----
-    float2 ek = tab[0];
-    for (int k = 0; k < max_steps; ++k) {
-        const float2 enext = tab[min(k + 1, n_steps - 1)];   // fetched a step ahead
-        const bool active = k < n_steps;
-        const bool averaged = k < n_steps - 1;
-        const float r2 = ek.x, eln2 = ek.y;
-        float f2[2], g2[2], av[2], bv[2], ft[2], gt[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f2[t] = f[t] * r2;
-            g2[t] = g[t] * r2;
-            av[t] = la2[t] + f2[t];
-            bv[t] = lb2[t] + g2[t];
-        }
-        float sc_[2] = {0.f, 0.f}, sr_[2] = {0.f, 0.f};
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const float uc = fmaf(-cost[x][y], r2, av[x]) + g2[y];
-                const float ur = fmaf(-cost[x][y], r2, bv[y]) + f2[x];
-                sc_[y] += __builtin_amdgcn_exp2f(rv[x] ? uc : kNegBig);
-                sr_[x] += __builtin_amdgcn_exp2f(cv[y] ? ur : kNegBig);
-            }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            gt[t] = eln2 * (g2[t] - __builtin_amdgcn_logf(row16_sum_i(sc_[t])));
-            ft[t] = eln2 * (f2[t] - __builtin_amdgcn_logf(quad_sum_j(sr_[t])));
-            const float gn = averaged ? 0.5f * (g[t] + gt[t]) : gt[t];
-            const float fn = averaged ? 0.5f * (f[t] + ft[t]) : ft[t];
-            g[t] = active ? gn : g[t];
-            f[t] = active ? fn : f[t];
-        }
-        ek = enext;
-    }
-    // ---- outputs ---------------------------------------------------------------------------------------------
-    float score;
-    if (a.want != ASPIRE_OT_PLAN_SIM) {
-        float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
-            acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
-        }
-        score = row16_sum_i(quad_sum_j(acc));
-        if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
-    } else {
-        const float eb = (float)a.blur, rb = rcp_refined(eb);
-        float acc = 0.f;
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const bool valid = rv[x] && cv[y];
-                const float negm = valid ? neg[x][y] : 0.f;
-                const float outer = valid ? f[x] + g[y] : 0.f;
-                acc += fast_exp(div_r(outer + negm, eb, rb)) * (wa[x] * wb[y]) * negm;
-            }
-        score = row16_sum_i(quad_sum_j(acc));
-    }
-    // the shifted log-sum-exp cannot leave fp32 range on sane inputs; if it did, or the schedule outgrew the
-    // table, or a document is longer than the tile, the pair is poisoned rather than silently wrong.
-    if (!(fabsf(score) < 1e30f) || overflow || q_len > 8 || c_len > 8) score = __builtin_nanf("");
-    if (real && l16 == 0) a.scores[p] = score;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2039,17 +1625,17 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pp = lane / NL, lp = lane % NL, li = lp / LD, lj = lp % LD;
-    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * PPW;
+    int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * PPW;
+    if (a.pairing == kPairMapped) {              // the slots of jobs [job0, job1); the grid is sized from an upper bound
+        slot0 += a.job_off[a.job0];
+        n_slots = a.job_off[a.job1];
+    }
     if (slot0 >= n_slots) return;
     const bool real = slot0 + pp < n_slots;                  // tail wave: surplus groups redo the last pair, store nothing
     const int64_t slot = real ? slot0 + pp : n_slots - 1;
-    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
-    const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
-    const int64_t q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
-    const int64_t c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
-    const int64_t p = paired ? c_idx : q_idx * a.c.n + c_idx;
-    const int q_len = a.q.len[q_idx], c_len = a.c.len[c_idx];
+    const PairIdx ix = pair_of_slot(a, slot);
+    const int64_t p = ix.p;
+    const int q_len = a.q.len[ix.q_idx], c_len = a.c.len[ix.c_idx];
 
     float cost[R][R];
     bool rv[R], cv[R];
@@ -2126,12 +1712,7 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
         }
     }
     load_block(ws.cost, cost);
-    float diam;
-    if (a.diameter == nullptr) {
-        diam = sqrtf(ws.diam2[slot]);
-    } else {
-        diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
-    }
+    const float diam = a.diameter == nullptr ? sqrtf(ws.diam2[slot]) : group_diameter_of(a, ix);
     // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = exp(ld + (k-1) lsc), n_mid+1 = blur, n_mid+2 = blur (final)
     float ldf;
     const int n_mid = schedule_mid_steps(a, diam, ldf);
@@ -2231,20 +1812,15 @@ template <int T>
 __global__ void __launch_bounds__(256) sinkhorn_repair_kernel(ScoreArgs a, PairWs<T> ws, int64_t n_slots) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (a.pairing == kPairMapped) {
+        base += a.job_off[a.job0];
+        n_slots = a.job_off[a.job1];
+    }
     if (base >= n_slots) return;
-    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
-    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
-    auto index_of = [&](int64_t slot, int64_t& q_idx, int64_t& c_idx) {
-        const uint32_t q_loc = paired ? 0u : (uint32_t)slot / ncand;
-        q_idx = paired ? a.cand0 + slot : (int64_t)q_loc;
-        c_idx = paired ? a.cand0 + slot : a.cand0 + ((uint32_t)slot - q_loc * ncand);
-        return paired ? c_idx : q_idx * a.c.n + c_idx;
-    };
     bool bad = false;
     if (base + lane < n_slots) {
-        int64_t qi, ci;
-        const float s = a.scores[index_of(base + lane, qi, ci)];
+        const float s = a.scores[pair_of_slot(a, base + lane).p];
         bad = !(fabsf(s) < 1e30f);
     }
     unsigned long long todo = __ballot(bad);
@@ -2252,30 +1828,26 @@ __global__ void __launch_bounds__(256) sinkhorn_repair_kernel(ScoreArgs a, PairW
         const int k = __builtin_ctzll(todo);
         todo &= todo - 1;
         const int64_t slot = base + k;
-        int64_t q_idx, c_idx;
-        const int64_t p = index_of(slot, q_idx, c_idx);
+        const PairIdx ix = pair_of_slot(a, slot);
         PairState<T> st;
         load_pair<T>(st, ws, slot, lane);
-        float diam;
-        if (a.diameter == nullptr) {
-            diam = sqrtf(ws.diam2[slot]);
-        } else {
-            diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
-        }
-        sinkhorn_pair<T>(a, st, a.q.len[q_idx], a.c.len[c_idx], diam, p, lane);
+        const float diam = a.diameter == nullptr ? sqrtf(ws.diam2[slot]) : group_diameter_of(a, ix);
+        sinkhorn_pair<T>(a, st, a.q.len[ix.q_idx], a.c.len[ix.c_idx], diam, ix.p, lane);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Batch bounding-box diameter (geomloss max_diameter over the call's x and y tensors)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) diameter_kernel(ScoreArgs a, int64_t group, float* out) {
+__global__ void __launch_bounds__(kBlock) diameter_kernel(ScoreArgs a, int64_t group, int64_t ngroups, float* out) {
     __shared__ float part[kWaves];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int dofs = threadIdx.x * 4;
-    const int64_t g = blockIdx.x;
     const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    // CROSS: block = (query, group) folded into grid.x (grid.y stops at 65535 queries)
+    const int64_t qy = paired ? 0 : (int64_t)(blockIdx.x / (uint32_t)ngroups);
+    const int64_t g = paired ? (int64_t)blockIdx.x : (int64_t)blockIdx.x - qy * ngroups;
     const int64_t c_lo = g * group, c_hi = min(a.c.n, c_lo + group);
     float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -2295,7 +1867,7 @@ __global__ void __launch_bounds__(kBlock) diameter_kernel(ScoreArgs a, int64_t g
             add_rows(a.c, k, true);
         }
     } else {
-        add_rows(a.q, blockIdx.y, false);
+        add_rows(a.q, qy, false);
         int lmin = 1 << 30, lmax = 0;
         for (int64_t k = c_lo; k < c_hi; ++k) {
             add_rows(a.c, k, false);
@@ -2313,8 +1885,7 @@ __global__ void __launch_bounds__(kBlock) diameter_kernel(ScoreArgs a, int64_t g
     if (lane == 0) part[wave] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int64_t o = paired ? g : (int64_t)blockIdx.y * gridDim.x + g;
-        out[o] = sqrtf(part[0] + part[1] + part[2]);
+        out[blockIdx.x] = sqrtf(part[0] + part[1] + part[2]);
     }
 }
 
@@ -2433,19 +2004,21 @@ size_t slot_bytes(int max_rows) {
 size_t qbox_bytes(const aspire_repset* q) { return (size_t)q->n * 2 * kD * sizeof(float); }
 constexpr size_t kWsCap = (size_t)1 << 30;  // suggested workspace is capped at 1 GiB; larger jobs run in chunks
 constexpr size_t kWsSlack = 48;             // alignment of the box tables behind the pair slots
+size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
 // workspace bytes one candidate of a chunk needs: its pair slots (+ its bounding box on the matrix-core path)
 size_t per_cand_bytes(const aspire_repset* q, const aspire_repset* c, int pairing) {
-    return slot_bytes(max_rows_of(q, c)) * (pairing == ASPIRE_PAIR_PAIRED ? 1 : (size_t)q->n) +
+    return slot_bytes(max_rows_of(q, c)) * (pairing == ASPIRE_PAIR_CROSS ? (size_t)q->n : 1) +
            (gram_path_wanted(q, c, pairing) ? gram_extra_bytes_per_cand() : 0);
 }
 }  // namespace
 
+// (a multiple of 16 bytes: the rank scratch of aspire_ot_rank_f32 -- 64-bit keys -- sits right behind it)
 extern "C" size_t aspire_ot_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int pairing) {
     if (!q || !c || q->n <= 0 || c->n <= 0) return 0;
     const size_t per_cand = per_cand_bytes(q, c, pairing);
     const size_t full = per_cand * (size_t)c->n;
-    if (full <= kWsCap) return full + qbox_bytes(q) + kWsSlack;
-    return (per_cand > kWsCap ? per_cand : kWsCap / per_cand * per_cand) + qbox_bytes(q) + kWsSlack;
+    if (full <= kWsCap) return align16(full + qbox_bytes(q) + kWsSlack);
+    return align16((per_cand > kWsCap ? per_cand : kWsCap / per_cand * per_cand) + qbox_bytes(q) + kWsSlack);
 }
 
 namespace {
@@ -2457,28 +2030,17 @@ struct RankReq {
     uint64_t* keys;
 };
 
-int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing, const aspire_ot_params* prm,
-           const float* diameter, int64_t diam_group, int want, float* scores, float* out_qdistr, float* out_cdistr,
-           float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes, void* stream, const RankReq& rank) {
-    if (int rc = check_repsets(q, c, D, pairing)) return rc;
-    if (q->n == 0 || c->n == 0) return ASPIRE_OK;   // nothing to score (an empty pool has no buffers either)
-    ASPIRE_REQUIRE(prm && scores, ASPIRE_ERR_INVALID_ARG, "null params/scores");
+int check_ot_params(const aspire_ot_params* prm, int want) {
+    ASPIRE_REQUIRE(prm, ASPIRE_ERR_INVALID_ARG, "null params");
     ASPIRE_REQUIRE(want == ASPIRE_OT_DISTANCE || want == ASPIRE_OT_PLAN_SIM || want == ASPIRE_OT_SIMILARITY, ASPIRE_ERR_INVALID_ARG,
                    "bad want %d", want);
     ASPIRE_REQUIRE(prm->blur > 0 && prm->scaling > 0 && prm->scaling < 1 && prm->sent_sm_temp > 0,
                    ASPIRE_ERR_INVALID_ARG, "need blur > 0, 0 < scaling < 1, temp > 0");
-    const bool extra = out_qdistr || out_cdistr || out_pairsims || out_plan;
-    ASPIRE_REQUIRE(!extra || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
-                   "pair outputs need padded extents (ext > 0)");
-    ASPIRE_REQUIRE(!diameter || diam_group > 0, ASPIRE_ERR_INVALID_ARG, "diam_group must be positive");
-    if (q->n == 0 || c->n == 0) return ASPIRE_OK;
-    const int max_rows = max_rows_of(q, c);
-    const size_t per_cand = per_cand_bytes(q, c, pairing);
-    const bool gram = gram_path_wanted(q, c, pairing);
-    ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + kWsSlack, ASPIRE_ERR_INVALID_ARG,
-                   "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
-                   workspace_bytes, per_cand, aspire_ot_workspace_bytes(q, c, pairing));
-    ScoreArgs a{};
+    return ASPIRE_OK;
+}
+
+void fill_ot_args(ScoreArgs& a, const aspire_repset* q, const aspire_repset* c, int pairing, const aspire_ot_params* prm,
+                  const float* diameter, int64_t diam_group, int want, float* scores) {
     a.q = to_dev(q);
     a.c = to_dev(c);
     a.pairing = pairing;
@@ -2495,6 +2057,129 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
     a.n_groups = diameter ? (c->n + diam_group - 1) / diam_group : 0;
     a.want = want;
     a.scores = scores;
+}
+
+// ---- stage 1 of an otAspire pass: pairwise costs of the chunk [a.cand0, a.cand1) -> workspace slots ---------------------
+// (MAPPED pairing: the whole batch, or with `tile_blocks` > 0 the jobs [a.job0, a.job1) on the throughput kernel.)
+template <int T>
+int launch_cost_stage(const ScoreArgs& a, const aspire_repset* q, const aspire_repset* c, const PairWs<T>& ws, int64_t n_slots,
+                      int qchunks, bool gram, float* qbox, float* cbox, bool first_chunk, hipStream_t stream) {
+    const bool csr = q->ext == 0 && c->ext == 0;
+    if (gram) {
+        // many queries or long documents: Gram tiles on the matrix cores (gram.hip)
+        return launch_pair_gram_ot(a, T, q->max_len, c->max_len, ws.cost, ws.neg, a.diameter ? nullptr : ws.diam2, qbox, cbox, stream);
+    }
+    if (T == 1 && csr) {
+        PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
+        const int64_t ncand = a.cand1 - a.cand0;
+        // groups of four candidates x queries (MAPPED: an upper bound; the kernel reads the exact range from grp_off)
+        const int64_t groups4 = a.pairing == kPairMapped ? (int64_t)(a.job1 - a.job0) * a.max_job_groups
+                                                         : (ncand + 3) / 4 * (a.pairing == ASPIRE_PAIR_CROSS ? q->n : 0);
+        const bool tile = a.pairing == kPairMapped ? a.tile_form : (a.pairing == ASPIRE_PAIR_CROSS && groups4 >= 2048);
+        if (tile) {
+            // enough groups of 4 candidates to fill the chip: tiled form (lanes own finished (i,j) sums), one group per
+            // wave (measured 4.7 TB/s algorithmic at 1 x 20 000 against 1.8 TB/s for the accumulate-then-reduce kernel)
+            if (!a.diameter && first_chunk && a.pairing != kPairMapped) {   // per-coordinate boxes of the queries, once per call
+                hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, stream, a.q, qbox);
+                ASPIRE_LAUNCH_OK();
+            }
+            const int64_t waves = groups4 < 256 * 8 ? groups4 : 256 * 8;
+            hipLaunchKernelGGL((pair_tile_kernel<2, 1>), dim3((unsigned)((waves + 3) / 4)), dim3(256),
+                               4 * TileCfg<2>::kLdsFloats * sizeof(float), stream, a, ws1, qbox);
+        } else {
+            // small grids are latency bound: three waves per pair (a third of the coordinates each), persistent and
+            // software pipelined (measured 15.6 us per launch at 50-250 pairs against 20-23 us for the tiled form with its
+            // stages split over three or four waves).  One pair per workgroup up to 2048 pairs (at ~1000 pairs it beats
+            // 512 persistent workgroups with two each, alone and beside other launches); beyond, 512 persistent
+            // workgroups = what is resident at two per CU.
+            const int cap_t = tuning().cost1_blocks;
+            const int64_t cap = cap_t > 0 ? cap_t : (n_slots <= 2048 ? 2048 : 512);
+            const int64_t blocks = n_slots < cap ? n_slots : cap;
+            hipLaunchKernelGGL(pair_cost1_kernel, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float), stream, a,
+                               ws1, 1u);
+        }
+    } else if (csr && n_slots < 512) {
+        // CSR documents of more than 8 rows: every 8 x 8 sub-tile of every pair is an item of the small-pool kernel
+        // while the pairs alone would not fill the chip (1 x 125 x 20: 125 workgroups walking 9 tiles each -> 1024
+        // side by side, 54 -> 36 us; from ~1000 pairs the per-pair kernel is ahead again)
+        PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
+        const int64_t items = n_slots * T * T;
+        hipLaunchKernelGGL(pair_cost1_sub_kernel, dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
+                           Lds<1>::kTotal * sizeof(float), stream, a, ws1, (uint32_t)T);
+    } else if (csr) {
+        hipLaunchKernelGGL((pair_cost_kernel<T, false>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
+                           Lds<T>::kTotal * sizeof(float), stream, a, ws);
+    } else {
+        hipLaunchKernelGGL((pair_cost_kernel<T, true>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
+                           Lds<T>::kTotal * sizeof(float), stream, a, ws);
+    }
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+// ---- stage 2: one Sinkhorn solve per workspace slot.  n_slots: the slots of this launch (MAPPED: an upper bound, the
+// kernels read the exact range of jobs [a.job0, a.job1) from job_off). --------------------------------------------------
+// One solve per wave has the lowest latency (15.4 vs 26.7 us per call at 50 pairs), the block forms several times the
+// throughput; measured crossovers (1 x N x 8, cost + solve, us): N = 5000: wave 58 / 16-lane block 64 / 4-lane block 68;
+// 8000: 88 / 83 / 89; 12000: 119 / 109 / 106.  S = 12 / 20: even at 2000 / ~2500, block ahead at 3000.
+template <int T>
+int launch_sinkhorn_stage(const ScoreArgs& a, const PairWs<T>& ws, int64_t n_slots, int max_rows, bool extra, int form_hint,
+                          hipStream_t stream) {
+    const int pinned = tuning().sinkhorn_form;
+    const int form = pinned ? pinned : form_hint ? form_hint
+                     : T == 1 ? (n_slots < 7000 ? 1 : n_slots < 10000 ? 5 : 3)
+                              : (n_slots >= 2500 ? 3 : 1);
+    if (form >= 3 && !extra) {
+        // lanes per pair side LD and entries per lane side R: the smallest block grid that covers max_rows
+        auto launch_block = [&](auto ldc, auto rc) {
+            constexpr int LD = decltype(ldc)::value, R = decltype(rc)::value, PPB = 4 * 64 / (LD * LD);
+            if constexpr (LD * R <= 8 * T && LD * R > 8 * (T - 1)) {
+                hipLaunchKernelGGL((sinkhorn_block_kernel<T, LD, R>), dim3((unsigned)((n_slots + PPB - 1) / PPB)),
+                                   dim3(256), 0, stream, a, ws, n_slots);
+            }
+        };
+        using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>;
+        const int r4 = (max_rows + 3) / 4;
+        if (T == 1 && form == 5) launch_block(I4{}, I2{});
+        else if (T == 1) launch_block(I2{}, I4{});
+        else if (r4 == 3) launch_block(I4{}, std::integral_constant<int, 3>{});
+        else if (r4 == 4) launch_block(I4{}, I4{});
+        else if (r4 == 5) launch_block(I4{}, std::integral_constant<int, 5>{});
+        else if (r4 == 6) launch_block(I4{}, std::integral_constant<int, 6>{});
+        else if (r4 == 7) launch_block(I4{}, std::integral_constant<int, 7>{});
+        else launch_block(I4{}, std::integral_constant<int, 8>{});
+        ASPIRE_LAUNCH_OK();
+        if (form != 4)      // pairs whose sums left fp32 range (NaN score) are solved again with the max-shifted solver
+            hipLaunchKernelGGL(sinkhorn_repair_kernel<T>, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream, a, ws,
+                               n_slots);
+    } else {
+        hipLaunchKernelGGL(sinkhorn_kernel<T>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, stream, a, ws, n_slots);
+    }
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing, const aspire_ot_params* prm,
+           const float* diameter, int64_t diam_group, int want, float* scores, float* out_qdistr, float* out_cdistr,
+           float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes, void* stream, const RankReq& rank,
+           bool cost_only = false) {
+    if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    if (q->n == 0 || c->n == 0) return ASPIRE_OK;   // nothing to score (an empty pool has no buffers either)
+    if (int rc = check_ot_params(prm, want)) return rc;
+    ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "null scores");
+    const bool extra = out_qdistr || out_cdistr || out_pairsims || out_plan;
+    ASPIRE_REQUIRE(!extra || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
+                   "pair outputs need padded extents (ext > 0)");
+    ASPIRE_REQUIRE(!diameter || diam_group > 0, ASPIRE_ERR_INVALID_ARG, "diam_group must be positive");
+    const int max_rows = max_rows_of(q, c);
+    const size_t per_cand = per_cand_bytes(q, c, pairing);
+    const bool gram = gram_path_wanted(q, c, pairing);
+    ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + kWsSlack, ASPIRE_ERR_INVALID_ARG,
+                   "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
+                   workspace_bytes, per_cand, aspire_ot_workspace_bytes(q, c, pairing));
+    ScoreArgs a{};
+    fill_ot_args(a, q, c, pairing, prm, diameter, diam_group, want, scores);
     a.out_qdistr = out_qdistr;
     a.out_cdistr = out_cdistr;
     a.out_pairsims = out_pairsims;
@@ -2502,8 +2187,9 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
     const int qchunks = query_chunks(a);
     const int64_t cand_per_chunk = (int64_t)((((workspace_bytes - qbox_bytes(q)) & ~(size_t)15) - 32) / per_cand);
     const int64_t pairs_per_cand = pairing == ASPIRE_PAIR_PAIRED ? 1 : q->n;
-    const int64_t pairs_q = pairing == ASPIRE_PAIR_PAIRED ? 1 : q->n;
     const size_t ot_bytes = workspace_bytes;
+    // query boxes sit at a fixed place (the tail of the workspace) so that every candidate chunk finds them
+    float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
     const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         for (int64_t c0 = 0; c0 < c->n; c0 += cand_per_chunk) {
@@ -2514,139 +2200,20 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
             ws.cost = (float*)workspace;
             ws.neg = ws.cost + n_slots * PairWs<T>::kEntries;
             ws.diam2 = ws.neg + n_slots * PairWs<T>::kEntries;
-            // ASPIRE_HIP_SINKHORN=wave|packed|block pins the form (parity tests, tuning); default: by grid size
-            const char* env_form = getenv("ASPIRE_HIP_SINKHORN");
-            const int pinned = !env_form ? 0 : !strcmp(env_form, "wave") ? 1 : !strcmp(env_form, "packed") ? 2 : !strcmp(env_form, "block") ? 3 : !strcmp(env_form, "block-norepair") ? 4 : !strcmp(env_form, "block16") ? 5 : 0;
-            // measured crossovers (1 x N x 8, cost + solve, us): N = 5000: wave 58 / 16-lane block 64 / 4-lane block 68;
-            // 8000: 88 / 83 / 89; 12000: 119 / 109 / 106
-            const int form = pinned ? pinned
-                             : T == 1 ? (n_slots < 7000 ? 1 : n_slots < 10000 ? 5 : 3)
-                                      : (n_slots >= 2500 ? 3 : 1);      // S = 12 / 20: even at 2000 / ~2500, block ahead at 3000
-            // ASPIRE_HIP_STAGE=cost: launch the cost stage only (bench.py times the dominant kernel alone this way)
-            const char* env_stage = getenv("ASPIRE_HIP_STAGE");
-            const bool cost_only = env_stage && !strcmp(env_stage, "cost");
-            if (gram) {
-                // many queries or long documents: Gram tiles on the matrix cores (gram.hip)
-                float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
-                float* cbox = (float*)(((uintptr_t)(ws.diam2 + n_slots) + 15) & ~(uintptr_t)15);
-                if (int rc = launch_pair_gram_ot(a, T, q->max_len, c->max_len, ws.cost, ws.neg, diameter ? nullptr : ws.diam2,
-                                                 qbox, cbox, (hipStream_t)stream))
-                    return rc;
-            } else if (T == 1 && q->ext == 0 && c->ext == 0) {
-                // tiled form (lanes own finished (i,j) sums): R = 2 packs four candidates of one query into a
-                // wave (fewest LDS reads per FMA) once there are enough of them to fill the chip, R = 1 otherwise.
-                PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
-                // query boxes sit at a fixed place (the tail of the workspace) so that every candidate chunk finds them
-                float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
-                const int64_t ncand = a.cand1 - a.cand0;
-                const int64_t groups4 = (ncand + 3) / 4 * q->n;
-                if (pairing == ASPIRE_PAIR_CROSS && groups4 >= 2048) {
-                    // enough groups of 4 candidates to fill the chip: tiled form, one group per wave (measured
-                    // 2.9 TB/s algorithmic at 1 x 20 000 against 1.8 TB/s for the accumulate-then-reduce kernel)
-                    if (!diameter && c0 == 0) {   // per-coordinate boxes of the queries, once per call
-                        hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, (hipStream_t)stream, a.q, qbox);
-                        ASPIRE_LAUNCH_OK();
-                    }
-                    const int64_t waves = groups4 < 256 * 8 ? groups4 : 256 * 8;
-                    hipLaunchKernelGGL((pair_tile_kernel<2, 1>), dim3((unsigned)((waves + 3) / 4)), dim3(256),
-                                       4 * TileCfg<2>::kLdsFloats * sizeof(float), (hipStream_t)stream, a, ws1, qbox);
-                } else {
-                    // small grids are latency bound: three waves per pair (a third of the coordinates each),
-                    // persistent and software pipelined (measured 15.6 us per launch at 50-250 pairs against
-                    // 20-23 us for the tiled form with its stages split over three or four waves)
-                    const char* env_blocks = getenv("ASPIRE_HIP_COST1_BLOCKS");   // tuning only
-                    // One pair per workgroup up to 2048 pairs (at ~1000 pairs it beats 512 persistent workgroups with two
-                    // each, alone and beside other launches; 1300-1500 pairs: 119-121 vs 111-115 M alignments/s overlapped
-                    // against a 1024-workgroup grid with uneven shares); beyond, 512 persistent workgroups = what is
-                    // resident at two per CU (3000 pairs: 109 vs 103 M overlapped with 1024, the same alone)
-                    const int64_t cap = env_blocks ? atoi(env_blocks) : (n_slots <= 2048 ? 2048 : 512);
-                    const int64_t blocks = n_slots < cap ? n_slots : cap;
-                    // Two forms of the kernel for one item per workgroup (every launch of <= 1024 pairs), both kept
-                    // because they win different cases on the same box (bench.py, 1 x 1000 x 8, three runs each):
-                    //   two register sets, global loads, 197 registers: overlapped lanes 115 M alignments/s, lone 45 M
-                    //   one register set, buffer loads, 128 registers, 40 KB LDS claim (four workgroups per CU,
-                    //   28 KB used): overlapped 111 M, lone 47-49 M (17.1 vs 18.2 us per 1000-pair call)
-                    // The default serves throughput; ASPIRE_HIP_COST1=single picks the other.  Either way the budget
-                    // that matters is what the resident cost waves leave on a SIMD for OTHER queries' Sinkhorn /
-                    // top-k waves: at 256 registers (nothing fits beside two waves) the same kernels give ~70 M.
-                    const char* env_c1 = getenv("ASPIRE_HIP_COST1");
-                    const char* env_lds = getenv("ASPIRE_HIP_COST1_LDS");      // tuning only: KB of LDS claimed per workgroup
-                    const bool single = blocks >= n_slots && env_c1 && !strcmp(env_c1, "single");
-                    const size_t lds1_bytes = env_lds ? (size_t)atoi(env_lds) * 1024
-                                                      : single ? (size_t)40 * 1024 : Lds<1>::kTotal * sizeof(float);
-                    if (env_c1 && !strcmp(env_c1, "mfma") && pairing == ASPIRE_PAIR_CROSS && blocks >= n_slots)
-                        hipLaunchKernelGGL(pair_cost_mfma1_kernel, dim3((unsigned)(q->n * ((a.cand1 - a.cand0 + 1) / 2))), dim3(256), 0,
-                                           (hipStream_t)stream, a, ws1);
-                    else if (single)
-                        hipLaunchKernelGGL(pair_cost1_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds1_bytes,
-                                           (hipStream_t)stream, a, ws1, 1u);
-                    else
-                        hipLaunchKernelGGL(pair_cost1_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds1_bytes,
-                                           (hipStream_t)stream, a, ws1, 1u);
-                }
-            } else {
-                if (q->ext == 0 && c->ext == 0 && n_slots < 512) {
-                    // CSR documents of more than 8 rows: every 8 x 8 sub-tile of every pair is an item of the
-                    // small-pool kernel while the pairs alone would not fill the chip (1 x 125 x 20: 125 workgroups walking 9
-                    // tiles each -> 1024 side by side, 54 -> 36 us; from ~1000 pairs the per-pair kernel is ahead again)
-                    PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
-                    const int64_t items = n_slots * T * T;
-                    hipLaunchKernelGGL(pair_cost1_sub_kernel, dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
-                                       Lds<1>::kTotal * sizeof(float), (hipStream_t)stream, a, ws1, (uint32_t)T);
-                } else if (q->ext == 0 && c->ext == 0)
-                    hipLaunchKernelGGL((pair_cost_kernel<T, false>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
-                                       Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
-                else
-                    hipLaunchKernelGGL((pair_cost_kernel<T, true>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
-                                       Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a, ws);
-            }
-            ASPIRE_LAUNCH_OK();
+            float* cbox = (float*)(((uintptr_t)(ws.diam2 + n_slots) + 15) & ~(uintptr_t)15);
+            if (int rc = launch_cost_stage<T>(a, q, c, ws, n_slots, qchunks, gram, qbox, cbox, c0 == 0, (hipStream_t)stream)) return rc;
             if (cost_only) continue;
-            // Packed solves (4 per wave) have twice the throughput (1 x 20 000: 233 -> 197 us per call) but ~2x the
-            // latency of one solve per wave (26.7 vs 15.4 us per call at 50 pairs): use them once the grid is big
-            // enough that throughput is what counts.
-            if (form >= 3 && !extra) {
-                // lanes per pair side LD and entries per lane side R: the smallest block grid that covers max_rows
-                auto launch_block = [&](auto ldc, auto rc) {
-                    constexpr int LD = decltype(ldc)::value, R = decltype(rc)::value, PPB = 4 * 64 / (LD * LD);
-                    if constexpr (LD * R <= 8 * T && LD * R > 8 * (T - 1)) {
-                        hipLaunchKernelGGL((sinkhorn_block_kernel<T, LD, R>), dim3((unsigned)((n_slots + PPB - 1) / PPB)),
-                                           dim3(256), 0, (hipStream_t)stream, a, ws, n_slots);
-                    }
-                };
-                using I2 = std::integral_constant<int, 2>;
-                using I4 = std::integral_constant<int, 4>;
-                const int r4 = (max_rows + 3) / 4;
-                if (T == 1 && form == 5) launch_block(I4{}, I2{});
-                else if (T == 1) launch_block(I2{}, I4{});
-                else if (r4 == 3) launch_block(I4{}, std::integral_constant<int, 3>{});
-                else if (r4 == 4) launch_block(I4{}, I4{});
-                else if (r4 == 5) launch_block(I4{}, std::integral_constant<int, 5>{});
-                else if (r4 == 6) launch_block(I4{}, std::integral_constant<int, 6>{});
-                else if (r4 == 7) launch_block(I4{}, std::integral_constant<int, 7>{});
-                else launch_block(I4{}, std::integral_constant<int, 8>{});
-                ASPIRE_LAUNCH_OK();
-                if (form == 3 || form == 5)
-                    hipLaunchKernelGGL(sinkhorn_repair_kernel<T>, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0,
-                                       (hipStream_t)stream, a, ws, n_slots);
-            } else if (form == 2 && T == 1 && !extra) {
-                PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
-                hipLaunchKernelGGL(sinkhorn4_kernel, dim3((unsigned)((n_slots + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a,
-                                   ws1, n_slots);
-            } else {
-                hipLaunchKernelGGL(sinkhorn_kernel<T>, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                                   a, ws, n_slots);
-            }
-            ASPIRE_LAUNCH_OK();
+            if (int rc = launch_sinkhorn_stage<T>(a, ws, n_slots, max_rows, extra, 0, (hipStream_t)stream)) return rc;
         }
         return (int)ASPIRE_OK;
     });
     if (rc_run) return rc_run;
     if (rank.k > 0) {
-        // the rank kernels follow the scores on the same stream (their scratch sits behind the OT workspace proper)
-        const size_t need = aspire_topk_workspace_bytes(pairs_q, c->n, rank.k);
+        // the rank kernels follow the scores on the same stream (their scratch sits behind the OT workspace proper,
+        // which aspire_ot_workspace_bytes keeps a multiple of 16 bytes)
+        const size_t need = aspire_topk_workspace_bytes(q->n, c->n, rank.k);
         void* tws = need ? (char*)workspace + ot_bytes : nullptr;
-        return topk_run(scores, pairs_q, c->n, rank.k, rank.idx_base, rank.top_scores, rank.top_idx, rank.keys, tws, need, stream);
+        return topk_run(scores, q->n, c->n, rank.k, rank.idx_base, rank.top_scores, rank.top_idx, rank.keys, tws, need, stream);
     }
     return ASPIRE_OK;
 }
@@ -2658,6 +2225,14 @@ extern "C" int aspire_ot_sinkhorn_f32(const aspire_repset* q, const aspire_repse
                                       float* out_plan, void* workspace, size_t workspace_bytes, void* stream) {
     return ot_run(q, c, D, pairing, prm, diameter, diam_group, want, scores, out_qdistr, out_cdistr, out_pairsims, out_plan,
                   workspace, workspace_bytes, stream, RankReq{0, 0, nullptr, nullptr, nullptr});
+}
+
+// Diagnostics: the cost stage of aspire_ot_sinkhorn_f32 alone (bench.py times the HBM-bound kernel of a pass this way).
+extern "C" int aspire_debug_ot_cost_stage_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                              const aspire_ot_params* prm, float* scores, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    return ot_run(q, c, D, pairing, prm, nullptr, 0, ASPIRE_OT_DISTANCE, scores, nullptr, nullptr, nullptr, nullptr, workspace,
+                  workspace_bytes, stream, RankReq{0, 0, nullptr, nullptr, nullptr}, true);
 }
 
 extern "C" size_t aspire_ot_rank_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t k) {
@@ -2674,8 +2249,245 @@ extern "C" int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c
     ASPIRE_REQUIRE(q && c, ASPIRE_ERR_INVALID_ARG, "null repset");
     const size_t tneed = aspire_topk_workspace_bytes(q->n, c->n, k);
     ASPIRE_REQUIRE(workspace_bytes >= tneed, ASPIRE_ERR_INVALID_ARG, "workspace too small for the rank scratch");
+    // the OT part is what is left, rounded down to 16 bytes so that the 64-bit rank scratch behind it stays aligned
     return ot_run(q, c, D, ASPIRE_PAIR_CROSS, prm, diameter, diam_group, want, scores, nullptr, nullptr, nullptr, nullptr, workspace,
-                  workspace_bytes - tneed, stream, RankReq{k, idx_base, top_scores, top_idx, keys});
+                  (workspace_bytes - tneed) & ~(size_t)15, stream, RankReq{k, idx_base, top_scores, top_idx, keys});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched jobs: J independent (query, pool) re-ranks in one call
+// ---------------------------------------------------------------------------------------------
+namespace aspire {
+namespace {
+
+// One workgroup per job j: the per-coordinate box of query j (the cost kernel adds each candidate's rows to it), the
+// job's first group of four (groups never straddle jobs, so a wave of the cost kernel serves ONE query), and the
+// candidate -> job / group -> job tables the kernels index.
+__global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, const int32_t* __restrict__ job_off, int J, float* __restrict__ qbox,
+                                                         int32_t* __restrict__ cand_job, int32_t* __restrict__ grp_off,
+                                                         int32_t* __restrict__ grp_job) {
+    __shared__ int part[3];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    {
+        const int n = q.len[j];
+        const float* doc = q.rows + (size_t)q.start[j] * kD + tid * 4;
+        float4 mn = ld4(doc), mx = mn;
+        for (int r = 1; r < n; ++r) {
+            const float4 v = ld4(doc + (size_t)r * kD);
+            mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+            mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+        }
+        *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + tid * 4) = mn;
+        *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + kD + tid * 4) = mx;
+    }
+    int g = 0;
+    for (int i = tid; i < j; i += 192) g += (job_off[i + 1] - job_off[i] + 3) >> 2;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) g += __shfl_xor(g, m);
+    if ((tid & 63) == 0) part[tid >> 6] = g;
+    __syncthreads();
+    const int g0 = part[0] + part[1] + part[2];
+    const int c0 = job_off[j], c1 = job_off[j + 1], ng = (c1 - c0 + 3) >> 2;
+    if (tid == 0) {
+        grp_off[j] = g0;
+        if (j == J - 1) grp_off[J] = g0 + ng;
+    }
+    for (int c = c0 + tid; c < c1; c += 192) cand_job[c] = j;
+    for (int k = tid; k < ng; k += 192) grp_job[g0 + k] = j;
+}
+
+// The side stream (and the events that tie it to the caller's stream) on which a batch's Sinkhorn and rank kernels run
+// beside the next chunk's cost kernel.  One per device, created on first use; a ring of event sets so that overlapping
+// calls never re-record an event another call's wait still refers to before it was enqueued.
+constexpr int kMaxBatchChunks = 8;
+struct ForkJoin {
+    hipStream_t side = nullptr;
+    hipEvent_t fork[8], join[8], cost[8][kMaxBatchChunks];
+    int next = 0;
+    bool ok = false;
+};
+ForkJoin* fork_join_for_device(int dev) {
+    static std::mutex mu;
+    static ForkJoin* table[64] = {};
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!table[dev]) {
+        ForkJoin* f = new ForkJoin();
+        bool ok = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) == hipSuccess;
+        for (int r = 0; r < 8 && ok; ++r) {
+            ok = ok && hipEventCreateWithFlags(&f->fork[r], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&f->join[r], hipEventDisableTiming) == hipSuccess;
+            for (int k = 0; k < kMaxBatchChunks && ok; ++k)
+                ok = ok && hipEventCreateWithFlags(&f->cost[r][k], hipEventDisableTiming) == hipSuccess;
+        }
+        f->ok = ok;
+        table[dev] = f;
+    }
+    return table[dev]->ok ? table[dev] : nullptr;
+}
+int next_event_set(ForkJoin* f) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    const int r = f->next;
+    f->next = (f->next + 1) & 7;
+    return r;
+}
+
+struct BatchLayout {
+    size_t slots, qbox, cand_job, grp_job, grp_off, topk, total;
+};
+BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, int64_t k) {
+    BatchLayout L{};
+    size_t o = 0;
+    L.slots = o; o = align16(o + slot_bytes(max_rows) * (size_t)C);
+    L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));
+    L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
+    L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
+    L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
+    L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
+    L.total = o;
+    return L;
+}
+}  // namespace
+}  // namespace aspire
+
+extern "C" size_t aspire_ot_rank_batch_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t max_job, int64_t k) {
+    if (!q || !c || q->n <= 0 || c->n <= 0) return 0;
+    return batch_layout(q->n, c->n, max_rows_of(q, c), max_job, k).total;
+}
+
+namespace {
+constexpr int kStagePrep = 1, kStageCost = 2, kStageSolve = 4, kStageRank = 8, kStageAll = 15;
+int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off, int64_t max_job,
+                  const aspire_ot_params* prm, int want, float* scores, int64_t k, float* top_scores, int64_t* top_idx,
+                  void* workspace, size_t workspace_bytes, void* stream, int stages) {
+    if (int rc = check_repsets(q, c, D, ASPIRE_PAIR_CROSS)) return rc;
+    if (int rc = check_ot_params(prm, want)) return rc;
+    const int64_t J = q->n, C = c->n;
+    ASPIRE_REQUIRE(q->ext == 0 && c->ext == 0, ASPIRE_ERR_INVALID_ARG, "batched jobs take CSR rep sets (ext == 0)");
+    ASPIRE_REQUIRE(k >= 0 && (k == 0 || (top_scores && top_idx)), ASPIRE_ERR_INVALID_ARG, "k > 0 needs top_scores and top_idx");
+    if (J == 0) return ASPIRE_OK;
+    ASPIRE_REQUIRE(job_off && max_job >= 0 && max_job <= C, ASPIRE_ERR_INVALID_ARG, "need job_off and 0 <= max_job <= C");
+    ASPIRE_REQUIRE(J < ((int64_t)1 << 30) && C < ((int64_t)1 << 31) - 8, ASPIRE_ERR_UNSUPPORTED, "batch too large for 32-bit offsets");
+    hipStream_t s0 = (hipStream_t)stream;
+    if (C == 0) {
+        // every pool is empty: the lists are all padding
+        const float* unread = reinterpret_cast<const float*>(job_off);     // every segment is empty: never dereferenced
+        if (k > 0) return topk_run(unread, J, 0, k, 0, top_scores, top_idx, nullptr, nullptr, 0, stream, job_off);
+        return ASPIRE_OK;
+    }
+    ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "null scores");
+    const int max_rows = max_rows_of(q, c);
+    const BatchLayout L = batch_layout(J, C, max_rows, max_job, k);
+    ASPIRE_REQUIRE(workspace && workspace_bytes >= L.total, ASPIRE_ERR_INVALID_ARG,
+                   "workspace too small: %zu bytes given, aspire_ot_rank_batch_workspace_bytes says %zu", workspace_bytes, L.total);
+    ASPIRE_REQUIRE(((uintptr_t)workspace & 15) == 0, ASPIRE_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
+    char* wsb = (char*)workspace;
+    float* qbox = (float*)(wsb + L.qbox);
+    int32_t* cand_job = (int32_t*)(wsb + L.cand_job);
+    int32_t* grp_job = (int32_t*)(wsb + L.grp_job);
+    int32_t* grp_off = (int32_t*)(wsb + L.grp_off);
+    ScoreArgs a{};
+    fill_ot_args(a, q, c, kPairMapped, prm, nullptr, 0, want, scores);
+    a.q_per_block = 1;
+    a.cand0 = 0;
+    a.cand1 = C;
+    a.qmap = cand_job;
+    a.job_off = job_off;
+    a.grp_off = grp_off;
+    a.grp_job = grp_job;
+    a.job0 = 0;
+    a.job1 = (int32_t)J;
+    a.max_job_groups = (int32_t)((max_job + 3) / 4);
+    // throughput kernels (four candidates of a job per wave, sixteen solves per wave) once the batch fills the chip;
+    // below that the latency forms the single-pool entry points use
+    const int64_t groups_bound = J * ((max_job + 3) / 4);
+    const int form_t = tuning().batch_form;
+    a.tile_form = max_rows <= 8 && (form_t == 2 || (form_t == 0 && groups_bound >= 2048 && C >= 6000));
+    if (stages & kStagePrep) {
+        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, job_off, (int)J, qbox, cand_job, grp_off, grp_job);
+        ASPIRE_LAUNCH_OK();
+    }
+
+    // Job chunks: chunk i's Sinkhorn + rank kernels run on the side stream beside chunk i + 1's cost kernel (HBM bound)
+    // on the caller's stream.  Not while the caller's stream is being captured into a graph.
+    int n_chunks = 1;
+    if (a.tile_form && stages == kStageAll) {
+        const int t = tuning().batch_chunks;
+        n_chunks = t > 0 ? t : (C >= 16000 ? 4 : C >= 8000 ? 2 : 1);
+        if (n_chunks > J) n_chunks = (int)J;
+        if (n_chunks > kMaxBatchChunks) n_chunks = kMaxBatchChunks;
+    }
+    ForkJoin* fj = nullptr;
+    if (n_chunks > 1) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        int dev = 0;
+        if (hipStreamIsCapturing(s0, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone || hipGetDevice(&dev) != hipSuccess ||
+            !(fj = fork_join_for_device(dev)))
+            n_chunks = 1;
+    }
+    const int es = fj ? next_event_set(fj) : 0;
+    hipStream_t s1 = fj ? fj->side : s0;
+    if (fj) {
+        ASPIRE_HIP_OK(hipEventRecord(fj->fork[es], s0));
+        ASPIRE_HIP_OK(hipStreamWaitEvent(s1, fj->fork[es], 0));
+    }
+    const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
+    const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
+        constexpr int T = decltype(tc)::value;
+        PairWs<T> ws;
+        ws.cost = (float*)(wsb + L.slots);
+        ws.neg = ws.cost + C * PairWs<T>::kEntries;
+        ws.diam2 = ws.neg + C * PairWs<T>::kEntries;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            a.job0 = (int32_t)(J * ch / n_chunks);
+            a.job1 = (int32_t)(J * (ch + 1) / n_chunks);
+            const int64_t nj = a.job1 - a.job0;
+            // slots of this launch: exact for the whole batch, an upper bound for a chunk of jobs
+            const int64_t n_slots = n_chunks == 1 ? C : (nj * max_job < C ? nj * max_job : C);
+            if (stages & kStageCost)
+                if (int rc = launch_cost_stage<T>(a, q, c, ws, n_slots, 1, false, qbox, nullptr, ch == 0, s0)) return rc;
+            if (fj) {
+                ASPIRE_HIP_OK(hipEventRecord(fj->cost[es][ch], s0));
+                ASPIRE_HIP_OK(hipStreamWaitEvent(s1, fj->cost[es][ch], 0));
+            }
+            if (stages & kStageSolve)
+                if (int rc = launch_sinkhorn_stage<T>(a, ws, n_slots, max_rows, false, a.tile_form ? 3 : 0, s1)) return rc;
+            if (k > 0 && (stages & kStageRank)) {
+                if (int rc = topk_run(scores, nj, max_job, k, 0, top_scores + (int64_t)a.job0 * k, top_idx + (int64_t)a.job0 * k, nullptr,
+                                      topk_need ? wsb + L.topk : nullptr, topk_need, (void*)s1, job_off + a.job0))
+                    return rc;
+            }
+        }
+        return (int)ASPIRE_OK;
+    });
+    if (fj) {
+        // join even after a failed launch: the caller's stream must not run ahead of the side stream
+        (void)hipEventRecord(fj->join[es], s1);
+        (void)hipStreamWaitEvent(s0, fj->join[es], 0);
+    }
+    return rc_run;
+}
+}  // namespace
+
+extern "C" int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,
+                                        int64_t max_job, const aspire_ot_params* prm, int want, float* scores, int64_t k,
+                                        float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    return ot_rank_batch(q, c, D, job_off, max_job, prm, want, scores, k, top_scores, top_idx, workspace, workspace_bytes, stream,
+                         kStageAll);
+}
+
+// Diagnostics: chosen stages of aspire_ot_rank_batch_f32 on the caller's stream alone (1 tables + query boxes, 2 cost
+// kernel, 4 Sinkhorn kernel, 8 rank) -- bench.py times each stage of a pass this way, after a full call has filled the
+// workspace.
+extern "C" int aspire_debug_ot_rank_batch_stages_f32(const aspire_repset* q, const aspire_repset* c, int64_t D,
+                                                     const int32_t* job_off, int64_t max_job, const aspire_ot_params* prm,
+                                                     int want, float* scores, int64_t k, float* top_scores, int64_t* top_idx,
+                                                     void* workspace, size_t workspace_bytes, void* stream, int stages) {
+    ASPIRE_REQUIRE(stages > 0 && stages <= kStageAll, ASPIRE_ERR_INVALID_ARG, "bad stage mask %d", stages);
+    return ot_rank_batch(q, c, D, job_off, max_job, prm, want, scores, k, top_scores, top_idx, workspace, workspace_bytes, stream,
+                         stages);
 }
 
 extern "C" int aspire_group_diameter_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
@@ -2688,8 +2500,9 @@ extern "C" int aspire_group_diameter_f32(const aspire_repset* q, const aspire_re
     a.c = to_dev(c);
     a.pairing = pairing;
     const int64_t ngroups = (c->n + group - 1) / group;
-    dim3 grid((unsigned)ngroups, pairing == ASPIRE_PAIR_PAIRED ? 1u : (unsigned)q->n, 1);
-    hipLaunchKernelGGL(diameter_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a, group, diameter);
+    const int64_t blocks = pairing == ASPIRE_PAIR_PAIRED ? ngroups : ngroups * q->n;     // (query, group) folded into grid.x
+    ASPIRE_REQUIRE(blocks < ((int64_t)1 << 31), ASPIRE_ERR_UNSUPPORTED, "too many (query, group) boxes: %lld", (long long)blocks);
+    hipLaunchKernelGGL(diameter_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, group, ngroups, diameter);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

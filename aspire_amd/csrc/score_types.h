@@ -32,8 +32,45 @@ struct ScoreArgs {
     float* out_cdistr;
     float* out_pairsims;
     float* out_plan;
+    // MAPPED pairing (aspire_ot_rank_batch_f32: J independent (query, pool) jobs in one launch): candidate p is
+    // scored against query qmap[p], P = C.  job j owns candidates [job_off[j], job_off[j+1]) and the groups of four
+    // candidates [grp_off[j], grp_off[j+1]) (a group never straddles two jobs); grp_job[g] = job of group g.
+    const int32_t* qmap;
+    const int32_t* job_off;
+    const int32_t* grp_off;
+    const int32_t* grp_job;
+    int32_t job0, job1;       // the jobs this launch covers (chunks of a batch run side by side on two streams)
+    int32_t max_job_groups;   // host-side launch geometry: upper bound of a job's groups of four
+    int32_t tile_form;        // host-side: the batch runs on the throughput kernels
     long long* dbg;  // phase cycle stamps (only with -DASPIRE_PHASE_CLOCK)
 };
+
+// Internal third pairing next to ASPIRE_PAIR_CROSS / ASPIRE_PAIR_PAIRED (see ScoreArgs::qmap).
+constexpr int kPairMapped = 2;
+
+// (query, candidate, output index) of workspace slot `slot` of the current candidate chunk.
+struct PairIdx {
+    int64_t q_idx, c_idx, p;
+};
+__device__ __forceinline__ PairIdx pair_of_slot(const ScoreArgs& a, int64_t slot) {
+    PairIdx r;
+    if (a.pairing == ASPIRE_PAIR_CROSS) {
+        const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+        const uint32_t q_loc = (uint32_t)slot / ncand;     // 32-bit: 64-bit division costs hundreds of cycles here
+        r.q_idx = (int64_t)q_loc;
+        r.c_idx = a.cand0 + ((uint32_t)slot - q_loc * ncand);
+        r.p = r.q_idx * a.c.n + r.c_idx;
+    } else {
+        r.c_idx = a.cand0 + slot;
+        r.q_idx = a.pairing == kPairMapped ? (int64_t)a.qmap[r.c_idx] : r.c_idx;
+        r.p = r.c_idx;
+    }
+    return r;
+}
+__device__ __forceinline__ float group_diameter_of(const ScoreArgs& a, const PairIdx& i) {
+    return a.pairing == ASPIRE_PAIR_CROSS ? a.diameter[i.q_idx * a.n_groups + i.c_idx / a.diam_group]
+                                          : a.diameter[i.c_idx / a.diam_group];
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 

@@ -130,10 +130,16 @@ __device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_
                                                              int64_t in_stride, int64_t kk, uint64_t* __restrict__ keys_out,
                                                              int64_t out_stride, int64_t idx_base, int64_t k_final,
                                                              float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
-                                                             uint64_t* __restrict__ keys_final, int64_t in_k) {
+                                                             uint64_t* __restrict__ keys_final, int64_t in_k,
+                                                             const int32_t* __restrict__ seg_off = nullptr) {
     constexpr int N = E * kTopkThreads;
     const int tid = threadIdx.x;
     const int64_t base = chunk * N;
+    if (seg_off != nullptr) {      // segmented scores (batched jobs): query q owns scores[seg_off[q] .. seg_off[q + 1])
+        scores += seg_off[q];
+        n_in = seg_off[q + 1] - seg_off[q];
+        in_stride = 0;
+    }
     uint64_t key[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
@@ -157,7 +163,9 @@ __device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_
 }
 
 // host driver of the multi-pass rank (topk.hip); exactly one of (top_scores, top_idx) / keys_final is produced
+// seg_off != NULL (device int32 [Q + 1]): query q's scores are scores[seg_off[q] .. seg_off[q + 1]) and C is a host-known
+// upper bound of a segment's length.
 int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base, float* top_scores, int64_t* top_idx,
-             uint64_t* keys_final, void* workspace, size_t workspace_bytes, void* stream);
+             uint64_t* keys_final, void* workspace, size_t workspace_bytes, void* stream, const int32_t* seg_off = nullptr);
 
 }  // namespace aspire

@@ -1,0 +1,23 @@
+// Diagnostic switches of libaspire_hip.so.  Defaults are the product behaviour; the parity tests pin a kernel form to run
+// two forms on the same inputs, and tuning experiments pin grids.  The environment (ASPIRE_HIP_*) is read ONCE, on first
+// use -- never on the launch path -- and aspire_debug_set() (include/aspire_hip.h) changes a switch at run time.
+#pragma once
+
+namespace aspire {
+
+struct Tuning {
+    int sinkhorn_form = 0;   // ASPIRE_HIP_SINKHORN: 0 by grid size, 1 wave, 3 block, 4 block-norepair, 5 block16
+    int cost_path = 0;       // ASPIRE_HIP_COST_PATH: 0 by shape, 1 mfma (Gram kernel), 2 valu
+    int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
+    int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
+    int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
+    int batch_chunks = 0;    // ASPIRE_HIP_BATCH_CHUNKS: job chunks of aspire_ot_rank_batch_f32 (0 = by size, 1 = no overlap)
+    int batch_form = 0;      // ASPIRE_HIP_BATCH_FORM: 0 by size, 1 = small-pool kernels, 2 = throughput kernels
+};
+
+const Tuning& tuning();
+// key = the environment variable's name without the ASPIRE_HIP_ prefix (e.g. "SINKHORN"), value as in the environment;
+// value NULL or "" restores the default.  Returns false on an unknown key / value.
+bool tuning_set(const char* key, const char* value);
+
+}  // namespace aspire

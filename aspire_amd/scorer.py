@@ -81,7 +81,7 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
     if len(pool) == 0:
         return [[] for _ in query_reps_list]
     k = len(pool) if k is None else min(k, len(pool))
-    if method == 'ot' and schedule in ('pair', 'batch') and (len(pool) <= 4096 or k < 1024):
+    if method == 'ot' and schedule in ('pair', 'batch'):
         hparams = hparams or {}
         if hparams.get('geoml_reach', None) is not None:
             raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
@@ -100,6 +100,38 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
         top_s, top_i = ops.topk_desc(scores.contiguous(), k)
     top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
     return [[(pool.pids[i], float(s)) for s, i in zip(rs, ri) if i >= 0] for rs, ri in zip(top_s, top_i)]
+
+
+def rank_pools(query_reps_list, pools, k=None, hparams=None):
+    """The whole per-query loop of evaluate.py:58-76 in ONE library call: query j is scored against ITS OWN pool
+    pools[j] (every query of a dataset has its own candidate pool, evaluate.py:60-62) with otAspire, one epsilon schedule
+    per pair (AspireModel.get_similarity, models.py:190-197), and each pool is ranked on its own (stable descending,
+    evaluate.py:76).  pools: list of CandidatePool or lists of [S_i, 768] arrays.  Returns per query [(pid, score), ...]."""
+    hparams = hparams or {}
+    if hparams.get('geoml_reach', None) is not None:
+        raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
+    assert len(query_reps_list) == len(pools), 'one pool per query'
+    if not pools:
+        return []
+    pools = [_as_pool(p) for p in pools]
+    sizes = [len(p) for p in pools]
+    max_job = max(sizes)
+    if max_job == 0:
+        return [[] for _ in pools]
+    k = max_job if k is None else min(k, max_job)
+    dev = ops.require_gpu()
+    q = ops.DeviceRepSet.from_list(query_reps_list)
+    nonempty = [p.repset for p in pools if len(p)]
+    row_base = np.cumsum([0] + [int(r.rows.shape[0]) for r in nonempty])[:-1]
+    c = ops.DeviceRepSet(torch.cat([r.rows for r in nonempty], 0),
+                         torch.cat([r.start + int(b) for r, b in zip(nonempty, row_base)]).to(torch.int32).contiguous(),
+                         torch.cat([r.len for r in nonempty]).contiguous(), ext=0, max_len=max(r.max_len for r in nonempty))
+    job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    _, top_s, top_i = ops.ot_rank_batch(q, c, job_off, max_job, k, blur=hparams.get('geoml_blur', 0.05),
+                                        scaling=hparams.get('geoml_scaling', 0.9), sent_sm_temp=hparams.get('sent_sm_temp', 1.0),
+                                        want=_lib.OT_SIMILARITY)
+    top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
+    return [[(p.pids[i], float(sc)) for sc, i in zip(rs, ri) if i >= 0] for p, rs, ri in zip(pools, top_s, top_i)]
 
 
 def get_similarity(x, y, hparams=None):

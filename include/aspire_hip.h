@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASPIRE_ABI_VERSION 1
+#define ASPIRE_ABI_VERSION 2
 
 typedef enum {
     ASPIRE_OK = 0,
@@ -212,7 +212,8 @@ int aspire_group_diameter_f32(const aspire_repset* q, const aspire_repset* c, in
  *   idx_base  added to every output index (the shard's first global candidate id)
  *   top_scores [Q, k], top_idx [Q, k] out; if C < k the tail is (-inf, -1).
  *   workspace  device scratch of at least aspire_topk_workspace_bytes(Q, C, k) bytes (0 when C <= 4096).
- *   Limits: C <= 4096 for any k (full sort), otherwise k < 1024.
+ *   Any C < 2^32 - 1 and any k: pools beyond one 4096-key chunk are ranked by chunk winners (k < 1024) or fully sorted
+ *   (k >= 1024: sorted chunks + merge passes), e.g. k = C for the whole-pool sort of evaluate.py:76.
  */
 size_t aspire_topk_workspace_bytes(int64_t Q, int64_t C, int64_t k);
 int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base,
@@ -234,6 +235,30 @@ int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D
                        size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The per-query loop of evaluate.py:58-76 batched over queries: J independent (query, pool) re-ranks in ONE call.
+ * Job j scores the candidates [job_off[j], job_off[j+1]) of `c` -- query j's own pool (evaluate.py:60-62), all pools
+ * laid back to back in one CSR rep set -- against query j of `q`, one epsilon schedule per pair
+ * (AspireModel.get_similarity, src/evaluation/utils/models.py:190-197), and ranks each pool on its own (stable
+ * descending, evaluate.py:76).  One cost launch over all pairs, one Sinkhorn launch, one rank launch with a workgroup per
+ * job; large batches are cut into chunks of jobs whose Sinkhorn + rank kernels run on a library-owned side stream
+ * beside the next chunk's HBM-bound cost kernel (joined back into `stream` before the call returns its work to it).
+ *   q          J query documents (q->n == J), CSR (ext == 0)
+ *   c          every job's candidates (c->n == C == job_off[J]), CSR (ext == 0)
+ *   job_off    DEVICE int32 [J + 1], non-decreasing, job_off[0] == 0, job_off[J] == C
+ *   max_job    host-known upper bound of a job's candidate count (launch geometry only)
+ *   scores     [C] out: candidate p against its job's query, as aspire_ot_sinkhorn_f32 would give it (`want`)
+ *   k          0: scores only; else top_scores [J, k], top_idx [J, k] out: per job, index = position in the job's pool,
+ *              (-inf, -1) beyond the pool's size
+ *   workspace  16-byte aligned, aspire_ot_rank_batch_workspace_bytes(q, c, max_job, k) bytes
+ * Results equal J separate aspire_ot_rank_f32 calls up to the kernel form the grid size selects (bit for bit when the
+ * forms are pinned to the same ones, see aspire_debug_set).
+ * ------------------------------------------------------------------------------------------- */
+size_t aspire_ot_rank_batch_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t max_job, int64_t k);
+int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,
+                             int64_t max_job, const aspire_ot_params* prm, int want, float* scores, int64_t k,
+                             float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * SURVEY.md 8(e)  shard merge.  The same rank in KEY form for the candidate-pool shards of a multi-GPU job:
  *   aspire_topk_keys_f32    per-query local top-k as sortable 64-bit keys [Q, k]:
  *                           (order-preserving score bits << 32) | (0xFFFFFFFF - global index), 0 = padding.
@@ -248,6 +273,27 @@ int aspire_topk_keys_f32(const float* scores, int64_t Q, int64_t C, int64_t k, i
                          uint64_t* keys, void* workspace, size_t workspace_bytes, void* stream);
 int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k_in, int64_t k,
                            float* top_scores, int64_t* top_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics (tests, bench.py, tuning) -- not part of the surface that replaces reference code.
+ *   aspire_debug_set   pin a kernel form / grid: key = "SINKHORN" (wave | block | block-norepair | block16), "COST_PATH"
+ *                      (mfma | valu), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM_TILE" (96), "BATCH_CHUNKS" (n),
+ *                      "BATCH_FORM" (small | tile); value NULL or "" restores the default.  The same switches are read
+ *                      ONCE from the environment (ASPIRE_HIP_<key>) when the library is first used; nothing on the
+ *                      launch path reads the environment.
+ *   aspire_debug_ot_cost_stage_f32         the cost stage of aspire_ot_sinkhorn_f32 alone (no solve, scores untouched)
+ *   aspire_debug_ot_rank_batch_stages_f32  chosen stages of aspire_ot_rank_batch_f32 on `stream` alone:
+ *                      1 tables + query boxes, 2 cost kernel, 4 Sinkhorn kernel, 8 rank (bench.py times the stages of
+ *                      a pass one by one this way, after a full call has filled the workspace)
+ * ------------------------------------------------------------------------------------------- */
+int aspire_debug_set(const char* key, const char* value);
+int aspire_debug_ot_cost_stage_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
+                                   const aspire_ot_params* prm, float* scores, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+int aspire_debug_ot_rank_batch_stages_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,
+                                          int64_t max_job, const aspire_ot_params* prm, int want, float* scores, int64_t k,
+                                          float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
+                                          void* stream, int stages);
 
 /* Cross-lane primitive self test (DPP / permlane forms vs ds_bpermute); out_mismatch_host[16] receives
  * the number of mismatching lanes per check (all 0 = ok; order: xor 1,2,4,8,16,32, row sum, col sum,

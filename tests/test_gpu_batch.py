@@ -1,0 +1,229 @@
+"""aspire_ot_rank_batch_f32: J independent (query, pool) re-ranks in ONE call -- the per-query loop of evaluate.py:58-76
+batched over queries -- against J separate aspire_ot_rank_f32 calls, the oracle, and Python's stable sort.
+
+Bit-for-bit equality holds whenever both sides run the same kernel forms (the arithmetic of a pair never depends on the
+grid): the small-pool forms by default, the throughput forms when the batch entry is pinned to them for the one-job
+calls as well.  Between DIFFERENT forms (another summation order) scores agree to a few 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def amd():
+    from aspire_amd import ops, scorer, _lib
+    assert torch.cuda.is_available()
+    return type('NS', (), dict(ops=ops, scorer=scorer, lib=_lib, pinned=_lib.pinned))
+
+
+def _jobs(seed, sizes, smax, smin=1, d=768):
+    """queries [J], pools [J][n_j] of ragged documents"""
+    g = torch.Generator().manual_seed(seed)
+    queries = [torch.randn(int(torch.randint(smin, smax + 1, (1,), generator=g)), d, generator=g) for _ in sizes]
+    pools = [[torch.randn(int(n), d, generator=g) for n in torch.randint(smin, smax + 1, (int(sz),), generator=g)] for sz in sizes]
+    return queries, pools
+
+
+def _batch(amd, queries, pools, k, **kw):
+    q = amd.ops.DeviceRepSet.from_list(queries)
+    c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
+    sizes = [len(p) for p in pools]
+    job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).cuda()
+    s, ts, ti = amd.ops.ot_rank_batch(q, c, job_off, max(sizes), k, **kw)
+    torch.cuda.synchronize()
+    off = job_off.cpu().numpy()
+    return [s[off[j]:off[j + 1]].cpu() for j in range(len(pools))], ts.cpu(), ti.cpu()
+
+
+def _check_rank(scores_j, ts, ti, k):
+    """every job's list = the stable descending sort of ITS OWN scores (evaluate.py:76), padded with (-inf, -1)"""
+    for j, s in enumerate(scores_j):
+        n = len(s)
+        order = np.argsort(-s.numpy().astype(np.float64), kind='stable')[:k]
+        kk = min(k, n)
+        assert ti[j, :kk].tolist() == order.tolist(), j
+        assert torch.equal(ts[j, :kk], s[order]), j
+        assert torch.all(ti[j, kk:] == -1) and torch.all(ts[j, kk:] == float('-inf'))
+
+
+def test_small_batch_equals_separate_calls_bit_for_bit(amd):
+    """ragged pools (one of them empty, one with a single candidate), ragged documents of 1..8 rows"""
+    queries, pools = _jobs(11, [37, 0, 1, 64, 5, 120], 8)
+    k = 50
+    sc, ts, ti = _batch(amd, queries, pools, k)
+    _check_rank(sc, ts, ti, k)
+    for j, (qd, pool) in enumerate(zip(queries, pools)):
+        if not pool:
+            continue
+        kk = min(k, len(pool))
+        s1, t1, i1 = amd.ops.ot_rank(amd.ops.DeviceRepSet.from_list([qd]), amd.ops.DeviceRepSet.from_list(pool), kk,
+                                     want=amd.lib.OT_SIMILARITY)
+        assert torch.equal(s1[0].cpu(), sc[j]), j
+        assert torch.equal(i1[0].cpu(), ti[j, :kk]) and torch.equal(t1[0].cpu(), ts[j, :kk])
+        want = np.array([orc.get_similarity(qd, c) for c in pool], dtype=np.float32)
+        np.testing.assert_allclose(sc[j].numpy(), want, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('smax', [12, 20, 32])
+def test_long_document_batches(amd, smax):
+    """documents of more than 8 rows: sub-tile items (few pairs) and the per-pair tile-loop kernel (many pairs)"""
+    for sizes in ([30, 45, 7], [300, 420, 100]):
+        queries, pools = _jobs(20 + smax, sizes, smax, smin=max(1, smax - 9))
+        sc, ts, ti = _batch(amd, queries, pools, 25)
+        _check_rank(sc, ts, ti, 25)
+        for j in (0, 2):
+            s1 = amd.scorer.score_pool([queries[j]], pools[j], method='ot', schedule='pair')[0].cpu()
+            if sum(sizes) < 512:       # both sides on the sub-tile kernel
+                assert torch.equal(s1, sc[j]), (sizes, j)
+            else:                      # per-pair tile-loop kernel here, sub-tile items there
+                np.testing.assert_allclose(sc[j].numpy(), s1.numpy(), atol=3e-5, rtol=0)
+        want = np.array([orc.get_similarity(queries[1], c) for c in pools[1][:12]], dtype=np.float32)
+        np.testing.assert_allclose(sc[1][:12].numpy(), want, atol=TOL, rtol=0)
+
+
+def test_throughput_form_chunks_and_single_jobs(amd):
+    """the throughput kernels (four candidates of ONE job per wave, sixteen solves per wave): job sizes that are not
+    multiples of four, jobs of fewer than four candidates, chunked over two streams or not -- always the same bits"""
+    sizes = [1503, 2, 997, 1250, 3, 2048, 1, 1100, 777]
+    queries, pools = _jobs(31, sizes, 8)
+    k = 100
+    with amd.pinned(BATCH_FORM='tile', BATCH_CHUNKS=1):
+        base = _batch(amd, queries, pools, k)
+    _check_rank(*base, k)
+    for chunks in (2, 4, 8):
+        with amd.pinned(BATCH_FORM='tile', BATCH_CHUNKS=chunks):
+            got = _batch(amd, queries, pools, k)
+        for a, b in zip(base[0], got[0]):
+            assert torch.equal(a, b), chunks
+        assert torch.equal(base[1], got[1]) and torch.equal(base[2], got[2]), chunks
+    dflt = _batch(amd, queries, pools, k)          # C = 8681: the default picks the throughput form, two chunks
+    for a, b in zip(base[0], dflt[0]):
+        assert torch.equal(a, b)
+    # J separate one-job calls on the same kernel forms: bit for bit
+    with amd.pinned(BATCH_FORM='tile'):
+        for j in (0, 1, 4, 6, 8):
+            one = _batch(amd, [queries[j]], [pools[j]], k)
+            assert torch.equal(one[0][0], base[0][j]), j
+            assert torch.equal(one[2][0], base[2][j]) and torch.equal(one[1][0], base[1][j]), j
+    # ... and the default single-pool entry point (small-pool kernels, another summation order) to a few 1e-5
+    for j in (0, 2, 6):
+        s1 = amd.scorer.score_pool([queries[j]], pools[j], method='ot', schedule='pair')[0].cpu()
+        np.testing.assert_allclose(base[0][j].numpy(), s1.numpy(), atol=5e-5, rtol=0)
+    rng = np.random.default_rng(0)
+    for j in (0, 3, 5):
+        pick = rng.choice(sizes[j], 6, replace=False)
+        want = np.array([orc.get_similarity(queries[j], pools[j][i]) for i in pick], dtype=np.float32)
+        np.testing.assert_allclose(base[0][j].numpy()[pick], want, atol=TOL, rtol=0)
+
+
+def test_batch_hparams_and_wants(amd):
+    queries, pools = _jobs(41, [40, 25], 8)
+    for want, sign in ((amd.lib.OT_DISTANCE, -1.0), (amd.lib.OT_SIMILARITY, 1.0)):
+        sc, ts, ti = _batch(amd, queries, pools, 10, want=want, blur=0.1, scaling=0.8, sent_sm_temp=5.0)
+        _check_rank(sc, ts, ti, 10)
+        hp = dict(geoml_blur=0.1, geoml_scaling=0.8, sent_sm_temp=5.0)
+        ref = np.array([orc.get_similarity(queries[1], c, hp) for c in pools[1]], dtype=np.float32)
+        np.testing.assert_allclose(sign * sc[1].numpy(), ref, atol=TOL, rtol=0)
+
+
+def test_batch_under_graph_capture(amd):
+    """a captured call must not fork onto the library's side stream: it runs its chunks on the capturing stream"""
+    sizes = [1200] * 8
+    queries, pools = _jobs(51, sizes, 8, smin=8)
+    q = amd.ops.DeviceRepSet.from_list(queries)
+    c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
+    job_off = torch.arange(0, 9601, 1200, dtype=torch.int32).cuda()
+    eager = amd.ops.ot_rank_batch(q, c, job_off, 1200, 100)
+    torch.cuda.synchronize()
+    out = tuple(torch.empty_like(t) for t in eager)
+    qs, cs = q.struct(), c.struct()
+    import ctypes
+    ws = torch.empty(amd.lib.lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), 1200, 100),
+                     dtype=torch.uint8, device='cuda')
+    amd.ops.ot_rank_batch(q, c, job_off, 1200, 100, out=out, workspace=ws)      # warm up outside the capture
+    torch.cuda.synchronize()
+    for t in out:
+        t.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        amd.ops.ot_rank_batch(q, c, job_off, 1200, 100, out=out, workspace=ws)
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, out):
+        assert torch.equal(a, b)
+
+
+def test_back_to_back_batches_share_a_workspace(amd):
+    """consecutive calls on one stream reuse the same workspace: the side stream of call n is joined before call n + 1's
+    cost kernel may overwrite the slots"""
+    import ctypes
+    sizes = [1000] * 10
+    runs = []
+    ws = None
+    for seed in (61, 62, 63):
+        queries, pools = _jobs(seed, sizes, 8, smin=6)
+        q = amd.ops.DeviceRepSet.from_list(queries)
+        c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
+        runs.append((q, c))
+    job_off = torch.arange(0, 10001, 1000, dtype=torch.int32).cuda()
+    qs, cs = runs[0][0].struct(), runs[0][1].struct()
+    ws = torch.empty(amd.lib.lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), 1000, 100) + 4096,
+                     dtype=torch.uint8, device='cuda')
+    alone = []
+    for q, c in runs:
+        alone.append(amd.ops.ot_rank_batch(q, c, job_off, 1000, 100))
+        torch.cuda.synchronize()
+    outs = [tuple(torch.empty_like(t) for t in alone[0]) for _ in runs]
+    for rep in range(3):
+        for (q, c), out in zip(runs, outs):
+            amd.ops.ot_rank_batch(q, c, job_off, 1000, 100, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    for a, b in zip(alone, outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def test_rank_pools_is_the_evaluate_loop(amd):
+    """scorer.rank_pools(queries, pools) = [rank_pool(q, pool) for q, pool in ...], pids and all"""
+    queries, pools = _jobs(71, [33, 18, 60], 8)
+    cps = [amd.scorer.CandidatePool(p, pids=[f'j{j}c{i}' for i in range(len(p))]) for j, p in enumerate(pools)]
+    got = amd.scorer.rank_pools(queries, cps)
+    for j, (qd, cp) in enumerate(zip(queries, cps)):
+        want = amd.scorer.rank_pool([qd], cp)[0]
+        assert got[j] == want
+    assert amd.scorer.rank_pools([], []) == []
+    assert amd.scorer.rank_pools(queries[:1], [[]]) == [[]]
+
+
+def test_config2_batch_of_twenty_full_size(amd):
+    """BASELINE config 2 as the bench runs it: 20 steps = 20 (query, 1000-candidate pool) jobs, 8 sentences x 768-d.
+    Size-independent properties: each job's list is the stable sort of its scores, a job scored alone gives the same
+    bits (pinned to the same forms), permuting the jobs permutes the outputs, oracle spot checks."""
+    J, n, S = 20, 1000, 8
+    g = torch.Generator().manual_seed(0)
+    qrows = torch.randn(J * S, 768, generator=g).cuda()
+    crows = torch.randn(J * n * S, 768, generator=g).cuda()
+    ar = torch.arange(J * n, dtype=torch.int32).cuda()
+    q = amd.ops.DeviceRepSet(qrows, (ar[:J] * S).contiguous(), torch.full((J,), S, dtype=torch.int32).cuda(), 0, S)
+    c = amd.ops.DeviceRepSet(crows, (ar * S).contiguous(), torch.full((J * n,), S, dtype=torch.int32).cuda(), 0, S)
+    job_off = (torch.arange(J + 1, dtype=torch.int32) * n).cuda()
+    s, ts, ti = amd.ops.ot_rank_batch(q, c, job_off, n, 100)
+    torch.cuda.synchronize()
+    sj = [s[j * n:(j + 1) * n].cpu() for j in range(J)]
+    _check_rank(sj, ts.cpu(), ti.cpu(), 100)
+    assert torch.isfinite(s).all() and (s < 0).all()
+    # reversed job order
+    perm = torch.arange(J - 1, -1, -1)
+    q2 = amd.ops.DeviceRepSet(qrows.view(J, S, 768)[perm.cuda()].reshape(J * S, 768).contiguous(), q.start, q.len, 0, S)
+    c2 = amd.ops.DeviceRepSet(crows.view(J, n * S, 768)[perm.cuda()].reshape(J * n * S, 768).contiguous(), c.start, c.len, 0, S)
+    s2, ts2, ti2 = amd.ops.ot_rank_batch(q2, c2, job_off, n, 100)
+    assert torch.equal(s2.view(J, n)[perm.cuda()], s.view(J, n)) and torch.equal(ti2[perm.cuda()], ti)
+    for j in (0, 7, 19):
+        want = np.array([orc.get_similarity(qrows[j * S:(j + 1) * S].cpu(), crows[(j * n + i) * S:(j * n + i + 1) * S].cpu())
+                         for i in (0, 499, 999)], dtype=np.float32)
+        np.testing.assert_allclose(sj[j].numpy()[[0, 499, 999]], want, atol=TOL, rtol=0)

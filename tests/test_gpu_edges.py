@@ -219,7 +219,7 @@ def test_big_pool_clustered_vectors(amd):
     np.testing.assert_allclose(big[idx], want, atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize('form', ['wave', 'packed', 'block'])
+@pytest.mark.parametrize('form', ['wave', 'block16', 'block'])
 def test_schedule_length_at_its_discontinuities(amd, form):
     """geomloss's schedule has ceil((log blur - log diam) / log scaling) annealed steps -- float64, and discontinuous in
     the diameter.  The kernels form the quotient in fp32 and redo it in float64 only when it is close to an integer:
@@ -239,16 +239,10 @@ def test_schedule_length_at_its_discontinuities(amd, form):
     n = len(diams)
     qs = amd.ops.DeviceRepSet.from_list([q])
     cs = amd.ops.DeviceRepSet.from_list([c] * n)
-    old = os.environ.get('ASPIRE_HIP_SINKHORN')
-    os.environ['ASPIRE_HIP_SINKHORN'] = form
-    try:
+    from aspire_amd._lib import pinned
+    with pinned(SINKHORN=form):
         got = amd.ops.ot_sinkhorn(qs, cs, blur=blur, scaling=scaling, diameter=torch.from_numpy(diams).cuda(),
                                   diam_group=1).cpu().numpy()
-    finally:
-        if old is None:
-            del os.environ['ASPIRE_HIP_SINKHORN']
-        else:
-            os.environ['ASPIRE_HIP_SINKHORN'] = old
     w = orc.AllPairMaskedWasserstein({'geoml_blur': blur, 'geoml_scaling': scaling})
     qt = orc.RepLen(q[None].permute(0, 2, 1), [6])
     ct = orc.RepLen(c[None].permute(0, 2, 1), [7])

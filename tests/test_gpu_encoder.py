@@ -52,20 +52,17 @@ def test_bert_forward_matches_transformers(n_layers, b, l):
 
 
 def test_fused_attention_matches_three_kernel_form():
-    """ASPIRE_HIP_ATTN=gemm runs attention as QK^T GEMM + masked soft-max + PV GEMM; the fused kernel (default) must
+    """aspire_debug_set("ATTN", "gemm") runs attention as QK^T GEMM + masked soft-max + PV GEMM; the fused kernel (default) must
     give the same hidden states (key tiles of 128: lengths on, just past and between tile edges, ragged masks)."""
-    import os
+    from aspire_amd._lib import pinned
     from aspire_amd.encoder import HipBertEncoder
     m = _bert(2, seed=5)
     enc = HipBertEncoder(m)
     for l in (128, 131, 257):
         tok, seg, mask, _ = _batch(3, l, 3000, seed=100 + l)
         fused = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
-        os.environ['ASPIRE_HIP_ATTN'] = 'gemm'
-        try:
+        with pinned(ATTN='gemm'):
             ref = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
-        finally:
-            del os.environ['ASPIRE_HIP_ATTN']
         assert (fused - ref).abs().max().item() < 2e-5, l
 
 

@@ -1,6 +1,6 @@
 """Matrix-core cost stage (aspire_amd/csrc/gram.hip) against the oracle and against the VALU kernels.
 
-The library picks the form by shape; ASPIRE_HIP_COST_PATH=mfma|valu pins it so both can be run on the same
+The library picks the form by shape; aspire_debug_set("COST_PATH", mfma|valu) pins it so both can be run on the same
 inputs.  Every comparison goes through the C ABI (ops -> libaspire_hip.so)."""
 import os
 
@@ -21,19 +21,9 @@ def amd():
     return type('NS', (), dict(ops=ops, scorer=scorer, pd=pair_distances, lib=_lib))
 
 
-class cost_path:
-    def __init__(self, which):
-        self.which = which
-
-    def __enter__(self):
-        self.old = os.environ.get('ASPIRE_HIP_COST_PATH')
-        os.environ['ASPIRE_HIP_COST_PATH'] = self.which
-
-    def __exit__(self, *a):
-        if self.old is None:
-            del os.environ['ASPIRE_HIP_COST_PATH']
-        else:
-            os.environ['ASPIRE_HIP_COST_PATH'] = self.old
+def cost_path(which):
+    from aspire_amd._lib import pinned
+    return pinned(COST_PATH=which)
 
 
 def _docs(seed, lens, scale=1.0):

@@ -1,6 +1,5 @@
-"""The three forms of the Sinkhorn kernel (one solve per wave / four packed per wave / block form) agree with each
-other and with the oracle.  ASPIRE_HIP_SINKHORN=wave|packed|block pins the form; the default picks by grid size."""
-import os
+"""The forms of the Sinkhorn kernel (one solve per wave / block forms) agree with each other and with the oracle.
+aspire_debug_set("SINKHORN", wave|block|block16) pins the form; the default picks by grid size."""
 
 import numpy as np
 import pytest
@@ -19,20 +18,9 @@ def amd():
     return type('NS', (), dict(ops=ops, scorer=scorer, lib=_lib))
 
 
-class pinned:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+def pinned(**kv):
+    from aspire_amd._lib import pinned as _pinned
+    return _pinned(**kv)
 
 
 def _docs(seed, lens, scale=1.0):
@@ -50,7 +38,7 @@ def _docs(seed, lens, scale=1.0):
 @pytest.mark.parametrize('cost', ['valu', 'mfma'])
 def test_block_form_matches_oracle(amd, qlens, clens, cost):
     q, c = _docs(51, qlens), _docs(52, clens)
-    with pinned(ASPIRE_HIP_SINKHORN='block', ASPIRE_HIP_COST_PATH=cost):
+    with pinned(SINKHORN='block', COST_PATH=cost):
         got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
     want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
@@ -62,9 +50,9 @@ def test_block_form_hparams_and_repair(amd, hp):
     """Small scaling makes the shifted sums overflow in the block form: those pairs come back through the
     repair kernel (max-shifted solver) -- nothing is left NaN."""
     q, c = _docs(61, [8, 6]), _docs(62, [8, 2, 7, 5] * 4)
-    with pinned(ASPIRE_HIP_SINKHORN='block'):
+    with pinned(SINKHORN='block'):
         got = amd.scorer.score_pool(q, c, method='ot', schedule='pair', hparams=hp).cpu().numpy()
-    with pinned(ASPIRE_HIP_SINKHORN='wave'):
+    with pinned(SINKHORN='wave'):
         ref = amd.scorer.score_pool(q, c, method='ot', schedule='pair', hparams=hp).cpu().numpy()
     assert np.isfinite(got).all()
     want = np.array([[orc.get_similarity(x, y, hp) for y in c] for x in q], dtype=np.float32)
@@ -75,7 +63,7 @@ def test_block_form_hparams_and_repair(amd, hp):
 @pytest.mark.parametrize('scale', [1e-3, 30.0])
 def test_block_form_extreme_diameters(amd, scale):
     q, c = _docs(71, [8], scale), _docs(72, [8, 4, 6, 1] * 2, scale)
-    with pinned(ASPIRE_HIP_SINKHORN='block'):
+    with pinned(SINKHORN='block'):
         got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
     want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
     np.testing.assert_allclose(got, want, atol=TOL * max(1.0, scale), rtol=0)
@@ -92,9 +80,9 @@ def test_forms_agree_at_size(amd, nq, nc, s, want):
     c = amd.ops.DeviceRepSet.from_list([torch.randn(int(n), 768, generator=g) for n in lens_c])
     w = amd.lib.OT_DISTANCE if want == 'distance' else amd.lib.OT_PLAN_SIM
     out = {}
-    forms = ['wave', 'block'] + (['packed'] if s <= 8 else [])
+    forms = ['wave', 'block'] + (['block16'] if s <= 8 else [])
     for form in forms:
-        with pinned(ASPIRE_HIP_SINKHORN=form):
+        with pinned(SINKHORN=form):
             out[form] = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
     dflt = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
     tol = 5e-5 if want == 'distance' else 1e-2     # plan-weighted similarity: see test_gpu_scoring.PLAN_SIM_TOL
@@ -103,7 +91,7 @@ def test_forms_agree_at_size(amd, nq, nc, s, want):
         np.testing.assert_allclose(out[form], out['wave'], atol=tol, rtol=0)
     assert np.array_equal(dflt, out['block'])       # >= 4096 pairs: the block form is the default
     # at the reference's hyper-parameters the block form needs no repairs (its sums stay in fp32 range)
-    with pinned(ASPIRE_HIP_SINKHORN='block-norepair'):
+    with pinned(SINKHORN='block-norepair'):
         raw = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
     assert np.array_equal(raw, out['block'])
 
@@ -111,18 +99,36 @@ def test_forms_agree_at_size(amd, nq, nc, s, want):
 @pytest.mark.parametrize('qlens,clens', [
     ([8], [8, 5, 1, 3, 8, 7, 2, 6] * 5),          # ragged single-tile pool
     ([3, 8], [1, 8, 4] * 7),                      # two queries: items alternate between them
-    ([5], [8, 2, 7] * 5),                         # odd pool: the matrix-core form's last workgroup holds one candidate
+    ([5], [8, 2, 7] * 5),                         # odd pool
 ])
-def test_small_pool_cost_kernel_forms_match_oracle(amd, qlens, clens):
-    """Both forms of the small-pool cost kernel (two register sets + global loads, the default; one register set +
-    buffer loads, ASPIRE_HIP_COST1=single) against the oracle, and against each other bit for bit on the scores'
-    ranking (they accumulate in the same order: only the loads differ)."""
+@pytest.mark.parametrize('blocks', [0, 7])
+def test_small_pool_cost_kernel_matches_oracle(amd, qlens, clens, blocks):
+    """The small-pool cost kernel against the oracle, one pair per workgroup (default) and with 7 persistent workgroups
+    walking several pairs each (the software-pipelined loop: next item's rows in flight, the redo mask's own LDS word)
+    -- bit for bit the same either way."""
     q, c = _docs(61, qlens), _docs(62, clens)
     want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
-    got = {}
-    for form in ('prefetch', 'single', 'mfma'):
-        with pinned(ASPIRE_HIP_COST1=form):
-            got[form] = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
-        np.testing.assert_allclose(got[form], want, atol=TOL, rtol=0)
-    np.testing.assert_array_equal(got['prefetch'], got['single'])
-    np.testing.assert_allclose(got['mfma'], got['prefetch'], atol=5e-5, rtol=0)      # another summation order
+    ref = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    with pinned(COST1_BLOCKS=blocks):
+        got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_persistent_cost_kernel_with_duplicate_sentences(amd):
+    """Several items per workgroup AND entries that take the direct-formula redo path (a candidate sharing sentences with
+    the query): the redo mask of one item must not be clobbered by the next item's reduction scratch."""
+    g = torch.Generator().manual_seed(5)
+    query = torch.randn(8, 768, generator=g)
+    cands = []
+    for i in range(40):
+        c = torch.randn(int(torch.randint(1, 9, (1,), generator=g)), 768, generator=g)
+        if i % 3 == 0:
+            c[0] = query[i % 8]
+        cands.append(c)
+    want = np.array([orc.get_similarity(query, c) for c in cands], dtype=np.float32)
+    ref = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
+    with pinned(COST1_BLOCKS=3):
+        got = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
+    np.testing.assert_allclose(ref, want, atol=2e-3, rtol=0)      # duplicate sentences: geomloss's cancellation noise (see test_gpu_edges)
+    np.testing.assert_array_equal(got, ref)
