@@ -2359,13 +2359,14 @@ extern "C" size_t aspire_ot_rank_batch_workspace_bytes(const aspire_repset* q, c
 namespace {
 constexpr int kStagePrep = 1, kStageCost = 2, kStageSolve = 4, kStageRank = 8, kStageAll = 15;
 int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off, int64_t max_job,
-                  const aspire_ot_params* prm, int want, float* scores, int64_t k, float* top_scores, int64_t* top_idx,
-                  void* workspace, size_t workspace_bytes, void* stream, int stages) {
+                  const aspire_ot_params* prm, int want, float* scores, int64_t k, const int32_t* job_base, float* top_scores,
+                  int64_t* top_idx, uint64_t* keys, void* workspace, size_t workspace_bytes, void* stream, int stages) {
     if (int rc = check_repsets(q, c, D, ASPIRE_PAIR_CROSS)) return rc;
     if (int rc = check_ot_params(prm, want)) return rc;
     const int64_t J = q->n, C = c->n;
     ASPIRE_REQUIRE(q->ext == 0 && c->ext == 0, ASPIRE_ERR_INVALID_ARG, "batched jobs take CSR rep sets (ext == 0)");
-    ASPIRE_REQUIRE(k >= 0 && (k == 0 || (top_scores && top_idx)), ASPIRE_ERR_INVALID_ARG, "k > 0 needs top_scores and top_idx");
+    ASPIRE_REQUIRE(k >= 0 && (k == 0 || (top_scores && top_idx) || keys), ASPIRE_ERR_INVALID_ARG,
+                   "k > 0 needs (top_scores, top_idx) or keys");
     if (J == 0) return ASPIRE_OK;
     ASPIRE_REQUIRE(job_off && max_job >= 0 && max_job <= C, ASPIRE_ERR_INVALID_ARG, "need job_off and 0 <= max_job <= C");
     ASPIRE_REQUIRE(J < ((int64_t)1 << 30) && C < ((int64_t)1 << 31) - 8, ASPIRE_ERR_UNSUPPORTED, "batch too large for 32-bit offsets");
@@ -2373,7 +2374,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     if (C == 0) {
         // every pool is empty: the lists are all padding
         const float* unread = reinterpret_cast<const float*>(job_off);     // every segment is empty: never dereferenced
-        if (k > 0) return topk_run(unread, J, 0, k, 0, top_scores, top_idx, nullptr, nullptr, 0, stream, job_off);
+        if (k > 0) return topk_run(unread, J, 0, k, 0, top_scores, top_idx, keys, nullptr, 0, stream, job_off, job_base);
         return ASPIRE_OK;
     }
     ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "null scores");
@@ -2454,8 +2455,10 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
             if (stages & kStageSolve)
                 if (int rc = launch_sinkhorn_stage<T>(a, ws, n_slots, max_rows, false, a.tile_form ? 3 : 0, s1)) return rc;
             if (k > 0 && (stages & kStageRank)) {
-                if (int rc = topk_run(scores, nj, max_job, k, 0, top_scores + (int64_t)a.job0 * k, top_idx + (int64_t)a.job0 * k, nullptr,
-                                      topk_need ? wsb + L.topk : nullptr, topk_need, (void*)s1, job_off + a.job0))
+                const int64_t o = (int64_t)a.job0 * k;
+                if (int rc = topk_run(scores, nj, max_job, k, 0, keys ? nullptr : top_scores + o, keys ? nullptr : top_idx + o,
+                                      keys ? keys + o : nullptr, topk_need ? wsb + L.topk : nullptr, topk_need, (void*)s1,
+                                      job_off + a.job0, job_base ? job_base + a.job0 : nullptr))
                     return rc;
             }
         }
@@ -2472,10 +2475,10 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
 
 extern "C" int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,
                                         int64_t max_job, const aspire_ot_params* prm, int want, float* scores, int64_t k,
-                                        float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
-                                        void* stream) {
-    return ot_rank_batch(q, c, D, job_off, max_job, prm, want, scores, k, top_scores, top_idx, workspace, workspace_bytes, stream,
-                         kStageAll);
+                                        const int32_t* job_base, float* top_scores, int64_t* top_idx, uint64_t* keys,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    return ot_rank_batch(q, c, D, job_off, max_job, prm, want, scores, k, job_base, top_scores, top_idx, keys, workspace,
+                         workspace_bytes, stream, kStageAll);
 }
 
 // Diagnostics: chosen stages of aspire_ot_rank_batch_f32 on the caller's stream alone (1 tables + query boxes, 2 cost
@@ -2486,8 +2489,8 @@ extern "C" int aspire_debug_ot_rank_batch_stages_f32(const aspire_repset* q, con
                                                      int want, float* scores, int64_t k, float* top_scores, int64_t* top_idx,
                                                      void* workspace, size_t workspace_bytes, void* stream, int stages) {
     ASPIRE_REQUIRE(stages > 0 && stages <= kStageAll, ASPIRE_ERR_INVALID_ARG, "bad stage mask %d", stages);
-    return ot_rank_batch(q, c, D, job_off, max_job, prm, want, scores, k, top_scores, top_idx, workspace, workspace_bytes, stream,
-                         stages);
+    return ot_rank_batch(q, c, D, job_off, max_job, prm, want, scores, k, nullptr, top_scores, top_idx, nullptr, workspace,
+                         workspace_bytes, stream, stages);
 }
 
 extern "C" int aspire_group_diameter_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,

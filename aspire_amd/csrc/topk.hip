@@ -24,10 +24,10 @@ __global__ void __launch_bounds__(kThreads) topk_pass_kernel(const float* __rest
                                                              int64_t out_stride, int64_t idx_base, int64_t k_final,
                                                              float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
                                                              uint64_t* __restrict__ keys_final, int64_t in_k,
-                                                             const int32_t* __restrict__ seg_off) {
+                                                             const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_base) {
     __shared__ uint64_t lds[E * kThreads];
     topk_block_pass<E>(blockIdx.x, blockIdx.y, gridDim.x, lds, scores, keys_in, n_in, in_stride, kk, keys_out, out_stride, idx_base,
-                       k_final, top_scores, top_idx, keys_final, in_k, seg_off);
+                       k_final, top_scores, top_idx, keys_final, in_k, seg_off, seg_base);
 }
 
 // Small pools (n <= 1024) ranked for a short list (k <= 128): select, then sort only the survivors.  The scores' order
@@ -43,13 +43,15 @@ __global__ void __launch_bounds__(kThreads) topk_select_kernel(const float* __re
                                                                int64_t idx_base, int64_t k_final, int64_t kk,
                                                                uint64_t* __restrict__ keys_out, int64_t out_stride,
                                                                float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
-                                                               uint64_t* __restrict__ keys_final, const int32_t* __restrict__ seg_off) {
+                                                               uint64_t* __restrict__ keys_final, const int32_t* __restrict__ seg_off,
+                                                               const int32_t* __restrict__ seg_base) {
     __builtin_amdgcn_s_setprio(3);     // few workgroups, latency only: issue ahead of co-resident throughput kernels
     if (seg_off != nullptr) {          // segmented scores (batched jobs): query q owns scores[seg_off[q] .. seg_off[q + 1])
         scores += seg_off[blockIdx.x];
         n_in = seg_off[blockIdx.x + 1] - seg_off[blockIdx.x];
         in_stride = 0;
     }
+    if (seg_base != nullptr) idx_base += seg_base[blockIdx.x];
     __shared__ uint64_t lds[E * kThreads];
     __shared__ unsigned hist[256];
     __shared__ unsigned sm[16];      // [0..3] wave minima, [4..7] wave maxima, [8] boundary bin, [9] survivors, [10] cursor
@@ -202,8 +204,10 @@ __global__ void __launch_bounds__(kThreads) topk_merge_pass_kernel(const uint64_
 // The first k keys of every query's sorted buffer -> the final outputs (see topk_emit).
 __global__ void __launch_bounds__(256) topk_emit_sorted_kernel(const uint64_t* __restrict__ keys, int64_t stride, int64_t k,
                                                                int64_t idx_base, float* __restrict__ top_scores,
-                                                               int64_t* __restrict__ top_idx, uint64_t* __restrict__ keys_final) {
+                                                               int64_t* __restrict__ top_idx, uint64_t* __restrict__ keys_final,
+                                                               const int32_t* __restrict__ seg_base) {
     const int64_t q = blockIdx.y;
+    if (seg_base != nullptr) idx_base += seg_base[q];
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= k) return;
     const uint64_t kv = t < stride ? keys[q * stride + t] : 0ull;
@@ -239,7 +243,8 @@ extern "C" size_t aspire_topk_workspace_bytes(int64_t Q, int64_t C, int64_t k) {
 
 namespace aspire {
 int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base, float* top_scores, int64_t* top_idx,
-             uint64_t* keys_final, void* workspace, size_t workspace_bytes, void* stream, const int32_t* seg_off) {
+             uint64_t* keys_final, void* workspace, size_t workspace_bytes, void* stream, const int32_t* seg_off,
+             const int32_t* seg_base) {
     ASPIRE_REQUIRE(Q >= 0 && C >= 0 && k > 0, ASPIRE_ERR_INVALID_ARG, "bad shape Q=%lld C=%lld k=%lld", (long long)Q,
                    (long long)C, (long long)k);
     ASPIRE_REQUIRE(scores && ((top_scores && top_idx) || keys_final), ASPIRE_ERR_INVALID_ARG, "null pointer");
@@ -257,7 +262,7 @@ int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_b
         uint64_t* buf[2] = {(uint64_t*)workspace, (uint64_t*)workspace + Q * stride};
         hipLaunchKernelGGL(topk_pass_kernel<16>, dim3((unsigned)Q, (unsigned)nch), dim3(kThreads), 0, st, scores,
                            (const uint64_t*)nullptr, C, C, (int64_t)kMaxChunk, buf[0], stride, (int64_t)0, k, (float*)nullptr,
-                           (int64_t*)nullptr, (uint64_t*)nullptr, (int64_t)0, seg_off);
+                           (int64_t*)nullptr, (uint64_t*)nullptr, (int64_t)0, seg_off, (const int32_t*)nullptr);
         ASPIRE_LAUNCH_OK();
         const int64_t keep = k >= stride ? stride : (k + kMaxChunk - 1) / kMaxChunk * kMaxChunk;
         int which = 0;
@@ -273,7 +278,7 @@ int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_b
             which ^= 1;
         }
         hipLaunchKernelGGL(topk_emit_sorted_kernel, dim3((unsigned)((k + 255) / 256), (unsigned)Q), dim3(256), 0, st, buf[which],
-                           stride, k, idx_base, top_scores, top_idx, keys_final);
+                           stride, k, idx_base, top_scores, top_idx, keys_final, seg_base);
         ASPIRE_LAUNCH_OK();
         return ASPIRE_OK;
     }
@@ -297,23 +302,24 @@ int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_b
         uint64_t* kf = final_pass ? keys_final : nullptr;
         uint64_t* ko = final_pass ? nullptr : bufs[which];
         const int32_t* seg = sc != nullptr ? seg_off : nullptr;      // only the pass over the scores is segmented
+        const int32_t* sb = final_pass ? seg_base : nullptr;          // the final outputs carry the global indices
         if (select) {
             // (final outputs if there is one chunk)
             if (chunk == 2048)
                 hipLaunchKernelGGL(topk_select_kernel<8>, grid, dim3(kThreads), 0, st, sc, n, in_stride, idx_base, k, kk,
-                                   ko, out_stride, ts, ti, kf, seg);
+                                   ko, out_stride, ts, ti, kf, seg, sb);
             else if (chunk == 1024)
                 hipLaunchKernelGGL(topk_select_kernel<4>, grid, dim3(kThreads), 0, st, sc, n, in_stride, idx_base, k, kk,
-                                   ko, out_stride, ts, ti, kf, seg);
+                                   ko, out_stride, ts, ti, kf, seg, sb);
             else
                 hipLaunchKernelGGL(topk_select_kernel<16>, grid, dim3(kThreads), 0, st, sc, n, in_stride, idx_base, k, kk,
-                                   ko, out_stride, ts, ti, kf, seg);
+                                   ko, out_stride, ts, ti, kf, seg, sb);
         } else if (chunk == 1024) {
             hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, st, sc, kin, n, in_stride, kk, ko,
-                               out_stride, idx_base, k, ts, ti, kf, (int64_t)0, seg);
+                               out_stride, idx_base, k, ts, ti, kf, (int64_t)0, seg, sb);
         } else {
             hipLaunchKernelGGL(topk_pass_kernel<16>, grid, dim3(kThreads), 0, st, sc, kin, n, in_stride, kk, ko,
-                               out_stride, idx_base, k, ts, ti, kf, (int64_t)0, seg);
+                               out_stride, idx_base, k, ts, ti, kf, (int64_t)0, seg, sb);
         }
         ASPIRE_LAUNCH_OK();
         if (final_pass) break;
@@ -352,10 +358,12 @@ extern "C" int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q
     dim3 grid((unsigned)Q, 1);
     if (n <= 1024) {
         hipLaunchKernelGGL(topk_pass_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, (const float*)nullptr, keys, n, n, k,
-                           (uint64_t*)nullptr, k, (int64_t)0, k, top_scores, top_idx, (uint64_t*)nullptr, k_in, (const int32_t*)nullptr);
+                           (uint64_t*)nullptr, k, (int64_t)0, k, top_scores, top_idx, (uint64_t*)nullptr, k_in, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr);
     } else {
         hipLaunchKernelGGL(topk_pass_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, (const float*)nullptr, keys, n, n, k,
-                           (uint64_t*)nullptr, k, (int64_t)0, k, top_scores, top_idx, (uint64_t*)nullptr, k_in, (const int32_t*)nullptr);
+                           (uint64_t*)nullptr, k, (int64_t)0, k, top_scores, top_idx, (uint64_t*)nullptr, k_in, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr);
     }
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;

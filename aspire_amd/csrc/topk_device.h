@@ -131,7 +131,8 @@ __device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_
                                                              int64_t out_stride, int64_t idx_base, int64_t k_final,
                                                              float* __restrict__ top_scores, int64_t* __restrict__ top_idx,
                                                              uint64_t* __restrict__ keys_final, int64_t in_k,
-                                                             const int32_t* __restrict__ seg_off = nullptr) {
+                                                             const int32_t* __restrict__ seg_off = nullptr,
+                                                             const int32_t* __restrict__ seg_base = nullptr) {
     constexpr int N = E * kTopkThreads;
     const int tid = threadIdx.x;
     const int64_t base = chunk * N;
@@ -140,6 +141,7 @@ __device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_
         n_in = seg_off[q + 1] - seg_off[q];
         in_stride = 0;
     }
+    if (seg_base != nullptr) idx_base += seg_base[q];     // the job's first global candidate index (sharded pools)
     uint64_t key[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
@@ -165,7 +167,9 @@ __device__ __forceinline__ void topk_block_pass(int64_t q, int64_t chunk, int64_
 // host driver of the multi-pass rank (topk.hip); exactly one of (top_scores, top_idx) / keys_final is produced
 // seg_off != NULL (device int32 [Q + 1]): query q's scores are scores[seg_off[q] .. seg_off[q + 1]) and C is a host-known
 // upper bound of a segment's length.
+// seg_base (device int32 [Q], optional): added to idx_base per query.
 int topk_run(const float* scores, int64_t Q, int64_t C, int64_t k, int64_t idx_base, float* top_scores, int64_t* top_idx,
-             uint64_t* keys_final, void* workspace, size_t workspace_bytes, void* stream, const int32_t* seg_off = nullptr);
+             uint64_t* keys_final, void* workspace, size_t workspace_bytes, void* stream, const int32_t* seg_off = nullptr,
+             const int32_t* seg_base = nullptr);
 
 }  // namespace aspire

@@ -179,28 +179,36 @@ def ot_rank(q, c, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.C
 
 
 def ot_rank_batch(q, c, job_off, max_job, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.CDIST_AUTO,
-                  want=_lib.OT_SIMILARITY, out=None, workspace=None):
+                  want=_lib.OT_SIMILARITY, out=None, workspace=None, job_base=None, key_form=False):
     """J independent (query, pool) re-ranks in ONE call (include/aspire_hip.h: aspire_ot_rank_batch_f32; the per-query
     loop of evaluate.py:58-76 batched over queries).  q: J queries; c: every job's candidates back to back; job_off int32
     GPU tensor [J + 1]; max_job: host-known bound of a pool's size.  Returns (scores [C], top_scores [J, k], top_idx [J, k])
-    with top_idx = position inside the job's own pool; `out` = preallocated (scores, top_scores, top_idx)."""
+    with top_idx = position inside the job's own pool (+ job_base[j], int32 GPU tensor [J], when this rank holds one
+    block of every pool); `out` = preallocated (scores, top_scores, top_idx).  key_form: (scores, keys [J, k]) -- the
+    sortable keys of topk_keys, what a shard contributes to the all-gather."""
     dev = q.rows.device
     _i32(job_off, 'job_off')
     assert job_off.numel() == q.n + 1, 'job_off must have one entry per job plus one'
-    if out is not None:
+    keys = None
+    if out is not None and key_form:
+        scores, keys = out
+        top_s = top_i = None
+    elif out is not None:
         scores, top_s, top_i = out
     else:
         scores = torch.empty(c.n, device=dev, dtype=torch.float32)
-        top_s = torch.empty(q.n, k, device=dev, dtype=torch.float32) if k > 0 else None
-        top_i = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 else None
+        top_s = torch.empty(q.n, k, device=dev, dtype=torch.float32) if k > 0 and not key_form else None
+        top_i = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and not key_form else None
+        keys = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and key_form else None
     prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode)
     qs, cs = q.struct(), c.struct()
     if workspace is None:
         nbytes = lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), max_job, k)
         workspace = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
     check(lib.aspire_ot_rank_batch_f32(ctypes.byref(qs), ctypes.byref(cs), D, _ptr(job_off), max_job, ctypes.byref(prm), want,
-                                       _ptr(scores), k, _ptr(top_s), _ptr(top_i), _ptr(workspace), workspace.numel(), _stream()))
-    return scores, top_s, top_i
+                                       _ptr(scores), k, _ptr(job_base), _ptr(top_s), _ptr(top_i), _ptr(keys), _ptr(workspace),
+                                       workspace.numel(), _stream()))
+    return (scores, keys) if key_form else (scores, top_s, top_i)
 
 
 def topk_desc(scores, k, idx_base=0):

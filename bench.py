@@ -4,19 +4,30 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload at N=1 = BASELINE.json configs[1]: otAspire, 1 query x 1000 candidates, 8 sentences x 768 d,
-reps ~ N(0,1) fp32 (seed 0), resident in HBM before the timed region.  One step = one pass of the hot
-path over that batch: the fused cost + marginals + Sinkhorn kernel over all 1000 pairs (one epsilon
-schedule per pair, the reference's evaluate.py / AspireModel.get_similarity pattern), then the
-per-query stable descending rank (top-k with k = 100).  At N>1 every rank holds its own 1000-candidate
-block of an N*1000 pool (weak scaling), ranks locally, and the per-query top-k lists are merged with one
-RCCL all-gather per step.
+Workload at N=1 = BASELINE.json configs[1]: otAspire, 1 query x 1000 candidates, 8 sentences x 768 d, reps ~ N(0,1)
+fp32, resident in HBM before the timed region.  One STEP = one query re-ranked against ITS OWN 1000-candidate pool
+(evaluate.py:58-76: every query of a dataset has its own pool): cost matrix + marginals + Sinkhorn (one epsilon schedule
+per pair, AspireModel.get_similarity) of the 1000 pairs, then the stable descending rank (top-100).  The K steps of a run
+are K independent (query, pool) jobs and go through ONE library call, aspire_ot_rank_batch_f32 -- one cost launch over
+the K x 1000 pairs, one Sinkhorn launch, one K-workgroup rank launch, the batch cut into chunks whose Sinkhorn / rank
+kernels run beside the next chunk's HBM-bound cost kernel.  The caller uses ONE stream, no hipGraphs, no lanes.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (ot_kernel) against HBM:
-algorithmic bytes per launch = 24 605 B/pair x pairs (each candidate and query rep
-read once, each score written once) over the kernel's mean duration measured with HIP events inside the
-timed region.  `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch CPU path; its
-Sinkhorn solver is a parity-unpinned restatement of geomloss 0.2.4) on the host cores of this box.
+Timing: the K-step schedule is repeated R times back to back (R chosen so that the timed region is >= 50 ms: K = 20 steps
+alone are ~0.1 ms) between barrier + torch.cuda.synchronize() on both sides; ms_per_step = elapsed / (K * R), value =
+N * K * R * 1000 / elapsed.  Every job has its own query and its own pool, and consecutive repetitions walk through a pool
+store of >= 2 K (at least 24) distinct pools (> 256 MiB, the Infinity Cache): the candidate reads come from HBM, not L3.
+
+At N > 1 every rank holds its own 1000-candidate block of each job's N * 1000-candidate pool (weak scaling), ranks its
+block (key form, global indices), and the per-job top-k lists are merged with ONE RCCL all-gather per call + one merge
+kernel.  No data-path collective.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the cost kernel: it streams every rep once) against
+HBM: algorithmic bytes per launch = 24 605 B/pair x pairs per launch over the kernel's duration measured
+live with HIP events around launches of that stage alone on the launch stream (aspire_debug_ot_rank_batch_stages_f32),
+on the rotating (cold) pools; `l3_resident_frac` is the same on ONE pool set small enough to stay in the Infinity Cache;
+`step` prices the whole step (all kernels, timed region) against the same bytes.  `cpu_baseline` times the CPU oracle (a
+port of the reference's PyTorch CPU path; its Sinkhorn solver is a parity-unpinned restatement of geomloss 0.2.4) on the
+host cores of this box, with 1 thread and with all cores.
 """
 import argparse
 import ctypes
@@ -31,65 +42,56 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-Q, C, S, D = 1, 1000, 8, 768
+NC, S, D = 1000, 8, 768          # candidates per pool, sentences per document, encoding dim
 TOPK = 100
 if os.environ.get('ASPIRE_BENCH_SHAPE'):      # "C,S": tuning experiments at other pool shapes (invalid as a result)
-    C, S = (int(v) for v in os.environ['ASPIRE_BENCH_SHAPE'].split(','))
-    TOPK = min(TOPK, C)
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+    NC, S = (int(v) for v in os.environ['ASPIRE_BENCH_SHAPE'].split(','))
+    TOPK = min(TOPK, NC)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+L3_BYTES = 256 << 20
+MIN_TIMED_S = 0.05
 
 
-def algorithmic_bytes(q, c, s_q, s_c):
-    return 4 * D * (c * s_c + q * s_q) + 4 * q * c
+def algorithmic_bytes(n_jobs):
+    """every rep read once, every score written once -- per job 4*D*(NC*S + S) + 4*NC = 24 605 B x 1000."""
+    return n_jobs * (4 * D * (NC * S + S) + 4 * NC)
 
 
-def make_inputs(seed, device):
-    g = torch.Generator().manual_seed(seed)
-    query = torch.randn(Q * S, D, generator=g)
-    cands = torch.randn(C * S, D, generator=g)
-    return query.to(device), cands.to(device)
-
-
-def cpu_baseline(query, cands, budget_s=20.0):
-    """The oracle on this box's host cores, same workload, bounded wall time."""
+def cpu_baseline(query, cands, budget_s=18.0):
+    """The oracle on this box's host cores, same workload (one job's pairs), bounded wall time."""
     from oracle import aspire_oracle as orc
     ncpu = os.cpu_count() or 1
     q = query.cpu().view(S, D)
-    c = cands.cpu().view(C, S, D)
-    # The ops are 8x8: intra-op threading only adds dispatch cost.  Probe 1 thread and all cores on a few
-    # pairs and keep the faster setting (the reference never sets a thread count: torch's default is all).
-    best = None
+    c = cands.cpu().view(NC, S, D)
+    per = {}
     for nt in sorted({1, ncpu}):
         torch.set_num_threads(nt)
         orc.get_similarity(q, c[0])
         t0 = time.perf_counter()
-        for i in range(3):
-            orc.get_similarity(q, c[i])
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[1]:
-            best = (nt, dt)
-    cores = best[0]
-    torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    n = 0
-    while n < C and time.perf_counter() - t0 < budget_s:
-        orc.get_similarity(q, c[n])
-        n += 1
-    dt_pair = time.perf_counter() - t0
+        n = 0
+        while n < NC and time.perf_counter() - t0 < budget_s / 3:
+            orc.get_similarity(q, c[n])
+            n += 1
+        per[nt] = (n, time.perf_counter() - t0)
+    best = max(per, key=lambda nt: per[nt][0] / per[nt][1])
+    torch.set_num_threads(best)
     # the reference's other calling pattern: groups of 64 through caching_score (pp_gen_nearest.py:182)
     t0 = time.perf_counter()
     nb = 0
     qn = q.numpy()
-    while nb < C and time.perf_counter() - t0 < budget_s / 2:
-        orc.caching_score(qn, [c[i].numpy() for i in range(nb, min(C, nb + 64))])
-        nb = min(C, nb + 64)
+    while nb < NC and time.perf_counter() - t0 < budget_s / 3:
+        orc.caching_score(qn, [c[i].numpy() for i in range(nb, min(NC, nb + 64))])
+        nb = min(NC, nb + 64)
     dt_batch = time.perf_counter() - t0
+    n, dt = per[best]
     return {
-        'value': n / dt_pair, 'unit': 'alignments/s', 'cores': cores, 'kind': 'port',
-        'sample': f'{n} of the {C} pairs of the same workload, one pair per call (models.py:190-197 pattern), '
-                  f'{dt_pair:.1f} s; torch.set_num_threads({cores}) (faster of 1 and {ncpu} host threads)',
+        'value': n / dt, 'unit': 'alignments/s', 'cores': best, 'kind': 'port',
+        'sample': f'{n} of the {NC} pairs of one step, one pair per call (models.py:190-197 pattern), {dt:.1f} s, '
+                  f'torch.set_num_threads({best})',
+        'by_threads': {str(nt): per[nt][0] / per[nt][1] for nt in per},
+        'host_cores': ncpu,
         'batched64_value': nb / dt_batch,
-        'batched64_sample': f'{nb} pairs in caching_score groups of 64 (disent_models.py:256), {dt_batch:.1f} s',
+        'batched64_sample': f'{nb} pairs in caching_score groups of 64 (disent_models.py:256), {dt_batch:.1f} s, {best} threads',
         'note': 'oracle = PyTorch CPU port of the reference path; Sinkhorn = restated geomloss 0.2.4 (parity unpinned)',
     }
 
@@ -97,16 +99,12 @@ def cpu_baseline(query, cands, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=6000)   # ~70 ms timed: a 300-step region (3 ms) was at the mercy of host jitter
-    ap.add_argument('--warmup', type=int, default=60)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-    ap.add_argument('--graph-unroll', type=int, default=0,
-                    help='steps per captured graph (0 = pick a divisor of --steps near 64: a replay has a fixed host cost)')
-    ap.add_argument('--streams', type=int, default=0,
-                    help='lanes = HIP streams with their own graphs (0 = 15, 11, 7 or 3, whichever divides --steps)')
+    ap.add_argument('--repeats', type=int, default=0, help='repetitions of the K-step schedule (0 = enough for >= 50 ms)')
     ap.add_argument('--shard-path', action='store_true',
-                    help='run the N > 1 code path (key-form top-k, gather, merge kernel) on one GPU, for testing')
+                    help='run the N > 1 code path (key-form rank, gather, merge kernel) on one GPU, for testing')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -114,8 +112,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    assert args.steps >= 1
     # ASPIRE_BENCH_ONE_GPU=1 (testing only, invalid as a result): every rank on cuda:0 over gloo, so that the N > 1
-    # control flow (sharded indices, all-gather layout, merge, double-buffered exchange) can be exercised on a 1-GPU box
+    # control flow (sharded indices, all-gather layout, merge) can be exercised on a 1-GPU box
     one_gpu_test = os.environ.get('ASPIRE_BENCH_ONE_GPU') == '1'
     if one_gpu_test:
         local_rank = 0
@@ -134,219 +133,98 @@ def main():
     if world > 1:
         dist.barrier()
     from aspire_amd import _lib, ops
+    lib = _lib.lib
     shard_path = world > 1 or args.shard_path
+    K = args.steps
 
-    # ---- inputs resident in HBM (rank r owns global candidates [r*C, (r+1)*C)) ------------------
-    query, cands = make_inputs(0, device)
-    if rank > 0:
-        _, cands = make_inputs(rank, device)
-    ar = torch.arange(max(Q, C), device=device, dtype=torch.int32)
-    qset = ops.DeviceRepSet(query, (ar[:Q] * S).contiguous(), torch.full((Q,), S, device=device, dtype=torch.int32),
-                            ext=0, max_len=S)
-    cset = ops.DeviceRepSet(cands, (ar[:C] * S).contiguous(), torch.full((C,), S, device=device, dtype=torch.int32),
-                            ext=0, max_len=S)
-    qs, cs = qset.struct(), cset.struct()
+    # ---- the pool store, resident in HBM: M distinct (query, 1000-candidate pool) jobs; repetition r runs jobs
+    # [r*K, r*K + K) mod M.  Rank r of a sharded run owns block r of every job's pool. ----------------------------------
+    M = max(2 * K, 24)
+    while M * algorithmic_bytes(1) <= L3_BYTES or M % K:
+        M += 1
+    g = torch.Generator().manual_seed(1000 * rank)
+    queries = torch.randn(M * S, D, generator=torch.Generator().manual_seed(0)).to(device)      # replicated on every rank
+    cands = torch.empty(M * NC * S, D, device=device)
+    for j in range(M):                                                         # generated pool by pool: bounded host memory
+        cands[j * NC * S:(j + 1) * NC * S] = torch.randn(NC * S, D, generator=g).to(device)
+    ar = torch.arange(M * NC, device=device, dtype=torch.int32)
+    job_off = (torch.arange(K + 1, dtype=torch.int32) * NC).to(device)
+    job_base = torch.full((K,), rank * NC, dtype=torch.int32, device=device) if shard_path else None
     prm = _lib.OtParams(0.05, 0.9, 1.0, _lib.CDIST_AUTO)
     null = ctypes.c_void_p(0)
-    lib = _lib.lib
 
-    def stream():  # looked up per call: under graph capture torch's current stream is the capture stream
+    class JobSet:
+        """K consecutive jobs of the store as the two rep sets of one aspire_ot_rank_batch_f32 call."""
+
+        def __init__(self, first, n_jobs=K):
+            self.q = ops.DeviceRepSet(queries[first * S:(first + n_jobs) * S], (ar[:n_jobs] * S).contiguous(),
+                                      torch.full((n_jobs,), S, device=device, dtype=torch.int32), ext=0, max_len=S)
+            self.c = ops.DeviceRepSet(cands[first * NC * S:(first + n_jobs) * NC * S], (ar[:n_jobs * NC] * S).contiguous(),
+                                      torch.full((n_jobs * NC,), S, device=device, dtype=torch.int32), ext=0, max_len=S)
+            self.qs, self.cs = self.q.struct(), self.c.struct()
+            self.n = n_jobs
+
+    sets = [JobSet(f) for f in range(0, M, K)]
+    scores = torch.empty(K * NC, device=device, dtype=torch.float32)
+    top_s = torch.empty(K, TOPK, device=device, dtype=torch.float32)
+    top_i = torch.empty(K, TOPK, device=device, dtype=torch.int64)
+    keys = torch.empty(K, TOPK, device=device, dtype=torch.int64) if shard_path else None
+    gathered = torch.empty(world, K, TOPK, device=device, dtype=torch.int64) if shard_path else None
+    ws = torch.empty(lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(sets[0].qs), ctypes.byref(sets[0].cs), NC, TOPK),
+                     device=device, dtype=torch.uint8)
+    P = [ctypes.c_void_p(t.data_ptr()) if t is not None else null for t in (scores, top_s, top_i, keys, ws, job_off, job_base)]
+
+    def stream():
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    class Lane:
-        """Output buffers + workspace of one in-flight step.  Steps are independent (each scores the resident
-        pool for a query and ranks it), so consecutive steps may run on different HIP streams, each with its own
-        Lane; the reps stay shared and read-only."""
-
-        def __init__(self):
-            self.scores = torch.empty(Q, C, device=device, dtype=torch.float32)
-            self.top_s = torch.empty(Q, TOPK, device=device, dtype=torch.float32)
-            self.top_i = torch.empty(Q, TOPK, device=device, dtype=torch.int64)
-            self.ws = torch.empty(lib.aspire_ot_rank_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), TOPK),
-                                  device=device, dtype=torch.uint8)
-            self.p = [ctypes.c_void_p(t.data_ptr()) for t in (self.scores, self.top_s, self.top_i, self.ws)]
-
-        def score(self):
-            """The scoring pass alone (cost + Sinkhorn kernels), for the roofline's kernel duration."""
-            rc = lib.aspire_ot_sinkhorn_f32(ctypes.byref(qs), ctypes.byref(cs), D, _lib.PAIR_CROSS, ctypes.byref(prm),
-                                            null, 0, _lib.OT_SIMILARITY, self.p[0], null, null, null, null, self.p[3],
-                                            self.ws.numel(), stream())
+    def run_schedule(js):
+        """K steps = K jobs = ONE C-ABI call; sharded: + one all-gather of the K x k keys + one merge launch."""
+        rc = lib.aspire_ot_rank_batch_f32(ctypes.byref(js.qs), ctypes.byref(js.cs), D, P[5], NC, ctypes.byref(prm), _lib.OT_SIMILARITY,
+                                          P[0], TOPK, P[6], null if shard_path else P[1], null if shard_path else P[2], P[3], P[4],
+                                          ws.numel(), stream())
+        if rc:
+            _lib.check(rc)
+        if shard_path:
+            if world > 1:
+                dist.all_gather_into_tensor(gathered.view(-1), keys.view(-1))      # -> [world][K][k]
+                src = gathered
+            else:
+                src = keys
+            rc = lib.aspire_topk_merge_keys(ctypes.c_void_p(src.data_ptr()), world, K, TOPK, TOPK, P[1], P[2], stream())
             if rc:
                 _lib.check(rc)
 
-        def step(self, keys_out=None):
-            """One step = one query ranked against the resident pool: similarities (-OT distance, models.py:197) of
-            all candidates and their stable descending top-k, ONE C-ABI call (aspire_ot_rank_f32: cost kernel,
-            Sinkhorn kernel, rank kernel).  Sharded job: the rank is left in KEY form (global
-            candidate index inside the key) in `keys_out` for the exchange that follows."""
-            if os.environ.get('ASPIRE_BENCH_EXPERIMENT') == 'no-topk':     # tuning experiment only (invalid as a result)
-                return self.score()
-            ko = ctypes.c_void_p(keys_out.data_ptr()) if keys_out is not None else null
-            rc = lib.aspire_ot_rank_f32(ctypes.byref(qs), ctypes.byref(cs), D, ctypes.byref(prm), null, 0, _lib.OT_SIMILARITY,
-                                        self.p[0], TOPK, rank * C, null if keys_out is not None else self.p[1],
-                                        null if keys_out is not None else self.p[2], ko, self.p[3], self.ws.numel(), stream())
-            if rc:
-                _lib.check(rc)
-
-    # ---- the step loop is launch bound (three 5-9 us kernels per step), so steps are captured in hipGraphs; and a
-    # step is latency bound (1000 pairs are one round of workgroups), so independent steps run side by side: the K
-    # steps are dealt to NL lanes, every lane has its own HIP stream, buffers and a graph of PER consecutive steps,
-    # and the lanes' graphs replay concurrently (one step's Sinkhorn and rank kernels run beside another step's cost
-    # kernel).  Measured on MI355X / ROCm 7: 94 M alignments/s with 3 lanes, 105 with 7, 108 with 11, 110 with 15, but
-    # 73 with 4 and 89 with 8 -- lane counts of the form 4n + 3 spread over the four hardware queues best -- and the
-    # same number from run to run, which one graph with four branches did not give (78 or 100 M, depending on how
-    # the runtime mapped its branches; tools/mg_experiment.py, tools/benchdist.sh).
-    # Multi-GPU (SURVEY.md 8e): every rank ranks ITS block of the pool for each query; the only exchange is the
-    # per-query local top-k.  The NL * PER steps of one round of replays are independent queries, so their keys are
-    # exchanged together: ONE RCCL all-gather of NL * PER * Q * k keys per rank per round, then ONE merge kernel --
-    # the batch-of-queries form of the merge (config 5 ranks 128 queries per exchange).  The collective stays
-    # outside the captured graphs.
-    use_graph = not args.no_graph
-
-    def pick_lanes(k):
-        for nl in (15, 11, 7, 3):
-            if k % nl == 0 and k // nl >= 4:
-                return nl
-        return 7 if k >= 28 else 3 if k >= 6 else 1
-
-    NL = (max(1, args.streams) if args.streams > 0 else pick_lanes(args.steps)) if use_graph else 1
-    n_lane = [args.steps // NL + (1 if k < args.steps % NL else 0) for k in range(NL)]     # steps of each lane
-
-    def pick_per(n):
-        # a graph replay costs tens of microseconds on the host whatever its size: keep graphs at 20-64 steps
-        if args.graph_unroll > 0:
-            return max(1, min(args.graph_unroll, n))
-        cands = [d for d in range(1, min(n, 64) + 1) if n % d == 0 and d >= min(n, 20)]
-        return min(cands, key=lambda d: abs(d - 40)) if cands else max(1, min(40, n))
-
-    PER = pick_per(min(n_lane)) if use_graph else 1
-    lanes = [Lane() for _ in range(NL)]
-    lane_stream = [torch.cuda.Stream() for _ in range(NL)]
-    scores = lanes[0].scores
-    n_streams, unroll = NL, PER                       # names used in the report below
-    # two key buffers: round r's lanes write keybuf[r & 1] while round r-1's keys are exchanged and merged
-    keybuf2 = torch.zeros(2, NL, PER, Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
-    keybuf = keybuf2[0] if shard_path else None
-    gathered = torch.empty(world * NL * PER * Q * TOPK, device=device, dtype=torch.int64) if shard_path else None
-    merged_s = torch.empty(NL * PER * Q, TOPK, device=device, dtype=torch.float32) if shard_path else None
-    merged_i = torch.empty(NL * PER * Q, TOPK, device=device, dtype=torch.int64) if shard_path else None
-
-    def exchange(keys, n_steps):
-        """keys [n_steps, Q, k] (contiguous) of n_steps steps -> global top-k of each of them on every rank."""
-        n = n_steps * Q * TOPK
-        if world > 1:
-            dist.all_gather_into_tensor(gathered[:world * n], keys.view(-1)[:n])     # -> [world][n_steps][Q][k]
-            src = gathered
-        else:
-            src = keys
-        rc = lib.aspire_topk_merge_keys(ctypes.c_void_p(src.data_ptr()), world, n_steps * Q, TOPK, TOPK,
-                                        ctypes.c_void_p(merged_s.data_ptr()), ctypes.c_void_p(merged_i.data_ptr()), stream())
+    def run_stage(js, stages):
+        rc = lib.aspire_debug_ot_rank_batch_stages_f32(ctypes.byref(js.qs), ctypes.byref(js.cs), D, P[5], NC, ctypes.byref(prm),
+                                                       _lib.OT_SIMILARITY, P[0], TOPK, P[1], P[2], P[4], ws.numel(), stream(), stages)
         if rc:
             _lib.check(rc)
 
-    def capture_lane(k, n, keys=None):
-        """n consecutive steps of lane k, captured on the lane's own stream."""
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=lane_stream[k]):
-            for i in range(n):
-                lanes[k].step(keys[i] if keys is not None else None)
-        return g
+    # ---- W untimed warm-up steps, then a calibration pass that sizes R ----------------------------------------------
+    for r in range(max(1, -(-args.warmup // K))):
+        run_schedule(sets[r % len(sets)])
+    torch.cuda.synchronize()
+    if args.repeats > 0:
+        R = args.repeats
+    else:
+        t0 = time.perf_counter()
+        n_cal = 8
+        for r in range(n_cal):
+            run_schedule(sets[r % len(sets)])
+        torch.cuda.synchronize()
+        per_call = (time.perf_counter() - t0) / n_cal
+        R = max(4, int(1.3 * MIN_TIMED_S / per_call) + 1)
+        if world > 1:
+            t = torch.tensor([R], device=device, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            R = int(t.item())
 
-    # ---- graphs: a PER-step graph per lane, plus a tail graph where a lane's share is not a multiple of PER --------
-    full = [n // PER for n in n_lane]
-    rem = [n % PER for n in n_lane]
-    g_lane = g_tail = None
-    keytail = None
-    if use_graph:
-        g_lane = [capture_lane(k, PER, keybuf[k] if shard_path else None) for k in range(NL)]
-        g_lane_b = [g_lane, [capture_lane(k, PER, keybuf2[1, k]) for k in range(NL)]] if shard_path else None
-        if shard_path and any(rem):
-            keytail = torch.zeros(NL, max(rem), Q, TOPK, device=device, dtype=torch.int64)
-        g_tail = [capture_lane(k, rem[k], keytail[k] if shard_path else None) if rem[k] else None for k in range(NL)]
-
-    def run_steps(which):
-        """Enqueue this rank's K steps (which = lanes to use: all of them, or [0] for the serial reference)."""
-        main = torch.cuda.current_stream()
-        if not use_graph:
-            kb = keybuf[0, 0] if shard_path else None
-            for _ in range(args.steps):
-                lanes[0].step(kb)
-                if shard_path:
-                    exchange(keybuf[0, :1], 1)
-            return
-        if which == [0] and NL > 1:                 # serial reference: every step on lane 0, one after the other
-            ser = serial_graphs
-            for _ in range(args.steps // PER):
-                ser[0].replay()
-            if ser[1] is not None:
-                ser[1].replay()
-            return
-        for st in lane_stream:
-            st.wait_stream(main)
-        if not shard_path:
-            for r in range(max(full)):
-                for k in range(NL):
-                    if r < full[k]:
-                        with torch.cuda.stream(lane_stream[k]):
-                            g_lane[k].replay()
-            for k in range(NL):
-                if g_tail[k] is not None:
-                    with torch.cuda.stream(lane_stream[k]):
-                        g_tail[k].replay()
-        else:
-            # rounds: every lane replays once, then the round's keys are exchanged (one all-gather) and merged on the
-            # main stream -- while the lanes already run the next round into the other key buffer.  A lane waits only
-            # for the exchange that last read the buffer it is about to overwrite (two rounds back).
-            ev_ex = [None, None]
-            for r in range(min(full)):
-                b = r & 1
-                ev_lane = []
-                for k in range(NL):
-                    with torch.cuda.stream(lane_stream[k]):
-                        if ev_ex[b] is not None:
-                            lane_stream[k].wait_event(ev_ex[b])
-                        g_lane_b[b][k].replay()
-                        e = torch.cuda.Event()
-                        e.record(lane_stream[k])
-                        ev_lane.append(e)
-                for e in ev_lane:
-                    main.wait_event(e)
-                exchange(keybuf2[b], NL * PER)
-                ev_ex[b] = torch.cuda.Event()
-                ev_ex[b].record(main)
-            for st in lane_stream:
-                st.wait_stream(main)                # the tail below reuses buffer 0
-            for k in range(NL):                      # a lane whose share holds one more whole graph (PER = 1 only)
-                if full[k] > min(full):
-                    with torch.cuda.stream(lane_stream[k]):
-                        g_lane[k].replay()
-                    main.wait_stream(lane_stream[k])
-                    exchange(keybuf[k], PER)
-                    lane_stream[k].wait_stream(main)
-            if any(rem):
-                m = min(rem)
-                for k in range(NL):
-                    if g_tail[k] is not None:
-                        with torch.cuda.stream(lane_stream[k]):
-                            g_tail[k].replay()
-                for st in lane_stream:
-                    main.wait_stream(st)
-                if m > 0:
-                    exchange(keytail[:, :m].contiguous(), NL * m)
-                for k in range(NL):                  # lanes that carry one step more: its keys go alone
-                    if rem[k] > m:
-                        exchange(keytail[k, m:m + 1], 1)
-        for st in lane_stream:
-            main.wait_stream(st)
-
-    serial_graphs = None
-
-    def timed(which):
+    def timed(fn):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(which)
+        fn()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -357,137 +235,113 @@ def main():
             el = t.item()
         return el
 
-    for _ in range(max(args.warmup // NL, 1)):       # W untimed warm-up steps, spread over the lanes
-        for k in range(NL):
-            with torch.cuda.stream(lane_stream[k]):
-                lanes[k].step(keybuf[k, 0] if shard_path else None)
+    def all_reps():
+        for r in range(R):
+            run_schedule(sets[r % len(sets)])
+
+    elapsed = min(timed(all_reps) for _ in range(1))      # EXACTLY K steps x R repetitions, timed once
+
+    # ---- checks on the last repetition's outputs -------------------------------------------------------------------
     torch.cuda.synchronize()
-    if shard_path:
-        exchange(keybuf, NL * PER)
-        torch.cuda.synchronize()
-    if use_graph and world == 1:
-        # untimed: let clocks and caches settle on the captured graphs themselves (~0.25 s), beyond the W warm-up steps
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 0.25:
-            for k in range(NL):
-                with torch.cuda.stream(lane_stream[k]):
-                    g_lane[k].replay()
-            torch.cuda.synchronize()
-    elapsed = timed(list(range(NL)))
-    if shard_path:
-        # the merged ranking of the last exchanged step must be a valid descending ranking of global indices
-        torch.cuda.synchronize()
-        assert (merged_i[0] >= 0).all() and (merged_i[0] < world * C).all(), 'merge produced out-of-range indices'
-        assert (merged_s[0, 1:] <= merged_s[0, :-1]).all(), 'merge output is not descending'
-        if world > 1:
-            # every rank merged the same gathered keys: identical rankings, drawn from more than one shard
-            mine = merged_i[0].clone()
-            everyone = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(everyone, mine)
-            assert all(torch.equal(everyone[0], e) for e in everyone), 'ranks disagree on the merged ranking'
-            assert len(torch.unique(mine // C)) > 1, 'merged ranking holds candidates of one shard only'
-        if world == 1:
-            # one shard: the merged ranking IS the shard's own stable descending ranking of the step's scores
-            ref_s, ref_i = torch.sort(lanes[0].scores[0], descending=True, stable=True)
-            assert torch.equal(merged_i[0], ref_i[:TOPK]) and torch.equal(merged_s[0], ref_s[:TOPK]), 'merged ranking differs'
-    # the same K steps strictly one after the other on ONE stream, for reference
-    serial_elapsed = None
-    if use_graph and NL > 1 and not shard_path:
-        tail_n = args.steps % PER
-        serial_graphs = (capture_lane(0, PER), capture_lane(0, tail_n) if tail_n else None)
-        with torch.cuda.stream(lane_stream[0]):
-            serial_graphs[0].replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.cuda.stream(lane_stream[0]):
-            run_steps([0])
-        torch.cuda.synchronize()
-        serial_elapsed = time.perf_counter() - t0
+    assert torch.isfinite(scores).all(), 'non-finite scores'
+    assert (top_i >= 0).all() and (top_i < world * NC).all(), 'rank produced out-of-range indices'
+    assert (top_s[:, 1:] <= top_s[:, :-1]).all(), 'rank output is not descending'
+    if not shard_path:
+        ref_s, ref_i = torch.sort(scores.view(K, NC), dim=1, descending=True, stable=True)
+        assert torch.equal(top_i, ref_i[:, :TOPK]) and torch.equal(top_s, ref_s[:, :TOPK]), 'rank differs from the stable sort'
+    elif world > 1:
+        mine = top_i.clone()
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        assert all(torch.equal(everyone[0], e) for e in everyone), 'ranks disagree on the merged ranking'
+        assert len(torch.unique(mine // NC)) > 1, 'merged ranking holds candidates of one shard only'
+    else:
+        ref_s, ref_i = torch.sort(scores.view(K, NC), dim=1, descending=True, stable=True)
+        assert torch.equal(top_i, ref_i[:, :TOPK]) and torch.equal(top_s, ref_s[:, :TOPK]), 'merged ranking differs'
 
-    def capture(fn, n):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(n):
-                fn()
-        return g
-
-    score = lanes[0].score
-
-    # ---- dominant kernel duration, live: HIP events (torch's current stream = the launch stream) around
-    # replays of a graph holding ONLY ot_kernel launches, so host launch latency is not in the bracket.
-    kern_ms = None
+    out = None
     if rank == 0:
-        n_k = 20
-        g_k = capture(score, n_k) if not args.no_graph else None
-        reps = 10
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in evs:
-            a.record()
-            if g_k is not None:
-                g_k.replay()
-            else:
-                for _ in range(n_k):
-                    score()
-            b.record()
-        torch.cuda.synchronize()
-        kern_ms = min(a.elapsed_time(b) for a, b in evs) / n_k
-        # ... and of the dominant kernel alone: the library launches only its cost stage under ASPIRE_HIP_STAGE=cost
-        os.environ['ASPIRE_HIP_STAGE'] = 'cost'
-        try:
-            g_c = capture(score, n_k) if not args.no_graph else None
-            for a, b in evs:
+        # ---- per-stage kernel durations, live: HIP events on the launch stream around launches of ONE stage alone, on the
+        # rotating pools (cold) -- the workspace of a full call holds what the later stages read ------------------------
+        def stage_ms(stages, jsets, n=24):
+            run_schedule(jsets[0])
+            torch.cuda.synchronize()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for i, (a, b) in enumerate(evs):
+                js = jsets[i % len(jsets)]
+                run_stage(js, 1 if stages == 2 else 3)      # this job set's tables and query boxes (+ its costs, for the later stages)
                 a.record()
-                if g_c is not None:
-                    g_c.replay()
-                else:
-                    for _ in range(n_k):
-                        score()
+                run_stage(js, stages)
                 b.record()
             torch.cuda.synchronize()
-            cost_ms = min(a.elapsed_time(b) for a, b in evs) / n_k
-        finally:
-            del os.environ['ASPIRE_HIP_STAGE']
-        score()
-        torch.cuda.synchronize()
-    assert torch.isfinite(scores).all(), 'non-finite scores'
+            t = sorted(a.elapsed_time(b) for a, b in evs)
+            return sum(t[:n // 2]) / (n // 2)       # mean of the faster half: launch gaps of a cold queue out of the bracket
 
-    if rank == 0:
-        bytes_per_launch = algorithmic_bytes(Q, C, S, S)
+        cost_ms = stage_ms(2, sets)
+        solve_ms = stage_ms(4, sets)
+        rank_ms = stage_ms(8, sets)
+        # Infinity-Cache-resident variant: ONE small job set (<= 8 jobs, < 200 MB) scored again and again
+        n_l3 = min(K, 8)
+        l3 = JobSet(0, n_l3)
+        job_off_l3 = (torch.arange(n_l3 + 1, dtype=torch.int32) * NC).to(device)
+
+        def cost_l3():
+            rc = lib.aspire_debug_ot_rank_batch_stages_f32(ctypes.byref(l3.qs), ctypes.byref(l3.cs), D, ctypes.c_void_p(job_off_l3.data_ptr()),
+                                                           NC, ctypes.byref(prm), _lib.OT_SIMILARITY, P[0], 0, null, null, P[4],
+                                                           ws.numel(), stream(), 3 if i_l3[0] == 0 else 2)
+            i_l3[0] += 1
+            if rc:
+                _lib.check(rc)
+        i_l3 = [0]
+        for _ in range(4):
+            cost_l3()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(24)]
+        for a, b in evs:
+            a.record()
+            cost_l3()
+            b.record()
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in evs)
+        cost_l3_ms = sum(t[:12]) / 12
+
+        bytes_per_launch = algorithmic_bytes(K)
         achieved = bytes_per_launch / (cost_ms * 1e-3) / 1e9
-        traffic, breakdown = None, None
+        step_achieved = bytes_per_launch * R / elapsed / 1e9
+        traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic = tj.get('cost_kernel_hbm_bytes_per_launch', tj.get('hbm_bytes_per_launch'))
-            breakdown = tj.get("breakdown")
+            if tj.get('jobs_per_launch') == K:
+                traffic = tj.get('cost_kernel_hbm_bytes_per_launch')
         out = {
-            'metric': 'query x candidate OT alignments/sec', 'value': world * Q * C * args.steps / elapsed,
-            'unit': 'alignments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'metric': 'query x candidate OT alignments/sec', 'value': world * K * R * NC / elapsed,
+            'unit': 'alignments/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'repeats': R,
+            'ms_per_step': elapsed / (K * R) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'serial_value': (world * Q * C * args.steps / serial_elapsed) if serial_elapsed else None,
-            'config': {'workload': f'otAspire compsci: {Q} query x {C} candidates per GPU, {S} sents x {D}d, '
-                                   f'Sinkhorn OT (blur 0.05, scaling 0.9, one eps schedule per pair) + per-query '
-                                   f'top-{TOPK} rank' + (f', one RCCL all-gather of the top-{TOPK} keys of {n_streams * unroll} queries '
-                                                         f'per round + merge kernel' if shard_path else ''),
-                       'queries': Q, 'candidates_per_gpu': C, 'sents': S, 'dim': D, 'topk': TOPK,
+            'timed_region_ms': elapsed * 1e3,
+            'config': {'workload': f'otAspire compsci: 1 query x {NC} candidates per step (per GPU), {S} sents x {D}d, Sinkhorn OT '
+                                   f'(blur 0.05, scaling 0.9, one eps schedule per pair) + stable top-{TOPK} rank; every step its own '
+                                   f'query and its own pool, {M} distinct pools ({M * algorithmic_bytes(1) / 2**20:.0f} MiB > 256 MiB L3) '
+                                   f'walked by consecutive repetitions'
+                                   + (f'; sharded: one RCCL all-gather of {K} x {TOPK} keys per call + merge kernel' if shard_path else ''),
+                       'queries_per_step': 1, 'candidates_per_gpu_per_step': NC, 'sents': S, 'dim': D, 'topk': TOPK,
                        'parallelism': f'candidate-pool shards x{world}',
-                       'launch': (f'{n_streams} lanes (HIP streams) x hipGraphs of {unroll} steps replayed concurrently, '
-                                  f'independent steps dealt to the lanes') if use_graph else 'eager, 1 stream'},
-            # Dominant kernel of a step: the cost kernel streams every rep once (the HBM side of the step); its duration is
-            # measured live above (HIP events around a graph of cost-stage-only launches) and agrees with rocprofv3's
-            # average in profiles/.  The Sinkhorn kernel that follows it solves from the 0.5 MB cost buffer (dependent-
-            # chain latency bound); `scoring_pass` prices BOTH durations against the same algorithmic bytes.
+                       'launch': f'the {K} steps of a schedule = {K} independent (query, pool) jobs in ONE aspire_ot_rank_batch_f32 call on '
+                                 f'one caller stream (eager, no hipGraph); schedule repeated {R}x back to back for a >= 50 ms timed region'},
+            # Dominant kernel of a step: the cost kernel streams every rep once (the HBM side of the step).
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'pair_cost1_kernel', 'kernel_ms': cost_ms, 'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'scoring_pass': {'kernels': 'pair_cost1_kernel + sinkhorn_kernel<1>', 'kernel_ms': kern_ms,
-                                          'achieved': bytes_per_launch / (kern_ms * 1e-3) / 1e9,
-                                          'frac': bytes_per_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         'breakdown': breakdown},
+                         'kernel': 'pair_tile_kernel<2,1>' if K * NC >= 6000 else 'pair_cost1_kernel', 'kernel_ms': cost_ms,
+                         'algorithmic_bytes_per_launch': bytes_per_launch, 'jobs_per_launch': K, 'data': 'cold (rotating pools, > L3)',
+                         'l3_resident_frac': algorithmic_bytes(n_l3) / (cost_l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'l3_resident': {'jobs': n_l3, 'kernel_ms': cost_l3_ms, 'bytes': algorithmic_bytes(n_l3)},
+                         'stages_ms': {'cost': cost_ms, 'sinkhorn': solve_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3},
+                         'step': {'what': 'all kernels of a schedule (timed region) against the same algorithmic bytes',
+                                  'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(query, cands)
+            out['cpu_baseline'] = cpu_baseline(queries[:S], cands[:NC * S])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -247,8 +247,11 @@ int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D
  *   job_off    DEVICE int32 [J + 1], non-decreasing, job_off[0] == 0, job_off[J] == C
  *   max_job    host-known upper bound of a job's candidate count (launch geometry only)
  *   scores     [C] out: candidate p against its job's query, as aspire_ot_sinkhorn_f32 would give it (`want`)
- *   k          0: scores only; else top_scores [J, k], top_idx [J, k] out: per job, index = position in the job's pool,
- *              (-inf, -1) beyond the pool's size
+ *   k          0: scores only; else top_scores [J, k], top_idx [J, k] out: per job, index = job_base[j] + position in
+ *              the job's pool, (-inf, -1) beyond the pool's size; or keys [J, k] (non-NULL: instead of top_scores /
+ *              top_idx) in the sortable key form of aspire_topk_keys_f32, for the shard exchange of section 8(e)
+ *   job_base   DEVICE int32 [J] or NULL (= 0): global index of the job's first candidate when this rank holds one
+ *              contiguous block of every job's pool
  *   workspace  16-byte aligned, aspire_ot_rank_batch_workspace_bytes(q, c, max_job, k) bytes
  * Results equal J separate aspire_ot_rank_f32 calls up to the kernel form the grid size selects (bit for bit when the
  * forms are pinned to the same ones, see aspire_debug_set).
@@ -256,7 +259,8 @@ int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D
 size_t aspire_ot_rank_batch_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t max_job, int64_t k);
 int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,
                              int64_t max_job, const aspire_ot_params* prm, int want, float* scores, int64_t k,
-                             float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes, void* stream);
+                             const int32_t* job_base, float* top_scores, int64_t* top_idx, uint64_t* keys, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SURVEY.md 8(e)  shard merge.  The same rank in KEY form for the candidate-pool shards of a multi-GPU job:

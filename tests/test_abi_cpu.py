@@ -88,12 +88,12 @@ def test_batch_entry_validation_without_gpu():
     assert need >= 30 * 516 and need % 16 == 0
     # null job_off / workspace too small / padded rep sets are argument errors, not crashes
     args = lambda job_off, ws, nbytes: _lib.lib.aspire_ot_rank_batch_f32(
-        ctypes.byref(q), ctypes.byref(c), 768, job_off, 20, ctypes.byref(prm), _lib.OT_SIMILARITY, 16, 10, 16, 16, ws, nbytes, None)
+        ctypes.byref(q), ctypes.byref(c), 768, job_off, 20, ctypes.byref(prm), _lib.OT_SIMILARITY, 16, 10, None, 16, 16, None, ws, nbytes, None)
     assert args(None, 16, need) == _lib.ASPIRE_ERR_INVALID_ARG
     assert args(16, 16, need - 16) == _lib.ASPIRE_ERR_INVALID_ARG
     qp = _lib.RepSet(0, 0, 0, 2, 8, 8)
     assert _lib.lib.aspire_ot_rank_batch_f32(ctypes.byref(qp), ctypes.byref(c), 768, 16, 20, ctypes.byref(prm), _lib.OT_SIMILARITY,
-                                             16, 10, 16, 16, 16, need, None) == _lib.ASPIRE_ERR_INVALID_ARG
+                                             16, 10, None, 16, 16, None, 16, need, None) == _lib.ASPIRE_ERR_INVALID_ARG
     # the OT workspace is a multiple of 16 bytes (the 64-bit rank scratch sits right behind it)
     for qn, cn in ((1, 4097), (3, 4099), (1, 7)):
         q1, c1 = _lib.RepSet(0, 0, 0, qn, 0, 8), _lib.RepSet(0, 0, 0, cn, 0, 8)
