@@ -1,0 +1,90 @@
+"""Per-stage and end-to-end timings of aspire_ot_rank_batch_f32 for a few (jobs, pool size) shapes and chunk counts.
+  python tools/batchbench.py [J,NC,S ...]
+Prints one line per configuration: stage durations (HIP events, stage alone on one stream, rotating cold pools), the
+call's end-to-end time for BATCH_CHUNKS = 1, 2, 4, 8 (back-to-back calls on one stream) and the host time per call."""
+import ctypes
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aspire_amd import _lib, ops  # noqa: E402
+
+lib = _lib.lib
+D = 768
+
+
+def bench(J, NC, S, k=100):
+    dev = torch.device('cuda')
+    nsets = max(2, -(-600_000_000 // (J * NC * S * D * 4)))
+    nsets = min(nsets, 12)
+    g = torch.Generator().manual_seed(0)
+    sets = []
+    ar = torch.arange(J * NC, device=dev, dtype=torch.int32)
+    for _ in range(nsets):
+        qrows = torch.randn(J * S, D, generator=g).to(dev)
+        crows = torch.randn(J * NC * S, D, device=dev)
+        q = ops.DeviceRepSet(qrows, (ar[:J] * S).contiguous(), torch.full((J,), S, device=dev, dtype=torch.int32), 0, S)
+        c = ops.DeviceRepSet(crows, (ar * S).contiguous(), torch.full((J * NC,), S, device=dev, dtype=torch.int32), 0, S)
+        sets.append((q, c, q.struct(), c.struct()))
+    job_off = (torch.arange(J + 1, dtype=torch.int32) * NC).to(dev)
+    prm = _lib.OtParams(0.05, 0.9, 1.0, 0)
+    scores = torch.empty(J * NC, device=dev)
+    ts = torch.empty(J, k, device=dev)
+    ti = torch.empty(J, k, device=dev, dtype=torch.int64)
+    ws = torch.empty(lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(sets[0][2]), ctypes.byref(sets[0][3]), NC, k),
+                     device=dev, dtype=torch.uint8)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def full(i):
+        _, _, qs, cs = sets[i % nsets]
+        _lib.check(lib.aspire_ot_rank_batch_f32(ctypes.byref(qs), ctypes.byref(cs), D, p(job_off), NC, ctypes.byref(prm), 2, p(scores), k,
+                                                None, p(ts), p(ti), None, p(ws), ws.numel(), st()))
+
+    def stage(i, m):
+        _, _, qs, cs = sets[i % nsets]
+        _lib.check(lib.aspire_debug_ot_rank_batch_stages_f32(ctypes.byref(qs), ctypes.byref(cs), D, p(job_off), NC, ctypes.byref(prm), 2,
+                                                             p(scores), k, p(ts), p(ti), p(ws), ws.numel(), st(), m))
+
+    def ev_time(m, n=20):
+        full(0)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for i, (a, b) in enumerate(evs):
+            stage(i, 1 if m == 2 else 3)
+            a.record()
+            stage(i, m)
+            b.record()
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in evs)
+        return 1e3 * sum(t[:n // 2]) / (n // 2)
+
+    out = {'prep': ev_time(1), 'cost': ev_time(2), 'solve': ev_time(4), 'rank': ev_time(8)}
+    bytes_ = J * NC * (S * D * 4) + J * S * D * 4
+    out['cost_TBs'] = bytes_ / out['cost'] / 1e6
+    e2e = {}
+    for chunks in (1, 2, 4, 8):
+        with _lib.pinned(BATCH_CHUNKS=chunks):
+            for i in range(4):
+                full(i)
+            torch.cuda.synchronize()
+            n = 40
+            t0 = time.perf_counter()
+            for i in range(n):
+                full(i)
+            t_host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            e2e[chunks] = (1e6 * (time.perf_counter() - t0) / n, 1e6 * t_host / n)
+    print(f'J={J} NC={NC} S={S}: ' + ' '.join(f'{k_}={v:.1f}us' for k_, v in out.items() if k_ != 'cost_TBs') +
+          f' cost={out["cost_TBs"]:.2f}TB/s | e2e(us)/host(us): ' +
+          ' '.join(f'ch{c}={a:.0f}/{h:.0f}' for c, (a, h) in e2e.items()) +
+          f' | best {J * NC / min(a for a, _ in e2e.values()):.0f} M pairs/s', flush=True)
+
+
+if __name__ == '__main__':
+    shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(20, 1000, 8), (8, 1000, 8), (40, 1000, 8), (100, 1000, 8), (20, 1000, 12), (50, 125, 8)]
+    for s in shapes:
+        bench(*s)
