@@ -1,0 +1,494 @@
+// otAspire throughput kernel: pairwise sentence costs AND the Sinkhorn solve of a pair in ONE launch, nothing handed over
+// through HBM (A5-A8; reference arithmetic: src/learning/facetid_models/pair_distances.py:21-92 + geomloss 0.2.4's
+// sinkhorn_tensorized, restated -- see score.hip).
+//
+// Why fused.  For few queries per candidate the cost stage is HBM bound (24.6 KB of candidate rows per pair, 98 K flop)
+// and the Sinkhorn stage is VALU / transcendental bound (~80 epsilon steps on an 8 x 8 problem).  As two kernels they
+// run one after the other (1 x 20 000: 110 + 50 us), and running them side by side on two streams costs more in
+// cross-stream waits than it hides (measured: 20 jobs x 1000 candidates 169 us on one stream, 213 / 266 / 403 us in 2 / 4 /
+// 8 chunks over two streams).  Here a wave that has finished the costs of its four candidates solves those four pairs at
+// once from its own registers while the other resident waves keep the memory system busy: the solve costs issue slots the
+// streaming phase leaves idle, and the 516 B / pair workspace round trip disappears.
+//
+// Work decomposition (gfx950, wave = 64 lanes), documents of <= 8 sentence rows, CSR inputs:
+//   * item = four consecutive candidates of ONE query (groups never straddle two jobs of a batch); a wave owns an item.
+//     Items are claimed dynamically (one atomic per item) so that all waves finish together: with a static stride a batch of
+//     5000 items on 2048 resident waves runs three rounds for 2.44 rounds of work.
+//   * cost phase = pair_tile_kernel<2,1> of score.hip: 16 lanes per candidate, lane (li, lj) owns the 2 x 2 entries
+//     (2 li + x, 2 lj + y) and walks all 768 coordinates itself; rows are staged 64 coordinates at a time (coalesced
+//     global_load_dwordx4 -> ds_write_b128 -> conflict-free broadcast ds_read_b128), next stage's loads in flight under
+//     this stage's arithmetic; row norms and the bounding-box term (geomloss's diameter) fall out of the staging.
+//   * solve phase: the same 16 lanes x (2 x 2) layout IS a Sinkhorn layout: row sums are two quad_perm DPP adds, column sums
+//     two row_ror DPP adds, both inside a DPP row of 16 lanes; four solves per wave, every pair on its own epsilon schedule
+//     (the loop runs to the longest of the four, finished pairs idle with h = 0).  One exponential per entry and step,
+//     K_ij = 2^((f_i + g_j - C_ij) log2e / eps), weights as plain factors, f_i -= h log2(sum_j b_j K_ij) (see
+//     sinkhorn_block_kernel in score.hip for the derivation).  A sum that leaves fp32 range (extreme scaling) is caught by
+//     one finiteness test at the end and the pair is solved again with max-shifted log-sum-exps.
+#include <math.h>
+
+#include "common.h"
+#include "score_device.h"
+#include "score_types.h"
+
+namespace aspire {
+namespace {
+
+constexpr int kCh = 16;                                  // 16-byte chunks per row per stage (64 coordinates)
+constexpr int kStages = kD / (4 * kCh);                  // 12
+constexpr int kRowStride = 4 * kCh + 4;                  // floats; (kRowStride / 4) odd -> rows land on distinct bank slots
+constexpr int kRows = 8 + 8 * 4;                         // staged rows: 8 query + 8 per candidate
+constexpr int kNormLd = 68;
+constexpr int kWaveLds = kRows * kRowStride + 16 * kNormLd;   // floats per wave (15.2 KB)
+
+__device__ __forceinline__ float sum_lj(float v) {       // all-reduce over the 4 lanes that share li (lane bits 0, 1)
+    v += lane_xor<1>(v);
+    return v + lane_xor<2>(v);
+}
+__device__ __forceinline__ float sum_li(float v) {       // all-reduce over the 4 lanes that share lj (lane bits 2, 3)
+    v += dpp_mov<0x124>(v, v);                           // row_ror:4
+    return v + dpp_mov<0x128>(v, v);                     // row_ror:8
+}
+__device__ __forceinline__ float max_lj(float v) {
+    v = fmaxf(v, lane_xor<1>(v));
+    return fmaxf(v, lane_xor<2>(v));
+}
+__device__ __forceinline__ float max_li(float v) {
+    v = fmaxf(v, dpp_mov<0x124>(v, v));
+    return fmaxf(v, dpp_mov<0x128>(v, v));
+}
+__device__ __forceinline__ float sum16(float v) { return sum_li(sum_lj(v)); }
+
+// The solve of the four pairs of a wave.  cost / neg: this lane's 2 x 2 entries of geomloss's cost and of -cdist; rv / cv:
+// row / column validity; diam: the pair's bounding-box diameter (uniform over its 16 lanes).  Returns the score (`want`).
+__device__ __forceinline__ float solve_pairs(const ScoreArgs& a, const float (&cost)[2][2], const float (&neg)[2][2],
+                                             const bool (&rv)[2], const bool (&cv)[2], float diam) {
+    // ---- marginals (pair_distances.py:57-60): soft-max over sentences of the best match / temp --------------------
+    const float temp = (float)a.temp;
+    float wa[2], wb[2];
+    {
+        float qm[2], cm[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+            qm[x] = max_lj(fmaxf((rv[x] && cv[0]) ? neg[x][0] : kNegBig, (rv[x] && cv[1]) ? neg[x][1] : kNegBig)) / temp;
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+            cm[y] = max_li(fmaxf((rv[0] && cv[y]) ? neg[0][y] : kNegBig, (rv[1] && cv[y]) ? neg[1][y] : kNegBig)) / temp;
+        const float mq = max_li(fmaxf(rv[0] ? qm[0] : kNegBig, rv[1] ? qm[1] : kNegBig));
+        const float mc = max_lj(fmaxf(cv[0] ? cm[0] : kNegBig, cv[1] ? cm[1] : kNegBig));
+        const float sq = (rv[0] ? fast_exp(qm[0] - mq) : 0.f) + (rv[1] ? fast_exp(qm[1] - mq) : 0.f);
+        const float sc = (cv[0] ? fast_exp(cm[0] - mc) : 0.f) + (cv[1] ? fast_exp(cm[1] - mc) : 0.f);
+        const float lsq = fast_log(sum_li(sq)), lsc = fast_log(sum_lj(sc));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;      // log_softmax(...).exp(); a zero weight is geomloss's
+            wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;      // log-weight -100000
+        }
+    }
+    // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = diam scaling^(k-1), n_mid+1 = blur, n_mid+2 = blur (final) ----
+    float ldf;
+    const int n_mid = schedule_mid_steps(a, diam, ldf);
+    const float lscf = a.log2_scaling;
+    const int n_steps = n_mid + 3;
+    int max_steps = n_steps;
+    max_steps = max(max_steps, __shfl_xor(max_steps, 16));
+    max_steps = max(max_steps, __shfl_xor(max_steps, 32));
+    max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+    const float c_r2 = 0.5287663729448977f - ldf;      // log2(log2 e) - log2(diam):  r2_k = exp2(c_r2 - (k-1) lscf)
+    const float c_h = -1.5287663729448977f + ldf;      // log2(ln2 / 2) + log2(diam): h_k  = exp2(c_h  + (k-1) lscf)
+    const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
+    const float eb = (float)a.blur;
+    const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
+    float mc_[2][2];           // masked cost: entries outside the valid block never enter a sum (their weights are 0)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) mc_[x][y] = (rv[x] && cv[y]) ? cost[x][y] : 0.f;
+
+    // ---- initialisation at eps = diam: softmin of the bare weights (no shift needed: the largest weight of a
+    // probability vector over <= 8 atoms is >= 1/8 and C / diam <= ~1) ---------------------------------------------
+    float f[2], g[2];
+    {
+        float rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const float k0 = __builtin_amdgcn_exp2f(-mc_[x][y] * r2_first);
+                rs[x] = fmaf(wb[y], k0, rs[x]);
+                cs[y] = fmaf(wa[x], k0, cs[y]);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_lj(rs[t]));
+            g[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_li(cs[t]));
+        }
+    }
+    // ---- the annealing loop -----------------------------------------------------------------------------------------
+    for (int k = 0; k < max_steps; ++k) {
+        const float kf = (float)(k - 1);
+        float r2 = __builtin_amdgcn_exp2f(fmaf(-kf, lscf, c_r2));
+        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, c_h));
+        if (k == 0) { r2 = r2_first; h = h_first; }
+        if (k > n_mid) { r2 = r2_blur; h = k == n_mid + 1 ? h_blur : (k == n_mid + 2 ? 2.f * h_blur : 0.f); }
+        float f2[2], g2[2], rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f2[t] = f[t] * r2;
+            g2[t] = g[t] * r2;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const float kxy = __builtin_amdgcn_exp2f(fmaf(-mc_[x][y], r2, f2[x] + g2[y]));
+                rs[x] = fmaf(wb[y], kxy, rs[x]);
+                cs[y] = fmaf(wa[x], kxy, cs[y]);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f[t] = fmaf(-h, __builtin_amdgcn_logf(sum_lj(rs[t])), f[t]);
+            g[t] = fmaf(-h, __builtin_amdgcn_logf(sum_li(cs[t])), g[t]);
+        }
+    }
+    const int lp = threadIdx.x & 15, li = lp >> 2, lj = lp & 3;
+    auto outputs = [&]() {
+        float score;
+        if (a.want != ASPIRE_OT_PLAN_SIM) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
+                acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
+            }
+            score = sum16(acc);
+            if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
+        } else {
+            const float rb = rcp_refined(eb);
+            float acc = 0.f;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const bool valid = rv[x] && cv[y];
+                    const float negm = valid ? neg[x][y] : 0.f;
+                    const float outer = valid ? f[x] + g[y] : 0.f;
+                    acc += fast_exp(div_r(outer + negm, eb, rb)) * (wa[x] * wb[y]) * negm;
+                }
+            score = sum16(acc);
+        }
+        return score;
+    };
+    float score = outputs();
+    // An overflowed / vanished sum has turned into inf / nan that sticks to the potentials and reaches the score: solve
+    // such a pair again (never at the reference's hyper-parameters; scaling = 0.01 does it) with max-shifted
+    // log-sum-exps, log-weights in the exponent and the float64 schedule -- geomloss's own formulation.
+    if (__builtin_expect(__any(!(fabsf(score) < 1e30f)), 0)) {
+        const bool redo = !(fabsf(score) < 1e30f);      // uniform over the pair's 16 lanes
+        float la[2], lb[2], fe[2], ge[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            la[t] = wa[t] > 0.f ? fast_log(wa[t]) : -100000.f;
+            lb[t] = wb[t] > 0.f ? fast_log(wb[t]) : -100000.f;
+        }
+        // softmin over j (rows) / i (columns) with the exact maximum: out = -eps * LSE(h - C / eps)
+        auto lse_rows = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const float t0 = cv[0] ? hh[0] - div_r(mc_[x][0], eps, reps) : kNegBig;
+                const float t1 = cv[1] ? hh[1] - div_r(mc_[x][1], eps, reps) : kNegBig;
+                const float m = max_lj(fmaxf(t0, t1));
+                out[x] = -eps * (m + fast_log(sum_lj(fast_exp(t0 - m) + fast_exp(t1 - m))));
+            }
+        };
+        auto lse_cols = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const float t0 = rv[0] ? hh[0] - div_r(mc_[0][y], eps, reps) : kNegBig;
+                const float t1 = rv[1] ? hh[1] - div_r(mc_[1][y], eps, reps) : kNegBig;
+                const float m = max_li(fmaxf(t0, t1));
+                out[y] = -eps * (m + fast_log(sum_li(fast_exp(t0 - m) + fast_exp(t1 - m))));
+            }
+        };
+        // one symmetric update at eps; `active` = false leaves the pair's potentials alone (a wave mate with a longer
+        // schedule is still annealing: all reductions stay inside the pair's own 16 lanes)
+        auto step = [&](float eps, bool averaged, bool active) {
+            const float reps = rcp_refined(eps);
+            float ha[2], hb[2], ft[2], gt[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ha[t] = la[t] + div_r(fe[t], eps, reps);
+                hb[t] = lb[t] + div_r(ge[t], eps, reps);
+            }
+            lse_cols(eps, reps, ha, gt);
+            lse_rows(eps, reps, hb, ft);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float gn = averaged ? 0.5f * (ge[t] + gt[t]) : gt[t];
+                const float fn = averaged ? 0.5f * (fe[t] + ft[t]) : ft[t];
+                ge[t] = active ? gn : ge[t];
+                fe[t] = active ? fn : fe[t];
+            }
+        };
+        {
+            const float reps = rcp_refined(diam);
+            lse_cols(diam, reps, la, ge);
+            lse_rows(diam, reps, lb, fe);
+        }
+        step(diam, true, true);
+        const double ld = log((double)diam);
+        int n_max = n_mid;
+        n_max = max(n_max, __shfl_xor(n_max, 16));
+        n_max = max(n_max, __shfl_xor(n_max, 32));
+        for (int k = 0; k < n_max; ++k)      // float64 schedule exactly as numpy builds geomloss's
+            step((float)exp(ld + (double)k * a.log_scaling), true, k < n_mid);
+        step(eb, true, true);
+        step(eb, false, true);
+        if (redo) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f[t] = fe[t];
+                g[t] = ge[t];
+            }
+        }
+        const float exact = outputs();
+        score = redo ? exact : score;
+    }
+    return score;
+}
+
+// counter[0] hands out the items beyond each wave's first, counter[1] counts the waves that have run out of items: the last
+// one leaves both at zero for the next launch (the launch before the first one on a fresh workspace clears them).
+__global__ void __launch_bounds__(256) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox, uint32_t* __restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* lds = lds_all + wave * kWaveLds;
+    float* nscr = lds + kRows * kRowStride;                 // [16][kNormLd]: norm partials
+    const bool mapped = a.pairing == kPairMapped;           // batched jobs: items are the groups of four of jobs [job0, job1)
+    const uint32_t nq = mapped ? 1u : (uint32_t)a.q.n;
+    const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
+    const uint32_t item_lo = mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
+    const uint32_t n_items = mapped ? (uint32_t)a.grp_off[a.job1] : ((ncand + 3) / 4) * nq;   // item = (candidate group, query), group-major
+    const uint32_t n_waves = gridDim.x * 4;
+    const bool own_diam = a.diameter == nullptr;            // else: the caller's per-group diameters (caching_score's batches)
+
+    // lane roles: p = candidate of this lane (compute AND staging); (li, lj) = its 2 x 2 block of the 8 x 8 entries;
+    // staging: the 16 lanes of group sg stage the 8 rows of candidate sg and query rows 2 sg, 2 sg + 1, chunk sc each
+    const int p = lane >> 4, lp = lane & 15, li = lp >> 2, lj = lp & 3;
+    const int sg = p, sc = lp;
+
+    for (uint32_t item = item_lo + blockIdx.x * 4 + wave; item < n_items;) {
+        uint32_t q_loc, c_loc0, c_end;
+        if (mapped) {
+            q_loc = (uint32_t)a.grp_job[item];
+            c_loc0 = (uint32_t)a.job_off[q_loc] + (item - (uint32_t)a.grp_off[q_loc]) * 4;
+            c_end = (uint32_t)a.job_off[q_loc + 1];
+        } else {
+            const uint32_t cg = nq == 1 ? item : item / nq;
+            q_loc = nq == 1 ? 0 : item - cg * nq;
+            c_loc0 = cg * 4;
+            c_end = ncand;
+        }
+        const uint32_t my_c_loc = min(c_loc0 + (uint32_t)p, c_end - 1);        // tail groups: clamp (duplicate work, not stored)
+        const bool my_c_real = c_loc0 + (uint32_t)p < c_end;
+        const int64_t c_idx = a.cand0 + my_c_loc;
+        const int64_t q_idx = (int64_t)q_loc;
+        const int c_len = a.c.len[c_idx], q_len = a.q.len[q_idx];
+        const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
+        const float* sy_doc = a.c.rows + (size_t)a.c.start[c_idx] * kD;       // staging group == compute group
+        const float* qb = qbox + (size_t)q_idx * 2 * kD;
+
+        float accg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        float ny[8], nx[2] = {0.f, 0.f}, dsq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ny[k] = 0.f;
+        float4 vy[8], vx[2], qmn, qmx;
+        auto issue_loads = [&](int st) {
+            const int dofs = (st * kCh + sc) * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
+            if (own_diam) {
+                qmn = ld4(qb + dofs);
+                qmx = ld4(qb + kD + dofs);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) vx[k] = ld4(qdoc + (size_t)min(2 * sg + k, q_len - 1) * kD + dofs);
+        };
+        issue_loads(0);
+#pragma unroll 1
+        for (int st = 0; st < kStages; ++st) {
+            // ---- stage: registers -> LDS, with box / norm side products; then the NEXT stage's loads go out so that
+            // they fly under this stage's arithmetic (no extra registers: the rows were just consumed) ----
+            {
+                float4 mn = vy[0], mx = vy[0];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ny[j] += sq4(vy[j]);
+                    if (j > 0) {
+                        mn.x = fminf(mn.x, vy[j].x); mn.y = fminf(mn.y, vy[j].y); mn.z = fminf(mn.z, vy[j].z); mn.w = fminf(mn.w, vy[j].w);
+                        mx.x = fmaxf(mx.x, vy[j].x); mx.y = fmaxf(mx.y, vy[j].y); mx.z = fmaxf(mx.z, vy[j].z); mx.w = fmaxf(mx.w, vy[j].w);
+                    }
+                    *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
+                }
+                if (own_diam) {
+                    const float dx = fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), dy = fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y);
+                    const float dz = fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), dw = fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w);
+                    dsq += fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    nx[k] += sq4(vx[k]);
+                    *reinterpret_cast<float4*>(lds + (2 * sg + k) * kRowStride + sc * 4) = vx[k];
+                }
+            }
+            if (st + 1 < kStages) issue_loads(st + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- accumulate: every lane walks the staged chunks for its own 2 x 2 entries ----------------------------
+            const float* xr = lds + (2 * li) * kRowStride;
+            const float* yr = lds + (8 + p * 8 + 2 * lj) * kRowStride;
+#pragma unroll 1
+            for (int c = 0; c < kCh; c += 2) {
+                // two chunks per trip: the second chunk's LDS reads are in flight under the first chunk's arithmetic
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    float4 xv[2], yv[2];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) xv[x] = *reinterpret_cast<const float4*>(xr + x * kRowStride + (c + cc) * 4);
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) yv[y] = *reinterpret_cast<const float4*>(yr + y * kRowStride + (c + cc) * 4);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y)
+                            accg[x][y] = fmaf(xv[x].w, yv[y].w, fmaf(xv[x].z, yv[y].z, fmaf(xv[x].y, yv[y].y, fmaf(xv[x].x, yv[y].x, accg[x][y]))));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- claim the next item now: the atomic's round trip hides behind the finish + solve below ------------------
+        uint32_t claimed = 0;
+        if (lane == 0) claimed = atomicAdd(counter, 1u);
+
+        // ---- norms: sum the staging lanes' partials through the scratch table nscr[value][lane] ----------------------
+        // value 0..7: |y_j|^2 partials of the lane's staged candidate; 8, 9: |x|^2 partials of its two query rows
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nscr[k * kNormLd + lane] = ny[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) nscr[(8 + k) * kNormLd + lane] = nx[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto table_sum = [&](int value, int lane0) {
+            const float4* src = reinterpret_cast<const float4*>(nscr + value * kNormLd + lane0);
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 u = src[m];
+                t += (u.x + u.y) + (u.z + u.w);
+            }
+            return t;
+        };
+        float xx[2], yy[2];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) yy[y] = table_sum(2 * lj + y, p * 16);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) xx[x] = table_sum(8 + ((2 * li + x) & 1), ((2 * li + x) >> 1) * 16);
+        // box terms were formed by the lanes that staged the candidate's rows = this candidate's 16 lanes
+        float diam2 = dsq;
+        diam2 += lane_xor<1>(diam2); diam2 += lane_xor<2>(diam2); diam2 += lane_xor<4>(diam2); diam2 += lane_xor<8>(diam2);
+
+        // ---- finish the entries.  Only x.y was accumulated: -cdist comes from the same expansion as geomloss's cost, and
+        // the entries where it cancels (torch.cdist's direct formula differs there) are redone below ----------------------
+        const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+        float cost[2][2], neg[2][2];
+        bool redo[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int i = 2 * li + x, j = 2 * lj + y;
+                const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
+                const float ns = xx[x] + yy[y];
+                redo[x][y] = !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
+                cost[x][y] = sqrtf(fmaxf(sq, 1e-8f));
+                neg[x][y] = -sqrtf(fmaxf(sq, 0.f));
+            }
+        {
+            // direct-formula redo, the 16 lanes of a candidate together: 48 coordinates per lane, 4-step DPP-row sum
+            const float* crow = sy_doc + 4 * lp;
+            const float* qrow = qdoc + 4 * lp;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const unsigned long long wm = __ballot(redo[x][y]);
+                    unsigned gm = (unsigned)(wm >> (16 * p)) & 0xFFFFu;        // flagged lanes of this candidate's group
+                    while (__any(gm != 0)) {
+                        const bool act = gm != 0;
+                        const int b16 = act ? __builtin_ctz(gm) : 0;
+                        gm &= gm - 1;
+                        const int i = 2 * (b16 >> 2) + x, j = 2 * (b16 & 3) + y;
+                        float p0 = 0.f;
+                        if (act) {
+#pragma unroll
+                            for (int cc = 0; cc < 12; ++cc) {
+                                const float4 u = ld4(qrow + (size_t)i * kD + 64 * cc), v = ld4(crow + (size_t)j * kD + 64 * cc);
+                                const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+                                p0 = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, p0))));
+                            }
+                        }
+                        p0 += lane_xor<1>(p0);
+                        p0 += lane_xor<2>(p0);
+                        p0 += lane_xor<4>(p0);
+                        p0 += lane_xor<8>(p0);
+                        if (act && lp == b16) neg[x][y] = -sqrtf(p0);
+                    }
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch table is rewritten by the next item
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- solve the four pairs in place and store their scores -----------------------------------------------------
+        bool rv[2], cv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            rv[t] = 2 * li + t < q_len;
+            cv[t] = 2 * lj + t < c_len;
+        }
+        const float diam = own_diam ? sqrtf(diam2) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
+        float score = solve_pairs(a, cost, neg, rv, cv, diam);
+        if (q_len > 8 || c_len > 8) score = __builtin_nanf("");      // longer than the tile: poison, never truncate silently
+        if (my_c_real && lp == 0) a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = score;
+
+        item = item_lo + n_waves + __builtin_amdgcn_readfirstlane(claimed);
+    }
+    if (lane == 0 && atomicAdd(counter + 1, 1u) == n_waves - 1) {      // every wave has made its last claim by now
+        counter[0] = 0u;
+        counter[1] = 0u;
+    }
+}
+
+}  // namespace
+
+bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
+    const int mq = q->max_len, mc = c->max_len;
+    return q->ext == 0 && c->ext == 0 && mq > 0 && mc > 0 && mq <= 8 && mc <= 8;
+}
+
+size_t fused_lds_bytes(void) { return 4 * kWaveLds * sizeof(float); }
+
+// groups_bound: upper bound of the launch's items (groups of four candidates x queries); `counter` must be zero when the
+// kernel starts (the launch before it on the stream clears it).
+int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, uint32_t* counter, hipStream_t stream) {
+    const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;      // two 4-wave workgroups per CU are resident
+    hipLaunchKernelGGL(pair_fused_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, qbox,
+                       counter);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+}  // namespace aspire

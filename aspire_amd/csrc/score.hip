@@ -18,12 +18,12 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
 #include <type_traits>
 
 #include "common.h"
 #include "tuning.h"
 #include "score_types.h"
+#include "score_device.h"
 #include "topk_device.h"
 
 namespace aspire {
@@ -91,13 +91,6 @@ __device__ __forceinline__ void load_rows(float4 (&r)[N], const float* doc, int 
     }
 }
 
-// (v_pk_mul_f32 + v_pk_fma_f32 + add -- three issue slots instead of four -- measured no faster than this chain, alone
-// or overlapped: 104-105 vs 106-108 M alignments/s in bench.py.)
-__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
-    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
-}
-__device__ __forceinline__ float sq4(const float4& a) { return dot4(a, a); }
-
 // Per-wave partial sums of half an 8x8 tile (4 query rows x 8 candidate rows) -> LDS.
 // red layout: [tile][2][64] (0: x.y dot, 1: sum (x-y)^2), element 8*i + j.  Only 32 accumulators, 4 query
 // rows and 8 candidate rows are live at a time (64 accumulators + both 8-row operand tiles cap the kernel
@@ -130,17 +123,6 @@ __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const f
         if ((lane & 1) == 0) red_half[(lane >> 1)] = r;
     }
     __builtin_amdgcn_sched_barrier(0);
-}
-
-// x / e with e's reciprocal r: one Newton step makes the quotient correctly rounded in all but
-// pathological cases (what the v_div_* sequence does, minus its denormal scaling).
-__device__ __forceinline__ float div_r(float x, float e, float r) {
-    const float q = x * r;
-    return fmaf(fmaf(-q, e, x), r, q);
-}
-__device__ __forceinline__ float rcp_refined(float e) {
-    float r = __builtin_amdgcn_rcpf(e);
-    return fmaf(fmaf(-e, r, 1.0f), r, r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,16 +454,6 @@ __device__ __forceinline__ void load_pair(PairState<T>& s, const PairWs<T>& ws, 
         }
 }
 
-// Masked entries carry this instead of -inf so that fully masked (pad) lanes never form inf - inf.
-constexpr float kNegBig = -1.0e30f;
-constexpr float kLog2e = 1.44269504088896340736f;
-constexpr float kLn2 = 0.69314718055994530942f;
-// exp / log on the hardware transcendentals: v_exp_f32 / v_log_f32 are base 2, ~1 ulp.  The arguments
-// met here are <= 0 (or within a few units of 0) for exp and in [2^-100, 2^100] for log: no denormal
-// or range handling is needed, which is what makes libm's logf 12 instructions instead of 2.
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
-__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
-
 #ifdef ASPIRE_PHASE_CLOCK
 // debug build only (tools/k1phases.py): cycle stamps of one wave into the buffer set by aspire_debug_k1_buffer
 static __device__ long long* g_k1dbg = nullptr;
@@ -495,23 +467,6 @@ static __device__ long long* g_k1dbg = nullptr;
     do {               \
     } while (0)
 #endif
-
-// Length of geomloss's annealing schedule, n_mid = ceil((log blur - log diam) / log scaling) in float64 (numpy's
-// arange) -- a discontinuous function of the diameter, so it has to be the float64 value.  The float64 logarithm of
-// the diameter cost ~0.5 us of every solve's prologue: here the quotient is formed in fp32 (v_log_f32; the logs of blur
-// and scaling come from the host) with a bound on its error, and only a quotient that close to an integer (a few
-// pairs in 10^4) is redone in float64.
-__device__ __forceinline__ int schedule_mid_steps(const ScoreArgs& a, float diam, float& log2_diam) {
-    log2_diam = __builtin_amdgcn_logf(diam);
-    const float x = (a.log2_blur - log2_diam) / a.log2_scaling;
-    const float err = (fabsf(a.log2_blur) + fabsf(log2_diam) + 1.f) * 3e-7f / fabsf(a.log2_scaling) + fabsf(x) * 2e-7f;
-    int n_mid;
-    if (__builtin_expect(fabsf(x - rintf(x)) < 8.f * err, 0))
-        n_mid = (int)ceil((a.log_blur - log((double)diam)) / a.log_scaling);
-    else
-        n_mid = (int)ceilf(x);
-    return n_mid < 0 ? 0 : n_mid;
-}
 
 template <int T>
 __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_len, int c_len, float diam, int64_t p,
@@ -1240,8 +1195,9 @@ struct TileCfg {
 };
 
 // per-coordinate bounding box of each query's valid rows: qbox[q][0][768] = min, qbox[q][1][768] = max
-__global__ void __launch_bounds__(192) doc_box_kernel(RepSet d, float* __restrict__ box) {
+__global__ void __launch_bounds__(192) doc_box_kernel(RepSet d, float* __restrict__ box, uint32_t* __restrict__ zero_me) {
     const int64_t k = blockIdx.x;
+    if (zero_me != nullptr && k == 0 && threadIdx.x < 2) zero_me[threadIdx.x] = 0u;       // the fused kernel's item counter and exit count
     const int n = d.len[k];
     const float* doc = d.rows + (size_t)d.start[k] * kD + threadIdx.x * 4;
     float4 mn = ld4(doc), mx = mn;
@@ -2075,12 +2031,14 @@ int launch_cost_stage(const ScoreArgs& a, const aspire_repset* q, const aspire_r
         // groups of four candidates x queries (MAPPED: an upper bound; the kernel reads the exact range from grp_off)
         const int64_t groups4 = a.pairing == kPairMapped ? (int64_t)(a.job1 - a.job0) * a.max_job_groups
                                                          : (ncand + 3) / 4 * (a.pairing == ASPIRE_PAIR_CROSS ? q->n : 0);
-        const bool tile = a.pairing == kPairMapped ? a.tile_form : (a.pairing == ASPIRE_PAIR_CROSS && groups4 >= 2048);
+        const int form_t = tuning().ot_form;
+        const bool tile = a.pairing == kPairMapped ? a.tile_form
+                                                   : (a.pairing == ASPIRE_PAIR_CROSS && (form_t == 2 || (form_t != 1 && groups4 >= 2048)));
         if (tile) {
             // enough groups of 4 candidates to fill the chip: tiled form (lanes own finished (i,j) sums), one group per
             // wave (measured 4.7 TB/s algorithmic at 1 x 20 000 against 1.8 TB/s for the accumulate-then-reduce kernel)
             if (!a.diameter && first_chunk && a.pairing != kPairMapped) {   // per-coordinate boxes of the queries, once per call
-                hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, stream, a.q, qbox);
+                hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, stream, a.q, qbox, (uint32_t*)nullptr);
                 ASPIRE_LAUNCH_OK();
             }
             const int64_t waves = groups4 < 256 * 8 ? groups4 : 256 * 8;
@@ -2190,7 +2148,25 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
     const size_t ot_bytes = workspace_bytes;
     // query boxes sit at a fixed place (the tail of the workspace) so that every candidate chunk finds them
     float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
-    const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
+    // Few queries against a big pool of short documents: costs and solves in ONE launch, no workspace slots, no candidate
+    // chunks (fused.hip).  The first word of the workspace is its item counter.
+    const int form_t = tuning().ot_form;
+    const int64_t groups4_all = (c->n + 3) / 4 * q->n;
+    const bool fused = pairing == ASPIRE_PAIR_CROSS && !extra && !gram && !cost_only && fused_path_ok(q, c) &&
+                       (form_t == 3 || (form_t == 0 && groups4_all >= 2048));
+    if (fused) {
+        a.cand0 = 0;
+        a.cand1 = c->n;
+        uint32_t* counter = (uint32_t*)workspace;
+        if (!diameter) {   // per-coordinate boxes of the queries (the kernel adds each candidate's rows); clears the counter
+            hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, (hipStream_t)stream, a.q, qbox, counter);
+            ASPIRE_LAUNCH_OK();
+        } else {
+            ASPIRE_HIP_OK(hipMemsetAsync(counter, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
+        }
+        if (int rc = launch_pair_fused(a, groups4_all, qbox, counter, (hipStream_t)stream)) return rc;
+    }
+    const int rc_run = fused ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         for (int64_t c0 = 0; c0 < c->n; c0 += cand_per_chunk) {
             a.cand0 = c0;
@@ -2265,9 +2241,10 @@ namespace {
 // candidate -> job / group -> job tables the kernels index.
 __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, const int32_t* __restrict__ job_off, int J, float* __restrict__ qbox,
                                                          int32_t* __restrict__ cand_job, int32_t* __restrict__ grp_off,
-                                                         int32_t* __restrict__ grp_job) {
+                                                         int32_t* __restrict__ grp_job, uint32_t* __restrict__ counter) {
     __shared__ int part[3];
     const int j = blockIdx.x, tid = threadIdx.x;
+    if (j == 0 && tid < 2) counter[tid] = 0u;    // the fused kernel's item counter and exit count
     {
         const int n = q.len[j];
         const float* doc = q.rows + (size_t)q.start[j] * kD + tid * 4;
@@ -2296,49 +2273,13 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, const int32_t
     for (int k = tid; k < ng; k += 192) grp_job[g0 + k] = j;
 }
 
-// The side stream (and the events that tie it to the caller's stream) on which a batch's Sinkhorn and rank kernels run
-// beside the next chunk's cost kernel.  One per device, created on first use; a ring of event sets so that overlapping
-// calls never re-record an event another call's wait still refers to before it was enqueued.
-constexpr int kMaxBatchChunks = 8;
-struct ForkJoin {
-    hipStream_t side = nullptr;
-    hipEvent_t fork[8], join[8], cost[8][kMaxBatchChunks];
-    int next = 0;
-    bool ok = false;
-};
-ForkJoin* fork_join_for_device(int dev) {
-    static std::mutex mu;
-    static ForkJoin* table[64] = {};
-    if (dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!table[dev]) {
-        ForkJoin* f = new ForkJoin();
-        bool ok = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) == hipSuccess;
-        for (int r = 0; r < 8 && ok; ++r) {
-            ok = ok && hipEventCreateWithFlags(&f->fork[r], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&f->join[r], hipEventDisableTiming) == hipSuccess;
-            for (int k = 0; k < kMaxBatchChunks && ok; ++k)
-                ok = ok && hipEventCreateWithFlags(&f->cost[r][k], hipEventDisableTiming) == hipSuccess;
-        }
-        f->ok = ok;
-        table[dev] = f;
-    }
-    return table[dev]->ok ? table[dev] : nullptr;
-}
-int next_event_set(ForkJoin* f) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    const int r = f->next;
-    f->next = (f->next + 1) & 7;
-    return r;
-}
-
 struct BatchLayout {
-    size_t slots, qbox, cand_job, grp_job, grp_off, topk, total;
+    size_t counter, slots, qbox, cand_job, grp_job, grp_off, topk, total;
 };
 BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, int64_t k) {
     BatchLayout L{};
     size_t o = 0;
+    L.counter = o; o = 16;                      // the fused kernel's item counter
     L.slots = o; o = align16(o + slot_bytes(max_rows) * (size_t)C);
     L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
@@ -2400,76 +2341,45 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     a.job0 = 0;
     a.job1 = (int32_t)J;
     a.max_job_groups = (int32_t)((max_job + 3) / 4);
-    // throughput kernels (four candidates of a job per wave, sixteen solves per wave) once the batch fills the chip;
-    // below that the latency forms the single-pool entry points use
+    // Forms.  Small batches are latency bound and take the kernels the single-pool entry points use.  Once the batch fills
+    // the chip (documents of <= 8 rows): the fused kernel -- four candidates of a job per wave, costs and solves in one
+    // launch (fused.hip) -- or, pinned for A/B tests, the same cost kernel + the block Sinkhorn kernel as two launches.
+    // (Chunks of jobs on two streams, Sinkhorn of chunk i beside the cost kernel of chunk i + 1, were measured and dropped:
+    // 20 x 1000: 169 us on one stream, 213 / 266 / 403 us in 2 / 4 / 8 chunks -- cross-stream waits cost more than they hide.)
     const int64_t groups_bound = J * ((max_job + 3) / 4);
-    const int form_t = tuning().batch_form;
-    a.tile_form = max_rows <= 8 && (form_t == 2 || (form_t == 0 && groups_bound >= 2048 && C >= 6000));
+    const int form_t = tuning().ot_form;
+    const bool big = max_rows <= 8 && groups_bound >= 2048 && C >= 6000;
+    const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
+    a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
+    uint32_t* counter = (uint32_t*)(wsb + L.counter);
     if (stages & kStagePrep) {
-        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, job_off, (int)J, qbox, cand_job, grp_off, grp_job);
+        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, job_off, (int)J, qbox, cand_job, grp_off, grp_job,
+                           counter);
         ASPIRE_LAUNCH_OK();
     }
-
-    // Job chunks: chunk i's Sinkhorn + rank kernels run on the side stream beside chunk i + 1's cost kernel (HBM bound)
-    // on the caller's stream.  Not while the caller's stream is being captured into a graph.
-    int n_chunks = 1;
-    if (a.tile_form && stages == kStageAll) {
-        const int t = tuning().batch_chunks;
-        n_chunks = t > 0 ? t : (C >= 16000 ? 4 : C >= 8000 ? 2 : 1);
-        if (n_chunks > J) n_chunks = (int)J;
-        if (n_chunks > kMaxBatchChunks) n_chunks = kMaxBatchChunks;
-    }
-    ForkJoin* fj = nullptr;
-    if (n_chunks > 1) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        int dev = 0;
-        if (hipStreamIsCapturing(s0, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone || hipGetDevice(&dev) != hipSuccess ||
-            !(fj = fork_join_for_device(dev)))
-            n_chunks = 1;
-    }
-    const int es = fj ? next_event_set(fj) : 0;
-    hipStream_t s1 = fj ? fj->side : s0;
-    if (fj) {
-        ASPIRE_HIP_OK(hipEventRecord(fj->fork[es], s0));
-        ASPIRE_HIP_OK(hipStreamWaitEvent(s1, fj->fork[es], 0));
-    }
     const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
-    const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
-        constexpr int T = decltype(tc)::value;
-        PairWs<T> ws;
-        ws.cost = (float*)(wsb + L.slots);
-        ws.neg = ws.cost + C * PairWs<T>::kEntries;
-        ws.diam2 = ws.neg + C * PairWs<T>::kEntries;
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            a.job0 = (int32_t)(J * ch / n_chunks);
-            a.job1 = (int32_t)(J * (ch + 1) / n_chunks);
-            const int64_t nj = a.job1 - a.job0;
-            // slots of this launch: exact for the whole batch, an upper bound for a chunk of jobs
-            const int64_t n_slots = n_chunks == 1 ? C : (nj * max_job < C ? nj * max_job : C);
+    if (fused) {
+        if (stages & (kStageCost | kStageSolve))
+            if (int rc = launch_pair_fused(a, groups_bound, qbox, counter, s0)) return rc;
+    } else {
+        const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
+            constexpr int T = decltype(tc)::value;
+            PairWs<T> ws;
+            ws.cost = (float*)(wsb + L.slots);
+            ws.neg = ws.cost + C * PairWs<T>::kEntries;
+            ws.diam2 = ws.neg + C * PairWs<T>::kEntries;
             if (stages & kStageCost)
-                if (int rc = launch_cost_stage<T>(a, q, c, ws, n_slots, 1, false, qbox, nullptr, ch == 0, s0)) return rc;
-            if (fj) {
-                ASPIRE_HIP_OK(hipEventRecord(fj->cost[es][ch], s0));
-                ASPIRE_HIP_OK(hipStreamWaitEvent(s1, fj->cost[es][ch], 0));
-            }
+                if (int rc = launch_cost_stage<T>(a, q, c, ws, C, 1, false, qbox, nullptr, true, s0)) return rc;
             if (stages & kStageSolve)
-                if (int rc = launch_sinkhorn_stage<T>(a, ws, n_slots, max_rows, false, a.tile_form ? 3 : 0, s1)) return rc;
-            if (k > 0 && (stages & kStageRank)) {
-                const int64_t o = (int64_t)a.job0 * k;
-                if (int rc = topk_run(scores, nj, max_job, k, 0, keys ? nullptr : top_scores + o, keys ? nullptr : top_idx + o,
-                                      keys ? keys + o : nullptr, topk_need ? wsb + L.topk : nullptr, topk_need, (void*)s1,
-                                      job_off + a.job0, job_base ? job_base + a.job0 : nullptr))
-                    return rc;
-            }
-        }
-        return (int)ASPIRE_OK;
-    });
-    if (fj) {
-        // join even after a failed launch: the caller's stream must not run ahead of the side stream
-        (void)hipEventRecord(fj->join[es], s1);
-        (void)hipStreamWaitEvent(s0, fj->join[es], 0);
+                if (int rc = launch_sinkhorn_stage<T>(a, ws, C, max_rows, false, a.tile_form ? 3 : 0, s0)) return rc;
+            return (int)ASPIRE_OK;
+        });
+        if (rc_run) return rc_run;
     }
-    return rc_run;
+    if (k > 0 && (stages & kStageRank))
+        return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
+                        topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);
+    return ASPIRE_OK;
 }
 }  // namespace
 

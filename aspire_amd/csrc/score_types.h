@@ -97,4 +97,8 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
                         float* cbox, hipStream_t stream);
 int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t stream);
 
+// fused.hip: cost + Sinkhorn solve in one launch for documents of <= 8 rows (CSR inputs, CROSS or MAPPED pairing)
+bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
+int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, uint32_t* counter, hipStream_t stream);
+
 }  // namespace aspire

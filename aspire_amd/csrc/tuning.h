@@ -11,8 +11,8 @@ struct Tuning {
     int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
-    int batch_chunks = 0;    // ASPIRE_HIP_BATCH_CHUNKS: job chunks of aspire_ot_rank_batch_f32 (0 = by size, 1 = no overlap)
-    int batch_form = 0;      // ASPIRE_HIP_BATCH_FORM: 0 by size, 1 = small-pool kernels, 2 = throughput kernels
+    int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
+                             // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch
 };
 
 const Tuning& tuning();

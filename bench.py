@@ -8,9 +8,10 @@ Workload at N=1 = BASELINE.json configs[1]: otAspire, 1 query x 1000 candidates,
 fp32, resident in HBM before the timed region.  One STEP = one query re-ranked against ITS OWN 1000-candidate pool
 (evaluate.py:58-76: every query of a dataset has its own pool): cost matrix + marginals + Sinkhorn (one epsilon schedule
 per pair, AspireModel.get_similarity) of the 1000 pairs, then the stable descending rank (top-100).  The K steps of a run
-are K independent (query, pool) jobs and go through ONE library call, aspire_ot_rank_batch_f32 -- one cost launch over
-the K x 1000 pairs, one Sinkhorn launch, one K-workgroup rank launch, the batch cut into chunks whose Sinkhorn / rank
-kernels run beside the next chunk's HBM-bound cost kernel.  The caller uses ONE stream, no hipGraphs, no lanes.
+are K independent (query, pool) jobs and go through ONE library call, aspire_ot_rank_batch_f32 -- a small launch that
+builds the job tables and query boxes, ONE scoring launch over the K x 1000 pairs (costs and Sinkhorn solves fused: a
+wave streams four candidates' rows, then solves those four pairs from its registers while other waves stream), one
+K-workgroup rank launch.  The caller uses ONE stream, no hipGraphs, no lanes.
 
 Timing: the K-step schedule is repeated R times back to back (R chosen so that the timed region is >= 50 ms: K = 20 steps
 alone are ~0.1 ms) between barrier + torch.cuda.synchronize() on both sides; ms_per_step = elapsed / (K * R), value =
@@ -21,11 +22,12 @@ At N > 1 every rank holds its own 1000-candidate block of each job's N * 1000-ca
 block (key form, global indices), and the per-job top-k lists are merged with ONE RCCL all-gather per call + one merge
 kernel.  No data-path collective.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the cost kernel: it streams every rep once) against
-HBM: algorithmic bytes per launch = 24 605 B/pair x pairs per launch over the kernel's duration measured
-live with HIP events around launches of that stage alone on the launch stream (aspire_debug_ot_rank_batch_stages_f32),
-on the rotating (cold) pools; `l3_resident_frac` is the same on ONE pool set small enough to stay in the Infinity Cache;
-`step` prices the whole step (all kernels, timed region) against the same bytes.  `cpu_baseline` times the CPU oracle (a
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the scoring kernel: it streams every rep once)
+against HBM: algorithmic bytes per launch = 24 605 B/pair x pairs per launch over the kernel's duration
+measured live with HIP events around launches of that stage alone on the launch stream
+(aspire_debug_ot_rank_batch_stages_f32), on the rotating (cold) pools; `l3_resident_frac` is the same on ONE pool set small
+enough to stay in the Infinity Cache; `step` prices the whole step (all kernels, timed region) against the same bytes;
+`two_kernel_form` gives the durations of the separate cost and Sinkhorn kernels (OT_FORM=tile) for comparison.  `cpu_baseline` times the CPU oracle (a
 port of the reference's PyTorch CPU path; its Sinkhorn solver is a parity-unpinned restatement of geomloss 0.2.4) on the
 host cores of this box, with 1 thread and with all cores.
 """
@@ -269,7 +271,8 @@ def main():
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
             for i, (a, b) in enumerate(evs):
                 js = jsets[i % len(jsets)]
-                run_stage(js, 1 if stages == 2 else 3)      # this job set's tables and query boxes (+ its costs, for the later stages)
+                if stages != 1:
+                    run_stage(js, 1 if stages in (2, 6) else 7)      # this job set's tables and query boxes (+ costs and scores, for the later stages)
                 a.record()
                 run_stage(js, stages)
                 b.record()
@@ -277,9 +280,15 @@ def main():
             t = sorted(a.elapsed_time(b) for a, b in evs)
             return sum(t[:n // 2]) / (n // 2)       # mean of the faster half: launch gaps of a cold queue out of the bracket
 
-        cost_ms = stage_ms(2, sets)
-        solve_ms = stage_ms(4, sets)
+        fused_form = K * NC >= 6000 and K * ((NC + 3) // 4) >= 2048      # the library's own rule (score.hip: ot_rank_batch)
+        prep_ms = stage_ms(1, sets)
+        cost_ms = stage_ms(6, sets)              # the scoring launch (fused form: costs + solves in one kernel)
         rank_ms = stage_ms(8, sets)
+        with _lib.pinned(OT_FORM='tile' if fused_form else 'small'):
+            cost_only_ms = stage_ms(2, sets)
+            solve_only_ms = stage_ms(4, sets)
+        run_schedule(sets[0])                   # the workspace tables back in the default form's state
+        torch.cuda.synchronize()
         # Infinity-Cache-resident variant: ONE small job set (<= 8 jobs, < 200 MB) scored again and again
         n_l3 = min(K, 8)
         l3 = JobSet(0, n_l3)
@@ -288,7 +297,7 @@ def main():
         def cost_l3():
             rc = lib.aspire_debug_ot_rank_batch_stages_f32(ctypes.byref(l3.qs), ctypes.byref(l3.cs), D, ctypes.c_void_p(job_off_l3.data_ptr()),
                                                            NC, ctypes.byref(prm), _lib.OT_SIMILARITY, P[0], 0, null, null, P[4],
-                                                           ws.numel(), stream(), 3 if i_l3[0] == 0 else 2)
+                                                           ws.numel(), stream(), 7 if i_l3[0] == 0 else 6)
             i_l3[0] += 1
             if rc:
                 _lib.check(rc)
@@ -332,11 +341,14 @@ def main():
             # Dominant kernel of a step: the cost kernel streams every rep once (the HBM side of the step).
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'pair_tile_kernel<2,1>' if K * NC >= 6000 else 'pair_cost1_kernel', 'kernel_ms': cost_ms,
+                         'kernel': 'pair_fused_kernel (costs + Sinkhorn solves)' if fused_form else 'pair_cost1_kernel + sinkhorn_kernel<1>',
+                         'kernel_ms': cost_ms,
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'jobs_per_launch': K, 'data': 'cold (rotating pools, > L3)',
                          'l3_resident_frac': algorithmic_bytes(n_l3) / (cost_l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'l3_resident': {'jobs': n_l3, 'kernel_ms': cost_l3_ms, 'bytes': algorithmic_bytes(n_l3)},
-                         'stages_ms': {'cost': cost_ms, 'sinkhorn': solve_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3},
+                         'stages_ms': {'tables+boxes': prep_ms, 'score': cost_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3},
+                         'two_kernel_form': {'cost_ms': cost_only_ms, 'sinkhorn_ms': solve_only_ms,
+                                             'cost_frac': bytes_per_launch / (cost_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'step': {'what': 'all kernels of a schedule (timed region) against the same algorithmic bytes',
                                   'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS}},
         }

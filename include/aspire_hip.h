@@ -239,9 +239,8 @@ int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D
  * Job j scores the candidates [job_off[j], job_off[j+1]) of `c` -- query j's own pool (evaluate.py:60-62), all pools
  * laid back to back in one CSR rep set -- against query j of `q`, one epsilon schedule per pair
  * (AspireModel.get_similarity, src/evaluation/utils/models.py:190-197), and ranks each pool on its own (stable
- * descending, evaluate.py:76).  One cost launch over all pairs, one Sinkhorn launch, one rank launch with a workgroup per
- * job; large batches are cut into chunks of jobs whose Sinkhorn + rank kernels run on a library-owned side stream
- * beside the next chunk's HBM-bound cost kernel (joined back into `stream` before the call returns its work to it).
+ * descending, evaluate.py:76).  Three launches on `stream`: job tables + query boxes, ONE scoring launch over all pairs
+ * (costs and Sinkhorn solves fused once the batch fills the chip), one rank launch with a workgroup per job.
  *   q          J query documents (q->n == J), CSR (ext == 0)
  *   c          every job's candidates (c->n == C == job_off[J]), CSR (ext == 0)
  *   job_off    DEVICE int32 [J + 1], non-decreasing, job_off[0] == 0, job_off[J] == C
@@ -281,14 +280,15 @@ int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (tests, bench.py, tuning) -- not part of the surface that replaces reference code.
  *   aspire_debug_set   pin a kernel form / grid: key = "SINKHORN" (wave | block | block-norepair | block16), "COST_PATH"
- *                      (mfma | valu), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM_TILE" (96), "BATCH_CHUNKS" (n),
- *                      "BATCH_FORM" (small | tile); value NULL or "" restores the default.  The same switches are read
+ *                      (mfma | valu), "OT_FORM" (small | tile | fused), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM_TILE" (96);
+ *                      value NULL or "" restores the default.  The same switches are read
  *                      ONCE from the environment (ASPIRE_HIP_<key>) when the library is first used; nothing on the
  *                      launch path reads the environment.
  *   aspire_debug_ot_cost_stage_f32         the cost stage of aspire_ot_sinkhorn_f32 alone (no solve, scores untouched)
- *   aspire_debug_ot_rank_batch_stages_f32  chosen stages of aspire_ot_rank_batch_f32 on `stream` alone:
- *                      1 tables + query boxes, 2 cost kernel, 4 Sinkhorn kernel, 8 rank (bench.py times the stages of
- *                      a pass one by one this way, after a full call has filled the workspace)
+ *   aspire_debug_ot_rank_batch_stages_f32  chosen stages of aspire_ot_rank_batch_f32 alone: 1 tables + query boxes,
+ *                      2 costs, 4 Sinkhorn solves (2 and 4 are ONE kernel in the fused form: either bit launches it),
+ *                      8 rank (bench.py times the stages of a pass one by one this way, after a full call has filled
+ *                      the workspace)
  * ------------------------------------------------------------------------------------------- */
 int aspire_debug_set(const char* key, const char* value);
 int aspire_debug_ot_cost_stage_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,

@@ -62,7 +62,7 @@ def test_diagnostic_switches_without_gpu():
     assert _lib.lib.aspire_debug_set(b'SINKHORN', None) == _lib.ASPIRE_OK
     assert _lib.lib.aspire_debug_set(b'SINKHORN', b'packed') == _lib.ASPIRE_ERR_INVALID_ARG     # a form that is no longer built
     assert _lib.lib.aspire_debug_set(b'NO_SUCH_SWITCH', b'1') == _lib.ASPIRE_ERR_INVALID_ARG
-    with _lib.pinned(COST_PATH='valu', BATCH_CHUNKS=2):
+    with _lib.pinned(COST_PATH='valu', OT_FORM='tile'):
         pass
     with pytest.raises(AssertionError):
         with _lib.pinned(COST_PATH='bogus'):

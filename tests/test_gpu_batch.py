@@ -2,8 +2,7 @@
 batched over queries -- against J separate aspire_ot_rank_f32 calls, the oracle, and Python's stable sort.
 
 Bit-for-bit equality holds whenever both sides run the same kernel forms (the arithmetic of a pair never depends on the
-grid): the small-pool forms by default, the throughput forms when the batch entry is pinned to them for the one-job
-calls as well.  Between DIFFERENT forms (another summation order) scores agree to a few 1e-5."""
+grid): the small-pool forms for small batches, the throughput forms when the one-job calls are pinned to them as well.  Between DIFFERENT forms (another summation order) scores agree to a few 1e-5."""
 import numpy as np
 import pytest
 import torch
@@ -86,39 +85,35 @@ def test_long_document_batches(amd, smax):
         np.testing.assert_allclose(sc[1][:12].numpy(), want, atol=TOL, rtol=0)
 
 
-def test_throughput_form_chunks_and_single_jobs(amd):
-    """the throughput kernels (four candidates of ONE job per wave, sixteen solves per wave): job sizes that are not
-    multiples of four, jobs of fewer than four candidates, chunked over two streams or not -- always the same bits"""
+def test_throughput_forms_and_single_jobs(amd):
+    """the throughput kernels (four candidates of ONE job per wave; costs + solves fused in one launch, or the tile cost
+    kernel + the block Sinkhorn kernel): job sizes that are not multiples of four, jobs of fewer than four candidates.
+    A job scored alone on the same form gives the same bits; the forms agree with each other and the oracle."""
     sizes = [1503, 2, 997, 1250, 3, 2048, 1, 1100, 777]
     queries, pools = _jobs(31, sizes, 8)
     k = 100
-    with amd.pinned(BATCH_FORM='tile', BATCH_CHUNKS=1):
-        base = _batch(amd, queries, pools, k)
-    _check_rank(*base, k)
-    for chunks in (2, 4, 8):
-        with amd.pinned(BATCH_FORM='tile', BATCH_CHUNKS=chunks):
-            got = _batch(amd, queries, pools, k)
-        for a, b in zip(base[0], got[0]):
-            assert torch.equal(a, b), chunks
-        assert torch.equal(base[1], got[1]) and torch.equal(base[2], got[2]), chunks
-    dflt = _batch(amd, queries, pools, k)          # C = 8681: the default picks the throughput form, two chunks
-    for a, b in zip(base[0], dflt[0]):
+    out = {}
+    for form in ('fused', 'tile'):
+        with amd.pinned(OT_FORM=form):
+            out[form] = _batch(amd, queries, pools, k)
+            _check_rank(*out[form], k)
+            for j in (0, 1, 4, 6, 8):      # J separate one-job calls on the same kernel form: bit for bit
+                one = _batch(amd, [queries[j]], [pools[j]], k)
+                assert torch.equal(one[0][0], out[form][0][j]), (form, j)
+                assert torch.equal(one[2][0], out[form][2][j]) and torch.equal(one[1][0], out[form][1][j]), (form, j)
+    dflt = _batch(amd, queries, pools, k)          # C = 8681: the default is the fused form
+    for a, b, t in zip(dflt[0], out['fused'][0], out['tile'][0]):
         assert torch.equal(a, b)
-    # J separate one-job calls on the same kernel forms: bit for bit
-    with amd.pinned(BATCH_FORM='tile'):
-        for j in (0, 1, 4, 6, 8):
-            one = _batch(amd, [queries[j]], [pools[j]], k)
-            assert torch.equal(one[0][0], base[0][j]), j
-            assert torch.equal(one[2][0], base[2][j]) and torch.equal(one[1][0], base[1][j]), j
+        np.testing.assert_allclose(b.numpy(), t.numpy(), atol=5e-5, rtol=0)
     # ... and the default single-pool entry point (small-pool kernels, another summation order) to a few 1e-5
     for j in (0, 2, 6):
         s1 = amd.scorer.score_pool([queries[j]], pools[j], method='ot', schedule='pair')[0].cpu()
-        np.testing.assert_allclose(base[0][j].numpy(), s1.numpy(), atol=5e-5, rtol=0)
+        np.testing.assert_allclose(dflt[0][j].numpy(), s1.numpy(), atol=5e-5, rtol=0)
     rng = np.random.default_rng(0)
     for j in (0, 3, 5):
         pick = rng.choice(sizes[j], 6, replace=False)
         want = np.array([orc.get_similarity(queries[j], pools[j][i]) for i in pick], dtype=np.float32)
-        np.testing.assert_allclose(base[0][j].numpy()[pick], want, atol=TOL, rtol=0)
+        np.testing.assert_allclose(dflt[0][j].numpy()[pick], want, atol=TOL, rtol=0)
 
 
 def test_batch_hparams_and_wants(amd):
@@ -132,7 +127,7 @@ def test_batch_hparams_and_wants(amd):
 
 
 def test_batch_under_graph_capture(amd):
-    """a captured call must not fork onto the library's side stream: it runs its chunks on the capturing stream"""
+    """the call is capturable into a hipGraph (everything runs on the caller's stream) and replays to the same bits"""
     sizes = [1200] * 8
     queries, pools = _jobs(51, sizes, 8, smin=8)
     q = amd.ops.DeviceRepSet.from_list(queries)
@@ -159,8 +154,7 @@ def test_batch_under_graph_capture(amd):
 
 
 def test_back_to_back_batches_share_a_workspace(amd):
-    """consecutive calls on one stream reuse the same workspace: the side stream of call n is joined before call n + 1's
-    cost kernel may overwrite the slots"""
+    """consecutive calls on one stream reuse the same workspace (item counter, tables, rank scratch)"""
     import ctypes
     sizes = [1000] * 10
     runs = []

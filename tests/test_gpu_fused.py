@@ -1,0 +1,124 @@
+"""The fused otAspire kernel (fused.hip: costs + Sinkhorn solves of four pairs per wave in one launch, items claimed
+dynamically) against the oracle and against the two-kernel forms, for single big pools (CROSS) and batched jobs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def amd():
+    from aspire_amd import ops, scorer, _lib
+    assert torch.cuda.is_available()
+    return type('NS', (), dict(ops=ops, scorer=scorer, lib=_lib, pinned=_lib.pinned))
+
+
+def _pool(seed, n, smin=1, smax=8):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(smin, smax + 1, (n,), generator=g).tolist()
+    return [torch.randn(l, 768, generator=g) for l in lens]
+
+
+@pytest.mark.parametrize('nq,nc', [(1, 8203), (2, 4101)])
+@pytest.mark.parametrize('want', ['distance', 'similarity', 'plan'])
+def test_fused_single_pool_matches_oracle_and_tile_form(amd, nq, nc, want):
+    cands = _pool(100 + nc, nc)
+    queries = _pool(7, nq, 3, 8)
+    q, c = amd.ops.DeviceRepSet.from_list(queries), amd.ops.DeviceRepSet.from_list(cands)
+    w = dict(distance=amd.lib.OT_DISTANCE, similarity=amd.lib.OT_SIMILARITY, plan=amd.lib.OT_PLAN_SIM)[want]
+    dflt = amd.ops.ot_sinkhorn(q, c, want=w).view(nq, nc).cpu().numpy()
+    with amd.pinned(OT_FORM='fused'):
+        fused = amd.ops.ot_sinkhorn(q, c, want=w).view(nq, nc).cpu().numpy()
+    with amd.pinned(OT_FORM='tile'):
+        tile = amd.ops.ot_sinkhorn(q, c, want=w).view(nq, nc).cpu().numpy()
+    assert np.array_equal(dflt, fused) and np.isfinite(fused).all()
+    np.testing.assert_allclose(fused, tile, atol=5e-5 if want != 'plan' else 1e-2, rtol=0)
+    idx = [0, 1, 2, 3, nc // 2, nc - 3, nc - 2, nc - 1]
+    if want == 'plan':
+        ref = np.array([[orc.AllPairMaskedWasserstein({}).compute_distance(
+            orc.RepLen(x[None].permute(0, 2, 1), [len(x)]), orc.RepLen(cands[i][None].permute(0, 2, 1), [len(cands[i])]),
+            return_pair_sims=True)[0].item() for i in idx] for x in queries], dtype=np.float32)
+        np.testing.assert_allclose(fused[:, idx], ref, atol=1e-2, rtol=0)       # fp32 conditioning of exp((f + g - d) / 0.05)
+    else:
+        sign = 1.0 if want == 'similarity' else -1.0
+        ref = np.array([[orc.get_similarity(x, cands[i]) for i in idx] for x in queries], dtype=np.float32)
+        np.testing.assert_allclose(sign * fused[:, idx], ref, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('hp', [dict(geoml_scaling=0.5), dict(geoml_blur=0.5, geoml_scaling=0.99), dict(sent_sm_temp=5000.0),
+                                dict(geoml_scaling=0.01), dict(geoml_blur=1e-3)])
+def test_fused_hparams_and_exact_fallback(amd, hp):
+    """scaling = 0.01 overflows the shifted sums: those pairs are solved again in the kernel with max-shifted log-sum-exps"""
+    cands = _pool(5, 40)
+    query = _pool(6, 1, 8, 8)
+    with amd.pinned(OT_FORM='fused'):
+        got = amd.scorer.score_pool(query, cands, method='ot', schedule='pair', hparams=hp).cpu().numpy()[0]
+    want = np.array([orc.get_similarity(query[0], y, hp) for y in cands], dtype=np.float32)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
+def test_fused_duplicate_sentences_and_group_schedule(amd):
+    """candidates sharing sentences with the query (the direct-formula redo path) and caching_score's one schedule per
+    group of 64 (caller-supplied diameters): fused = two-kernel form to a few 1e-5"""
+    g = torch.Generator().manual_seed(9)
+    query = torch.randn(8, 768, generator=g)
+    cands = _pool(10, 300)
+    for i in range(0, 300, 7):
+        cands[i][0] = query[i % 8]
+    res = {}
+    for form in ('fused', 'tile', 'small'):
+        with amd.pinned(OT_FORM=form):
+            res[form] = (amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0],
+                         amd.scorer.score_pool([query], cands, method='ot', schedule='batch').cpu().numpy()[0])
+    for k in range(2):
+        np.testing.assert_allclose(res['fused'][k], res['small'][k], atol=1e-2 if k else 2e-2, rtol=0)
+        clean = np.array([i % 7 != 0 for i in range(300)])
+        np.testing.assert_allclose(res['fused'][k][clean], res['tile'][k][clean], atol=1e-2 if k else 5e-5, rtol=0)
+        np.testing.assert_allclose(res['fused'][k][clean], res['small'][k][clean], atol=1e-2 if k else 5e-5, rtol=0)
+    want = orc.caching_score(query.numpy(), [c.numpy() for c in cands[64:128]])['batch_scores']
+    np.testing.assert_allclose(res['fused'][1][64:128][clean[64:128]], want[clean[64:128]], atol=1e-2, rtol=0)
+
+
+@pytest.mark.parametrize('form', ['fused'])
+def test_fused_schedule_length_at_its_discontinuities(amd, form):
+    """as test_gpu_edges.test_schedule_length_at_its_discontinuities, for the fused kernel's copy of the schedule"""
+    blur, scaling = 0.05, 0.9
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(6, 768, generator=g)
+    c = torch.randn(7, 768, generator=g)
+    diams = []
+    for k in (60, 68, 72, 80):
+        d0 = blur * scaling ** (-k)
+        for rel in (0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-3, -1e-3):
+            diams.append(np.float32(d0 * (1.0 + rel)))
+    diams = np.array(diams, dtype=np.float32)
+    n = len(diams)
+    qs = amd.ops.DeviceRepSet.from_list([q])
+    cs = amd.ops.DeviceRepSet.from_list([c] * n)
+    with amd.pinned(OT_FORM=form):
+        got = amd.ops.ot_sinkhorn(qs, cs, blur=blur, scaling=scaling, diameter=torch.from_numpy(diams).cuda(), diam_group=1).cpu().numpy()
+    w = orc.AllPairMaskedWasserstein({'geoml_blur': blur, 'geoml_scaling': scaling})
+    qt = orc.RepLen(q[None].permute(0, 2, 1), [6])
+    ct = orc.RepLen(c[None].permute(0, 2, 1), [7])
+    want = np.array([w.compute_distance(qt, ct, diameter=float(d)).item() for d in diams], dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
+
+
+def test_fused_repeated_launches_reset_their_item_counter(amd):
+    """the kernel's last wave leaves the item counter at zero: back-to-back launches on one workspace score every pair"""
+    cands = _pool(21, 9000, 8, 8)
+    query = _pool(22, 1, 8, 8)
+    q, c = amd.ops.DeviceRepSet.from_list(query), amd.ops.DeviceRepSet.from_list(cands)
+    import ctypes
+    qs, cs = q.struct(), c.struct()
+    ws = torch.empty(amd.lib.lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), 0), dtype=torch.uint8, device='cuda')
+    first = amd.ops.ot_sinkhorn(q, c, workspace=ws).clone()
+    for _ in range(5):
+        out = torch.full((9000,), float('nan'), device='cuda')
+        amd.ops.ot_sinkhorn(q, c, out=out, workspace=ws)
+        assert torch.equal(out, first)

@@ -81,17 +81,25 @@ def test_forms_agree_at_size(amd, nq, nc, s, want):
     w = amd.lib.OT_DISTANCE if want == 'distance' else amd.lib.OT_PLAN_SIM
     out = {}
     forms = ['wave', 'block'] + (['block16'] if s <= 8 else [])
+    # documents of <= 8 rows at this size run costs + solves fused in one launch by default: OT_FORM='tile' is the two-kernel
+    # form whose Sinkhorn kernel SINKHORN= pins
     for form in forms:
-        with pinned(SINKHORN=form):
+        with pinned(SINKHORN=form, OT_FORM='tile'):
             out[form] = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
     dflt = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
     tol = 5e-5 if want == 'distance' else 1e-2     # plan-weighted similarity: see test_gpu_scoring.PLAN_SIM_TOL
     for form in forms[1:]:
         assert np.isfinite(out[form]).all()
         np.testing.assert_allclose(out[form], out['wave'], atol=tol, rtol=0)
-    assert np.array_equal(dflt, out['block'])       # >= 4096 pairs: the block form is the default
+    if s <= 8:
+        with pinned(OT_FORM='fused'):
+            fused = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
+        assert np.array_equal(dflt, fused)          # few queries x a big pool of short documents: the fused kernel
+        np.testing.assert_allclose(fused, out['wave'], atol=tol, rtol=0)
+    else:
+        assert np.array_equal(dflt, out['block'])   # >= 2500 pairs of long documents: the block form is the default
     # at the reference's hyper-parameters the block form needs no repairs (its sums stay in fp32 range)
-    with pinned(SINKHORN='block-norepair'):
+    with pinned(SINKHORN='block-norepair', OT_FORM='tile'):
         raw = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
     assert np.array_equal(raw, out['block'])
 
