@@ -1,7 +1,7 @@
 """Per-stage and end-to-end timings of aspire_ot_rank_batch_f32 for a few (jobs, pool size) shapes and chunk counts.
   python tools/batchbench.py [J,NC,S ...]
 Prints one line per configuration: stage durations (HIP events, stage alone on one stream, rotating cold pools), the
-call's end-to-end time for BATCH_CHUNKS = 1, 2, 4, 8 (back-to-back calls on one stream) and the host time per call."""
+call's end-to-end time for OT_FORM = fused, tile, small (back-to-back calls on one stream) and the host time per call."""
 import ctypes
 import os
 import sys
@@ -54,7 +54,8 @@ def bench(J, NC, S, k=100):
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for i, (a, b) in enumerate(evs):
-            stage(i, 1 if m == 2 else 3)
+            if m != 1:
+                stage(i, 1 if m in (2, 6) else 7)
             a.record()
             stage(i, m)
             b.record()
@@ -62,12 +63,15 @@ def bench(J, NC, S, k=100):
         t = sorted(a.elapsed_time(b) for a, b in evs)
         return 1e3 * sum(t[:n // 2]) / (n // 2)
 
-    out = {'prep': ev_time(1), 'cost': ev_time(2), 'solve': ev_time(4), 'rank': ev_time(8)}
+    out = {'prep': ev_time(1), 'score': ev_time(6), 'rank': ev_time(8)}
+    with _lib.pinned(OT_FORM='tile' if S <= 8 else 'small'):
+        out['cost(2k)'] = ev_time(2)
+        out['solve(2k)'] = ev_time(4)
     bytes_ = J * NC * (S * D * 4) + J * S * D * 4
-    out['cost_TBs'] = bytes_ / out['cost'] / 1e6
+    out['cost_TBs'] = bytes_ / out['score'] / 1e6
     e2e = {}
-    for chunks in (1, 2, 4, 8):
-        with _lib.pinned(BATCH_CHUNKS=chunks):
+    for chunks in (['fused', 'tile', 'small'] if S <= 8 else ['small']):
+        with _lib.pinned(OT_FORM=chunks):
             for i in range(4):
                 full(i)
             torch.cuda.synchronize()
@@ -79,8 +83,8 @@ def bench(J, NC, S, k=100):
             torch.cuda.synchronize()
             e2e[chunks] = (1e6 * (time.perf_counter() - t0) / n, 1e6 * t_host / n)
     print(f'J={J} NC={NC} S={S}: ' + ' '.join(f'{k_}={v:.1f}us' for k_, v in out.items() if k_ != 'cost_TBs') +
-          f' cost={out["cost_TBs"]:.2f}TB/s | e2e(us)/host(us): ' +
-          ' '.join(f'ch{c}={a:.0f}/{h:.0f}' for c, (a, h) in e2e.items()) +
+          f' score={out["cost_TBs"]:.2f}TB/s | e2e(us)/host(us): ' +
+          ' '.join(f'{c}={a:.0f}/{h:.0f}' for c, (a, h) in e2e.items()) +
           f' | best {J * NC / min(a for a, _ in e2e.values()):.0f} M pairs/s', flush=True)
 
 
