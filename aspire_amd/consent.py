@@ -9,7 +9,17 @@ src/learning/facetid_models/disent_models.py:470-535).
 
 The BERT forward and the span pooling both run in libaspire_hip.so; outputs are returned on the device of
 ``bert_batch['tokid_tt']`` (CPU tensors in, CPU tensors out, as in the reference's examples).
+
+Beyond the drop-in ``forward`` the class carries the callers' encode steps in two forms:
+  * the reference's own, host-out ones -- ``caching_encode`` (WordSentAlignBiEnc.caching_encode,
+    src/learning/facetid_models/disent_models.py:344-371) and ``encode`` (AspireModel.encode,
+    src/evaluation/utils/models.py:199-209): un-padded per-document reps;
+  * the device-resident one -- ``forward_device`` / ``encode_to_pool``: token ids go in, the pooled sentence reps are
+    written by the pooling kernel straight into a rows + CSR rep store in HBM (no padding rows, no host round trip) and
+    come back as a ``CandidatePool`` that the scoring calls read in place.  1 M documents x 12 sentences = 36.9 GB fit one
+    MI355X's 288 GB seven times over.
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -67,3 +77,71 @@ class AspireConSent:
         doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
         # the reference squeezes and re-unsqueezes (:76, :46-49): shapes are [B,768] and [B,S,768] for every B.
         return doc_cls_reps.to(out_dev), sent_reps.to(out_dev)
+
+    # ---- the callers' encode steps -------------------------------------------------------------------------------------
+    def forward_device(self, bert_batch, abs_lens, sent_tok_idxs):
+        """``forward`` with the outputs left on the GPU: (doc_cls_reps [B, 768], sent_reps [B, max_sents, 768])."""
+        gpu = ops.require_gpu()
+        dev_batch = dict(bert_batch)
+        for k in ('tokid_tt', 'seg_tt', 'attnmask_tt'):
+            dev_batch[k] = bert_batch[k].to(gpu)
+        return self.consent_reps_bert(bert_batch=dev_batch, num_sents=abs_lens, batch_senttok_idxs=sent_tok_idxs)
+
+    def caching_encode(self, batch_dict):
+        """WordSentAlignBiEnc.caching_encode (disent_models.py:344-371): batch_dict with 'bert_batch', 'abs_lens',
+        'senttok_idxs' -> list of {'doc_cls_reps': np [768], 'sent_reps': np [num_sents, 768]} (un-padded)."""
+        doc_cls_reps, sent_reps = self.forward_device(batch_dict['bert_batch'], batch_dict['abs_lens'], batch_dict['senttok_idxs'])
+        sent_reps = sent_reps.cpu().numpy()
+        doc_cls_reps = doc_cls_reps.cpu().numpy()
+        return [{'doc_cls_reps': doc_cls_reps[i, :], 'sent_reps': sent_reps[i, :num_sents, :]}
+                for i, num_sents in enumerate(batch_dict['abs_lens'])]
+
+    def encode(self, batch_papers, pt_lm_tokenizer):
+        """AspireModel.encode (src/evaluation/utils/models.py:199-209): papers -> list of [abs_len, 768] tensors."""
+        from .batch_prep import prepare_abstracts
+        bert_batch, abs_lens, sent_token_idxs = prepare_abstracts(batch_abs=batch_papers, pt_lm_tokenizer=pt_lm_tokenizer)
+        _, batch_reps_sent = self.forward(bert_batch=bert_batch, abs_lens=abs_lens, sent_tok_idxs=sent_token_idxs)
+        return [batch_reps_sent[i, :abs_lens[i]] for i in range(len(abs_lens))]
+
+    def encode_to_pool(self, batches, pids=None, want_cls=False):
+        """Encode document batches straight into a resident candidate pool.
+
+        batches: iterable of (bert_batch, abs_lens, sent_tok_idxs) as prepare_abstracts returns them (it is consumed
+        twice when it is a list; a generator is materialised).  The store's row matrix [sum(abs_lens), 768] is allocated
+        once in HBM; for every batch the encoder runs and the pooling kernel writes each sentence's mean straight into the
+        document's rows (aspire_span_mean_pool_rows_f32) -- no padded tensor, no copy back to the host.
+        Returns a scorer.CandidatePool (and the [N, 768] CLS reps on the GPU with want_cls)."""
+        from .scorer import CandidatePool
+        dev = ops.require_gpu()
+        batches = list(batches)
+        all_lens = [int(n) for _, abs_lens, _ in batches for n in abs_lens]
+        n_docs, total = len(all_lens), int(sum(all_lens))
+        lens_t = torch.tensor(all_lens, dtype=torch.int32)
+        start_t = (torch.cumsum(lens_t, 0) - lens_t).to(torch.int32)
+        rows = torch.empty(max(total, 1), 768, device=dev, dtype=torch.float32)[:total]
+        cls_all = torch.empty(n_docs, 768, device=dev, dtype=torch.float32) if want_cls else None
+        doc0 = 0
+        for bert_batch, abs_lens, sent_tok_idxs in batches:
+            b = len(abs_lens)
+            max_sents = max(abs_lens)
+            seq_lens = bert_batch['seq_lens']
+            max_seq_len = max(seq_lens)
+            tokid_tt = bert_batch['tokid_tt']
+            assert tokid_tt.shape == (b, max_seq_len)
+            for doc in sent_tok_idxs:
+                for span in doc:
+                    if span and (min(span) < 0 or max(span) >= max_seq_len):
+                        raise IndexError('sentence token index out of range')
+            hidden = self.bert_encoder.forward_hidden(tokid_tt, token_type_ids=bert_batch['seg_tt'],
+                                                      attention_mask=bert_batch['attnmask_tt'])
+            tok_idx, span_off = spans_to_csr(sent_tok_idxs, max_sents)
+            # slot (b, s) -> row of the store, -1 beyond the document's sentence count
+            out_row = np.full((b, max_sents), -1, dtype=np.int32)
+            for i, n in enumerate(abs_lens):
+                out_row[i, :n] = int(start_t[doc0 + i]) + np.arange(n, dtype=np.int32)
+            ops.span_mean_pool_rows(hidden, tok_idx.to(dev), span_off.to(dev), max_sents, torch.from_numpy(out_row.reshape(-1)).to(dev),
+                                    rows, cls_all[doc0:doc0 + b] if want_cls else None)
+            doc0 += b
+        repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0)
+        pool = CandidatePool.from_repset(repset, pids=pids)
+        return (pool, cls_all) if want_cls else pool

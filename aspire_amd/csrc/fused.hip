@@ -29,6 +29,7 @@
 #include "common.h"
 #include "score_device.h"
 #include "score_types.h"
+#include "tuning.h"
 
 namespace aspire {
 namespace {
@@ -58,13 +59,29 @@ __device__ __forceinline__ float max_li(float v) {
 }
 __device__ __forceinline__ float sum16(float v) { return sum_li(sum_lj(v)); }
 
-// The solve of the four pairs of a wave.  cost / neg: this lane's 2 x 2 entries of geomloss's cost and of -cdist; rv / cv:
-// row / column validity; diam: the pair's bounding-box diameter (uniform over its 16 lanes).  Returns the score (`want`).
-__device__ __forceinline__ float solve_pairs(const ScoreArgs& a, const float (&cost)[2][2], const float (&neg)[2][2],
-                                             const bool (&rv)[2], const bool (&cv)[2], float diam) {
-    // ---- marginals (pair_distances.py:57-60): soft-max over sentences of the best match / temp --------------------
+// ---------------------------------------------------------------------------------------------------------------------
+// The Sinkhorn solve of the four pairs of a wave as a resumable state machine.  A solve is ~80 dependent epsilon steps of
+// ~50 instructions each -- latency bound for a lone wave (two resident per SIMD here), ~18 us per item when run in one
+// piece.  So the solve of item i is cut into slices that run INSIDE the cost stages of item i + 1, each slice in the
+// shadow of that stage's HBM loads: the wave was going to wait there anyway.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Solve {
+    float mc[2][2];        // masked cost: entries outside the valid block are 0 and never enter a sum (their weights are 0)
+    float neg[2][2];       // -cdist of the valid block (plan-weighted similarity output only)
+    float wa[2], wb[2];    // marginals (pair_distances.py:57-60)
+    float f[2], g[2];      // potentials
+    float c_r2, c_h, diam;
+    int n_mid;             // annealed values between diam and blur; step k: 0 = diam, 1 .. n_mid, n_mid + 1 = blur, n_mid + 2 = final
+    int k, max_steps;      // wave-uniform: next step, steps of the longest of the wave's four schedules
+    unsigned valid;        // bit x: row x valid, bit 2 + y: column y valid
+    int64_t out;           // index into scores, < 0 = nothing to store (clamped tail candidate)
+    bool poisoned;         // a document longer than the tile
+};
+
+__device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const float (&cost)[2][2], const float (&neg)[2][2],
+                                            const bool (&rv)[2], const bool (&cv)[2], float diam) {
+    // ---- marginals: soft-max over sentences of the best match / temp --------------------------------------------------
     const float temp = (float)a.temp;
-    float wa[2], wb[2];
     {
         float qm[2], cm[2];
 #pragma unroll
@@ -80,185 +97,197 @@ __device__ __forceinline__ float solve_pairs(const ScoreArgs& a, const float (&c
         const float lsq = fast_log(sum_li(sq)), lsc = fast_log(sum_lj(sc));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;      // log_softmax(...).exp(); a zero weight is geomloss's
-            wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;      // log-weight -100000
+            s.wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;      // log_softmax(...).exp(); a zero weight is geomloss's
+            s.wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;      // log-weight -100000
         }
     }
-    // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = diam scaling^(k-1), n_mid+1 = blur, n_mid+2 = blur (final) ----
+    s.valid = (rv[0] ? 1u : 0u) | (rv[1] ? 2u : 0u) | (cv[0] ? 4u : 0u) | (cv[1] ? 8u : 0u);
+    // ---- epsilon schedule ----------------------------------------------------------------------------------------------
     float ldf;
-    const int n_mid = schedule_mid_steps(a, diam, ldf);
-    const float lscf = a.log2_scaling;
-    const int n_steps = n_mid + 3;
-    int max_steps = n_steps;
-    max_steps = max(max_steps, __shfl_xor(max_steps, 16));
-    max_steps = max(max_steps, __shfl_xor(max_steps, 32));
-    max_steps = __builtin_amdgcn_readfirstlane(max_steps);
-    const float c_r2 = 0.5287663729448977f - ldf;      // log2(log2 e) - log2(diam):  r2_k = exp2(c_r2 - (k-1) lscf)
-    const float c_h = -1.5287663729448977f + ldf;      // log2(ln2 / 2) + log2(diam): h_k  = exp2(c_h  + (k-1) lscf)
+    s.n_mid = schedule_mid_steps(a, diam, ldf);
+    int ms = s.n_mid + 3;
+    ms = max(ms, __shfl_xor(ms, 16));
+    ms = max(ms, __shfl_xor(ms, 32));
+    s.max_steps = __builtin_amdgcn_readfirstlane(ms);
+    s.k = 0;
+    s.diam = diam;
+    s.c_r2 = 0.5287663729448977f - ldf;      // log2(log2 e) - log2(diam):  r2_k = exp2(c_r2 - (k-1) lscf)
+    s.c_h = -1.5287663729448977f + ldf;      // log2(ln2 / 2) + log2(diam): h_k  = exp2(c_h  + (k-1) lscf)
     const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
-    const float eb = (float)a.blur;
-    const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
-    float mc_[2][2];           // masked cost: entries outside the valid block never enter a sum (their weights are 0)
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) mc_[x][y] = (rv[x] && cv[y]) ? cost[x][y] : 0.f;
-
-    // ---- initialisation at eps = diam: softmin of the bare weights (no shift needed: the largest weight of a
-    // probability vector over <= 8 atoms is >= 1/8 and C / diam <= ~1) ---------------------------------------------
-    float f[2], g[2];
-    {
-        float rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const float k0 = __builtin_amdgcn_exp2f(-mc_[x][y] * r2_first);
-                rs[x] = fmaf(wb[y], k0, rs[x]);
-                cs[y] = fmaf(wa[x], k0, cs[y]);
-            }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_lj(rs[t]));
-            g[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_li(cs[t]));
+        for (int y = 0; y < 2; ++y) {
+            s.mc[x][y] = (rv[x] && cv[y]) ? cost[x][y] : 0.f;
+            s.neg[x][y] = (rv[x] && cv[y]) ? neg[x][y] : 0.f;
         }
+    // ---- initialisation at eps = diam: softmin of the bare weights (no shift needed: the largest weight of a
+    // probability vector over <= 8 atoms is >= 1/8 and C / diam <= ~1) -------------------------------------------------
+    float rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const float k0 = __builtin_amdgcn_exp2f(-s.mc[x][y] * r2_first);
+            rs[x] = fmaf(s.wb[y], k0, rs[x]);
+            cs[y] = fmaf(s.wa[x], k0, cs[y]);
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        s.f[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_lj(rs[t]));
+        s.g[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_li(cs[t]));
     }
-    // ---- the annealing loop -----------------------------------------------------------------------------------------
-    for (int k = 0; k < max_steps; ++k) {
+}
+
+// up to `n` more annealing steps (all of the rest with n < 0)
+__device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n) {
+    const float lscf = a.log2_scaling;
+    const float eb = (float)a.blur;
+    const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
+    const int k_end = (n < 0 || s.k + n > s.max_steps) ? s.max_steps : s.k + n;
+#pragma unroll 1
+    for (int k = s.k; k < k_end; ++k) {
         const float kf = (float)(k - 1);
-        float r2 = __builtin_amdgcn_exp2f(fmaf(-kf, lscf, c_r2));
-        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, c_h));
-        if (k == 0) { r2 = r2_first; h = h_first; }
-        if (k > n_mid) { r2 = r2_blur; h = k == n_mid + 1 ? h_blur : (k == n_mid + 2 ? 2.f * h_blur : 0.f); }
+        float r2 = __builtin_amdgcn_exp2f(fmaf(-kf, lscf, s.c_r2));
+        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, s.c_h));
+        if (k == 0) { r2 = kLog2e * rcp_refined(s.diam); h = 0.5f * kLn2 * s.diam; }
+        if (k > s.n_mid) { r2 = r2_blur; h = k == s.n_mid + 1 ? h_blur : (k == s.n_mid + 2 ? 2.f * h_blur : 0.f); }
         float f2[2], g2[2], rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f2[t] = f[t] * r2;
-            g2[t] = g[t] * r2;
+            f2[t] = s.f[t] * r2;
+            g2[t] = s.g[t] * r2;
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
-                const float kxy = __builtin_amdgcn_exp2f(fmaf(-mc_[x][y], r2, f2[x] + g2[y]));
-                rs[x] = fmaf(wb[y], kxy, rs[x]);
-                cs[y] = fmaf(wa[x], kxy, cs[y]);
+                const float kxy = __builtin_amdgcn_exp2f(fmaf(-s.mc[x][y], r2, f2[x] + g2[y]));
+                rs[x] = fmaf(s.wb[y], kxy, rs[x]);
+                cs[y] = fmaf(s.wa[x], kxy, cs[y]);
             }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f[t] = fmaf(-h, __builtin_amdgcn_logf(sum_lj(rs[t])), f[t]);
-            g[t] = fmaf(-h, __builtin_amdgcn_logf(sum_li(cs[t])), g[t]);
+            s.f[t] = fmaf(-h, __builtin_amdgcn_logf(sum_lj(rs[t])), s.f[t]);
+            s.g[t] = fmaf(-h, __builtin_amdgcn_logf(sum_li(cs[t])), s.g[t]);
         }
     }
+    s.k = k_end;
+}
+
+__device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a, const float (&f)[2], const float (&g)[2]) {
     const int lp = threadIdx.x & 15, li = lp >> 2, lj = lp & 3;
-    auto outputs = [&]() {
-        float score;
-        if (a.want != ASPIRE_OT_PLAN_SIM) {
-            float acc = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                acc += (lj == 0 && rv[t]) ? wa[t] * f[t] : 0.f;
-                acc += (li == 0 && cv[t]) ? wb[t] * g[t] : 0.f;
-            }
-            score = sum16(acc);
-            if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
-        } else {
-            const float rb = rcp_refined(eb);
-            float acc = 0.f;
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    const bool valid = rv[x] && cv[y];
-                    const float negm = valid ? neg[x][y] : 0.f;
-                    const float outer = valid ? f[x] + g[y] : 0.f;
-                    acc += fast_exp(div_r(outer + negm, eb, rb)) * (wa[x] * wb[y]) * negm;
-                }
-            score = sum16(acc);
-        }
-        return score;
-    };
-    float score = outputs();
-    // An overflowed / vanished sum has turned into inf / nan that sticks to the potentials and reaches the score: solve
-    // such a pair again (never at the reference's hyper-parameters; scaling = 0.01 does it) with max-shifted
-    // log-sum-exps, log-weights in the exponent and the float64 schedule -- geomloss's own formulation.
-    if (__builtin_expect(__any(!(fabsf(score) < 1e30f)), 0)) {
-        const bool redo = !(fabsf(score) < 1e30f);      // uniform over the pair's 16 lanes
-        float la[2], lb[2], fe[2], ge[2];
+    const bool rv[2] = {(s.valid & 1u) != 0, (s.valid & 2u) != 0}, cv[2] = {(s.valid & 4u) != 0, (s.valid & 8u) != 0};
+    float score;
+    if (a.want != ASPIRE_OT_PLAN_SIM) {
+        float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            la[t] = wa[t] > 0.f ? fast_log(wa[t]) : -100000.f;
-            lb[t] = wb[t] > 0.f ? fast_log(wb[t]) : -100000.f;
+            acc += (lj == 0 && rv[t]) ? s.wa[t] * f[t] : 0.f;
+            acc += (li == 0 && cv[t]) ? s.wb[t] * g[t] : 0.f;
         }
-        // softmin over j (rows) / i (columns) with the exact maximum: out = -eps * LSE(h - C / eps)
-        auto lse_rows = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
+        score = sum16(acc);
+        if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
+    } else {
+        const float eb = (float)a.blur, rb = rcp_refined(eb);
+        float acc = 0.f;
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const float t0 = cv[0] ? hh[0] - div_r(mc_[x][0], eps, reps) : kNegBig;
-                const float t1 = cv[1] ? hh[1] - div_r(mc_[x][1], eps, reps) : kNegBig;
-                const float m = max_lj(fmaxf(t0, t1));
-                out[x] = -eps * (m + fast_log(sum_lj(fast_exp(t0 - m) + fast_exp(t1 - m))));
-            }
-        };
-        auto lse_cols = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
-                const float t0 = rv[0] ? hh[0] - div_r(mc_[0][y], eps, reps) : kNegBig;
-                const float t1 = rv[1] ? hh[1] - div_r(mc_[1][y], eps, reps) : kNegBig;
-                const float m = max_li(fmaxf(t0, t1));
-                out[y] = -eps * (m + fast_log(sum_li(fast_exp(t0 - m) + fast_exp(t1 - m))));
+                const bool valid = rv[x] && cv[y];
+                const float outer = valid ? f[x] + g[y] : 0.f;
+                acc += fast_exp(div_r(outer + s.neg[x][y], eb, rb)) * (s.wa[x] * s.wb[y]) * s.neg[x][y];
             }
-        };
-        // one symmetric update at eps; `active` = false leaves the pair's potentials alone (a wave mate with a longer
-        // schedule is still annealing: all reductions stay inside the pair's own 16 lanes)
-        auto step = [&](float eps, bool averaged, bool active) {
-            const float reps = rcp_refined(eps);
-            float ha[2], hb[2], ft[2], gt[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                ha[t] = la[t] + div_r(fe[t], eps, reps);
-                hb[t] = lb[t] + div_r(ge[t], eps, reps);
-            }
-            lse_cols(eps, reps, ha, gt);
-            lse_rows(eps, reps, hb, ft);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float gn = averaged ? 0.5f * (ge[t] + gt[t]) : gt[t];
-                const float fn = averaged ? 0.5f * (fe[t] + ft[t]) : ft[t];
-                ge[t] = active ? gn : ge[t];
-                fe[t] = active ? fn : fe[t];
-            }
-        };
-        {
-            const float reps = rcp_refined(diam);
-            lse_cols(diam, reps, la, ge);
-            lse_rows(diam, reps, lb, fe);
-        }
-        step(diam, true, true);
-        const double ld = log((double)diam);
-        int n_max = n_mid;
-        n_max = max(n_max, __shfl_xor(n_max, 16));
-        n_max = max(n_max, __shfl_xor(n_max, 32));
-        for (int k = 0; k < n_max; ++k)      // float64 schedule exactly as numpy builds geomloss's
-            step((float)exp(ld + (double)k * a.log_scaling), true, k < n_mid);
-        step(eb, true, true);
-        step(eb, false, true);
-        if (redo) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f[t] = fe[t];
-                g[t] = ge[t];
-            }
-        }
-        const float exact = outputs();
-        score = redo ? exact : score;
+        score = sum16(acc);
     }
     return score;
 }
 
+// geomloss's own formulation -- max-shifted log-sum-exps, log-weights in the exponent, float64 schedule -- for a pair
+// whose shifted sums left fp32 range (never at the reference's hyper-parameters; scaling = 0.01 does it).
+__device__ __forceinline__ float solve_exact(const Solve& s, const ScoreArgs& a, float score, bool redo) {
+    const bool rv[2] = {(s.valid & 1u) != 0, (s.valid & 2u) != 0}, cv[2] = {(s.valid & 4u) != 0, (s.valid & 8u) != 0};
+    const float eb = (float)a.blur, diam = s.diam;
+    float la[2], lb[2], fe[2], ge[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        la[t] = s.wa[t] > 0.f ? fast_log(s.wa[t]) : -100000.f;
+        lb[t] = s.wb[t] > 0.f ? fast_log(s.wb[t]) : -100000.f;
+    }
+    // softmin over j (rows) / i (columns) with the exact maximum: out = -eps * LSE(h - C / eps)
+    auto lse_rows = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float t0 = cv[0] ? hh[0] - div_r(s.mc[x][0], eps, reps) : kNegBig;
+            const float t1 = cv[1] ? hh[1] - div_r(s.mc[x][1], eps, reps) : kNegBig;
+            const float m = max_lj(fmaxf(t0, t1));
+            out[x] = -eps * (m + fast_log(sum_lj(fast_exp(t0 - m) + fast_exp(t1 - m))));
+        }
+    };
+    auto lse_cols = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const float t0 = rv[0] ? hh[0] - div_r(s.mc[0][y], eps, reps) : kNegBig;
+            const float t1 = rv[1] ? hh[1] - div_r(s.mc[1][y], eps, reps) : kNegBig;
+            const float m = max_li(fmaxf(t0, t1));
+            out[y] = -eps * (m + fast_log(sum_li(fast_exp(t0 - m) + fast_exp(t1 - m))));
+        }
+    };
+    // one symmetric update at eps; `active` = false leaves the pair's potentials alone (a wave mate with a longer
+    // schedule is still annealing: all reductions stay inside the pair's own 16 lanes)
+    auto step = [&](float eps, bool averaged, bool active) {
+        const float reps = rcp_refined(eps);
+        float ha[2], hb[2], ft[2], gt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ha[t] = la[t] + div_r(fe[t], eps, reps);
+            hb[t] = lb[t] + div_r(ge[t], eps, reps);
+        }
+        lse_cols(eps, reps, ha, gt);
+        lse_rows(eps, reps, hb, ft);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float gn = averaged ? 0.5f * (ge[t] + gt[t]) : gt[t];
+            const float fn = averaged ? 0.5f * (fe[t] + ft[t]) : ft[t];
+            ge[t] = active ? gn : ge[t];
+            fe[t] = active ? fn : fe[t];
+        }
+    };
+    {
+        const float reps = rcp_refined(diam);
+        lse_cols(diam, reps, la, ge);
+        lse_rows(diam, reps, lb, fe);
+    }
+    step(diam, true, true);
+    const double ld = log((double)diam);
+    int n_max = s.n_mid;
+    n_max = max(n_max, __shfl_xor(n_max, 16));
+    n_max = max(n_max, __shfl_xor(n_max, 32));
+    for (int k = 0; k < n_max; ++k)      // float64 schedule exactly as numpy builds geomloss's
+        step((float)exp(ld + (double)k * a.log_scaling), true, k < s.n_mid);
+    step(eb, true, true);
+    step(eb, false, true);
+    const float exact = solve_output(s, a, fe, ge);
+    return redo ? exact : score;
+}
+
+// finish a solve: remaining steps, the score, the store
+__device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
+    solve_steps(s, a, -1);
+    float score = solve_output(s, a, s.f, s.g);
+    // An overflowed / vanished sum has turned into inf / nan that sticks to the potentials and reaches the score
+    const bool bad = !(fabsf(score) < 1e30f);
+    if (__builtin_expect(__any(bad), 0)) score = solve_exact(s, a, score, bad);
+    if (s.poisoned) score = __builtin_nanf("");      // a document longer than the tile: poison, never truncate silently
+    if (s.out >= 0 && (threadIdx.x & 15) == 0) a.scores[s.out] = score;
+}
+
 // counter[0] hands out the items beyond each wave's first, counter[1] counts the waves that have run out of items: the last
 // one leaves both at zero for the next launch (the launch before the first one on a fresh workspace clears them).
-__global__ void __launch_bounds__(256) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox, uint32_t* __restrict__ counter) {
+// a.agg == 1 (diagnostics): skip the solves (the cost phase alone, for timing).
+template <int CPT>      // staged chunks per trip of the accumulate loop (2: the second chunk's LDS reads fly under the first one's arithmetic)
+__global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox, uint32_t* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -271,11 +300,16 @@ __global__ void __launch_bounds__(256) pair_fused_kernel(ScoreArgs a, const floa
     const uint32_t n_items = mapped ? (uint32_t)a.grp_off[a.job1] : ((ncand + 3) / 4) * nq;   // item = (candidate group, query), group-major
     const uint32_t n_waves = gridDim.x * 4;
     const bool own_diam = a.diameter == nullptr;            // else: the caller's per-group diameters (caching_score's batches)
+    const bool with_solve = a.agg != 1;
 
     // lane roles: p = candidate of this lane (compute AND staging); (li, lj) = its 2 x 2 block of the 8 x 8 entries;
     // staging: the 16 lanes of group sg stage the 8 rows of candidate sg and query rows 2 sg, 2 sg + 1, chunk sc each
     const int p = lane >> 4, lp = lane & 15, li = lp >> 2, lj = lp & 3;
     const int sg = p, sc = lp;
+
+    Solve pend;                    // the previous item's solve, advanced inside this item's cost stages
+    bool have_pend = false;
+    int slice = 0;                 // steps of the pending solve per cost stage
 
     for (uint32_t item = item_lo + blockIdx.x * 4 + wave; item < n_items;) {
         uint32_t q_loc, c_loc0, c_end;
@@ -349,10 +383,9 @@ __global__ void __launch_bounds__(256) pair_fused_kernel(ScoreArgs a, const floa
             const float* xr = lds + (2 * li) * kRowStride;
             const float* yr = lds + (8 + p * 8 + 2 * lj) * kRowStride;
 #pragma unroll 1
-            for (int c = 0; c < kCh; c += 2) {
-                // two chunks per trip: the second chunk's LDS reads are in flight under the first chunk's arithmetic
+            for (int c = 0; c < kCh; c += CPT) {
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
+                for (int cc = 0; cc < CPT; ++cc) {
                     float4 xv[2], yv[2];
 #pragma unroll
                     for (int x = 0; x < 2; ++x) xv[x] = *reinterpret_cast<const float4*>(xr + x * kRowStride + (c + cc) * 4);
@@ -367,9 +400,11 @@ __global__ void __launch_bounds__(256) pair_fused_kernel(ScoreArgs a, const floa
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
             __builtin_amdgcn_wave_barrier();
+            // ---- a slice of the PREVIOUS item's solve, in the shadow of the loads just issued ------------------------
+            if (have_pend) solve_steps(pend, a, slice);
         }
 
-        // ---- claim the next item now: the atomic's round trip hides behind the finish + solve below ------------------
+        // ---- claim the next item now: the atomic's round trip hides behind the finish below ----------------------------
         uint32_t claimed = 0;
         if (lane == 0) claimed = atomicAdd(counter, 1u);
 
@@ -452,20 +487,27 @@ __global__ void __launch_bounds__(256) pair_fused_kernel(ScoreArgs a, const floa
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch table is rewritten by the next item
         __builtin_amdgcn_wave_barrier();
 
-        // ---- solve the four pairs in place and store their scores -----------------------------------------------------
-        bool rv[2], cv[2];
+        // ---- the previous item's solve ends here (its last steps, score, store); this item's begins ---------------------
+        if (have_pend) solve_finish(pend, a);
+        if (with_solve) {
+            bool rv[2], cv[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            rv[t] = 2 * li + t < q_len;
-            cv[t] = 2 * lj + t < c_len;
+            for (int t = 0; t < 2; ++t) {
+                rv[t] = 2 * li + t < q_len;
+                cv[t] = 2 * lj + t < c_len;
+            }
+            const float diam = own_diam ? sqrtf(diam2) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
+            solve_begin(pend, a, cost, neg, rv, cv, diam);
+            pend.out = my_c_real ? (mapped ? c_idx : q_idx * a.c.n + c_idx) : (int64_t)-1;
+            pend.poisoned = q_len > 8 || c_len > 8;
+            slice = (pend.max_steps + kStages - 1) / kStages;
+            have_pend = true;
+        } else if (my_c_real && lp == 0) {
+            a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = diam2;
         }
-        const float diam = own_diam ? sqrtf(diam2) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
-        float score = solve_pairs(a, cost, neg, rv, cv, diam);
-        if (q_len > 8 || c_len > 8) score = __builtin_nanf("");      // longer than the tile: poison, never truncate silently
-        if (my_c_real && lp == 0) a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = score;
-
         item = item_lo + n_waves + __builtin_amdgcn_readfirstlane(claimed);
     }
+    if (have_pend) solve_finish(pend, a);       // the wave's last item: nothing left to hide it behind
     if (lane == 0 && atomicAdd(counter + 1, 1u) == n_waves - 1) {      // every wave has made its last claim by now
         counter[0] = 0u;
         counter[1] = 0u;
@@ -483,10 +525,16 @@ size_t fused_lds_bytes(void) { return 4 * kWaveLds * sizeof(float); }
 
 // groups_bound: upper bound of the launch's items (groups of four candidates x queries); `counter` must be zero when the
 // kernel starts (the launch before it on the stream clears it).
-int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, uint32_t* counter, hipStream_t stream) {
+int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, uint32_t* counter, hipStream_t stream) {
+    ScoreArgs a = a_in;
+    a.agg = tuning().fused_nosolve ? 1 : 0;
     const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;      // two 4-wave workgroups per CU are resident
-    hipLaunchKernelGGL(pair_fused_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, qbox,
-                       counter);
+    if (tuning().fused_cpt == 1)
+        hipLaunchKernelGGL(pair_fused_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a,
+                           qbox, counter);
+    else
+        hipLaunchKernelGGL(pair_fused_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a,
+                           qbox, counter);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

@@ -34,6 +34,10 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "GEMM_TILE")) {
         if (!unset && strcmp(v, "96")) return false;
         t.gemm_tile96 = unset ? 0 : 1;
+    } else if (!strcmp(key, "FUSED_CPT")) {
+        t.fused_cpt = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "FUSED_NOSOLVE")) {
+        t.fused_nosolve = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "OT_FORM")) {
         const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : !strcmp(v, "fused") ? 3 : -1;
         if (f < 0) return false;
@@ -45,7 +49,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_CPT", "FUSED_NOSOLVE"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

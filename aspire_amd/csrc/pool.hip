@@ -12,10 +12,19 @@ __global__ void __launch_bounds__(192) span_mean_pool_kernel(const float* __rest
                                                              const int32_t* __restrict__ tok_idx,
                                                              const int32_t* __restrict__ span_off, int64_t S,
                                                              float* __restrict__ sent_reps,
-                                                             float* __restrict__ cls_reps) {
+                                                             float* __restrict__ cls_reps,
+                                                             const int32_t* __restrict__ out_row) {
     const int64_t slot = blockIdx.x;          // b * S + s
     const int64_t b = slot / S;
     const int d = threadIdx.x * 4;
+    // out_row (rep-store form): slot (b, s) is row out_row[slot] of a rows + CSR store, < 0 = the document has no
+    // sentence s (nothing is written: the store holds no padding rows)
+    const int64_t orow = out_row != nullptr ? (int64_t)out_row[slot] : slot;
+    if (cls_reps != nullptr && slot % S == 0) {
+        *reinterpret_cast<float4*>(cls_reps + (size_t)b * kD + d) =
+            *reinterpret_cast<const float4*>(hidden + (size_t)b * L * kD + d);
+    }
+    if (orow < 0) return;
     const float* doc = hidden + (size_t)b * L * kD;
     const int lo = span_off[slot], hi = span_off[slot + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -38,10 +47,7 @@ __global__ void __launch_bounds__(192) span_mean_pool_kernel(const float* __rest
     // torch.count_nonzero(mask).clamp(min=1): an empty slot stays exactly zero.
     const float cnt = (float)max(hi - lo, 1);
     acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;
-    *reinterpret_cast<float4*>(sent_reps + (size_t)slot * kD + d) = acc;
-    if (cls_reps != nullptr && slot % S == 0) {
-        *reinterpret_cast<float4*>(cls_reps + (size_t)b * kD + d) = *reinterpret_cast<const float4*>(doc + d);
-    }
+    *reinterpret_cast<float4*>(sent_reps + (size_t)orow * kD + d) = acc;
 }
 
 }  // namespace
@@ -59,7 +65,22 @@ extern "C" int aspire_span_mean_pool_f32(const float* hidden, int64_t B, int64_t
     ASPIRE_REQUIRE(hidden && span_off && sent_reps, ASPIRE_ERR_INVALID_ARG, "null pointer");
     if (B == 0) return ASPIRE_OK;
     hipLaunchKernelGGL(span_mean_pool_kernel, dim3((unsigned)(B * S)), dim3(192), 0, (hipStream_t)stream, hidden, L,
-                       tok_idx, span_off, S, sent_reps, cls_reps);
+                       tok_idx, span_off, S, sent_reps, cls_reps, (const int32_t*)nullptr);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+extern "C" int aspire_span_mean_pool_rows_f32(const float* hidden, int64_t B, int64_t L, int64_t D, const int32_t* tok_idx,
+                                              const int32_t* span_off, int64_t S, const int32_t* out_row, float* rows,
+                                              float* cls_reps, void* stream) {
+    ASPIRE_REQUIRE(D == kD, ASPIRE_ERR_UNSUPPORTED, "encoding dim %lld unsupported (kernels are built for 768)",
+                   (long long)D);
+    ASPIRE_REQUIRE(B >= 0 && L > 0 && S > 0, ASPIRE_ERR_INVALID_ARG, "bad shape B=%lld L=%lld S=%lld", (long long)B,
+                   (long long)L, (long long)S);
+    ASPIRE_REQUIRE(hidden && span_off && out_row && rows, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    if (B == 0) return ASPIRE_OK;
+    hipLaunchKernelGGL(span_mean_pool_kernel, dim3((unsigned)(B * S)), dim3(192), 0, (hipStream_t)stream, hidden, L,
+                       tok_idx, span_off, S, rows, cls_reps, out_row);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

@@ -94,6 +94,18 @@ def span_mean_pool(hidden, tok_idx, span_off, max_sents, want_cls=True):
     return cls, sent
 
 
+def span_mean_pool_rows(hidden, tok_idx, span_off, max_sents, out_row, rows, cls=None):
+    """The pooling written straight into a resident rep store (include/aspire_hip.h: aspire_span_mean_pool_rows_f32): slot
+    (b, s) -> rows[out_row[b * S + s]] (skipped when negative); cls [B, 768] optional.  Nothing is returned: `rows` (a view
+    into the store's row matrix) and `cls` are filled in place."""
+    _f32(hidden, 'hidden')
+    _f32(rows, 'rows')
+    b, l, d = hidden.shape
+    assert out_row.numel() == b * max_sents
+    check(lib.aspire_span_mean_pool_rows_f32(_ptr(hidden), b, l, d, _ptr(_i32(tok_idx, 'tok_idx')), _ptr(_i32(span_off, 'span_off')),
+                                             max_sents, _ptr(_i32(out_row, 'out_row')), _ptr(rows), _ptr(cls), _stream()))
+
+
 def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want_pair_sims=False):
     """A9 (pair_distances.py:138-186).  Returns sims [P] (and pair_sims [P, q.ext, c.ext])."""
     p = _npairs(q, c, pairing)

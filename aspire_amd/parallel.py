@@ -24,6 +24,19 @@ def shard_bounds(n_items, world_size, rank, multiple=1):
     return min(lo_u * multiple, n_items), min(hi_u * multiple, n_items)
 
 
+def all_gather_flat(out, inp, group=None):
+    """dist.all_gather_into_tensor(out, inp) for 1-D tensors.  RCCL ("nccl") gathers GPU tensors in place over xGMI; the gloo
+    backend (CPU tests, the one-GPU rehearsals of the multi-rank code) has no GPU all-gather, so there the data takes a
+    round trip through host memory."""
+    if dist.get_backend(group) == 'gloo' and inp.is_cuda:
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+    return out
+
+
 def merge_topk(scores, idx, k):
     """scores/idx [Q, M] candidates from all shards (idx = global ids, -1 = padding) ->
     (top scores [Q, k], top idx [Q, k]) descending, ties by ascending global index.
@@ -51,7 +64,7 @@ def all_gather_topk(local_scores, local_idx, k, group=None):
     packed = torch.stack([local_scores.contiguous().view(torch.int32).to(torch.int64), local_idx], dim=-1)
     flat = packed.contiguous().view(-1)
     out = torch.empty(world * flat.numel(), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, flat, group=group)   # rank-major concatenation on every backend
+    all_gather_flat(out, flat, group)                      # rank-major concatenation on every backend
     out = out.view(world, qn, kl, 2).permute(1, 0, 2, 3).reshape(qn, world * kl, 2)
     scores = out[..., 0].to(torch.int32).view(torch.float32)
     return merge_topk(scores, out[..., 1].contiguous(), k)
@@ -65,7 +78,7 @@ def all_gather_topk_keys(local_keys, k, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         gathered = torch.empty((world,) + tuple(local_keys.shape), dtype=local_keys.dtype, device=local_keys.device)
-        dist.all_gather_into_tensor(gathered.view(-1), local_keys.contiguous().view(-1), group=group)
+        all_gather_flat(gathered.view(-1), local_keys.contiguous().view(-1), group)
     else:
         gathered = local_keys.contiguous().unsqueeze(0)
     return ops.topk_merge_keys(gathered, k)
@@ -76,9 +89,11 @@ class ShardedPoolRanker:
     pool.  `pool_reps` is the FULL pool (list of [S_i, 768] arrays) or, with `presharded=True`, only this
     rank's block together with `global_offset`."""
 
-    def __init__(self, pool_reps, presharded=False, global_offset=0, multiple=64, group=None):
+    def __init__(self, pool_reps, presharded=False, global_offset=0, multiple=64, group=None, n_total=None):
         from .scorer import CandidatePool
         self.group = group
+        self.multiple = multiple
+        self.n_total = n_total if presharded else len(pool_reps)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if presharded:
@@ -105,3 +120,30 @@ class ShardedPoolRanker:
             ls = torch.full((len(query_reps_list), k), float('-inf'), device=dev)
             li = torch.full((len(query_reps_list), k), -1, dtype=torch.int64, device=dev)
         return all_gather_topk(ls, li, k, self.group)
+
+    def rank_queries_full(self, query_reps_list, **score_kw):
+        """Full re-rank (the CSFCube / evaluate.py:76 case: the WHOLE pool is sorted, SURVEY.md 8e "all-gather all
+        Q * C / 8 scores instead"): every rank scores its block, ONE all-gather moves the blocks' scores (padded to the
+        longest block), and every rank sorts the un-sharded [Q, C] score matrix with the full stable sort.  Blocks are
+        contiguous in pool order, so rank-major concatenation IS pool order and ties keep it.
+        Returns (scores [Q, C] sorted descending, global candidate idx [Q, C])."""
+        from . import ops
+        from .scorer import score_pool
+        dev = ops.require_gpu()
+        qn = len(query_reps_list)
+        sizes = [shard_bounds(self.n_total, self.world, r, self.multiple) for r in range(self.world)] if self.n_total is not None else None
+        assert sizes is not None, 'rank_queries_full needs the full pool size (construct without presharded=True or pass n_total)'
+        lens = [hi - lo for lo, hi in sizes]
+        width = max(max(lens), 1)
+        local = torch.full((qn, width), float('-inf'), device=dev)
+        if len(self.pool) > 0:
+            local[:, :len(self.pool)] = score_pool(query_reps_list, self.pool, **score_kw)
+        if self.world > 1:
+            gathered = torch.empty(self.world, qn, width, device=dev)
+            all_gather_flat(gathered.view(-1), local.view(-1), self.group)
+        else:
+            gathered = local.unsqueeze(0)
+        full = torch.cat([gathered[r, :, :lens[r]] for r in range(self.world)], dim=1).contiguous()     # [Q, C] in pool order
+        if full.shape[1] == 0:
+            return full, torch.empty(qn, 0, dtype=torch.int64, device=dev)
+        return ops.topk_desc(full, full.shape[1])

@@ -26,6 +26,15 @@ class CandidatePool:
         self.pids = list(pids) if pids is not None else list(range(self.repset.n))
         assert len(self.pids) == self.repset.n
 
+    @classmethod
+    def from_repset(cls, repset, pids=None):
+        """Wrap reps that are already resident (AspireConSent.encode_to_pool writes them there): no copy."""
+        self = cls.__new__(cls)
+        self.repset = repset
+        self.pids = list(pids) if pids is not None else list(range(repset.n))
+        assert len(self.pids) == repset.n
+        return self
+
     def __len__(self):
         return self.repset.n
 

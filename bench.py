@@ -135,6 +135,7 @@ def main():
     if world > 1:
         dist.barrier()
     from aspire_amd import _lib, ops
+    from aspire_amd.parallel import all_gather_flat
     lib = _lib.lib
     shard_path = world > 1 or args.shard_path
     K = args.steps
@@ -188,7 +189,7 @@ def main():
             _lib.check(rc)
         if shard_path:
             if world > 1:
-                dist.all_gather_into_tensor(gathered.view(-1), keys.view(-1))      # -> [world][K][k]
+                all_gather_flat(gathered.view(-1), keys.view(-1))      # -> [world][K][k]; RCCL over xGMI
                 src = gathered
             else:
                 src = keys

@@ -57,6 +57,14 @@ int aspire_max_sents(void);
 int aspire_span_mean_pool_f32(const float* hidden, int64_t B, int64_t L, int64_t D,
                               const int32_t* tok_idx, const int32_t* span_off, int64_t S,
                               float* sent_reps, float* cls_reps, void* stream);
+/* The same pooling written straight into a resident rep store (rows + CSR, no padding rows): slot (b, s) goes to row
+ * out_row[b*S+s] of `rows` (device int32 [B*S]; < 0 = document b has no sentence s, nothing is written).  This is the
+ * un-padding of caching_encode (src/learning/facetid_models/disent_models.py:363-370: sent_reps[i, :, :num_sents]) and of
+ * AspireModel.encode (src/evaluation/utils/models.py:208) done by the kernel's store addresses instead of a host loop,
+ * so encoded documents never leave HBM on their way into the candidate pool. */
+int aspire_span_mean_pool_rows_f32(const float* hidden, int64_t B, int64_t L, int64_t D,
+                                   const int32_t* tok_idx, const int32_t* span_off, int64_t S,
+                                   const int32_t* out_row, float* rows, float* cls_reps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1  BERT-base encoder forward.  Replaces `self.bert_encoder(tokid_tt, token_type_ids=seg_tt,

@@ -70,8 +70,11 @@ def bench(J, NC, S, k=100):
     bytes_ = J * NC * (S * D * 4) + J * S * D * 4
     out['cost_TBs'] = bytes_ / out['score'] / 1e6
     e2e = {}
-    for chunks in (['fused', 'tile', 'small'] if S <= 8 else ['small']):
-        with _lib.pinned(OT_FORM=chunks):
+    variants = [('fused', dict(OT_FORM='fused')), ('fused-cpt1', dict(OT_FORM='fused', FUSED_CPT=1)),
+                ('fused-nosolve', dict(OT_FORM='fused', FUSED_NOSOLVE=1)), ('tile', dict(OT_FORM='tile')),
+                ('small', dict(OT_FORM='small'))] if S <= 8 else [('small', dict(OT_FORM='small'))]
+    for chunks, pins in variants:
+        with _lib.pinned(**pins):
             for i in range(4):
                 full(i)
             torch.cuda.synchronize()
