@@ -63,6 +63,7 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p]),
     'aspire_span_mean_pool_rows_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    'aspire_cls_l2_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p, c_void_p]),
     'aspire_bert_workspace_bytes': (c_size_t, [ctypes.POINTER(BertWeights), c_int64, c_int64]),
     'aspire_bert_forward_f32': (c_int, [ctypes.POINTER(BertWeights), c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -142,6 +142,7 @@ class AspireConSent:
             ops.span_mean_pool_rows(hidden, tok_idx.to(dev), span_off.to(dev), max_sents, torch.from_numpy(out_row.reshape(-1)).to(dev),
                                     rows, cls_all[doc0:doc0 + b] if want_cls else None)
             doc0 += b
-        repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0)
+        repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0,
+                                  lens_host=all_lens)
         pool = CandidatePool.from_repset(repset, pids=pids)
         return (pool, cls_all) if want_cls else pool

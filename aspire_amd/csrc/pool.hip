@@ -50,10 +50,47 @@ __global__ void __launch_bounds__(192) span_mean_pool_kernel(const float* __rest
     *reinterpret_cast<float4*>(sent_reps + (size_t)orow * kD + d) = acc;
 }
 
+// caching_score's document-level term: ||q_cls - c_cls + eps||_2 (torch.nn.functional.pairwise_distance), one wave per
+// pair, 12 coordinates per lane.
+__global__ void __launch_bounds__(256) cls_l2_kernel(const float* __restrict__ q_cls, int64_t Q, const float* __restrict__ c_cls,
+                                                     int64_t C, int paired, float eps, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t P = paired ? C : Q * C;
+    if (pair >= P) return;
+    const int64_t qi = paired ? pair : pair / C, ci = paired ? pair : pair - qi * C;
+    const float* x = q_cls + (size_t)qi * kD + lane * 4;
+    const float* y = c_cls + (size_t)ci * kD + lane * 4;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 u = *reinterpret_cast<const float4*>(x + 256 * k), v = *reinterpret_cast<const float4*>(y + 256 * k);
+        const float d0 = (u.x - v.x) + eps, d1 = (u.y - v.y) + eps, d2 = (u.z - v.z) + eps, d3 = (u.w - v.w) + eps;
+        acc = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, acc))));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[pair] = sqrtf(acc);
+}
+
 }  // namespace
 }  // namespace aspire
 
 using namespace aspire;
+
+extern "C" int aspire_cls_l2_f32(const float* q_cls, int64_t Q, const float* c_cls, int64_t C, int64_t D, int pairing, double eps,
+                                 float* dist, void* stream) {
+    ASPIRE_REQUIRE(D == kD, ASPIRE_ERR_UNSUPPORTED, "encoding dim %lld unsupported (kernels are built for 768)", (long long)D);
+    ASPIRE_REQUIRE(pairing == ASPIRE_PAIR_CROSS || pairing == ASPIRE_PAIR_PAIRED, ASPIRE_ERR_INVALID_ARG, "bad pairing %d", pairing);
+    ASPIRE_REQUIRE(Q >= 0 && C >= 0 && (pairing != ASPIRE_PAIR_PAIRED || Q == C), ASPIRE_ERR_INVALID_ARG,
+                   "paired distances need equal batch sizes (query %lld vs cand %lld)", (long long)Q, (long long)C);
+    const int64_t P = pairing == ASPIRE_PAIR_PAIRED ? C : Q * C;
+    if (P == 0) return ASPIRE_OK;
+    ASPIRE_REQUIRE(q_cls && c_cls && dist, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    hipLaunchKernelGGL(cls_l2_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q_cls, Q, c_cls, C,
+                       pairing == ASPIRE_PAIR_PAIRED ? 1 : 0, (float)eps, dist);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
 
 extern "C" int aspire_span_mean_pool_f32(const float* hidden, int64_t B, int64_t L, int64_t D, const int32_t* tok_idx,
                                          const int32_t* span_off, int64_t S, float* sent_reps, float* cls_reps,

@@ -39,7 +39,8 @@ class DeviceRepSet:
 
     rows [total, 768] fp32; start/len int32 [n]; ext > 0 marks a padded [n, ext, 768] tensor."""
 
-    def __init__(self, rows, start, lens, ext=0, max_len=None):
+    def __init__(self, rows, start, lens, ext=0, max_len=None, lens_host=None):
+        self.lens_host = list(lens_host) if lens_host is not None else None      # host copy of len[], when the caller has one
         self.rows = _f32(rows, 'rows')
         assert rows.shape[-1] == D, f'encoding dim must be {D}'
         self.start = _i32(start, 'start')
@@ -69,14 +70,19 @@ class DeviceRepSet:
         rows = torch.cat(ts, dim=0).to(dev).contiguous() if ts else torch.zeros(0, D, device=dev)
         lens = torch.tensor(lens_host, dtype=torch.int32)
         start = (torch.cumsum(lens, 0) - lens).to(torch.int32)
-        return cls(rows, start.to(dev), lens.to(dev), ext=0, max_len=max(lens_host) if lens_host else 0)
+        return cls(rows, start.to(dev), lens.to(dev), ext=0, max_len=max(lens_host) if lens_host else 0, lens_host=lens_host)
 
     def struct(self):
         return RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len)
 
     def slice(self, lo, hi):
         return DeviceRepSet(self.rows, self.start[lo:hi].contiguous(), self.len[lo:hi].contiguous(), self.ext,
-                            self.max_len)
+                            self.max_len, lens_host=self.lens_host[lo:hi] if self.lens_host is not None else None)
+
+    def host_lens(self):
+        if self.lens_host is None:
+            self.lens_host = self.len.cpu().tolist()
+        return self.lens_host
 
 
 def _npairs(q, c, pairing):
@@ -104,6 +110,16 @@ def span_mean_pool_rows(hidden, tok_idx, span_off, max_sents, out_row, rows, cls
     assert out_row.numel() == b * max_sents
     check(lib.aspire_span_mean_pool_rows_f32(_ptr(hidden), b, l, d, _ptr(_i32(tok_idx, 'tok_idx')), _ptr(_i32(span_off, 'span_off')),
                                              max_sents, _ptr(_i32(out_row, 'out_row')), _ptr(rows), _ptr(cls), _stream()))
+
+
+def cls_l2(q_cls, c_cls, pairing=_lib.PAIR_PAIRED, eps=1e-6):
+    """functional.pairwise_distance(q_cls, c_cls, p=2.0) (disent_models.py:306): ||q - c + eps||_2, [P] on the GPU."""
+    _f32(q_cls, 'q_cls')
+    _f32(c_cls, 'c_cls')
+    qn, cn = q_cls.shape[0], c_cls.shape[0]
+    out = torch.empty(cn if pairing == _lib.PAIR_PAIRED else qn * cn, device=q_cls.device, dtype=torch.float32)
+    check(lib.aspire_cls_l2_f32(_ptr(q_cls), qn, _ptr(c_cls), cn, D, pairing, float(eps), _ptr(out), _stream()))
+    return out
 
 
 def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want_pair_sims=False):

@@ -43,6 +43,29 @@ def _as_pool(x):
     return x if isinstance(x, CandidatePool) else CandidatePool(x)
 
 
+def _cdist_runs(q, c, group):
+    """torch.cdist picks its formula from the extents of the tensors it is given (direct differences up to 25 rows on
+    both sides, the matmul expansion beyond).  caching_score hands it one padded group of `group` candidates at a time
+    (disent_models.py:269-297 via pp_gen_nearest.py:182-196), so EVERY pair of a group whose longest candidate -- or whose
+    query -- has more than 25 rows takes the expansion, short documents included (2.7e-5 apart on N(0,1) data: enough to swap
+    near-ties).  Returns [(lo, hi, cdist_mode)] runs of whole groups; one run (AUTO) when no document is that long."""
+    if c.max_len <= 25 and q.max_len <= 25:
+        return [(0, c.n, _lib.CDIST_AUTO)]
+    if q.n == 1 and q.max_len > 25:
+        return [(0, c.n, _lib.CDIST_MM)]
+    assert q.max_len <= 25, 'several queries of which some are long are scored one query per call (score_pool does)'
+    lens = c.host_lens()
+    runs = []
+    for lo in range(0, c.n, group):
+        hi = min(c.n, lo + group)
+        mode = _lib.CDIST_MM if max(lens[lo:hi]) > 25 else _lib.CDIST_DIRECT
+        if runs and runs[-1][2] == mode:
+            runs[-1] = (runs[-1][0], hi, mode)
+        else:
+            runs.append((lo, hi, mode))
+    return runs
+
+
 def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None, score_batch_size=64):
     """Scores [Q, C] (GPU tensor, higher = more similar) of every query against every candidate.
 
@@ -58,29 +81,41 @@ def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None
     pool = _as_pool(pool)
     q = ops.DeviceRepSet.from_list(query_reps_list)
     c = pool.repset
+    if method not in ('ot', 'l2max', 'l2top2', 'l2attention'):
+        raise ValueError(f'Unknown aggregation: {method}')
+    if schedule not in ('pair', 'batch'):
+        raise ValueError(f'Unknown schedule: {schedule}')
+    # schedule 'pair': one pair per reference call (evaluate.py) -> cdist's formula per pair (AUTO).  'batch': per padded
+    # group of score_batch_size candidates (caching_score) -> per group, see _cdist_runs.
+    if schedule == 'batch' and q.n > 1 and q.max_len > 25 and c.n > 0:
+        # the formula is per (query, group) and a launch takes one mode: long queries go one per call
+        return torch.cat([score_pool([qr], pool, method, schedule, hparams, score_batch_size) for qr in query_reps_list], dim=0)
+    runs = _cdist_runs(q, c, score_batch_size) if schedule == 'batch' and q.n > 0 and c.n > 0 else [(0, c.n, _lib.CDIST_AUTO)]
+    if len(runs) > 1:
+        parts = [_score_run(q, c.slice(lo, hi), method, schedule, hparams, score_batch_size, mode) for lo, hi, mode in runs]
+        return torch.cat(parts, dim=1)
+    return _score_run(q, c, method, schedule, hparams, score_batch_size, runs[0][2])
+
+
+def _score_run(q, c, method, schedule, hparams, score_batch_size, cdist_mode):
     if method == 'l2max':
-        # cdist's formula switch looks at the padded batch extents in the reference; per pair here.
-        return ops.l2max_scores(q, c, pairing=_lib.PAIR_CROSS).view(q.n, c.n)
+        return ops.l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=cdist_mode).view(q.n, c.n)
     if method == 'l2top2':
-        return ops.l2agg_scores(q, c, _lib.AGG_TOP2, pairing=_lib.PAIR_CROSS).view(q.n, c.n)
+        return ops.l2agg_scores(q, c, _lib.AGG_TOP2, pairing=_lib.PAIR_CROSS, cdist_mode=cdist_mode).view(q.n, c.n)
     if method == 'l2attention':
         return ops.l2agg_scores(q, c, _lib.AGG_ATTENTION, temp=hparams.get('cdatt_sm_temp', 1.0),
-                                pairing=_lib.PAIR_CROSS).view(q.n, c.n)
-    if method != 'ot':
-        raise ValueError(f'Unknown aggregation: {method}')
+                                pairing=_lib.PAIR_CROSS, cdist_mode=cdist_mode).view(q.n, c.n)
     kw = dict(blur=hparams.get('geoml_blur', 0.05), scaling=hparams.get('geoml_scaling', 0.9),
-              sent_sm_temp=hparams.get('sent_sm_temp', 1.0))
+              sent_sm_temp=hparams.get('sent_sm_temp', 1.0), cdist_mode=cdist_mode)
     if hparams.get('geoml_reach', None) is not None:
         raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
     if schedule == 'pair':
         dist = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_DISTANCE, **kw)
         return (-dist).view(q.n, c.n)
-    if schedule == 'batch':
-        diam = ops.group_diameter(q, c, _lib.PAIR_CROSS, group=score_batch_size)
-        sims = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_PLAN_SIM, diameter=diam,
-                               diam_group=score_batch_size, **kw)
-        return sims.view(q.n, c.n)
-    raise ValueError(f'Unknown schedule: {schedule}')
+    diam = ops.group_diameter(q, c, _lib.PAIR_CROSS, group=score_batch_size)
+    sims = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_PLAN_SIM, diameter=diam,
+                           diam_group=score_batch_size, **kw)
+    return sims.view(q.n, c.n)
 
 
 def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hparams=None, score_batch_size=64):
@@ -90,11 +125,15 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
     if len(pool) == 0:
         return [[] for _ in query_reps_list]
     k = len(pool) if k is None else min(k, len(pool))
-    if method == 'ot' and schedule in ('pair', 'batch'):
+    q = ops.DeviceRepSet.from_list(query_reps_list)
+    # one fused score + rank call unless caching_score's per-group cdist formula differs between groups (documents of more
+    # than 25 rows, see _cdist_runs)
+    one_call = method == 'ot' and (schedule == 'pair' or (schedule == 'batch' and (
+        q.max_len <= 25 or q.n == 1) and len(_cdist_runs(q, pool.repset, score_batch_size)) == 1))
+    if one_call:
         hparams = hparams or {}
         if hparams.get('geoml_reach', None) is not None:
             raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
-        q = ops.DeviceRepSet.from_list(query_reps_list)
         kw = dict(blur=hparams.get('geoml_blur', 0.05), scaling=hparams.get('geoml_scaling', 0.9),
                   sent_sm_temp=hparams.get('sent_sm_temp', 1.0))
         if schedule == 'pair':
@@ -102,7 +141,8 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
         else:
             diam = ops.group_diameter(q, pool.repset, _lib.PAIR_CROSS, group=score_batch_size)
             _, top_s, top_i = ops.ot_rank(q, pool.repset, k, want=_lib.OT_PLAN_SIM, diameter=diam,
-                                          diam_group=score_batch_size, **kw)
+                                          diam_group=score_batch_size,
+                                          cdist_mode=_cdist_runs(q, pool.repset, score_batch_size)[0][2], **kw)
     else:
         scores = score_pool(query_reps_list, pool, method=method, schedule=schedule, hparams=hparams,
                             score_batch_size=score_batch_size)
@@ -154,9 +194,11 @@ def get_similarity(x, y, hparams=None):
 
 
 def caching_score(query_encode_ret_dict, cand_encode_ret_dicts, score_agg_type='l2wasserstein', hparams=None,
-                  sent_loss_prop=1.0):
-    """WordSentAlignBiEnc.caching_score (src/learning/facetid_models/disent_models.py:256-342) for the
-    sentence-level term (abs_loss_prop = 0.0 in every Aspire model class, :253).
+                  sent_loss_prop=1.0, abs_loss_prop=0.0):
+    """WordSentAlignBiEnc.caching_score (src/learning/facetid_models/disent_models.py:256-342): the sentence-level term
+    scaled by sent_loss_prop (:300-304) plus, when abs_loss_prop > 0 (:305-307; the model classes read both from their
+    hyper-parameters, disent_models.py:583, 714 -- every published config sets abs_loss_prop 0.0), abs_loss_prop times the
+    negative L2 distance of the documents' CLS reps ('doc_cls_reps' of the encode dicts).
     Returns {'batch_scores': np.ndarray [B], 'pair_scores': un-padded per-candidate extras}."""
     query_sent_reps = np.asarray(query_encode_ret_dict['sent_reps'])
     cand_sent_reps = [np.asarray(d['sent_reps']) for d in cand_encode_ret_dicts]
@@ -185,7 +227,13 @@ def caching_score(query_encode_ret_dict, cand_encode_ret_dicts, score_agg_type='
             query=qt, cand=ct, return_pair_sims=True)
     else:
         raise ValueError(f'Unknown aggregation: {score_agg_type}')
-    batch_scores = (sent_loss_prop * batch_sent_sims).cpu().numpy()
+    batch_scores = sent_loss_prop * batch_sent_sims
+    if abs_loss_prop > 0.0:
+        query_cls_reps = torch.as_tensor(np.vstack([query_encode_ret_dict['doc_cls_reps']] * batch_size), dtype=torch.float32, device=dev)
+        cand_cls_reps = torch.as_tensor(np.vstack([d['doc_cls_reps'] for d in cand_encode_ret_dicts]), dtype=torch.float32, device=dev)
+        batch_doc_sims = -1 * ops.cls_l2(query_cls_reps.contiguous(), cand_cls_reps.contiguous(), pairing=_lib.PAIR_PAIRED)
+        batch_scores = batch_scores + abs_loss_prop * batch_doc_sims.to(batch_scores.device)
+    batch_scores = batch_scores.cpu().numpy()
     if isinstance(pair_sims, list):
         pair_sims = [t.cpu().numpy() for t in pair_sims]
     else:

@@ -100,6 +100,15 @@ int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64_t* tok_ids
                             const int64_t* attn_mask, int64_t B, int64_t L, float* hidden_out,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * caching_score's document-level term (src/learning/facetid_models/disent_models.py:305-307, taken when
+ * abs_loss_prop > 0): functional.pairwise_distance(query_cls_reps, cand_cls_reps, p=2.0) = ||q - c + eps||_2 with torch's
+ * eps = 1e-6 added to every coordinate of the difference.  (The caller negates and scales it.)
+ *   q_cls [Q, 768], c_cls [C, 768]; dist [P] out: P = Q * C (CROSS, pair = q * C + c) or Q == C (PAIRED)
+ * ------------------------------------------------------------------------------------------- */
+int aspire_cls_l2_f32(const float* q_cls, int64_t Q, const float* c_cls, int64_t C, int64_t D, int pairing, double eps,
+                      float* dist, void* stream);
+
 /* cdist formula selection, mirroring torch.cdist's default compute mode (used at
  * pair_distances.py:49 and :167): rows <= 25 on both sides -> direct sqrt(sum (x-y)^2),
  * otherwise the matmul expansion. */

@@ -82,7 +82,7 @@ def test_fused_duplicate_sentences_and_group_schedule(amd):
         clean = np.array([i % 7 != 0 for i in range(300)])
         np.testing.assert_allclose(res['fused'][k][clean], res['tile'][k][clean], atol=1e-2 if k else 5e-5, rtol=0)
         np.testing.assert_allclose(res['fused'][k][clean], res['small'][k][clean], atol=1e-2 if k else 5e-5, rtol=0)
-    want = orc.caching_score(query.numpy(), [c.numpy() for c in cands[64:128]])['batch_scores']
+    want = orc.caching_score(query.numpy(), [c.numpy() for c in cands[64:128]])[0]
     np.testing.assert_allclose(res['fused'][1][64:128][clean[64:128]], want[clean[64:128]], atol=1e-2, rtol=0)
 
 

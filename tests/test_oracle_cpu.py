@@ -151,3 +151,18 @@ def test_sibling_aggregations_match_reference(siblings, name):
         assert np.array_equal(ps.numpy(), z[f'{name}_att_{t}_pair'])
         assert np.array_equal(sm.numpy(), z[f'{name}_att_{t}_softmax'])
         assert np.array_equal(ms.numpy(), z[f'{name}_att_{t}_masked'])
+
+
+def test_caching_score_cls_term_is_the_reference_expression():
+    """disent_models.py:300-307: batch_scores = sent_loss_prop * sims + abs_loss_prop * (-pairwise_distance(q_cls, c_cls, p=2))"""
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(5, 768, generator=g).numpy()
+    cands = [torch.randn(int(n), 768, generator=g).numpy() for n in (4, 7, 2)]
+    qc = torch.randn(768, generator=g).numpy()
+    cc = [torch.randn(768, generator=g).numpy() for _ in cands]
+    base, _ = orc.caching_score(q, cands, score_agg_type='l2max')
+    got, _ = orc.caching_score(q, cands, score_agg_type='l2max', sent_loss_prop=0.5, abs_loss_prop=2.0, query_cls_rep=qc, cand_cls_reps=cc)
+    want = 0.5 * base - 2.0 * np.array([np.sqrt(((qc.astype(np.float64) - c + 1e-6) ** 2).sum()) for c in cc])
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
+    same, _ = orc.caching_score(q, cands, score_agg_type='l2max', sent_loss_prop=1.0, abs_loss_prop=0.0)
+    np.testing.assert_array_equal(same, base)
