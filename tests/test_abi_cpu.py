@@ -102,6 +102,38 @@ def test_batch_entry_validation_without_gpu():
     assert _lib.lib.aspire_topk_workspace_bytes(1, 50000, 50000) == 2 * 13 * 4096 * 8
 
 
+def _top_level_args(text):
+    depth, n, cur = 0, 0, ''
+    for ch in text:
+        if ch in '([{':
+            depth += 1
+        elif ch in ')]}':
+            depth -= 1
+        if ch == ',' and depth == 0:
+            n += 1 if cur.strip() else 0
+            cur = ''
+        else:
+            cur += ch
+    return n + (1 if cur.strip() else 0)
+
+
+def test_integration_md_stub_passes_every_argument():
+    """The ctypes stub shown in INTEGRATION.md must pass exactly the parameters include/aspire_hip.h declares (round 1's
+    stub dropped workspace / workspace_bytes: the stream landed in the workspace slot)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(root, 'include', 'aspire_hip.h')).read(), flags=re.S)
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    for fn in ('aspire_ot_sinkhorn_f32', 'aspire_ot_workspace_bytes'):
+        decl = re.search(fn + r'\s*\((.*?)\)\s*;', hdr, flags=re.S).group(1)
+        start = doc.index('lib.' + fn + '(') + len('lib.' + fn + '(')
+        depth, end = 1, start
+        while depth:
+            depth += {'(': 1, ')': -1}.get(doc[end], 0)
+            end += 1
+        call = doc[start:end - 1]
+        assert _top_level_args(call) == _top_level_args(decl), (fn, _top_level_args(call), _top_level_args(decl))
+
+
 def test_compute_requires_gpu():
     from aspire_amd import ops
     if torch.cuda.is_available():
