@@ -34,6 +34,8 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "GEMM_TILE")) {
         if (!unset && strcmp(v, "96")) return false;
         t.gemm_tile96 = unset ? 0 : 1;
+    } else if (!strcmp(key, "GRAM_OCC")) {
+        t.gram_occ = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_CPT")) {
         t.fused_cpt = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {
@@ -49,7 +51,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_CPT", "FUSED_NOSOLVE"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_CPT", "FUSED_NOSOLVE", "GRAM_OCC"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);
