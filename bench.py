@@ -180,6 +180,14 @@ def main():
     def stream():
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def reduce_max(v):
+        """max over ranks of a host scalar (RCCL on the GPUs; gloo, in the one-GPU rehearsal, reduces host tensors)"""
+        if world == 1:
+            return v
+        t = torch.tensor([float(v)], dtype=torch.float64, device='cpu' if one_gpu_test else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
     def run_schedule(js):
         """K steps = K jobs = ONE C-ABI call; sharded: + one all-gather of the K x k keys + one merge launch."""
         rc = lib.aspire_ot_rank_batch_f32(ctypes.byref(js.qs), ctypes.byref(js.cs), D, P[5], NC, ctypes.byref(prm), _lib.OT_SIMILARITY,
@@ -217,10 +225,7 @@ def main():
         torch.cuda.synchronize()
         per_call = (time.perf_counter() - t0) / n_cal
         R = max(4, int(1.3 * MIN_TIMED_S / per_call) + 1)
-        if world > 1:
-            t = torch.tensor([R], device=device, dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            R = int(t.item())
+        R = int(reduce_max(R))
 
     def timed(fn):
         if world > 1:
@@ -231,12 +236,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = t.item()
-        return el
+        return reduce_max(time.perf_counter() - t0)
 
     def all_reps():
         for r in range(R):
@@ -254,9 +254,9 @@ def main():
         assert torch.equal(top_i, ref_i[:, :TOPK]) and torch.equal(top_s, ref_s[:, :TOPK]), 'rank differs from the stable sort'
     elif world > 1:
         mine = top_i.clone()
-        everyone = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(everyone, mine)
-        assert all(torch.equal(everyone[0], e) for e in everyone), 'ranks disagree on the merged ranking'
+        everyone = torch.empty(world, K, TOPK, device=device, dtype=torch.int64)
+        all_gather_flat(everyone.view(-1), mine.view(-1))
+        assert all(torch.equal(everyone[0], everyone[r]) for r in range(world)), 'ranks disagree on the merged ranking'
         assert len(torch.unique(mine // NC)) > 1, 'merged ranking holds candidates of one shard only'
     else:
         ref_s, ref_i = torch.sort(scores.view(K, NC), dim=1, descending=True, stable=True)

@@ -42,7 +42,7 @@ def _worker(rank, world, port, n_pool, k, method, out_dir):
     from aspire_amd.parallel import ShardedPoolRanker
     pool = _pool(n_pool, 5)
     g = torch.Generator().manual_seed(6)
-    queries = [torch.randn(8, 768, generator=g), torch.randn(3, 768, generator=g), pool[7].clone()]
+    queries = [torch.randn(8, 768, generator=g), torch.randn(3, 768, generator=g), pool[min(7, n_pool - 1)].clone()]
     ranker = ShardedPoolRanker(pool)
     ts, ti = ranker.rank_queries(queries, k, method=method)
     fs, fi = ranker.rank_queries_full(queries, method=method)
@@ -63,7 +63,7 @@ def test_sharded_ranker_equals_unsharded(tmp_path, world, n_pool, k, method):
     from aspire_amd import scorer
     pool = _pool(n_pool, 5)
     g = torch.Generator().manual_seed(6)
-    queries = [torch.randn(8, 768, generator=g), torch.randn(3, 768, generator=g), pool[7].clone()]
+    queries = [torch.randn(8, 768, generator=g), torch.randn(3, 768, generator=g), pool[min(7, n_pool - 1)].clone()]
     scores = scorer.score_pool(queries, pool, method=method).cpu()
     outs = [torch.load(os.path.join(str(tmp_path), f'r{r}.pt')) for r in range(world)]
     assert sum(o['n_local'] for o in outs) == n_pool
