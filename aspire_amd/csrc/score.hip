@@ -1909,7 +1909,7 @@ extern "C" void aspire_debug_k1_buffer(void* p) {
 }
 #endif
 
-extern "C" int aspire_max_sents(void) { return 8 * kMaxT; }
+extern "C" int aspire_max_sents(void) { return generic_max_rows(); }
 
 extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
                                        int cdist_mode, int agg, double temp, float* scores, float* pair_sims,
@@ -1936,14 +1936,26 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     a.out_plan = pair_softmax;
     if (agg == ASPIRE_AGG_MAX && !pair_sims && gram_path_wanted(q, c, pairing))
         return launch_pair_gram_l2max(a, q->max_len, c->max_len, (hipStream_t)stream);
+    // Documents beyond the tile kernels' 32 rows (max-sim only): padded tensors that wide go through the one-workgroup-
+    // per-pair kernel for every pair; CSR pools run the tile kernel on 32-row tiles first (it covers every pair of short
+    // documents) and the long-document kernel then rewrites the pairs that hold a longer one.
+    const int rows_q = q->ext > 0 ? q->ext : q->max_len, rows_c = c->ext > 0 ? c->ext : c->max_len;
+    const bool long_docs = max_rows_of(q, c) > 8 * kMaxT;
+    ASPIRE_REQUIRE(!long_docs || agg == ASPIRE_AGG_MAX, ASPIRE_ERR_UNSUPPORTED,
+                   "documents with more than %d sentence rows: only the max-sim and otAspire scores are built (got %d)", 8 * kMaxT,
+                   max_rows_of(q, c));
+    if (long_docs && (q->ext > 0 || c->ext > 0)) return launch_pair_generic(a, 1, 0, rows_q, rows_c, (hipStream_t)stream);
     dim3 grid;
     grid = dim3((unsigned)a.c.n, (unsigned)query_chunks(a), 1);
-    return dispatch_T(max_rows_of(q, c), [&](auto tc) -> int {
+    const int tile_rows = long_docs ? 8 * kMaxT : max_rows_of(q, c);
+    const int rc_tiles = dispatch_T(tile_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         hipLaunchKernelGGL(l2max_kernel<T>, grid, dim3(kBlock), Lds<T>::kTotal * sizeof(float), (hipStream_t)stream, a);
         ASPIRE_LAUNCH_OK();
         return (int)ASPIRE_OK;
     });
+    if (rc_tiles || !long_docs) return rc_tiles;
+    return launch_pair_generic(a, 1, 8 * kMaxT, rows_q, rows_c, (hipStream_t)stream);
 }
 
 extern "C" int aspire_l2max_scores_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
@@ -2118,10 +2130,60 @@ int launch_sinkhorn_stage(const ScoreArgs& a, const PairWs<T>& ws, int64_t n_slo
     return ASPIRE_OK;
 }
 
+int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing, const aspire_ot_params* prm,
+                 const float* diameter, int64_t diam_group, int want, float* scores, float* out_qdistr, float* out_cdistr,
+                 float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes, void* stream, const RankReq& rank,
+                 bool cost_only);
+
+// Documents beyond the tile kernels' 32 rows: padded tensors that wide go through the one-workgroup-per-pair kernel
+// (generic.hip) for every pair; CSR pools run the tile kernels with their documents' bound clamped to 32 rows (every pair
+// of short documents is scored there, a pair that holds a longer one gets NaN) and the long-document kernel then rewrites
+// exactly those pairs.  The rank follows.
 int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing, const aspire_ot_params* prm,
            const float* diameter, int64_t diam_group, int want, float* scores, float* out_qdistr, float* out_cdistr,
            float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes, void* stream, const RankReq& rank,
            bool cost_only = false) {
+    if (int rc = check_repsets(q, c, D, pairing)) return rc;
+    const int tile_max = 8 * kMaxT;
+    if (q->n == 0 || c->n == 0 || max_rows_of(q, c) <= tile_max)
+        return ot_run_tiles(q, c, D, pairing, prm, diameter, diam_group, want, scores, out_qdistr, out_cdistr, out_pairsims, out_plan,
+                            workspace, workspace_bytes, stream, rank, cost_only);
+    if (int rc = check_ot_params(prm, want)) return rc;
+    ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "null scores");
+    ASPIRE_REQUIRE(!diameter || diam_group > 0, ASPIRE_ERR_INVALID_ARG, "diam_group must be positive");
+    const bool extra = out_qdistr || out_cdistr || out_pairsims || out_plan;
+    ASPIRE_REQUIRE(!extra || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG, "pair outputs need padded extents (ext > 0)");
+    const int rows_q = q->ext > 0 ? q->ext : q->max_len, rows_c = c->ext > 0 ? c->ext : c->max_len;
+    ScoreArgs a{};
+    fill_ot_args(a, q, c, pairing, prm, diameter, diam_group, want, scores);
+    a.out_qdistr = out_qdistr;
+    a.out_cdistr = out_cdistr;
+    a.out_pairsims = out_pairsims;
+    a.out_plan = out_plan;
+    int skip = 0;
+    if (q->ext == 0 && c->ext == 0) {
+        aspire_repset q32 = *q, c32 = *c;
+        q32.max_len = q->max_len < tile_max ? q->max_len : tile_max;
+        c32.max_len = c->max_len < tile_max ? c->max_len : tile_max;
+        if (int rc = ot_run_tiles(&q32, &c32, D, pairing, prm, diameter, diam_group, want, scores, nullptr, nullptr, nullptr, nullptr,
+                                  workspace, workspace_bytes, stream, RankReq{0, 0, nullptr, nullptr, nullptr}, cost_only))
+            return rc;
+        skip = tile_max;
+    }
+    if (cost_only) return ASPIRE_OK;
+    if (int rc = launch_pair_generic(a, 0, skip, rows_q, rows_c, (hipStream_t)stream)) return rc;
+    if (rank.k > 0) {
+        const size_t need = aspire_topk_workspace_bytes(q->n, c->n, rank.k);
+        void* tws = need ? (char*)workspace + workspace_bytes : nullptr;
+        return topk_run(scores, q->n, c->n, rank.k, rank.idx_base, rank.top_scores, rank.top_idx, rank.keys, tws, need, stream);
+    }
+    return ASPIRE_OK;
+}
+
+int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing, const aspire_ot_params* prm,
+                 const float* diameter, int64_t diam_group, int want, float* scores, float* out_qdistr, float* out_cdistr,
+                 float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes, void* stream, const RankReq& rank,
+                 bool cost_only) {
     if (int rc = check_repsets(q, c, D, pairing)) return rc;
     if (q->n == 0 || c->n == 0) return ASPIRE_OK;   // nothing to score (an empty pool has no buffers either)
     if (int rc = check_ot_params(prm, want)) return rc;

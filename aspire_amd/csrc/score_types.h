@@ -97,6 +97,10 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
                         float* cbox, hipStream_t stream);
 int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t stream);
 
+// generic.hip: one workgroup per pair for documents beyond the tile kernels' 32 rows (mode 0 otAspire, 1 max-sim)
+int generic_max_rows(void);
+int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q, int rows_c, hipStream_t stream);
+
 // fused.hip: cost + Sinkhorn solve in one launch for documents of <= 8 rows (CSR inputs, CROSS or MAPPED pairing)
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, uint32_t* counter, hipStream_t stream);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature in aspire_amd/_lib.py'
     assert sorted(_lib.SIGNATURES) == declared
     assert _lib.lib.aspire_abi_version() == 2
-    assert _lib.lib.aspire_max_sents() == 32
+    assert _lib.lib.aspire_max_sents() == 128
 
 
 def test_no_product_module_imports_the_oracle():
@@ -188,7 +188,7 @@ def test_header_is_plain_c_and_links(tmp_path):
                    'typedef void (*fn_t)(void);\n'
                    'int main(void) {\n  fn_t fns[] = {' + ', '.join(f'(fn_t){n}' for n in names) + '};\n'
                    '  aspire_repset r; aspire_ot_params p; (void)r; (void)p;\n'
-                   '  if (aspire_abi_version() != ASPIRE_ABI_VERSION || aspire_max_sents() != 32) return 1;\n'
+                   '  if (aspire_abi_version() != ASPIRE_ABI_VERSION || aspire_max_sents() != 128) return 1;\n'
                    '  if (aspire_ot_workspace_bytes(0, 0, ASPIRE_PAIR_CROSS) != 0) return 2;\n'
                    '  if (aspire_topk_desc_f32(0, 1, 1, 0, 0, 0, 0, 0, 0, 0) != ASPIRE_ERR_INVALID_ARG) return 3;\n'
                    '  printf("%d %s\\n", (int)(sizeof(fns) / sizeof(fns[0])), aspire_last_error());\n  return 0;\n}\n')

@@ -38,10 +38,10 @@ def test_size_limits(amd):
     got = amd.scorer.score_pool([q], c, method='ot', schedule='pair').cpu().numpy()[0]
     want = np.array([orc.get_similarity(q, x) for x in c], dtype=np.float32)
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
-    with pytest.raises(NotImplementedError):
-        amd.scorer.score_pool([q], _docs(5, [33]), method='ot')
-    with pytest.raises(NotImplementedError):
-        amd.scorer.score_pool(_docs(6, [40]), c, method='l2max')
+    with pytest.raises(NotImplementedError):      # beyond the long-document kernel's 128 rows
+        amd.scorer.score_pool([q], _docs(5, [129]), method='ot')
+    with pytest.raises(NotImplementedError):      # the sibling aggregations stop at the tile kernels' 32 rows
+        amd.scorer.score_pool(_docs(6, [40]), c, method='l2top2')
     with pytest.raises(AssertionError):      # encoding dim != 768
         amd.ops.DeviceRepSet.from_list([torch.zeros(3, 512)])
 
@@ -250,3 +250,46 @@ def test_schedule_length_at_its_discontinuities(amd, form):
     lens = np.array([len(orc.epsilon_schedule(1, float(d), blur, scaling)) for d in diams])
     assert len(set(lens)) >= 8          # the diameters do straddle schedule lengths
     np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
+
+
+def test_documents_beyond_32_rows(amd):
+    """The reference has no sentence-count limit (only the 500-word-piece cap; AspireNER appends entity "sentences",
+    models.py:224-233).  A pool with a few documents of 33..128 rows: the tile kernels score the short pairs, the
+    one-workgroup-per-pair kernel the long ones; both against the oracle, otAspire and tsAspire, plus the drop-in
+    compute_distance on padded tensors wider than 32 rows with its five pair outputs."""
+    lens = [8, 33, 5, 40, 12, 64, 3, 128, 20, 57]
+    cands = _docs(81, lens)
+    queries = _docs(82, [9, 45])
+    got = amd.scorer.score_pool(queries, cands, method='ot', schedule='pair').cpu().numpy()
+    want = np.array([[orc.get_similarity(x, y) for y in cands] for x in queries], dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    got = amd.scorer.score_pool(queries, cands, method='l2max').cpu().numpy()
+    want_l2 = np.array([[-orc.allpair_masked_dist_l2max(orc.RepLen(x[None].permute(0, 2, 1), [len(x)]),
+                                                        orc.RepLen(y[None].permute(0, 2, 1), [len(y)])).item() for y in cands]
+                        for x in queries], dtype=np.float32)
+    np.testing.assert_allclose(got, want_l2, atol=TOL, rtol=0)
+    ranked = amd.scorer.rank_pool(queries, cands, method='ot', schedule='pair')
+    for qi in range(2):
+        assert [i for i, _ in ranked[qi]] == orc.rank_descending(want[qi].tolist())
+    # padded tensors wider than 32 rows through the reference's own signature
+    from aspire_amd import AllPairMaskedWasserstein, allpair_masked_dist_l2max, rep_len_tup
+    g = torch.Generator().manual_seed(83)
+    qlens, clens = [40, 7, 36], [50, 33, 12]
+    qpad, cpad = torch.zeros(3, 40, 768), torch.zeros(3, 50, 768)
+    for b in range(3):
+        qpad[b, :qlens[b]] = torch.randn(qlens[b], 768, generator=g)
+        cpad[b, :clens[b]] = torch.randn(clens[b], 768, generator=g)
+    qt, ct = rep_len_tup(qpad.permute(0, 2, 1), qlens), rep_len_tup(cpad.permute(0, 2, 1), clens)
+    oq, oc = orc.RepLen(qpad.permute(0, 2, 1), qlens), orc.RepLen(cpad.permute(0, 2, 1), clens)
+    dist = AllPairMaskedWasserstein({}).compute_distance(qt, ct)
+    np.testing.assert_allclose(dist.numpy(), orc.AllPairMaskedWasserstein({}).compute_distance(oq, oc).numpy(), atol=TOL, rtol=0)
+    sims, extra = AllPairMaskedWasserstein({}).compute_distance(qt, ct, return_pair_sims=True)
+    wsims, wextra = orc.AllPairMaskedWasserstein({}).compute_distance(oq, oc, return_pair_sims=True)
+    for k in range(3):
+        np.testing.assert_allclose(extra[k].numpy(), wextra[k].numpy(), atol=1e-5 if k < 2 else TOL, rtol=0)
+    np.testing.assert_allclose(extra[3].numpy(), wextra[3].numpy(), atol=5e-4, rtol=0)          # transport plan (fp32 conditioning)
+    np.testing.assert_allclose(sims.numpy(), wsims.numpy(), atol=1e-2, rtol=0)
+    d2, ps = allpair_masked_dist_l2max(qt, ct, return_pair_sims=True)
+    wd2, wps = orc.allpair_masked_dist_l2max(oq, oc, return_pair_sims=True)
+    np.testing.assert_allclose(d2.numpy(), wd2.numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(ps.numpy(), wps.numpy(), atol=TOL, rtol=1e-6)
