@@ -188,14 +188,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item()
 
-    def run_schedule(js):
-        """K steps = K jobs = ONE C-ABI call; sharded: + one all-gather of the K x k keys + one merge launch."""
+    def run_schedule(js, exchange=True):
+        """K steps = K jobs = ONE C-ABI call; sharded: + one all-gather of the K x k keys + one merge launch
+        (exchange=False: this rank's kernels only -- the stage timings below run on rank 0 alone)."""
         rc = lib.aspire_ot_rank_batch_f32(ctypes.byref(js.qs), ctypes.byref(js.cs), D, P[5], NC, ctypes.byref(prm), _lib.OT_SIMILARITY,
                                           P[0], TOPK, P[6], null if shard_path else P[1], null if shard_path else P[2], P[3], P[4],
                                           ws.numel(), stream())
         if rc:
             _lib.check(rc)
-        if shard_path:
+        if shard_path and exchange:
             if world > 1:
                 all_gather_flat(gathered.view(-1), keys.view(-1))      # -> [world][K][k]; RCCL over xGMI
                 src = gathered
@@ -267,7 +268,7 @@ def main():
         # ---- per-stage kernel durations, live: HIP events on the launch stream around launches of ONE stage alone, on the
         # rotating pools (cold) -- the workspace of a full call holds what the later stages read ------------------------
         def stage_ms(stages, jsets, n=24):
-            run_schedule(jsets[0])
+            run_schedule(jsets[0], exchange=False)
             torch.cuda.synchronize()
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
             for i, (a, b) in enumerate(evs):
@@ -288,7 +289,7 @@ def main():
         with _lib.pinned(OT_FORM='tile' if fused_form else 'small'):
             cost_only_ms = stage_ms(2, sets)
             solve_only_ms = stage_ms(4, sets)
-        run_schedule(sets[0])                   # the workspace tables back in the default form's state
+        run_schedule(sets[0], exchange=False)   # the workspace tables back in the default form's state
         torch.cuda.synchronize()
         # Infinity-Cache-resident variant: ONE small job set (<= 8 jobs, < 200 MB) scored again and again
         n_l3 = min(K, 8)
