@@ -286,8 +286,11 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 // counter[0] hands out the items beyond each wave's first, counter[1] counts the waves that have run out of items: the last
 // one leaves both at zero for the next launch (the launch before the first one on a fresh workspace clears them).
 // a.agg == 1 (diagnostics): skip the solves (the cost phase alone, for timing).
-template <int CPT>      // staged chunks per trip of the accumulate loop (2: the second chunk's LDS reads fly under the first one's arithmetic)
-__global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox, uint32_t* __restrict__ counter) {
+// CPT: staged chunks per trip of the accumulate loop (2: the second chunk's LDS reads fly under the first one's arithmetic)
+// VAR (experiments): bit 0 = side products pinned before the LDS stores, bit 1 = one accumulator per vector component
+// (16 independent FMA chains instead of 4), bit 2 = no minimum-occupancy hint
+template <int CPT, int VAR>
+__global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox, uint32_t* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -338,6 +341,11 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         const int qb_hi = own_diam ? kD : 0;
 
         float accg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        float4 acc4[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) acc4[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);
         float ny[8], nx[2] = {0.f, 0.f}, dsq = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) ny[k] = 0.f;
@@ -376,6 +384,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                     *reinterpret_cast<float4*>(lds + (2 * sg + k) * kRowStride + sc * 4) = vx[k];
                 }
             }
+            if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < kStages) issue_loads(st + 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -395,8 +404,16 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 #pragma unroll
                     for (int x = 0; x < 2; ++x)
 #pragma unroll
-                        for (int y = 0; y < 2; ++y)
-                            accg[x][y] = fmaf(xv[x].w, yv[y].w, fmaf(xv[x].z, yv[y].z, fmaf(xv[x].y, yv[y].y, fmaf(xv[x].x, yv[y].x, accg[x][y]))));
+                        for (int y = 0; y < 2; ++y) {
+                            if constexpr (VAR & 2) {
+                                acc4[x][y].x = fmaf(xv[x].x, yv[y].x, acc4[x][y].x);
+                                acc4[x][y].y = fmaf(xv[x].y, yv[y].y, acc4[x][y].y);
+                                acc4[x][y].z = fmaf(xv[x].z, yv[y].z, acc4[x][y].z);
+                                acc4[x][y].w = fmaf(xv[x].w, yv[y].w, acc4[x][y].w);
+                            } else {
+                                accg[x][y] = fmaf(xv[x].w, yv[y].w, fmaf(xv[x].z, yv[y].z, fmaf(xv[x].y, yv[y].y, fmaf(xv[x].x, yv[y].x, accg[x][y]))));
+                            }
+                        }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
@@ -405,6 +422,12 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             if (have_pend) solve_steps(pend, a, slice);
         }
 
+        if constexpr (VAR & 2) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) accg[x][y] = (acc4[x][y].x + acc4[x][y].y) + (acc4[x][y].z + acc4[x][y].w);
+        }
         // ---- claim the next item now: the atomic's round trip hides behind the finish below ----------------------------
         uint32_t claimed = 0;
         if (lane == 0) claimed = atomicAdd(counter, 1u);
@@ -530,12 +553,18 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     ScoreArgs a = a_in;
     a.agg = tuning().fused_nosolve ? 1 : 0;
     const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;      // two 4-wave workgroups per CU are resident
-    if (tuning().fused_cpt == 1)
-        hipLaunchKernelGGL(pair_fused_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a,
-                           qbox, counter);
-    else
-        hipLaunchKernelGGL(pair_fused_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a,
-                           qbox, counter);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    const size_t lds = 4 * kWaveLds * sizeof(float);
+#define FUSED_LAUNCH(CPT, VAR) hipLaunchKernelGGL((pair_fused_kernel<CPT, VAR>), grid, dim3(256), lds, stream, a, qbox, counter)
+    const int var = tuning().fused_variant;
+    if (tuning().fused_cpt == 1) {
+        if (var == 1) FUSED_LAUNCH(1, 1); else if (var == 2) FUSED_LAUNCH(1, 2); else if (var == 3) FUSED_LAUNCH(1, 3);
+        else if (var == 4) FUSED_LAUNCH(1, 4); else if (var == 7) FUSED_LAUNCH(1, 7); else FUSED_LAUNCH(1, 0);
+    } else {
+        if (var == 1) FUSED_LAUNCH(2, 1); else if (var == 2) FUSED_LAUNCH(2, 2); else if (var == 3) FUSED_LAUNCH(2, 3);
+        else if (var == 4) FUSED_LAUNCH(2, 4); else if (var == 7) FUSED_LAUNCH(2, 7); else FUSED_LAUNCH(2, 0);
+    }
+#undef FUSED_LAUNCH
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

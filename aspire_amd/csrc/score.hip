@@ -1276,15 +1276,18 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
         for (int k = 0; k < C::kXRows; ++k) nx[k] = 0.f;
 
         float4 vy[8], vx[C::kXRows], qmn, qmx;
+        const float* qb = own_diam ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
+        const int qb_hi = own_diam ? kD : 0;
         auto issue_loads = [&](int st) {
             const int dofs = (st * C::kCh + sc) * 4;
             if (stages_y) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(j, sy_len - 1) * kD + dofs);
-                if (own_diam) {
-                    qmn = ld4(qbox + (size_t)q_idx * 2 * kD + dofs);
-                    qmx = ld4(qbox + (size_t)q_idx * 2 * kD + kD + dofs);
-                }
+                // UNCONDITIONAL (with caller-supplied diameters the candidate's first row stands in and the box term
+                // is unused): a branch around these two loads made the compiler wait for the row loads just issued
+                // at the join -- every stage's HBM latency in series with its arithmetic (see fused.hip)
+                qmn = ld4(qb + dofs);
+                qmx = ld4(qb + qb_hi + dofs);
             }
             if (stages_x) {
 #pragma unroll
