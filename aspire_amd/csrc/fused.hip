@@ -285,11 +285,10 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 
 // counter[0] hands out the items beyond each wave's first, counter[1] counts the waves that have run out of items: the last
 // one leaves both at zero for the next launch (the launch before the first one on a fresh workspace clears them).
-// a.agg == 1 (diagnostics): skip the solves (the cost phase alone, for timing).
 // CPT: staged chunks per trip of the accumulate loop (2: the second chunk's LDS reads fly under the first one's arithmetic)
 // VAR (experiments): bit 0 = side products pinned before the LDS stores, bit 1 = one accumulator per vector component
 // (16 independent FMA chains instead of 4), bit 2 = no minimum-occupancy hint
-template <int CPT, int VAR>
+template <int CPT, int VAR, bool SOLVE = true>
 __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox, uint32_t* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -303,7 +302,7 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
     const uint32_t n_items = mapped ? (uint32_t)a.grp_off[a.job1] : ((ncand + 3) / 4) * nq;   // item = (candidate group, query), group-major
     const uint32_t n_waves = gridDim.x * 4;
     const bool own_diam = a.diameter == nullptr;            // else: the caller's per-group diameters (caching_score's batches)
-    const bool with_solve = a.agg != 1;
+    constexpr bool with_solve = SOLVE;      // false (diagnostics): the cost phase alone, diam^2 as the score
 
     // lane roles: p = candidate of this lane (compute AND staging); (li, lj) = its 2 x 2 block of the 8 x 8 entries;
     // staging: the 16 lanes of group sg stage the 8 rows of candidate sg and query rows 2 sg, 2 sg + 1, chunk sc each
@@ -419,7 +418,8 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
             __builtin_amdgcn_wave_barrier();
             // ---- a slice of the PREVIOUS item's solve, in the shadow of the loads just issued ------------------------
-            if (have_pend) solve_steps(pend, a, slice);
+            if constexpr (SOLVE)
+                if (have_pend) solve_steps(pend, a, slice);
         }
 
         if constexpr (VAR & 2) {
@@ -512,8 +512,9 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
         __builtin_amdgcn_wave_barrier();
 
         // ---- the previous item's solve ends here (its last steps, score, store); this item's begins ---------------------
-        if (have_pend) solve_finish(pend, a);
-        if (with_solve) {
+        if constexpr (SOLVE)
+            if (have_pend) solve_finish(pend, a);
+        if constexpr (with_solve) {
             bool rv[2], cv[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -531,7 +532,8 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
         }
         item = item_lo + n_waves + __builtin_amdgcn_readfirstlane(claimed);
     }
-    if (have_pend) solve_finish(pend, a);       // the wave's last item: nothing left to hide it behind
+    if constexpr (SOLVE)
+        if (have_pend) solve_finish(pend, a);   // the wave's last item: nothing left to hide it behind
     if (lane == 0 && atomicAdd(counter + 1, 1u) == n_waves - 1) {      // every wave has made its last claim by now
         counter[0] = 0u;
         counter[1] = 0u;
@@ -550,14 +552,15 @@ size_t fused_lds_bytes(void) { return 4 * kWaveLds * sizeof(float); }
 // groups_bound: upper bound of the launch's items (groups of four candidates x queries); `counter` must be zero when the
 // kernel starts (the launch before it on the stream clears it).
 int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, uint32_t* counter, hipStream_t stream) {
-    ScoreArgs a = a_in;
-    a.agg = tuning().fused_nosolve ? 1 : 0;
+    const ScoreArgs& a = a_in;
     const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;      // two 4-wave workgroups per CU are resident
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = 4 * kWaveLds * sizeof(float);
 #define FUSED_LAUNCH(CPT, VAR) hipLaunchKernelGGL((pair_fused_kernel<CPT, VAR>), grid, dim3(256), lds, stream, a, qbox, counter)
     const int var = tuning().fused_variant;
-    if (tuning().fused_cpt == 1) {
+    if (tuning().fused_nosolve) {
+        hipLaunchKernelGGL((pair_fused_kernel<2, 0, false>), grid, dim3(256), lds, stream, a, qbox, counter);
+    } else if (tuning().fused_cpt == 1) {
         if (var == 1) FUSED_LAUNCH(1, 1); else if (var == 2) FUSED_LAUNCH(1, 2); else if (var == 3) FUSED_LAUNCH(1, 3);
         else if (var == 4) FUSED_LAUNCH(1, 4); else if (var == 7) FUSED_LAUNCH(1, 7); else FUSED_LAUNCH(1, 0);
     } else {
