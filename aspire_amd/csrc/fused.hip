@@ -11,9 +11,11 @@
 // streaming phase leaves idle, and the 516 B / pair workspace round trip disappears.
 //
 // Work decomposition (gfx950, wave = 64 lanes), documents of <= 8 sentence rows, CSR inputs:
-//   * item = four consecutive candidates of ONE query (groups never straddle two jobs of a batch); a wave owns an item.
-//     Items are claimed dynamically (one atomic per item) so that all waves finish together: with a static stride a batch of
-//     5000 items on 2048 resident waves runs three rounds for 2.44 rounds of work.
+//   * item = four consecutive candidates of ONE query (groups never straddle two jobs of a batch); a wave owns an item and
+//     walks the items with a static stride.  (Claiming items dynamically -- one atomicAdd on a shared counter per item --
+//     was measured and dropped: 2048 waves finishing an item together queue 2048 same-address atomics, ~40 us per round;
+//     and it buys nothing here: the kernel is bandwidth bound, so a last partial round of fewer waves simply runs each
+//     of them faster.)
 //   * cost phase = pair_tile_kernel<2,1> of score.hip: 16 lanes per candidate, lane (li, lj) owns the 2 x 2 entries
 //     (2 li + x, 2 lj + y) and walks all 768 coordinates itself; rows are staged 64 coordinates at a time (coalesced
 //     global_load_dwordx4 -> ds_write_b128 -> conflict-free broadcast ds_read_b128), next stage's loads in flight under
@@ -22,8 +24,9 @@
 //     two row_ror DPP adds, both inside a DPP row of 16 lanes; four solves per wave, every pair on its own epsilon schedule
 //     (the loop runs to the longest of the four, finished pairs idle with h = 0).  One exponential per entry and step,
 //     K_ij = 2^((f_i + g_j - C_ij) log2e / eps), weights as plain factors, f_i -= h log2(sum_j b_j K_ij) (see
-//     sinkhorn_block_kernel in score.hip for the derivation).  A sum that leaves fp32 range (extreme scaling) is caught by
-//     one finiteness test at the end and the pair is solved again with max-shifted log-sum-exps.
+//     sinkhorn_block_kernel in score.hip for the derivation).  A sum that leaves fp32 range (extreme scaling, never at the
+//     reference's hyper-parameters) poisons the pair's score with NaN; with such hyper-parameters the launcher follows up
+//     with the long-form kernel (generic.hip: max-shifted log-sum-exps), which re-solves exactly the NaN pairs.
 #include <math.h>
 
 #include "common.h"
@@ -70,12 +73,11 @@ struct Solve {
     float neg[2][2];       // -cdist of the valid block (plan-weighted similarity output only)
     float wa[2], wb[2];    // marginals (pair_distances.py:57-60)
     float f[2], g[2];      // potentials
-    float c_r2, c_h, diam;
+    float c_r2;            // log2(log2 e) - log2(diam): r2_k = log2e / eps_k = exp2(c_r2 - (k-1) lscf), h_k = eps_k ln2 / 2 = exp2(-1 - c_r2 + (k-1) lscf)
     int n_mid;             // annealed values between diam and blur; step k: 0 = diam, 1 .. n_mid, n_mid + 1 = blur, n_mid + 2 = final
     int k, max_steps;      // wave-uniform: next step, steps of the longest of the wave's four schedules
-    unsigned valid;        // bit x: row x valid, bit 2 + y: column y valid
+    unsigned valid;        // bit x: row x valid, bit 2 + y: column y valid, bit 4: a document longer than the tile (poison)
     int64_t out;           // index into scores, < 0 = nothing to store (clamped tail candidate)
-    bool poisoned;         // a document longer than the tile
 };
 
 __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const float (&cost)[2][2], const float (&neg)[2][2],
@@ -110,9 +112,7 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
     ms = max(ms, __shfl_xor(ms, 32));
     s.max_steps = __builtin_amdgcn_readfirstlane(ms);
     s.k = 0;
-    s.diam = diam;
-    s.c_r2 = 0.5287663729448977f - ldf;      // log2(log2 e) - log2(diam):  r2_k = exp2(c_r2 - (k-1) lscf)
-    s.c_h = -1.5287663729448977f + ldf;      // log2(ln2 / 2) + log2(diam): h_k  = exp2(c_h  + (k-1) lscf)
+    s.c_r2 = 0.5287663729448977f - ldf;
     const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -147,10 +147,9 @@ __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n)
     const int k_end = (n < 0 || s.k + n > s.max_steps) ? s.max_steps : s.k + n;
 #pragma unroll 1
     for (int k = s.k; k < k_end; ++k) {
-        const float kf = (float)(k - 1);
+        const float kf = (float)(k > 0 ? k - 1 : 0);        // steps 0 and 1 are both at eps = diam
         float r2 = __builtin_amdgcn_exp2f(fmaf(-kf, lscf, s.c_r2));
-        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, s.c_h));
-        if (k == 0) { r2 = kLog2e * rcp_refined(s.diam); h = 0.5f * kLn2 * s.diam; }
+        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, -1.f - s.c_r2));
         if (k > s.n_mid) { r2 = r2_blur; h = k == s.n_mid + 1 ? h_blur : (k == s.n_mid + 2 ? 2.f * h_blur : 0.f); }
         float f2[2], g2[2], rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
 #pragma unroll
@@ -204,92 +203,22 @@ __device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a
     return score;
 }
 
-// geomloss's own formulation -- max-shifted log-sum-exps, log-weights in the exponent, float64 schedule -- for a pair
-// whose shifted sums left fp32 range (never at the reference's hyper-parameters; scaling = 0.01 does it).
-__device__ __forceinline__ float solve_exact(const Solve& s, const ScoreArgs& a, float score, bool redo) {
-    const bool rv[2] = {(s.valid & 1u) != 0, (s.valid & 2u) != 0}, cv[2] = {(s.valid & 4u) != 0, (s.valid & 8u) != 0};
-    const float eb = (float)a.blur, diam = s.diam;
-    float la[2], lb[2], fe[2], ge[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        la[t] = s.wa[t] > 0.f ? fast_log(s.wa[t]) : -100000.f;
-        lb[t] = s.wb[t] > 0.f ? fast_log(s.wb[t]) : -100000.f;
-    }
-    // softmin over j (rows) / i (columns) with the exact maximum: out = -eps * LSE(h - C / eps)
-    auto lse_rows = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const float t0 = cv[0] ? hh[0] - div_r(s.mc[x][0], eps, reps) : kNegBig;
-            const float t1 = cv[1] ? hh[1] - div_r(s.mc[x][1], eps, reps) : kNegBig;
-            const float m = max_lj(fmaxf(t0, t1));
-            out[x] = -eps * (m + fast_log(sum_lj(fast_exp(t0 - m) + fast_exp(t1 - m))));
-        }
-    };
-    auto lse_cols = [&](float eps, float reps, const float (&hh)[2], float (&out)[2]) {
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const float t0 = rv[0] ? hh[0] - div_r(s.mc[0][y], eps, reps) : kNegBig;
-            const float t1 = rv[1] ? hh[1] - div_r(s.mc[1][y], eps, reps) : kNegBig;
-            const float m = max_li(fmaxf(t0, t1));
-            out[y] = -eps * (m + fast_log(sum_li(fast_exp(t0 - m) + fast_exp(t1 - m))));
-        }
-    };
-    // one symmetric update at eps; `active` = false leaves the pair's potentials alone (a wave mate with a longer
-    // schedule is still annealing: all reductions stay inside the pair's own 16 lanes)
-    auto step = [&](float eps, bool averaged, bool active) {
-        const float reps = rcp_refined(eps);
-        float ha[2], hb[2], ft[2], gt[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            ha[t] = la[t] + div_r(fe[t], eps, reps);
-            hb[t] = lb[t] + div_r(ge[t], eps, reps);
-        }
-        lse_cols(eps, reps, ha, gt);
-        lse_rows(eps, reps, hb, ft);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float gn = averaged ? 0.5f * (ge[t] + gt[t]) : gt[t];
-            const float fn = averaged ? 0.5f * (fe[t] + ft[t]) : ft[t];
-            ge[t] = active ? gn : ge[t];
-            fe[t] = active ? fn : fe[t];
-        }
-    };
-    {
-        const float reps = rcp_refined(diam);
-        lse_cols(diam, reps, la, ge);
-        lse_rows(diam, reps, lb, fe);
-    }
-    step(diam, true, true);
-    const double ld = log((double)diam);
-    int n_max = s.n_mid;
-    n_max = max(n_max, __shfl_xor(n_max, 16));
-    n_max = max(n_max, __shfl_xor(n_max, 32));
-    for (int k = 0; k < n_max; ++k)      // float64 schedule exactly as numpy builds geomloss's
-        step((float)exp(ld + (double)k * a.log_scaling), true, k < s.n_mid);
-    step(eb, true, true);
-    step(eb, false, true);
-    const float exact = solve_output(s, a, fe, ge);
-    return redo ? exact : score;
-}
-
 // finish a solve: remaining steps, the score, the store
 __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
     solve_steps(s, a, -1);
     float score = solve_output(s, a, s.f, s.g);
-    // An overflowed / vanished sum has turned into inf / nan that sticks to the potentials and reaches the score
-    const bool bad = !(fabsf(score) < 1e30f);
-    if (__builtin_expect(__any(bad), 0)) score = solve_exact(s, a, score, bad);
-    if (s.poisoned) score = __builtin_nanf("");      // a document longer than the tile: poison, never truncate silently
+    // An overflowed / vanished sum (extreme scaling) has turned into inf / nan that sticks to the potentials and reaches
+    // the score: the pair is poisoned with NaN and solved again by the long-form kernel that follows (launch_pair_fused);
+    // so is a document longer than the tile -- never truncated silently.
+    if (!(fabsf(score) < 1e30f) || (s.valid & 16u)) score = __builtin_nanf("");
     if (s.out >= 0 && (threadIdx.x & 15) == 0) a.scores[s.out] = score;
 }
 
-// counter[0] hands out the items beyond each wave's first, counter[1] counts the waves that have run out of items: the last
-// one leaves both at zero for the next launch (the launch before the first one on a fresh workspace clears them).
 // CPT: staged chunks per trip of the accumulate loop (2: the second chunk's LDS reads fly under the first one's arithmetic)
 // VAR (experiments): bit 0 = side products pinned before the LDS stores, bit 1 = one accumulator per vector component
 // (16 independent FMA chains instead of 4), bit 2 = no minimum-occupancy hint
 template <int CPT, int VAR, bool SOLVE = true>
-__global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox, uint32_t* __restrict__ counter) {
+__global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -313,7 +242,7 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
     bool have_pend = false;
     int slice = 0;                 // steps of the pending solve per cost stage
 
-    for (uint32_t item = item_lo + blockIdx.x * 4 + wave; item < n_items;) {
+    for (uint32_t item = item_lo + blockIdx.x * 4 + wave; item < n_items; item += n_waves) {
         uint32_t q_loc, c_loc0, c_end;
         if (mapped) {
             q_loc = (uint32_t)a.grp_job[item];
@@ -428,10 +357,6 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
 #pragma unroll
                 for (int y = 0; y < 2; ++y) accg[x][y] = (acc4[x][y].x + acc4[x][y].y) + (acc4[x][y].z + acc4[x][y].w);
         }
-        // ---- claim the next item now: the atomic's round trip hides behind the finish below ----------------------------
-        uint32_t claimed = 0;
-        if (lane == 0) claimed = atomicAdd(counter, 1u);
-
         // ---- norms: sum the staging lanes' partials through the scratch table nscr[value][lane] ----------------------
         // value 0..7: |y_j|^2 partials of the lane's staged candidate; 8, 9: |x|^2 partials of its two query rows
 #pragma unroll
@@ -524,20 +449,15 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
             const float diam = own_diam ? sqrtf(diam2) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
             solve_begin(pend, a, cost, neg, rv, cv, diam);
             pend.out = my_c_real ? (mapped ? c_idx : q_idx * a.c.n + c_idx) : (int64_t)-1;
-            pend.poisoned = q_len > 8 || c_len > 8;
+            if (q_len > 8 || c_len > 8) pend.valid |= 16u;
             slice = (pend.max_steps + kStages - 1) / kStages;
             have_pend = true;
         } else if (my_c_real && lp == 0) {
             a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = diam2;
         }
-        item = item_lo + n_waves + __builtin_amdgcn_readfirstlane(claimed);
     }
     if constexpr (SOLVE)
         if (have_pend) solve_finish(pend, a);   // the wave's last item: nothing left to hide it behind
-    if (lane == 0 && atomicAdd(counter + 1, 1u) == n_waves - 1) {      // every wave has made its last claim by now
-        counter[0] = 0u;
-        counter[1] = 0u;
-    }
 }
 
 }  // namespace
@@ -549,17 +469,16 @@ bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
 
 size_t fused_lds_bytes(void) { return 4 * kWaveLds * sizeof(float); }
 
-// groups_bound: upper bound of the launch's items (groups of four candidates x queries); `counter` must be zero when the
-// kernel starts (the launch before it on the stream clears it).
-int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, uint32_t* counter, hipStream_t stream) {
+// groups_bound: upper bound of the launch's items (groups of four candidates x queries)
+int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, hipStream_t stream) {
     const ScoreArgs& a = a_in;
     const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;      // two 4-wave workgroups per CU are resident
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = 4 * kWaveLds * sizeof(float);
-#define FUSED_LAUNCH(CPT, VAR) hipLaunchKernelGGL((pair_fused_kernel<CPT, VAR>), grid, dim3(256), lds, stream, a, qbox, counter)
+#define FUSED_LAUNCH(CPT, VAR) hipLaunchKernelGGL((pair_fused_kernel<CPT, VAR>), grid, dim3(256), lds, stream, a, qbox)
     const int var = tuning().fused_variant;
     if (tuning().fused_nosolve) {
-        hipLaunchKernelGGL((pair_fused_kernel<2, 0, false>), grid, dim3(256), lds, stream, a, qbox, counter);
+        hipLaunchKernelGGL((pair_fused_kernel<2, 0, false>), grid, dim3(256), lds, stream, a, qbox);
     } else if (tuning().fused_cpt == 1) {
         if (var == 1) FUSED_LAUNCH(1, 1); else if (var == 2) FUSED_LAUNCH(1, 2); else if (var == 3) FUSED_LAUNCH(1, 3);
         else if (var == 4) FUSED_LAUNCH(1, 4); else if (var == 7) FUSED_LAUNCH(1, 7); else FUSED_LAUNCH(1, 0);
@@ -569,6 +488,9 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     }
 #undef FUSED_LAUNCH
     ASPIRE_LAUNCH_OK();
+    // scaling below ~0.03 lets the shifted sums overflow (the exponent of K grows by 1 / scaling from one step to the next);
+    // far above that they cannot.  Below 0.25: re-solve the NaN pairs with geomloss's own max-shifted formulation.
+    if (a.scaling < 0.25) return launch_pair_generic(a, 2, 0, 8, 8, stream);
     return ASPIRE_OK;
 }
 

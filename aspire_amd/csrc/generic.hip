@@ -58,15 +58,22 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
     return r;
 }
 
-// mode 0: otAspire (a.want, extras);  mode 1: tsAspire max-sim (a.scores = max over valid entries of -cdist, pair_sims)
+// mode 0: otAspire (a.want, extras);  mode 1: tsAspire max-sim (a.scores = max over valid entries of -cdist, pair_sims);
+// mode 2: otAspire for exactly the pairs whose score is NaN (the fused kernel's poisoned pairs: overflowed sums at extreme
+// scaling, documents longer than its tile)
 __global__ void __launch_bounds__(kGenThreads) pair_generic_kernel(ScoreArgs a, int mode, int skip_up_to, int rows_q, int rows_c) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const bool paired = a.pairing == ASPIRE_PAIR_PAIRED;
+    const bool paired = a.pairing != ASPIRE_PAIR_CROSS;                // one query per candidate (PAIRED, MAPPED)
     const int64_t p = (int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x;
     const int64_t P = paired ? a.c.n : a.q.n * a.c.n;
     if (p >= P) return;
-    const int64_t q_idx = paired ? p : p / a.c.n, c_idx = paired ? p : p - q_idx * a.c.n;
+    if (mode == 2) {
+        if (a.scores[p] == a.scores[p]) return;                        // not NaN: the fused kernel's score stands
+        mode = 0;
+    }
+    const int64_t c_idx = paired ? p : p % a.c.n;
+    const int64_t q_idx = a.pairing == ASPIRE_PAIR_PAIRED ? p : a.pairing == kPairMapped ? (int64_t)a.qmap[p] : p / a.c.n;
     const int q_len = a.q.len[q_idx], c_len = a.c.len[c_idx];
     if (q_len <= skip_up_to && c_len <= skip_up_to) return;          // the tile kernels scored this pair
     if (q_len > rows_q || c_len > rows_c) {                            // longer than the host-known bound: poison
@@ -133,7 +140,7 @@ __global__ void __launch_bounds__(kGenThreads) pair_generic_kernel(ScoreArgs a, 
     // ---- diameter: the caller's (one per group) or the bounding box of the pair's own valid rows ------------------------
     float diam;
     if (a.diameter != nullptr) {
-        diam = paired ? a.diameter[c_idx / a.diam_group] : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];
+        diam = a.pairing == ASPIRE_PAIR_CROSS ? a.diameter[q_idx * a.n_groups + c_idx / a.diam_group] : a.diameter[c_idx / a.diam_group];
     } else {
         float acc = 0.f;
         for (int d = tid; d < kD; d += kGenThreads) {
@@ -264,7 +271,7 @@ int generic_max_rows(void) { return 128; }
 int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q, int rows_c, hipStream_t stream) {
     ASPIRE_REQUIRE(rows_q <= generic_max_rows() && rows_c <= generic_max_rows(), ASPIRE_ERR_UNSUPPORTED,
                    "documents with more than %d sentence rows are not supported (got %d x %d)", generic_max_rows(), rows_q, rows_c);
-    const int64_t P = a.pairing == ASPIRE_PAIR_PAIRED ? a.c.n : a.q.n * a.c.n;
+    const int64_t P = a.pairing == ASPIRE_PAIR_CROSS ? a.q.n * a.c.n : a.c.n;
     if (P == 0) return ASPIRE_OK;
     const size_t lds_bytes = (size_t)gen_layout(rows_q, rows_c).total * sizeof(float);
     if (lds_bytes > 64 * 1024) {      // more than the default dynamic LDS limit: raise it (per function, sticky, harmless to repeat)

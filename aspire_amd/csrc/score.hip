@@ -1195,9 +1195,8 @@ struct TileCfg {
 };
 
 // per-coordinate bounding box of each query's valid rows: qbox[q][0][768] = min, qbox[q][1][768] = max
-__global__ void __launch_bounds__(192) doc_box_kernel(RepSet d, float* __restrict__ box, uint32_t* __restrict__ zero_me) {
+__global__ void __launch_bounds__(192) doc_box_kernel(RepSet d, float* __restrict__ box) {
     const int64_t k = blockIdx.x;
-    if (zero_me != nullptr && k == 0 && threadIdx.x < 2) zero_me[threadIdx.x] = 0u;       // the fused kernel's item counter and exit count
     const int n = d.len[k];
     const float* doc = d.rows + (size_t)d.start[k] * kD + threadIdx.x * 4;
     float4 mn = ld4(doc), mx = mn;
@@ -2053,7 +2052,7 @@ int launch_cost_stage(const ScoreArgs& a, const aspire_repset* q, const aspire_r
             // enough groups of 4 candidates to fill the chip: tiled form (lanes own finished (i,j) sums), one group per
             // wave (measured 4.7 TB/s algorithmic at 1 x 20 000 against 1.8 TB/s for the accumulate-then-reduce kernel)
             if (!a.diameter && first_chunk && a.pairing != kPairMapped) {   // per-coordinate boxes of the queries, once per call
-                hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, stream, a.q, qbox, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, stream, a.q, qbox);
                 ASPIRE_LAUNCH_OK();
             }
             const int64_t waves = groups4 < 256 * 8 ? groups4 : 256 * 8;
@@ -2214,7 +2213,7 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     // query boxes sit at a fixed place (the tail of the workspace) so that every candidate chunk finds them
     float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
     // Few queries against a big pool of short documents: costs and solves in ONE launch, no workspace slots, no candidate
-    // chunks (fused.hip).  The first word of the workspace is its item counter.
+    // chunks (fused.hip).
     const int form_t = tuning().ot_form;
     const int64_t groups4_all = (c->n + 3) / 4 * q->n;
     const bool fused = pairing == ASPIRE_PAIR_CROSS && !extra && !gram && !cost_only && fused_path_ok(q, c) &&
@@ -2222,14 +2221,11 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     if (fused) {
         a.cand0 = 0;
         a.cand1 = c->n;
-        uint32_t* counter = (uint32_t*)workspace;
-        if (!diameter) {   // per-coordinate boxes of the queries (the kernel adds each candidate's rows); clears the counter
-            hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, (hipStream_t)stream, a.q, qbox, counter);
+        if (!diameter) {   // per-coordinate boxes of the queries (the kernel adds each candidate's rows)
+            hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, (hipStream_t)stream, a.q, qbox);
             ASPIRE_LAUNCH_OK();
-        } else {
-            ASPIRE_HIP_OK(hipMemsetAsync(counter, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
         }
-        if (int rc = launch_pair_fused(a, groups4_all, qbox, counter, (hipStream_t)stream)) return rc;
+        if (int rc = launch_pair_fused(a, groups4_all, qbox, (hipStream_t)stream)) return rc;
     }
     const int rc_run = fused ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
@@ -2306,10 +2302,9 @@ namespace {
 // candidate -> job / group -> job tables the kernels index.
 __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, const int32_t* __restrict__ job_off, int J, float* __restrict__ qbox,
                                                          int32_t* __restrict__ cand_job, int32_t* __restrict__ grp_off,
-                                                         int32_t* __restrict__ grp_job, uint32_t* __restrict__ counter) {
+                                                         int32_t* __restrict__ grp_job) {
     __shared__ int part[3];
     const int j = blockIdx.x, tid = threadIdx.x;
-    if (j == 0 && tid < 2) counter[tid] = 0u;    // the fused kernel's item counter and exit count
     {
         const int n = q.len[j];
         const float* doc = q.rows + (size_t)q.start[j] * kD + tid * 4;
@@ -2339,12 +2334,11 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, const int32_t
 }
 
 struct BatchLayout {
-    size_t counter, slots, qbox, cand_job, grp_job, grp_off, topk, total;
+    size_t slots, qbox, cand_job, grp_job, grp_off, topk, total;
 };
 BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, int64_t k) {
     BatchLayout L{};
     size_t o = 0;
-    L.counter = o; o = 16;                      // the fused kernel's item counter
     L.slots = o; o = align16(o + slot_bytes(max_rows) * (size_t)C);
     L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
@@ -2416,16 +2410,14 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const bool big = max_rows <= 8 && groups_bound >= 2048 && C >= 6000;
     const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
     a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
-    uint32_t* counter = (uint32_t*)(wsb + L.counter);
     if (stages & kStagePrep) {
-        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, job_off, (int)J, qbox, cand_job, grp_off, grp_job,
-                           counter);
+        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, job_off, (int)J, qbox, cand_job, grp_off, grp_job);
         ASPIRE_LAUNCH_OK();
     }
     const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
     if (fused) {
         if (stages & (kStageCost | kStageSolve))
-            if (int rc = launch_pair_fused(a, groups_bound, qbox, counter, s0)) return rc;
+            if (int rc = launch_pair_fused(a, groups_bound, qbox, s0)) return rc;
     } else {
         const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
             constexpr int T = decltype(tc)::value;
