@@ -44,6 +44,8 @@ constexpr int kRows = 8 + 8 * 4;                         // staged rows: 8 query
 constexpr int kNormLd = 68;
 constexpr int kWaveLds = kRows * kRowStride + 16 * kNormLd;   // floats per wave (15.2 KB)
 
+typedef float mfma4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float sum_lj(float v) {       // all-reduce over the 4 lanes that share li (lane bits 0, 1)
     v += lane_xor<1>(v);
     return v + lane_xor<2>(v);
@@ -216,7 +218,9 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 
 // CPT: staged chunks per trip of the accumulate loop (2: the second chunk's LDS reads fly under the first one's arithmetic)
 // VAR (experiments): bit 0 = side products pinned before the LDS stores, bit 1 = one accumulator per vector component
-// (16 independent FMA chains instead of 4), bit 2 = no minimum-occupancy hint
+// (16 independent FMA chains instead of 4), bit 2 = no minimum-occupancy hint, bit 3 = the dot products on the matrix
+// pipe (v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4 x 4 = the 64 entries of each of the wave's four pairs, one coordinate per
+// instruction), which leaves the VALU issue slots to the staging side products and to the solve slices
 template <int CPT, int VAR, bool SOLVE = true>
 __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -274,6 +278,9 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y) acc4[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mfma4_t macc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) macc[m] = mfma4_t{0.f, 0.f, 0.f, 0.f};
         float ny[8], nx[2] = {0.f, 0.f}, dsq = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) ny[k] = 0.f;
@@ -318,6 +325,23 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- accumulate: every lane walks the staged chunks for its own 2 x 2 entries ----------------------------
+            if constexpr (VAR & 8) {
+                // matrix-pipe form: block b = lane >> 2 = (p, iq, jq) is the 4 x 4 sub-block (rows 4 iq .., columns 4 jq ..) of
+                // pair p; lane t = lane & 3 feeds query row 4 iq + t as A and candidate row 4 jq + t as B, one coordinate per
+                // instruction; it ends up with column 4 jq + t of the block (4 accumulator registers = rows 4 iq .. + 3)
+                const int mb = lane >> 2, mt = lane & 3, miq = (mb >> 1) & 1, mjq = mb & 1;
+                const float* xm = lds + (4 * miq + mt) * kRowStride;
+                const float* ym = lds + (8 + p * 8 + 4 * mjq + mt) * kRowStride;
+#pragma unroll 4
+                for (int c = 0; c < kCh; ++c) {
+                    const float4 xa = *reinterpret_cast<const float4*>(xm + c * 4);
+                    const float4 yb = *reinterpret_cast<const float4*>(ym + c * 4);
+                    macc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.x, yb.x, macc[0], 0, 0, 0);
+                    macc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.y, yb.y, macc[1], 0, 0, 0);
+                    macc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.z, yb.z, macc[2], 0, 0, 0);
+                    macc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.w, yb.w, macc[3], 0, 0, 0);
+                }
+            } else {
             const float* xr = lds + (2 * li) * kRowStride;
             const float* yr = lds + (8 + p * 8 + 2 * lj) * kRowStride;
 #pragma unroll 1
@@ -344,6 +368,7 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
                         }
                 }
             }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
             __builtin_amdgcn_wave_barrier();
             // ---- a slice of the PREVIOUS item's solve, in the shadow of the loads just issued ------------------------
@@ -356,6 +381,22 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 2; ++y) accg[x][y] = (acc4[x][y].x + acc4[x][y].y) + (acc4[x][y].z + acc4[x][y].w);
+        }
+        if constexpr (VAR & 8) {
+            // block columns -> the solve's 2 x 2 layout, through the (idle) stage buffer: pair p's 8 x 8 entries row-major
+            const int mb = lane >> 2, mt = lane & 3, miq = (mb >> 1) & 1, mjq = mb & 1;
+            float* tr = lds + p * 64;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(4 * miq + r) * 8 + 4 * mjq + mt] = (macc[0][r] + macc[1][r]) + (macc[2][r] + macc[3][r]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) accg[x][y] = tr[(2 * li + x) * 8 + 2 * lj + y];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         // ---- norms: sum the staging lanes' partials through the scratch table nscr[value][lane] ----------------------
         // value 0..7: |y_j|^2 partials of the lane's staged candidate; 8, 9: |x|^2 partials of its two query rows
@@ -480,11 +521,9 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     if (tuning().fused_nosolve) {
         hipLaunchKernelGGL((pair_fused_kernel<2, 0, false>), grid, dim3(256), lds, stream, a, qbox);
     } else if (tuning().fused_cpt == 1) {
-        if (var == 1) FUSED_LAUNCH(1, 1); else if (var == 2) FUSED_LAUNCH(1, 2); else if (var == 3) FUSED_LAUNCH(1, 3);
-        else if (var == 4) FUSED_LAUNCH(1, 4); else if (var == 7) FUSED_LAUNCH(1, 7); else FUSED_LAUNCH(1, 0);
+        if (var == 1) FUSED_LAUNCH(1, 1); else if (var == 8) FUSED_LAUNCH(1, 8); else if (var == 9) FUSED_LAUNCH(1, 9); else FUSED_LAUNCH(1, 0);
     } else {
-        if (var == 1) FUSED_LAUNCH(2, 1); else if (var == 2) FUSED_LAUNCH(2, 2); else if (var == 3) FUSED_LAUNCH(2, 3);
-        else if (var == 4) FUSED_LAUNCH(2, 4); else if (var == 7) FUSED_LAUNCH(2, 7); else FUSED_LAUNCH(2, 0);
+        if (var == 1) FUSED_LAUNCH(2, 1); else FUSED_LAUNCH(2, 0);
     }
 #undef FUSED_LAUNCH
     ASPIRE_LAUNCH_OK();

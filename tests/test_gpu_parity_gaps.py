@@ -36,7 +36,7 @@ def test_cdist_formula_follows_the_group_extents_l2max(amd):
     # two fp32 evaluations of the SAME expansion differ by up to ~2e-5 (it cancels |x|^2 + |y|^2 ~ 1500 against 2 x.y)
     np.testing.assert_allclose(got, want, atol=4e-5, rtol=0)
     per_pair = amd.scorer.score_pool([query], cands, method='l2max', schedule='pair').cpu().numpy()[0]
-    np.testing.assert_allclose(per_pair[:64], want[:64], atol=1e-5, rtol=0)                    # groups without a long document: direct formula, tight
+    np.testing.assert_allclose(per_pair[:64], want[:64], atol=4e-5, rtol=0)                    # groups without a long document: the direct formula either way
     ranked = amd.scorer.rank_pool([query], cands, method='l2max', schedule='batch')[0]
     assert [i for i, _ in ranked] == np.argsort(-got.astype(np.float64), kind='stable').tolist()
 
