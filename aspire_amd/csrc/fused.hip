@@ -75,7 +75,8 @@ struct Solve {
     float neg[2][2];       // -cdist of the valid block (plan-weighted similarity output only)
     float wa[2], wb[2];    // marginals (pair_distances.py:57-60)
     float f[2], g[2];      // potentials
-    float c_r2;            // log2(log2 e) - log2(diam): r2_k = log2e / eps_k = exp2(c_r2 - (k-1) lscf), h_k = eps_k ln2 / 2 = exp2(-1 - c_r2 + (k-1) lscf)
+    float r2, h;           // this step's log2e / eps and eps ln2 / 2: through the annealed part of the schedule the next step's
+                           // follow by one multiply each (eps *= scaling) -- no transcendental for the constants
     int n_mid;             // annealed values between diam and blur; step k: 0 = diam, 1 .. n_mid, n_mid + 1 = blur, n_mid + 2 = final
     int k, max_steps;      // wave-uniform: next step, steps of the longest of the wave's four schedules
     unsigned valid;        // bit x: row x valid, bit 2 + y: column y valid, bit 4: a document longer than the tile (poison)
@@ -114,8 +115,9 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
     ms = max(ms, __shfl_xor(ms, 32));
     s.max_steps = __builtin_amdgcn_readfirstlane(ms);
     s.k = 0;
-    s.c_r2 = 0.5287663729448977f - ldf;
     const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
+    s.r2 = r2_first;
+    s.h = h_first;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -143,16 +145,20 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
 
 // up to `n` more annealing steps (all of the rest with n < 0)
 __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n) {
-    const float lscf = a.log2_scaling;
+    const float scal = (float)a.scaling, inv_scal = (float)(1.0 / a.scaling);
     const float eb = (float)a.blur;
     const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
     const int k_end = (n < 0 || s.k + n > s.max_steps) ? s.max_steps : s.k + n;
 #pragma unroll 1
     for (int k = s.k; k < k_end; ++k) {
-        const float kf = (float)(k > 0 ? k - 1 : 0);        // steps 0 and 1 are both at eps = diam
-        float r2 = __builtin_amdgcn_exp2f(fmaf(-kf, lscf, s.c_r2));
-        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, -1.f - s.c_r2));
+        // eps_k: diam at k = 0 and 1, diam scaling^(k-1) up to k = n_mid, then blur (averaged), blur (final, h doubled), and
+        // nothing (h = 0) while a wave mate with a longer schedule is still annealing
+        const bool anneal = k >= 2 && k <= s.n_mid;
+        float r2 = anneal ? s.r2 * inv_scal : s.r2;
+        float h = anneal ? s.h * scal : s.h;
         if (k > s.n_mid) { r2 = r2_blur; h = k == s.n_mid + 1 ? h_blur : (k == s.n_mid + 2 ? 2.f * h_blur : 0.f); }
+        s.r2 = r2;
+        s.h = h;
         float f2[2], g2[2], rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -216,13 +222,13 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
     if (s.out >= 0 && (threadIdx.x & 15) == 0) a.scores[s.out] = score;
 }
 
-// CPT: staged chunks per trip of the accumulate loop (2: the second chunk's LDS reads fly under the first one's arithmetic)
-// VAR (experiments): bit 0 = side products pinned before the LDS stores, bit 1 = one accumulator per vector component
-// (16 independent FMA chains instead of 4), bit 2 = no minimum-occupancy hint, bit 3 = the dot products on the matrix
-// pipe (v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4 x 4 = the 64 entries of each of the wave's four pairs, one coordinate per
-// instruction), which leaves the VALU issue slots to the staging side products and to the solve slices
-template <int CPT, int VAR, bool SOLVE = true>
-__global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
+// MFMA: the dot products on the matrix pipe (v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4 x 4 = the 64 entries of each of the
+// wave's four pairs, one coordinate per instruction, exact fp32 multiply-adds), which leaves the VALU issue slots to the
+// staging side products and to the solve slices -- with two waves per SIMD the kernel is otherwise VALU-issue bound
+// (20 x 1000 pairs: 146 -> 130 us; 100 x 1000: 661 -> 566 us).  !MFMA: the same sums as VALU FMAs (kept for A/B and parity
+// tests).  SOLVE = false (diagnostics): the cost phase alone, diam^2 as the score.
+template <bool MFMA, bool SOLVE = true>
+__global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -273,11 +279,6 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
         const int qb_hi = own_diam ? kD : 0;
 
         float accg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        float4 acc4[2][2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y) acc4[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);
         mfma4_t macc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) macc[m] = mfma4_t{0.f, 0.f, 0.f, 0.f};
@@ -319,13 +320,12 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
                     *reinterpret_cast<float4*>(lds + (2 * sg + k) * kRowStride + sc * 4) = vx[k];
                 }
             }
-            if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < kStages) issue_loads(st + 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- accumulate: every lane walks the staged chunks for its own 2 x 2 entries ----------------------------
-            if constexpr (VAR & 8) {
+            if constexpr (MFMA) {
                 // matrix-pipe form: block b = lane >> 2 = (p, iq, jq) is the 4 x 4 sub-block (rows 4 iq .., columns 4 jq ..) of
                 // pair p; lane t = lane & 3 feeds query row 4 iq + t as A and candidate row 4 jq + t as B, one coordinate per
                 // instruction; it ends up with column 4 jq + t of the block (4 accumulator registers = rows 4 iq .. + 3)
@@ -345,28 +345,17 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
             const float* xr = lds + (2 * li) * kRowStride;
             const float* yr = lds + (8 + p * 8 + 2 * lj) * kRowStride;
 #pragma unroll 1
-            for (int c = 0; c < kCh; c += CPT) {
+            for (int c = 0; c < kCh; ++c) {
+                float4 xv[2], yv[2];
 #pragma unroll
-                for (int cc = 0; cc < CPT; ++cc) {
-                    float4 xv[2], yv[2];
+                for (int x = 0; x < 2; ++x) xv[x] = *reinterpret_cast<const float4*>(xr + x * kRowStride + c * 4);
 #pragma unroll
-                    for (int x = 0; x < 2; ++x) xv[x] = *reinterpret_cast<const float4*>(xr + x * kRowStride + (c + cc) * 4);
+                for (int y = 0; y < 2; ++y) yv[y] = *reinterpret_cast<const float4*>(yr + y * kRowStride + c * 4);
 #pragma unroll
-                    for (int y = 0; y < 2; ++y) yv[y] = *reinterpret_cast<const float4*>(yr + y * kRowStride + (c + cc) * 4);
+                for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int x = 0; x < 2; ++x)
-#pragma unroll
-                        for (int y = 0; y < 2; ++y) {
-                            if constexpr (VAR & 2) {
-                                acc4[x][y].x = fmaf(xv[x].x, yv[y].x, acc4[x][y].x);
-                                acc4[x][y].y = fmaf(xv[x].y, yv[y].y, acc4[x][y].y);
-                                acc4[x][y].z = fmaf(xv[x].z, yv[y].z, acc4[x][y].z);
-                                acc4[x][y].w = fmaf(xv[x].w, yv[y].w, acc4[x][y].w);
-                            } else {
-                                accg[x][y] = fmaf(xv[x].w, yv[y].w, fmaf(xv[x].z, yv[y].z, fmaf(xv[x].y, yv[y].y, fmaf(xv[x].x, yv[y].x, accg[x][y]))));
-                            }
-                        }
-                }
+                    for (int y = 0; y < 2; ++y)
+                        accg[x][y] = fmaf(xv[x].w, yv[y].w, fmaf(xv[x].z, yv[y].z, fmaf(xv[x].y, yv[y].y, fmaf(xv[x].x, yv[y].x, accg[x][y]))));
             }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
@@ -376,13 +365,7 @@ __global__ void __launch_bounds__(256, (VAR & 4) ? 1 : 2) pair_fused_kernel(Scor
                 if (have_pend) solve_steps(pend, a, slice);
         }
 
-        if constexpr (VAR & 2) {
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) accg[x][y] = (acc4[x][y].x + acc4[x][y].y) + (acc4[x][y].z + acc4[x][y].w);
-        }
-        if constexpr (VAR & 8) {
+        if constexpr (MFMA) {
             // block columns -> the solve's 2 x 2 layout, through the (idle) stage buffer: pair p's 8 x 8 entries row-major
             const int mb = lane >> 2, mt = lane & 3, miq = (mb >> 1) & 1, mjq = mb & 1;
             float* tr = lds + p * 64;
@@ -516,16 +499,9 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;      // two 4-wave workgroups per CU are resident
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = 4 * kWaveLds * sizeof(float);
-#define FUSED_LAUNCH(CPT, VAR) hipLaunchKernelGGL((pair_fused_kernel<CPT, VAR>), grid, dim3(256), lds, stream, a, qbox)
-    const int var = tuning().fused_variant;
-    if (tuning().fused_nosolve) {
-        hipLaunchKernelGGL((pair_fused_kernel<2, 0, false>), grid, dim3(256), lds, stream, a, qbox);
-    } else if (tuning().fused_cpt == 1) {
-        if (var == 1) FUSED_LAUNCH(1, 1); else if (var == 8) FUSED_LAUNCH(1, 8); else if (var == 9) FUSED_LAUNCH(1, 9); else FUSED_LAUNCH(1, 0);
-    } else {
-        if (var == 1) FUSED_LAUNCH(2, 1); else FUSED_LAUNCH(2, 0);
-    }
-#undef FUSED_LAUNCH
+    if (tuning().fused_nosolve) hipLaunchKernelGGL((pair_fused_kernel<true, false>), grid, dim3(256), lds, stream, a, qbox);
+    else if (tuning().fused_valu) hipLaunchKernelGGL((pair_fused_kernel<false, true>), grid, dim3(256), lds, stream, a, qbox);
+    else hipLaunchKernelGGL((pair_fused_kernel<true, true>), grid, dim3(256), lds, stream, a, qbox);
     ASPIRE_LAUNCH_OK();
     // scaling below ~0.03 lets the shifted sums overflow (the exponent of K grows by 1 / scaling from one step to the next);
     // far above that they cannot.  Below 0.25: re-solve the NaN pairs with geomloss's own max-shifted formulation.

@@ -36,10 +36,8 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.gemm_tile96 = unset ? 0 : 1;
     } else if (!strcmp(key, "GRAM_OCC")) {
         t.gram_occ = unset ? 0 : atoi(v);
-    } else if (!strcmp(key, "FUSED_VARIANT")) {
-        t.fused_variant = unset ? 0 : atoi(v);
-    } else if (!strcmp(key, "FUSED_CPT")) {
-        t.fused_cpt = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "FUSED_VALU")) {
+        t.fused_valu = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {
         t.fused_nosolve = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "OT_FORM")) {
@@ -53,7 +51,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_CPT", "FUSED_NOSOLVE", "GRAM_OCC", "FUSED_VARIANT"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "GRAM_OCC"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

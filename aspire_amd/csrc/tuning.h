@@ -14,8 +14,7 @@ struct Tuning {
     int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
                              // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch
     int gram_occ = 0;        // ASPIRE_HIP_GRAM_OCC=3: the few-query Gram forms at three workgroups per CU (spilling; A/B experiments)
-    int fused_variant = 0;   // ASPIRE_HIP_FUSED_VARIANT: code-shape experiments of the fused kernel (fused.hip, VAR)
-    int fused_cpt = 0;       // ASPIRE_HIP_FUSED_CPT: chunks per trip of the fused kernel's accumulate loop (experiments)
+    int fused_valu = 0;      // ASPIRE_HIP_FUSED_VALU=1: the fused kernel's dot products as VALU FMAs instead of MFMA (A/B, parity tests)
     int fused_nosolve = 0;   // ASPIRE_HIP_FUSED_NOSOLVE=1: the fused kernel's cost phase alone (timing experiments)
 };
 

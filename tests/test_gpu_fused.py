@@ -113,8 +113,22 @@ def test_fused_schedule_length_at_its_discontinuities(amd, form):
     np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
 
 
-def test_fused_repeated_launches_reset_their_item_counter(amd):
-    """the kernel's last wave leaves the item counter at zero: back-to-back launches on one workspace score every pair"""
+def test_fused_matrix_pipe_and_valu_forms_agree(amd):
+    """the dot products on v_mfma_f32_4x4x1 (default) and as VALU FMAs: exact fp32 multiply-adds either way, another
+    summation order"""
+    cands = _pool(31, 8300)
+    queries = _pool(32, 2, 2, 8)
+    q, c = amd.ops.DeviceRepSet.from_list(queries), amd.ops.DeviceRepSet.from_list(cands)
+    with amd.pinned(OT_FORM='fused'):
+        mfma = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+    with amd.pinned(OT_FORM='fused', FUSED_VALU=1):
+        valu = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+    assert np.isfinite(mfma).all()
+    np.testing.assert_allclose(mfma, valu, atol=5e-5, rtol=0)
+
+
+def test_fused_repeated_launches_on_one_workspace(amd):
+    """back-to-back launches on one workspace score every pair"""
     cands = _pool(21, 9000, 8, 8)
     query = _pool(22, 1, 8, 8)
     q, c = amd.ops.DeviceRepSet.from_list(query), amd.ops.DeviceRepSet.from_list(cands)

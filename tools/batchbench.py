@@ -70,12 +70,8 @@ def bench(J, NC, S, k=100):
     bytes_ = J * NC * (S * D * 4) + J * S * D * 4
     out['cost_TBs'] = bytes_ / out['score'] / 1e6
     e2e = {}
-    variants = [('fused', dict(OT_FORM='fused')), ('fused-cpt1', dict(OT_FORM='fused', FUSED_CPT=1)),
+    variants = [('fused', dict(OT_FORM='fused')), ('fused-valu', dict(OT_FORM='fused', FUSED_VALU=1)),
                 ('fused-nosolve', dict(OT_FORM='fused', FUSED_NOSOLVE=1))]
-    for v in os.environ.get('BATCHBENCH_VARIANTS', '').split(','):
-        if v:
-            variants += [(f'v{v}', dict(OT_FORM='fused', FUSED_VARIANT=int(v))), (f'v{v}c1', dict(OT_FORM='fused', FUSED_VARIANT=int(v), FUSED_CPT=1)),
-                         (f'v{v}ns', dict(OT_FORM='fused', FUSED_VARIANT=int(v), FUSED_NOSOLVE=1))]
     variants += [('tile', dict(OT_FORM='tile')), ('small', dict(OT_FORM='small'))]
     if S > 8:
         variants = [('small', dict(OT_FORM='small'))]
