@@ -97,10 +97,11 @@ __device__ __noinline__ float direct_d2(unsigned long long x, unsigned long long
 
 // Three workgroups per CU for the 32/64-column tiles costs 80-144 B of scratch per lane (epilogue values) against
 // 178-194 registers at two per CU, and is still ahead: 1 x 20000 x 12 OT 347 vs 375 us, 1 x 4000 x 20 189 vs 235 us.
-// OCC = workgroups per CU the register budget is cut for: 3 (168 registers) makes the 32- / 64-column forms spill 80 / 144
-// bytes, 2 (no spills, 178 / 194 registers) leaves fewer waves to cover the HBM latency of these few-query tiles.
-template <int BN, bool L2MAX, bool BOX, int OCC = 2>
-__global__ void __launch_bounds__(256, OCC) pair_gram_kernel(GramArgs g) {
+// Two workgroups per CU for every form: at three (168 registers) the 32- / 64-column forms spilled 80 / 144 bytes; without
+// spills (178 / 194 registers) 1 x 20 000 x 12 is 8 % slower (371 vs 340 us) and 2 x 10 000 x 12 4 - 20 % faster (240 vs 248 us
+// otAspire, 103 vs 126 us max-sim).
+template <int BN, bool L2MAX, bool BOX>
+__global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     static_assert(!BOX || (!L2MAX && BN <= 64), "the fused diameter serves the few-query otAspire tiles");
     constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int WM = kBM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
@@ -557,18 +558,12 @@ int launch_gram(const GramArgs& g, int bn, hipStream_t stream) {
     const dim3 grid((unsigned)(g.n_ct * g.n_qt));
     const bool box = g.diam2 != nullptr;
     if constexpr (L2MAX) {
-        const bool occ3 = tuning().gram_occ == 3;
-        if (bn == 32 && occ3) hipLaunchKernelGGL((pair_gram_kernel<32, true, false, 3>), grid, dim3(256), 0, stream, g);
-        else if (bn == 32) hipLaunchKernelGGL((pair_gram_kernel<32, true, false>), grid, dim3(256), 0, stream, g);
-        else if (bn == 64 && occ3) hipLaunchKernelGGL((pair_gram_kernel<64, true, false, 3>), grid, dim3(256), 0, stream, g);
+        if (bn == 32) hipLaunchKernelGGL((pair_gram_kernel<32, true, false>), grid, dim3(256), 0, stream, g);
         else if (bn == 64) hipLaunchKernelGGL((pair_gram_kernel<64, true, false>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((pair_gram_kernel<128, true, false>), grid, dim3(256), 0, stream, g);
     } else {
-        const bool occ3 = tuning().gram_occ == 3;
-        if (bn == 32 && box && occ3) hipLaunchKernelGGL((pair_gram_kernel<32, false, true, 3>), grid, dim3(256), 0, stream, g);
-        else if (bn == 32 && box) hipLaunchKernelGGL((pair_gram_kernel<32, false, true>), grid, dim3(256), 0, stream, g);
+        if (bn == 32 && box) hipLaunchKernelGGL((pair_gram_kernel<32, false, true>), grid, dim3(256), 0, stream, g);
         else if (bn == 32) hipLaunchKernelGGL((pair_gram_kernel<32, false, false>), grid, dim3(256), 0, stream, g);
-        else if (bn == 64 && box && occ3) hipLaunchKernelGGL((pair_gram_kernel<64, false, true, 3>), grid, dim3(256), 0, stream, g);
         else if (bn == 64 && box) hipLaunchKernelGGL((pair_gram_kernel<64, false, true>), grid, dim3(256), 0, stream, g);
         else if (bn == 64) hipLaunchKernelGGL((pair_gram_kernel<64, false, false>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((pair_gram_kernel<128, false, false>), grid, dim3(256), 0, stream, g);

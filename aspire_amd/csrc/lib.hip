@@ -34,8 +34,6 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "GEMM_TILE")) {
         if (!unset && strcmp(v, "96")) return false;
         t.gemm_tile96 = unset ? 0 : 1;
-    } else if (!strcmp(key, "GRAM_OCC")) {
-        t.gram_occ = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_VALU")) {
         t.fused_valu = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {
@@ -51,7 +49,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "GRAM_OCC"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

@@ -13,7 +13,6 @@ struct Tuning {
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
     int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
                              // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch
-    int gram_occ = 0;        // ASPIRE_HIP_GRAM_OCC=3: the few-query Gram forms at three workgroups per CU (spilling; A/B experiments)
     int fused_valu = 0;      // ASPIRE_HIP_FUSED_VALU=1: the fused kernel's dot products as VALU FMAs instead of MFMA (A/B, parity tests)
     int fused_nosolve = 0;   // ASPIRE_HIP_FUSED_NOSOLVE=1: the fused kernel's cost phase alone (timing experiments)
 };

@@ -243,6 +243,13 @@ def main():
         for r in range(R):
             run_schedule(sets[r % len(sets)])
 
+    # untimed: clocks settle on the workload itself (~0.3 s), beyond the W warm-up steps
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.3:
+        for r in range(8):
+            run_schedule(sets[r % len(sets)], exchange=False)      # time-based loop: no collective inside
+        torch.cuda.synchronize()
+
     elapsed = min(timed(all_reps) for _ in range(1))      # EXACTLY K steps x R repetitions, timed once
 
     # ---- checks on the last repetition's outputs -------------------------------------------------------------------
