@@ -253,24 +253,35 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     int slice = 0;                 // steps of the pending solve per cost stage
 
     for (uint32_t item = item_lo + blockIdx.x * 4 + wave; item < n_items; item += n_waves) {
-        uint32_t q_loc, c_loc0, c_end;
+        int64_t c_idx, q_idx;
+        int c_len, q_len, c_start, q_start;
+        bool my_c_real;
         if (mapped) {
-            q_loc = (uint32_t)a.grp_job[item];
-            c_loc0 = (uint32_t)a.job_off[q_loc] + (item - (uint32_t)a.grp_off[q_loc]) * 4;
-            c_end = (uint32_t)a.job_off[q_loc + 1];
+            // the group's record (batch_prep_kernel): ONE memory round trip where the job tables + document tables take four
+            const int32_t* rec = a.grp_rec + (size_t)item * 16;
+            const int4 hd = *reinterpret_cast<const int4*>(rec);
+            q_idx = hd.x;
+            q_len = hd.y;
+            q_start = hd.z;
+            my_c_real = p < hd.w;
+            c_idx = rec[4 + p];
+            c_len = rec[8 + p];
+            c_start = rec[12 + p];
         } else {
             const uint32_t cg = nq == 1 ? item : item / nq;
-            q_loc = nq == 1 ? 0 : item - cg * nq;
-            c_loc0 = cg * 4;
-            c_end = ncand;
+            const uint32_t q_loc = nq == 1 ? 0 : item - cg * nq;
+            const uint32_t c_loc0 = cg * 4;
+            const uint32_t my_c_loc = min(c_loc0 + (uint32_t)p, ncand - 1);    // tail groups: clamp (duplicate work, not stored)
+            my_c_real = c_loc0 + (uint32_t)p < ncand;
+            c_idx = a.cand0 + my_c_loc;
+            q_idx = (int64_t)q_loc;
+            c_len = a.c.len[c_idx];
+            q_len = a.q.len[q_idx];
+            c_start = a.c.start[c_idx];
+            q_start = a.q.start[q_idx];
         }
-        const uint32_t my_c_loc = min(c_loc0 + (uint32_t)p, c_end - 1);        // tail groups: clamp (duplicate work, not stored)
-        const bool my_c_real = c_loc0 + (uint32_t)p < c_end;
-        const int64_t c_idx = a.cand0 + my_c_loc;
-        const int64_t q_idx = (int64_t)q_loc;
-        const int c_len = a.c.len[c_idx], q_len = a.q.len[q_idx];
-        const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
-        const float* sy_doc = a.c.rows + (size_t)a.c.start[c_idx] * kD;       // staging group == compute group
+        const float* qdoc = a.q.rows + (size_t)q_start * kD;
+        const float* sy_doc = a.c.rows + (size_t)c_start * kD;                 // staging group == compute group
         // the query's per-coordinate box; with caller-supplied diameters any readable row stands in (the box term is then
         // unused) -- the loads stay UNCONDITIONAL: a branch around them makes the compiler wait for the just-issued row
         // loads at the join (a register copy of the conditionally defined value), which serialises every stage's HBM

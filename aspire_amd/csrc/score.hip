@@ -2300,9 +2300,10 @@ namespace {
 // One workgroup per job j: the per-coordinate box of query j (the cost kernel adds each candidate's rows to it), the
 // job's first group of four (groups never straddle jobs, so a wave of the cost kernel serves ONE query), and the
 // candidate -> job / group -> job tables the kernels index.
-__global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, const int32_t* __restrict__ job_off, int J, float* __restrict__ qbox,
-                                                         int32_t* __restrict__ cand_job, int32_t* __restrict__ grp_off,
-                                                         int32_t* __restrict__ grp_job) {
+__global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, int J,
+                                                         float* __restrict__ qbox, int32_t* __restrict__ cand_job,
+                                                         int32_t* __restrict__ grp_off, int32_t* __restrict__ grp_job,
+                                                         int32_t* __restrict__ grp_rec) {
     __shared__ int part[3];
     const int j = blockIdx.x, tid = threadIdx.x;
     {
@@ -2331,10 +2332,26 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, const int32_t
     }
     for (int c = c0 + tid; c < c1; c += 192) cand_job[c] = j;
     for (int k = tid; k < ng; k += 192) grp_job[g0 + k] = j;
+    // the per-group records of the fused kernel (see ScoreArgs::grp_rec): thread = (group, field)
+    const int q_len = q.len[j], q_start = q.start[j];
+    for (int e = tid; e < ng * 16; e += 192) {
+        const int k = e >> 4, f = e & 15;
+        const int first = c0 + 4 * k;
+        const int cand = min(first + (f & 3), c1 - 1);
+        int v;
+        if (f == 0) v = j;
+        else if (f == 1) v = q_len;
+        else if (f == 2) v = q_start;
+        else if (f == 3) v = min(4, c1 - first);
+        else if (f < 8) v = cand;
+        else if (f < 12) v = c.len[cand];
+        else v = c.start[cand];
+        grp_rec[(size_t)(g0 + k) * 16 + f] = v;
+    }
 }
 
 struct BatchLayout {
-    size_t slots, qbox, cand_job, grp_job, grp_off, topk, total;
+    size_t slots, qbox, cand_job, grp_job, grp_off, grp_rec, topk, total;
 };
 BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, int64_t k) {
     BatchLayout L{};
@@ -2344,6 +2361,7 @@ BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, in
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
     L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
+    L.grp_rec = o; o = align16(o + (size_t)(C / 4 + J + 1) * 16 * sizeof(int32_t));
     L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
     L.total = o;
     return L;
@@ -2388,6 +2406,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     int32_t* cand_job = (int32_t*)(wsb + L.cand_job);
     int32_t* grp_job = (int32_t*)(wsb + L.grp_job);
     int32_t* grp_off = (int32_t*)(wsb + L.grp_off);
+    int32_t* grp_rec = (int32_t*)(wsb + L.grp_rec);
     ScoreArgs a{};
     fill_ot_args(a, q, c, kPairMapped, prm, nullptr, 0, want, scores);
     a.q_per_block = 1;
@@ -2397,6 +2416,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     a.job_off = job_off;
     a.grp_off = grp_off;
     a.grp_job = grp_job;
+    a.grp_rec = grp_rec;
     a.job0 = 0;
     a.job1 = (int32_t)J;
     a.max_job_groups = (int32_t)((max_job + 3) / 4);
@@ -2411,7 +2431,8 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
     a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
     if (stages & kStagePrep) {
-        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, job_off, (int)J, qbox, cand_job, grp_off, grp_job);
+        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, a.c, job_off, (int)J, qbox, cand_job, grp_off, grp_job,
+                           grp_rec);
         ASPIRE_LAUNCH_OK();
     }
     const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);

@@ -39,6 +39,10 @@ struct ScoreArgs {
     const int32_t* job_off;
     const int32_t* grp_off;
     const int32_t* grp_job;
+    // 16 int32 per group, everything a wave needs to start the group, in one 64-byte line (one memory round trip instead of
+    // four dependent ones): [0] query, [1] its len, [2] its first row, [3] real candidates in the group (1..4),
+    // [4..7] candidate index (clamped to the job's last), [8..11] their lens, [12..15] their first rows
+    const int32_t* grp_rec;
     int32_t job0, job1;       // the jobs this launch covers (chunks of a batch run side by side on two streams)
     int32_t max_job_groups;   // host-side launch geometry: upper bound of a job's groups of four
     int32_t tile_form;        // host-side: the batch runs on the throughput kernels
