@@ -2304,9 +2304,13 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
                                                          float* __restrict__ qbox, int32_t* __restrict__ cand_job,
                                                          int32_t* __restrict__ grp_off, int32_t* __restrict__ grp_job,
                                                          int32_t* __restrict__ grp_rec) {
+    // grid = (J, parts): every part of a job derives the job's first group itself (a block-wide sum over the earlier jobs'
+    // group counts) and then takes its share of the job's candidates / groups; part 0 also forms the query's box.  (One
+    // block per job made 20 blocks walk 250 groups each with dependent gathers: 20 us for a 20 x 1000 batch.)
     __shared__ int part[3];
     const int j = blockIdx.x, tid = threadIdx.x;
-    {
+    const int sub = blockIdx.y * 192 + tid, nsub = gridDim.y * 192;
+    if (blockIdx.y == 0) {
         const int n = q.len[j];
         const float* doc = q.rows + (size_t)q.start[j] * kD + tid * 4;
         float4 mn = ld4(doc), mx = mn;
@@ -2326,15 +2330,15 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
     __syncthreads();
     const int g0 = part[0] + part[1] + part[2];
     const int c0 = job_off[j], c1 = job_off[j + 1], ng = (c1 - c0 + 3) >> 2;
-    if (tid == 0) {
+    if (blockIdx.y == 0 && tid == 0) {
         grp_off[j] = g0;
         if (j == J - 1) grp_off[J] = g0 + ng;
     }
-    for (int c = c0 + tid; c < c1; c += 192) cand_job[c] = j;
-    for (int k = tid; k < ng; k += 192) grp_job[g0 + k] = j;
+    for (int cc = c0 + sub; cc < c1; cc += nsub) cand_job[cc] = j;
+    for (int k = sub; k < ng; k += nsub) grp_job[g0 + k] = j;
     // the per-group records of the fused kernel (see ScoreArgs::grp_rec): thread = (group, field)
     const int q_len = q.len[j], q_start = q.start[j];
-    for (int e = tid; e < ng * 16; e += 192) {
+    for (int e = sub; e < ng * 16; e += nsub) {
         const int k = e >> 4, f = e & 15;
         const int first = c0 + 4 * k;
         const int cand = min(first + (f & 3), c1 - 1);
@@ -2431,8 +2435,13 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
     a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
     if (stages & kStagePrep) {
-        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J), dim3(192), 0, s0, a.q, a.c, job_off, (int)J, qbox, cand_job, grp_off, grp_job,
-                           grp_rec);
+        // parts per job: enough blocks that a job's groups take a couple of trips each
+        const int64_t work = ((max_job + 3) / 4) * 16;
+        int64_t parts = (work + 2 * 192 - 1) / (2 * 192);
+        parts = parts < 1 ? 1 : parts > 64 ? 64 : parts;
+        while (parts > 1 && J * parts > 4096) parts /= 2;
+        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J, (unsigned)parts), dim3(192), 0, s0, a.q, a.c, job_off, (int)J, qbox, cand_job,
+                           grp_off, grp_job, grp_rec);
         ASPIRE_LAUNCH_OK();
     }
     const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
