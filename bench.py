@@ -361,6 +361,15 @@ def main():
                          'step': {'what': 'all kernels of a schedule (timed region) against the same algorithmic bytes',
                                   'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS}},
         }
+        spath = os.path.join(ROOT, 'profiles', 'sinkhorn_roofline.json')
+        if os.path.exists(spath):
+            # the stand-alone Sinkhorn kernel against ITS roof (VALU / transcendental issue), from the committed rocprofv3
+            # counter profile of the configs-3/5 shapes -- not measured in this run
+            sj = json.load(open(spath))
+            out['roofline']['sinkhorn'] = {k: {f: v[f] for f in ('what', 'kernel', 'ns_per_pair', 'valu_wave_instructions_per_pair', 'bound',
+                                                                  'achieved_frac', 'issue_floor_us', 'kernel_us_per_call')}
+                                           for k, v in sj.items() if isinstance(v, dict)}
+            out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r2.sh)'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(queries[:S], cands[:NC * S])
         print(json.dumps(out), flush=True)

@@ -1,34 +1,45 @@
-"""Rebuild profiles/traffic.json + the kernel-stats copy from a gpurun_out profile set.
-usage: python tools/make_traffic.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir>"""
-import csv, collections, json, shutil, sys
-stats_dir, fdir, wdir = sys.argv[1:4]
-shutil.copy(f'{stats_dir}/bench_kernel_stats.csv', 'profiles/r01_bench_ot1x1000_kernel_stats.csv')
-agg = collections.defaultdict(list)
-for d in (fdir, wdir):
-    for r in csv.DictReader(open(f'{d}/pmc_counter_collection.csv')):
-        n = r['Kernel_Name']
-        k = 'pair_cost' if 'pair_cost' in n else 'sinkhorn' if 'sinkhorn_kernel' in n else None
-        if k: agg[(k, r['Counter_Name'])].append(float(r['Counter_Value']))
-m = {k: sum(v) / len(v) for k, v in agg.items()}
+"""Rebuild profiles/traffic.json from the round's rocprofv3 PMC summaries (tools/profile_r2.sh -> tools/pmcsum.py).
+usage: python tools/make_traffic.py profiles/r02_bench_20x1000_fetch_size.txt profiles/r02_bench_20x1000_write_size.txt \
+                                    profiles/r02_bench_20x1000_kernel_stats.csv"""
+import csv, json, re, sys
+
+fetch_txt, write_txt, stats_csv = sys.argv[1:4]
+K, NC, S, D = 20, 1000, 8, 768
+
+
+def per_dispatch(path, counter, kernel):
+    cur = None
+    for line in open(path):
+        if 'dispatches' in line:
+            cur = line
+        elif counter in line and cur and kernel in cur:
+            return float(line.split('per dispatch')[1])
+    raise KeyError((path, counter, kernel))
+
+
+fetch_kb = per_dispatch(fetch_txt, 'FETCH_SIZE', 'pair_fused_kernel')
+write_kb = per_dispatch(write_txt, 'WRITE_SIZE', 'pair_fused_kernel')
 stats = {}
-for r in csv.DictReader(open('profiles/r01_bench_ot1x1000_kernel_stats.csv')):
-    n = r['Name']
-    k = 'pair_cost' if 'pair_cost' in n else 'sinkhorn' if 'sinkhorn_kernel' in n else 'topk' if 'topk' in n else None  # topk_select_kernel or topk_pass_kernel
-    if k: stats[k] = (float(r['AverageNs']), int(r['Calls']), n.split('(anonymous namespace)::')[1].split('(')[0] if '(anonymous namespace)::' in n else n)
-fetch = {k: m[(k, 'FETCH_SIZE')] for k in ('pair_cost', 'sinkhorn')}
-write = {k: m[(k, 'WRITE_SIZE')] for k in ('pair_cost', 'sinkhorn')}
-traffic = int(sum(2 * fetch[k] * 1024 + write[k] * 1024 for k in fetch))
+for r in csv.DictReader(open(stats_csv)):
+    m = re.search(r'(pair_fused_kernel|topk_select_kernel|batch_prep_kernel)', r['Name'])
+    if m and m.group(1) not in stats:
+        stats[m.group(1)] = dict(avg_us=float(r['AverageNs']) / 1e3, min_us=float(r['MinNs']) / 1e3, calls=int(r['Calls']))
+alg = K * (4 * D * (NC * S + S) + 4 * NC)
+traffic = int(2 * fetch_kb * 1024 + write_kb * 1024)
 json.dump({
-    'round': 1,
-    'command': 'rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python bench.py --steps 50 --no-graph --no-cpu-baseline',
-    'workload': '1 query x 1000 candidates x 8 sents x 768 d; one aspire_ot_sinkhorn_f32 call = cost kernel + sinkhorn_kernel<1>; hbm_bytes_per_launch = both kernels, cost_kernel_hbm_bytes_per_launch = the cost kernel alone',
-    'FETCH_SIZE_mean_KB': fetch, 'WRITE_SIZE_mean_KB': write,
-    'correction': 'MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced (16 B/lane) read stream -> doubled; WRITE_SIZE uncalibrated, taken as is',
-    'hbm_bytes_per_launch': traffic, 'cost_kernel_hbm_bytes_per_launch': int(2 * fetch['pair_cost'] * 1024 + write['pair_cost'] * 1024),
-    'algorithmic_bytes_per_launch': 24604576,
-    'breakdown': {'source': 'profiles/r01_bench_ot1x1000_kernel_stats.csv (rocprofv3 --kernel-trace --stats on bench.py --steps 480 --streams 1)',
-                  'cost_kernel': stats['pair_cost'][2], 'cost_kernel_us': stats['pair_cost'][0] / 1e3,
-                  'sinkhorn_kernel_us': stats['sinkhorn'][0] / 1e3, 'topk_pass_kernel_us': stats['topk'][0] / 1e3,
-                  'cost_kernel_GBs': 24604576 / stats['pair_cost'][0]},
+    'round': 2,
+    'command': 'rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python bench.py --steps 20 --warmup 5 '
+               '--repeats 6 --no-cpu-baseline   (tools/profile_r2.sh; summed per kernel by tools/pmcsum.py)',
+    'workload': 'bench.py: 20 jobs x (1 query x 1000 candidates x 8 sents x 768 d) per aspire_ot_rank_batch_f32 call; the scoring launch = '
+                'pair_fused_kernel<true, true> (costs + Sinkhorn solves), rotating cold pools',
+    'jobs_per_launch': K,
+    'FETCH_SIZE_KB_per_launch': fetch_kb, 'WRITE_SIZE_KB_per_launch': write_kb,
+    'correction': 'MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced (16 B/lane) '
+                  'read stream -> doubled; WRITE_SIZE uncalibrated, taken as is; Infinity-Cache hits are counted too, but every launch reads '
+                  '492 MB of pools that were last touched 492 MB ago (two alternating sets): nothing survives in the 256 MiB L3',
+    'cost_kernel_hbm_bytes_per_launch': traffic,
+    'algorithmic_bytes_per_launch': alg,
+    'ratio': traffic / alg,
+    'kernel_stats': {'source': stats_csv + ' (rocprofv3 --kernel-trace --stats on bench.py --steps 20 --warmup 5 --repeats 60)', **stats},
 }, open('profiles/traffic.json', 'w'), indent=1)
-print(json.dumps(json.load(open('profiles/traffic.json'))['breakdown']), traffic / 24604576)
+print(traffic, alg, traffic / alg, stats)
