@@ -70,15 +70,18 @@ __device__ __forceinline__ float sum16(float v) { return sum_li(sum_lj(v)); }
 // piece.  So the solve of item i is cut into slices that run INSIDE the cost stages of item i + 1, each slice in the
 // shadow of that stage's HBM loads: the wave was going to wait there anyway.
 // ---------------------------------------------------------------------------------------------------------------------
+typedef float f2_t __attribute__((ext_vector_type(2)));     // a register pair: v_pk_{mul,add,fma}_f32 work on both halves at once
+
 struct Solve {
-    float mc[2][2];        // masked cost: entries outside the valid block are 0 and never enter a sum (their weights are 0)
-    float neg[2][2];       // -cdist of the valid block (plan-weighted similarity output only)
-    float wa[2], wb[2];    // marginals (pair_distances.py:57-60)
-    float f[2], g[2];      // potentials
+    f2_t mc[2];            // masked cost, mc[x] = entries (x, 0), (x, 1): outside the valid block 0 (their weights are 0)
+    f2_t neg[2];           // -cdist of the valid block (plan-weighted similarity output only)
+    f2_t wa, wb;           // marginals (pair_distances.py:57-60)
+    f2_t f, g;             // potentials
     float r2, h;           // this step's log2e / eps and eps ln2 / 2: through the annealed part of the schedule the next step's
                            // follow by one multiply each (eps *= scaling) -- no transcendental for the constants
     int n_mid;             // annealed values between diam and blur; step k: 0 = diam, 1 .. n_mid, n_mid + 1 = blur, n_mid + 2 = final
     int k, max_steps;      // wave-uniform: next step, steps of the longest of the wave's four schedules
+    int n_mid_lo;          // wave-uniform: the shortest of the four schedules -- steps 2 .. n_mid_lo anneal in all four pairs
     unsigned valid;        // bit x: row x valid, bit 2 + y: column y valid, bit 4: a document longer than the tile (poison)
     int64_t out;           // index into scores, < 0 = nothing to store (clamped tail candidate)
 };
@@ -110,21 +113,22 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
     // ---- epsilon schedule ----------------------------------------------------------------------------------------------
     float ldf;
     s.n_mid = schedule_mid_steps(a, diam, ldf);
-    int ms = s.n_mid + 3;
+    int ms = s.n_mid, ml = s.n_mid;
     ms = max(ms, __shfl_xor(ms, 16));
     ms = max(ms, __shfl_xor(ms, 32));
-    s.max_steps = __builtin_amdgcn_readfirstlane(ms);
+    ml = min(ml, __shfl_xor(ml, 16));
+    ml = min(ml, __shfl_xor(ml, 32));
+    s.max_steps = __builtin_amdgcn_readfirstlane(ms) + 3;
+    s.n_mid_lo = __builtin_amdgcn_readfirstlane(ml);
     s.k = 0;
     const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
     s.r2 = r2_first;
     s.h = h_first;
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            s.mc[x][y] = (rv[x] && cv[y]) ? cost[x][y] : 0.f;
-            s.neg[x][y] = (rv[x] && cv[y]) ? neg[x][y] : 0.f;
-        }
+    for (int x = 0; x < 2; ++x) {
+        s.mc[x] = f2_t{(rv[x] && cv[0]) ? cost[x][0] : 0.f, (rv[x] && cv[1]) ? cost[x][1] : 0.f};
+        s.neg[x] = f2_t{(rv[x] && cv[0]) ? neg[x][0] : 0.f, (rv[x] && cv[1]) ? neg[x][1] : 0.f};
+    }
     // ---- initialisation at eps = diam: softmin of the bare weights (no shift needed: the largest weight of a
     // probability vector over <= 8 atoms is >= 1/8 and C / diam <= ~1) -------------------------------------------------
     float rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
@@ -143,46 +147,59 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
     }
 }
 
+// One epsilon step on the register pairs: K = 2^((f_x + g_y - C_xy) r2) as two packed rows, row sums / column sums with
+// the weights as factors, f -= h log2(row sums), g -= h log2(column sums) -- 32 issue slots, 8 of them transcendental
+// (as scalar code with per-step schedule selects it was 52: the solves are the kernel's largest VALU consumer and, with
+// two waves per SIMD, VALU issue is what the HBM stream competes with).
+__device__ __forceinline__ void solve_step(Solve& s, float r2, float h) {
+    const f2_t fr = s.f * r2, gr = s.g * r2;
+    const f2_t a0 = __builtin_elementwise_fma(s.mc[0], f2_t{-r2, -r2}, f2_t{fr.x, fr.x} + gr);
+    const f2_t a1 = __builtin_elementwise_fma(s.mc[1], f2_t{-r2, -r2}, f2_t{fr.y, fr.y} + gr);
+    const f2_t k0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)};
+    const f2_t k1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
+    const f2_t t0 = k0 * s.wb, t1 = k1 * s.wb;
+    const f2_t cs = __builtin_elementwise_fma(k1, f2_t{s.wa.y, s.wa.y}, k0 * f2_t{s.wa.x, s.wa.x});
+    const f2_t lr = {__builtin_amdgcn_logf(sum_lj(t0.x + t0.y)), __builtin_amdgcn_logf(sum_lj(t1.x + t1.y))};
+    const f2_t lc = {__builtin_amdgcn_logf(sum_li(cs.x)), __builtin_amdgcn_logf(sum_li(cs.y))};
+    s.f = __builtin_elementwise_fma(f2_t{-h, -h}, lr, s.f);
+    s.g = __builtin_elementwise_fma(f2_t{-h, -h}, lc, s.g);
+}
+
 // up to `n` more annealing steps (all of the rest with n < 0)
 __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n) {
     const float scal = (float)a.scaling, inv_scal = (float)(1.0 / a.scaling);
     const float eb = (float)a.blur;
     const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
     const int k_end = (n < 0 || s.k + n > s.max_steps) ? s.max_steps : s.k + n;
+    int k = s.k;
+    // eps_k: diam at k = 0 and 1, diam scaling^(k-1) up to k = n_mid, then blur (averaged), blur (final, h doubled), and
+    // nothing (h = 0) while a wave mate with a longer schedule is still annealing.  Steps 2 .. n_mid_lo anneal in all four
+    // pairs of the wave: no selects there.
+    auto general = [&](int upto) {
 #pragma unroll 1
-    for (int k = s.k; k < k_end; ++k) {
-        // eps_k: diam at k = 0 and 1, diam scaling^(k-1) up to k = n_mid, then blur (averaged), blur (final, h doubled), and
-        // nothing (h = 0) while a wave mate with a longer schedule is still annealing
-        const bool anneal = k >= 2 && k <= s.n_mid;
-        float r2 = anneal ? s.r2 * inv_scal : s.r2;
-        float h = anneal ? s.h * scal : s.h;
-        if (k > s.n_mid) { r2 = r2_blur; h = k == s.n_mid + 1 ? h_blur : (k == s.n_mid + 2 ? 2.f * h_blur : 0.f); }
-        s.r2 = r2;
-        s.h = h;
-        float f2[2], g2[2], rs[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f2[t] = s.f[t] * r2;
-            g2[t] = s.g[t] * r2;
+        for (; k < upto; ++k) {
+            const bool anneal = k >= 2 && k <= s.n_mid;
+            float r2 = anneal ? s.r2 * inv_scal : s.r2;
+            float h = anneal ? s.h * scal : s.h;
+            if (k > s.n_mid) { r2 = r2_blur; h = k == s.n_mid + 1 ? h_blur : (k == s.n_mid + 2 ? 2.f * h_blur : 0.f); }
+            s.r2 = r2;
+            s.h = h;
+            solve_step(s, r2, h);
         }
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const float kxy = __builtin_amdgcn_exp2f(fmaf(-s.mc[x][y], r2, f2[x] + g2[y]));
-                rs[x] = fmaf(s.wb[y], kxy, rs[x]);
-                cs[y] = fmaf(s.wa[x], kxy, cs[y]);
-            }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            s.f[t] = fmaf(-h, __builtin_amdgcn_logf(sum_lj(rs[t])), s.f[t]);
-            s.g[t] = fmaf(-h, __builtin_amdgcn_logf(sum_li(cs[t])), s.g[t]);
-        }
+    };
+    general(min(k_end, 2));
+    const int fast_end = min(k_end, s.n_mid_lo + 1);
+#pragma unroll 1
+    for (; k < fast_end; ++k) {
+        s.r2 *= inv_scal;
+        s.h *= scal;
+        solve_step(s, s.r2, s.h);
     }
+    general(k_end);
     s.k = k_end;
 }
 
-__device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a, const float (&f)[2], const float (&g)[2]) {
+__device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a, const f2_t f, const f2_t g) {
     const int lp = threadIdx.x & 15, li = lp >> 2, lj = lp & 3;
     const bool rv[2] = {(s.valid & 1u) != 0, (s.valid & 2u) != 0}, cv[2] = {(s.valid & 4u) != 0, (s.valid & 8u) != 0};
     float score;
@@ -293,9 +310,12 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         mfma4_t macc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) macc[m] = mfma4_t{0.f, 0.f, 0.f, 0.f};
-        float ny[8], nx[2] = {0.f, 0.f}, dsq = 0.f;
+        // squared-norm partials as register pairs ({x^2 + .., y^2 + ..} of the lane's chunks: two packed FMAs per row and
+        // stage), halves added once per item; the box term likewise
+        f2_t ny[8], nx[2], dsq = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ny[k] = 0.f;
+        for (int k = 0; k < 8; ++k) ny[k] = f2_t{0.f, 0.f};
+        nx[0] = nx[1] = f2_t{0.f, 0.f};
         float4 vy[8], vx[2], qmn, qmx;
         auto issue_loads = [&](int st) {
             const int dofs = (st * kCh + sc) * 4;
@@ -306,31 +326,39 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 #pragma unroll
             for (int k = 0; k < 2; ++k) vx[k] = ld4(qdoc + (size_t)min(2 * sg + k, q_len - 1) * kD + dofs);
         };
+        auto sq_acc = [](f2_t acc, const float4& v) {
+            acc = __builtin_elementwise_fma(f2_t{v.x, v.y}, f2_t{v.x, v.y}, acc);
+            return __builtin_elementwise_fma(f2_t{v.z, v.w}, f2_t{v.z, v.w}, acc);
+        };
         issue_loads(0);
 #pragma unroll 1
         for (int st = 0; st < kStages; ++st) {
-            // ---- stage: registers -> LDS, with box / norm side products; then the NEXT stage's loads go out so that
-            // they fly under this stage's arithmetic (no extra registers: the rows were just consumed) ----
+            // ---- stage: registers -> LDS, with box / norm side products; only THEN the next stage's loads go out, into
+            // the registers just consumed (hoisted above the side products they need a second set of 48 registers and a
+            // copy of all of them per stage); they fly under this stage's arithmetic ----
             {
                 float4 mn = vy[0], mx = vy[0];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    ny[j] += sq4(vy[j]);
+                    ny[j] = sq_acc(ny[j], vy[j]);
                     if (j > 0) {
                         mn.x = fminf(mn.x, vy[j].x); mn.y = fminf(mn.y, vy[j].y); mn.z = fminf(mn.z, vy[j].z); mn.w = fminf(mn.w, vy[j].w);
                         mx.x = fmaxf(mx.x, vy[j].x); mx.y = fmaxf(mx.y, vy[j].y); mx.z = fmaxf(mx.z, vy[j].z); mx.w = fmaxf(mx.w, vy[j].w);
                     }
                     *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
                 }
-                const float dx = fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), dy = fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y);
-                const float dz = fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), dw = fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w);
-                dsq += fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+                const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
+                const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
+                dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    nx[k] += sq4(vx[k]);
+                    nx[k] = sq_acc(nx[k], vx[k]);
                     *reinterpret_cast<float4*>(lds + (2 * sg + k) * kRowStride + sc * 4) = vx[k];
                 }
             }
+            // pin the side products HERE (the optimiser otherwise sinks these loop-carried sums below the loads)
+            asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
+                              "+v"(nx[0]), "+v"(nx[1]), "+v"(dsq) : : "memory");
             if (st + 1 < kStages) issue_loads(st + 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -395,9 +423,9 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         // ---- norms: sum the staging lanes' partials through the scratch table nscr[value][lane] ----------------------
         // value 0..7: |y_j|^2 partials of the lane's staged candidate; 8, 9: |x|^2 partials of its two query rows
 #pragma unroll
-        for (int k = 0; k < 8; ++k) nscr[k * kNormLd + lane] = ny[k];
+        for (int k = 0; k < 8; ++k) nscr[k * kNormLd + lane] = ny[k].x + ny[k].y;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) nscr[(8 + k) * kNormLd + lane] = nx[k];
+        for (int k = 0; k < 2; ++k) nscr[(8 + k) * kNormLd + lane] = nx[k].x + nx[k].y;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -417,7 +445,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 #pragma unroll
         for (int x = 0; x < 2; ++x) xx[x] = table_sum(8 + ((2 * li + x) & 1), ((2 * li + x) >> 1) * 16);
         // box terms were formed by the lanes that staged the candidate's rows = this candidate's 16 lanes
-        float diam2 = dsq;
+        float diam2 = dsq.x + dsq.y;
         diam2 += lane_xor<1>(diam2); diam2 += lane_xor<2>(diam2); diam2 += lane_xor<4>(diam2); diam2 += lane_xor<8>(diam2);
 
         // ---- finish the entries.  Only x.y was accumulated: -cdist comes from the same expansion as geomloss's cost, and
@@ -437,34 +465,54 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                 neg[x][y] = -sqrtf(fmaxf(sq, 0.f));
             }
         {
-            // direct-formula redo, the 16 lanes of a candidate together: 48 coordinates per lane, 4-step DPP-row sum
-            const float* crow = sy_doc + 4 * lp;
-            const float* qrow = qdoc + 4 * lp;
+            // direct-formula redo, the whole wave on one entry (12 coordinates per lane), FOUR entries per memory round trip:
+            // under a saturated HBM stream a dependent round trip is ~5 us, and a wave that falls behind by n of them
+            // finishes the launch n x 5 us late (one duplicate document = 8 entries in a 20 000-pair call, one entry per
+            // round trip: 145 instead of 101 us)
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 2; ++y) {
-                    const unsigned long long wm = __ballot(redo[x][y]);
-                    unsigned gm = (unsigned)(wm >> (16 * p)) & 0xFFFFu;        // flagged lanes of this candidate's group
-                    while (__any(gm != 0)) {
-                        const bool act = gm != 0;
-                        const int b16 = act ? __builtin_ctz(gm) : 0;
-                        gm &= gm - 1;
-                        const int i = 2 * (b16 >> 2) + x, j = 2 * (b16 & 3) + y;
-                        float p0 = 0.f;
-                        if (act) {
+                    unsigned long long wm = __ballot(redo[x][y]);
+                    while (wm != 0) {
+                        int owner[4];
+                        float part[4];
 #pragma unroll
-                            for (int cc = 0; cc < 12; ++cc) {
-                                const float4 u = ld4(qrow + (size_t)i * kD + 64 * cc), v = ld4(crow + (size_t)j * kD + 64 * cc);
-                                const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
-                                p0 = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, p0))));
+                        for (int e = 0; e < 4; ++e) {
+                            owner[e] = wm != 0 ? (int)__builtin_ctzll(wm) : -1;
+                            wm = wm != 0 ? wm & (wm - 1) : 0;
+                        }
+                        // all 24 loads go out before the first is consumed: no branch around them (an empty slot
+                        // repeats the first entry's rows)
+                        float4 u[4][3], v[4][3];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int o = owner[e] >= 0 ? owner[e] : owner[0];
+                            const int ol = o & 15, i = 2 * (ol >> 2) + x, j = 2 * (ol & 3) + y;
+                            const int cs_e = __builtin_amdgcn_readlane(c_start, o);
+                            const float* qrow = qdoc + (size_t)i * kD + 4 * lane;
+                            const float* crow = a.c.rows + ((size_t)cs_e + j) * kD + 4 * lane;
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                u[e][t] = ld4(qrow + 256 * t);
+                                v[e][t] = ld4(crow + 256 * t);
                             }
                         }
-                        p0 += lane_xor<1>(p0);
-                        p0 += lane_xor<2>(p0);
-                        p0 += lane_xor<4>(p0);
-                        p0 += lane_xor<8>(p0);
-                        if (act && lp == b16) neg[x][y] = -sqrtf(p0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            part[e] = 0.f;
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                const float d0 = u[e][t].x - v[e][t].x, d1 = u[e][t].y - v[e][t].y, d2 = u[e][t].z - v[e][t].z, d3 = u[e][t].w - v[e][t].w;
+                                part[e] = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, part[e]))));
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (owner[e] >= 0) {
+                                const float tot = wave_sum(part[e]);
+                                if (lane == owner[e]) neg[x][y] = -sqrtf(tot);
+                            }
                     }
                 }
         }
