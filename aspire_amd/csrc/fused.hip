@@ -42,7 +42,9 @@ constexpr int kStages = kD / (4 * kCh);                  // 12
 constexpr int kRowStride = 4 * kCh + 4;                  // floats; (kRowStride / 4) odd -> rows land on distinct bank slots
 constexpr int kRows = 8 + 8 * 4;                         // staged rows: 8 query + 8 per candidate
 constexpr int kNormLd = 68;
-constexpr int kWaveLds = kRows * kRowStride + 16 * kNormLd;   // floats per wave (15.2 KB)
+constexpr int kNormOfs = 256;                            // the norm table lives in the stage buffer, behind the 4 x 64 transposed entries
+constexpr int kWaveLds = kRows * kRowStride;             // floats per wave (10.9 KB)
+static_assert(kNormOfs + 16 * kNormLd <= kWaveLds, "norm table must fit the idle stage buffer");
 
 typedef float mfma4_t __attribute__((ext_vector_type(4)));
 
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* lds = lds_all + wave * kWaveLds;
-    float* nscr = lds + kRows * kRowStride;                 // [16][kNormLd]: norm partials
+    float* nscr = lds + kNormOfs;                           // [16][kNormLd]: norm partials, written once the stages are done
     const bool mapped = a.pairing == kPairMapped;           // batched jobs: items are the groups of four of jobs [job0, job1)
     const uint32_t nq = mapped ? 1u : (uint32_t)a.q.n;
     const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
@@ -269,34 +271,50 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     bool have_pend = false;
     int slice = 0;                 // steps of the pending solve per cost stage
 
-    for (uint32_t item = item_lo + blockIdx.x * 4 + wave; item < n_items; item += n_waves) {
+    // an item's documents: one memory round trip per item -- fetched one item AHEAD, so that the trip (several us under a
+    // saturated HBM stream) runs under the current item's stages instead of in front of the next item's first loads
+    struct Ctx {
         int64_t c_idx, q_idx;
         int c_len, q_len, c_start, q_start;
         bool my_c_real;
+    };
+    auto load_ctx = [&](uint32_t item) {
+        Ctx x;
         if (mapped) {
             // the group's record (batch_prep_kernel): ONE memory round trip where the job tables + document tables take four
             const int32_t* rec = a.grp_rec + (size_t)item * 16;
             const int4 hd = *reinterpret_cast<const int4*>(rec);
-            q_idx = hd.x;
-            q_len = hd.y;
-            q_start = hd.z;
-            my_c_real = p < hd.w;
-            c_idx = rec[4 + p];
-            c_len = rec[8 + p];
-            c_start = rec[12 + p];
+            x.q_idx = hd.x;
+            x.q_len = hd.y;
+            x.q_start = hd.z;
+            x.my_c_real = p < hd.w;
+            x.c_idx = rec[4 + p];
+            x.c_len = rec[8 + p];
+            x.c_start = rec[12 + p];
         } else {
             const uint32_t cg = nq == 1 ? item : item / nq;
             const uint32_t q_loc = nq == 1 ? 0 : item - cg * nq;
             const uint32_t c_loc0 = cg * 4;
             const uint32_t my_c_loc = min(c_loc0 + (uint32_t)p, ncand - 1);    // tail groups: clamp (duplicate work, not stored)
-            my_c_real = c_loc0 + (uint32_t)p < ncand;
-            c_idx = a.cand0 + my_c_loc;
-            q_idx = (int64_t)q_loc;
-            c_len = a.c.len[c_idx];
-            q_len = a.q.len[q_idx];
-            c_start = a.c.start[c_idx];
-            q_start = a.q.start[q_idx];
+            x.my_c_real = c_loc0 + (uint32_t)p < ncand;
+            x.c_idx = a.cand0 + my_c_loc;
+            x.q_idx = (int64_t)q_loc;
+            x.c_len = a.c.len[x.c_idx];
+            x.q_len = a.q.len[x.q_idx];
+            x.c_start = a.c.start[x.c_idx];
+            x.q_start = a.q.start[x.q_idx];
         }
+        return x;
+    };
+    const uint32_t item_first = item_lo + blockIdx.x * 4 + wave;
+    Ctx next = load_ctx(item_first < n_items ? item_first : item_lo);
+
+    for (uint32_t item = item_first; item < n_items; item += n_waves) {
+        const Ctx cur = next;
+        next = load_ctx(item + n_waves < n_items ? item + n_waves : item);      // (the last item fetches itself again)
+        const int64_t c_idx = cur.c_idx, q_idx = cur.q_idx;
+        const int c_len = cur.c_len, q_len = cur.q_len, c_start = cur.c_start, q_start = cur.q_start;
+        const bool my_c_real = cur.my_c_real;
         const float* qdoc = a.q.rows + (size_t)q_start * kD;
         const float* sy_doc = a.c.rows + (size_t)c_start * kD;                 // staging group == compute group
         // the query's per-coordinate box; with caller-supplied diameters any readable row stands in (the box term is then
@@ -555,7 +573,10 @@ size_t fused_lds_bytes(void) { return 4 * kWaveLds * sizeof(float); }
 // groups_bound: upper bound of the launch's items (groups of four candidates x queries)
 int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, hipStream_t stream) {
     const ScoreArgs& a = a_in;
-    const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;      // two 4-wave workgroups per CU are resident
+    // two 4-wave workgroups per CU are resident.  (Built for three -- 168 registers, the kernel-invariant values spilled,
+    // the norm table already shares the stage buffer so the LDS fits -- the 20 x 1000 call went from 120 to 144 us.)
+    const int64_t cap = tuning().fused_waves > 0 ? tuning().fused_waves : 256 * 8;
+    const int64_t waves = groups_bound < cap ? groups_bound : cap;
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = 4 * kWaveLds * sizeof(float);
     if (tuning().fused_nosolve) hipLaunchKernelGGL((pair_fused_kernel<true, false>), grid, dim3(256), lds, stream, a, qbox);

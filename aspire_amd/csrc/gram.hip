@@ -29,6 +29,7 @@
 
 #include "tuning.h"
 #include "score_types.h"
+#include "score_device.h"
 
 namespace aspire {
 namespace {
@@ -465,12 +466,8 @@ __global__ void __launch_bounds__(192) doc_box_range_kernel(RepSet d, int64_t fi
     const int64_t k = blockIdx.x;
     const int n = d.len[first + k];
     const float* doc = d.rows + (size_t)d.start[first + k] * kD + threadIdx.x * 4;
-    float4 mn = ld4(doc), mx = mn;
-    for (int r = 1; r < n; ++r) {
-        const float4 v = ld4(doc + (size_t)r * kD);
-        mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
-        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-    }
+    float4 mn, mx;
+    doc_box_chunk(doc, n, mn, mx);
     *reinterpret_cast<float4*>(box + k * 2 * kD + threadIdx.x * 4) = mn;
     *reinterpret_cast<float4*>(box + k * 2 * kD + kD + threadIdx.x * 4) = mx;
 }

@@ -38,6 +38,8 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.fused_valu = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {
         t.fused_nosolve = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "FUSED_WAVES")) {
+        t.fused_waves = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "OT_FORM")) {
         const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : !strcmp(v, "fused") ? 3 : -1;
         if (f < 0) return false;
@@ -49,7 +51,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

@@ -1199,12 +1199,8 @@ __global__ void __launch_bounds__(192) doc_box_kernel(RepSet d, float* __restric
     const int64_t k = blockIdx.x;
     const int n = d.len[k];
     const float* doc = d.rows + (size_t)d.start[k] * kD + threadIdx.x * 4;
-    float4 mn = ld4(doc), mx = mn;
-    for (int r = 1; r < n; ++r) {
-        const float4 v = ld4(doc + (size_t)r * kD);
-        mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
-        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-    }
+    float4 mn, mx;
+    doc_box_chunk(doc, n, mn, mx);
     *reinterpret_cast<float4*>(box + k * 2 * kD + threadIdx.x * 4) = mn;
     *reinterpret_cast<float4*>(box + k * 2 * kD + kD + threadIdx.x * 4) = mx;
 }
@@ -2304,24 +2300,23 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
                                                          float* __restrict__ qbox, int32_t* __restrict__ cand_job,
                                                          int32_t* __restrict__ grp_off, int32_t* __restrict__ grp_job,
                                                          int32_t* __restrict__ grp_rec) {
-    // grid = (J, parts): every part of a job derives the job's first group itself (a block-wide sum over the earlier jobs'
-    // group counts) and then takes its share of the job's candidates / groups; part 0 also forms the query's box.  (One
-    // block per job made 20 blocks walk 250 groups each with dependent gathers: 20 us for a 20 x 1000 batch.)
+    // grid = (J, parts + 1): block (j, parts) forms the query's box and nothing else -- its chain of dependent loads (length,
+    // start -> rows -> store) runs beside the table blocks' chain instead of in front of it; every other part of a job derives
+    // the job's first group itself (a block-wide sum over the earlier jobs' group counts) and then takes its share of the
+    // job's candidates / groups.  (One block per job made 20 blocks walk 250 groups each with dependent gathers: 20 us for
+    // a 20 x 1000 batch.)
     __shared__ int part[3];
     const int j = blockIdx.x, tid = threadIdx.x;
-    const int sub = blockIdx.y * 192 + tid, nsub = gridDim.y * 192;
-    if (blockIdx.y == 0) {
+    if (blockIdx.y == gridDim.y - 1) {
         const int n = q.len[j];
         const float* doc = q.rows + (size_t)q.start[j] * kD + tid * 4;
-        float4 mn = ld4(doc), mx = mn;
-        for (int r = 1; r < n; ++r) {
-            const float4 v = ld4(doc + (size_t)r * kD);
-            mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
-            mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-        }
+        float4 mn, mx;
+        doc_box_chunk(doc, n, mn, mx);
         *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + tid * 4) = mn;
         *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + kD + tid * 4) = mx;
+        return;
     }
+    const int sub = blockIdx.y * 192 + tid, nsub = (gridDim.y - 1) * 192;
     int g = 0;
     for (int i = tid; i < j; i += 192) g += (job_off[i + 1] - job_off[i] + 3) >> 2;
 #pragma unroll
@@ -2440,7 +2435,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
         int64_t parts = (work + 2 * 192 - 1) / (2 * 192);
         parts = parts < 1 ? 1 : parts > 64 ? 64 : parts;
         while (parts > 1 && J * parts > 4096) parts /= 2;
-        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J, (unsigned)parts), dim3(192), 0, s0, a.q, a.c, job_off, (int)J, qbox, cand_job,
+        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J, (unsigned)parts + 1), dim3(192), 0, s0, a.q, a.c, job_off, (int)J, qbox, cand_job,
                            grp_off, grp_job, grp_rec);
         ASPIRE_LAUNCH_OK();
     }

@@ -11,6 +11,23 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 }
 __device__ __forceinline__ float sq4(const float4& a) { return dot4(a, a); }
 
+// Per-coordinate box of a document's rows at one 16-byte chunk (doc = first row + the lane's chunk).  Eight rows per memory
+// round trip (rows past the end repeat the last one): one row per trip made these latency-bound prologue kernels wait for
+// eight dependent loads per 8-sentence document.
+__device__ __forceinline__ void doc_box_chunk(const float* doc, int n, float4& mn, float4& mx) {
+    mn = mx = ld4(doc);
+    for (int r0 = 0; r0 < n; r0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = ld4(doc + (size_t)min(r0 + r, n - 1) * kD);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            mn.x = fminf(mn.x, v[r].x); mn.y = fminf(mn.y, v[r].y); mn.z = fminf(mn.z, v[r].z); mn.w = fminf(mn.w, v[r].w);
+            mx.x = fmaxf(mx.x, v[r].x); mx.y = fmaxf(mx.y, v[r].y); mx.z = fmaxf(mx.z, v[r].z); mx.w = fmaxf(mx.w, v[r].w);
+        }
+    }
+}
+
 // x / e with e's reciprocal r: one Newton step makes the quotient correctly rounded in all but
 // pathological cases (what the v_div_* sequence does, minus its denormal scaling).
 __device__ __forceinline__ float div_r(float x, float e, float r) {
