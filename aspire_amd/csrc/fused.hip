@@ -246,7 +246,10 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 // staging side products and to the solve slices -- with two waves per SIMD the kernel is otherwise VALU-issue bound
 // (20 x 1000 pairs: 146 -> 130 us; 100 x 1000: 661 -> 566 us).  !MFMA: the same sums as VALU FMAs (kept for A/B and parity
 // tests).  SOLVE = false (diagnostics): the cost phase alone, diam^2 as the score.
-template <bool MFMA, bool SOLVE = true>
+// SELF (batches of <= 64 jobs): no tables, no query boxes from a launch in front of this one -- every wave derives an item's
+// documents from job_off itself (a 64-lane scan, once) and forms the query's box per stage from the query rows it has just
+// staged (+32 min/max and 8 LDS reads per stage, against ~7 us for the extra launch in a 115 us call).
+template <bool MFMA, bool SOLVE = true, bool SELF = false>
 __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -256,8 +259,23 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     const bool mapped = a.pairing == kPairMapped;           // batched jobs: items are the groups of four of jobs [job0, job1)
     const uint32_t nq = mapped ? 1u : (uint32_t)a.q.n;
     const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
-    const uint32_t item_lo = mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
-    const uint32_t n_items = mapped ? (uint32_t)a.grp_off[a.job1] : ((ncand + 3) / 4) * nq;   // item = (candidate group, query), group-major
+    // SELF: lane l holds job job0 + l's candidate range and the groups of four up to and including it
+    int jo0 = 0, jo1 = 0, gend = 0;
+    if constexpr (SELF) {
+        if (lane < a.job1 - a.job0) {
+            jo0 = a.job_off[a.job0 + lane];
+            jo1 = a.job_off[a.job0 + lane + 1];
+        }
+        gend = (jo1 - jo0 + 3) >> 2;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int t = __shfl_up(gend, m);
+            if (lane >= m) gend += t;
+        }
+    }
+    const uint32_t item_lo = SELF ? 0u : mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
+    const uint32_t n_items = SELF ? (uint32_t)__builtin_amdgcn_readlane(gend, 63)
+                                  : mapped ? (uint32_t)a.grp_off[a.job1] : ((ncand + 3) / 4) * nq;   // item = (candidate group, query), group-major
     const uint32_t n_waves = gridDim.x * 4;
     const bool own_diam = a.diameter == nullptr;            // else: the caller's per-group diameters (caching_score's batches)
     constexpr bool with_solve = SOLVE;      // false (diagnostics): the cost phase alone, diam^2 as the score
@@ -280,7 +298,20 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     };
     auto load_ctx = [&](uint32_t item) {
         Ctx x;
-        if (mapped) {
+        if constexpr (SELF) {
+            const int job = __popcll(__ballot(gend <= (int)item));          // jobs that end at or before this item (empty ones included)
+            const int g0 = job > 0 ? __builtin_amdgcn_readlane(gend, job - 1) : 0;
+            const int cj0 = __builtin_amdgcn_readlane(jo0, job), cj1 = __builtin_amdgcn_readlane(jo1, job);
+            const int first = cj0 + 4 * ((int)item - g0);
+            const int cand = min(first + p, cj1 - 1);
+            x.q_idx = a.job0 + job;
+            x.q_len = a.q.len[x.q_idx];
+            x.q_start = a.q.start[x.q_idx];
+            x.my_c_real = first + p < cj1;
+            x.c_idx = cand;
+            x.c_len = a.c.len[cand];
+            x.c_start = a.c.start[cand];
+        } else if (mapped) {
             // the group's record (batch_prep_kernel): ONE memory round trip where the job tables + document tables take four
             const int32_t* rec = a.grp_rec + (size_t)item * 16;
             const int4 hd = *reinterpret_cast<const int4*>(rec);
@@ -321,8 +352,8 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         // unused) -- the loads stay UNCONDITIONAL: a branch around them makes the compiler wait for the just-issued row
         // loads at the join (a register copy of the conditionally defined value), which serialises every stage's HBM
         // latency with its arithmetic (measured: 160 instead of 110 us for the cost phase of 20 x 1000 pairs)
-        const float* qb = own_diam ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
-        const int qb_hi = own_diam ? kD : 0;
+        const float* qb = (own_diam && !SELF) ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
+        const int qb_hi = (own_diam && !SELF) ? kD : 0;
 
         float accg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         mfma4_t macc[4];
@@ -339,8 +370,10 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
-            qmn = ld4(qb + dofs);
-            qmx = ld4(qb + qb_hi + dofs);
+            if constexpr (!SELF) {
+                qmn = ld4(qb + dofs);
+                qmx = ld4(qb + qb_hi + dofs);
+            }
 #pragma unroll
             for (int k = 0; k < 2; ++k) vx[k] = ld4(qdoc + (size_t)min(2 * sg + k, q_len - 1) * kD + dofs);
         };
@@ -354,8 +387,8 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             // ---- stage: registers -> LDS, with box / norm side products; only THEN the next stage's loads go out, into
             // the registers just consumed (hoisted above the side products they need a second set of 48 registers and a
             // copy of all of them per stage); they fly under this stage's arithmetic ----
+            float4 mn = vy[0], mx = vy[0];
             {
-                float4 mn = vy[0], mx = vy[0];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     ny[j] = sq_acc(ny[j], vy[j]);
@@ -365,9 +398,11 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                     }
                     *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
                 }
-                const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
-                const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
-                dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
+                if constexpr (!SELF) {
+                    const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
+                    const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
+                    dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
+                }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     nx[k] = sq_acc(nx[k], vx[k]);
@@ -375,12 +410,29 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                 }
             }
             // pin the side products HERE (the optimiser otherwise sinks these loop-carried sums below the loads)
-            asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
-                              "+v"(nx[0]), "+v"(nx[1]), "+v"(dsq) : : "memory");
+            if constexpr (SELF)
+                asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
+                                  "+v"(nx[0]), "+v"(nx[1]), "+v"(mn.x), "+v"(mn.y), "+v"(mn.z), "+v"(mn.w), "+v"(mx.x), "+v"(mx.y),
+                                  "+v"(mx.z), "+v"(mx.w) : : "memory");
+            else
+                asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
+                                  "+v"(nx[0]), "+v"(nx[1]), "+v"(dsq) : : "memory");
             if (st + 1 < kStages) issue_loads(st + 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (SELF) {
+                // the query's box at this lane's chunk, from the eight staged query rows (rows past the document's end are
+                // copies of its last row), joined with the candidate's
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float4 qv = *reinterpret_cast<const float4*>(lds + r * kRowStride + sc * 4);
+                    mn.x = fminf(mn.x, qv.x); mn.y = fminf(mn.y, qv.y); mn.z = fminf(mn.z, qv.z); mn.w = fminf(mn.w, qv.w);
+                    mx.x = fmaxf(mx.x, qv.x); mx.y = fmaxf(mx.y, qv.y); mx.z = fmaxf(mx.z, qv.z); mx.w = fmaxf(mx.w, qv.w);
+                }
+                const f2_t dlo = {mx.x - mn.x, mx.y - mn.y}, dhi = {mx.z - mn.z, mx.w - mn.w};
+                dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
+            }
             // ---- accumulate: every lane walks the staged chunks for its own 2 x 2 entries ----------------------------
             if constexpr (MFMA) {
                 // matrix-pipe form: block b = lane >> 2 = (p, iq, jq) is the 4 x 4 sub-block (rows 4 iq .., columns 4 jq ..) of
@@ -563,6 +615,12 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 
 }  // namespace
 
+// batched jobs: few enough jobs for the in-wave tables (one lane per job), and hyper-parameters that never need the repair
+// pass (which indexes the candidate -> job table)
+bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm) {
+    return jobs <= 64 && prm->scaling >= 0.25 && !tuning().fused_nosolve && !tuning().fused_valu && !tuning().fused_noself;
+}
+
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
     const int mq = q->max_len, mc = c->max_len;
     return q->ext == 0 && c->ext == 0 && mq > 0 && mc > 0 && mq <= 8 && mc <= 8;
@@ -579,8 +637,11 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     const int64_t waves = groups_bound < cap ? groups_bound : cap;
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = 4 * kWaveLds * sizeof(float);
+    const bool self = qbox == nullptr && a.pairing == kPairMapped;       // batched jobs without the tables launch (fused_self_ok)
+    if (self && (tuning().fused_nosolve || tuning().fused_valu)) return ASPIRE_ERR_INVALID_ARG;
     if (tuning().fused_nosolve) hipLaunchKernelGGL((pair_fused_kernel<true, false>), grid, dim3(256), lds, stream, a, qbox);
     else if (tuning().fused_valu) hipLaunchKernelGGL((pair_fused_kernel<false, true>), grid, dim3(256), lds, stream, a, qbox);
+    else if (self) hipLaunchKernelGGL((pair_fused_kernel<true, true, true>), grid, dim3(256), lds, stream, a, qbox);
     else hipLaunchKernelGGL((pair_fused_kernel<true, true>), grid, dim3(256), lds, stream, a, qbox);
     ASPIRE_LAUNCH_OK();
     // scaling below ~0.03 lets the shifted sums overflow (the exponent of K grows by 1 / scaling from one step to the next);

@@ -38,6 +38,8 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.fused_valu = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {
         t.fused_nosolve = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "FUSED_NOSELF")) {
+        t.fused_noself = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_WAVES")) {
         t.fused_waves = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "OT_FORM")) {
@@ -51,7 +53,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

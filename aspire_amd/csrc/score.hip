@@ -2429,7 +2429,9 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const bool big = max_rows <= 8 && groups_bound >= 2048 && C >= 6000;
     const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
     a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
-    if (stages & kStagePrep) {
+    // batches of <= 64 jobs on the fused kernel need no tables launch: the kernel's waves derive them (fused.hip, SELF)
+    const bool self = fused && fused_self_ok(J, prm);
+    if ((stages & kStagePrep) && !self) {
         // parts per job: enough blocks that a job's groups take a couple of trips each
         const int64_t work = ((max_job + 3) / 4) * 16;
         int64_t parts = (work + 2 * 192 - 1) / (2 * 192);
@@ -2442,7 +2444,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
     if (fused) {
         if (stages & (kStageCost | kStageSolve))
-            if (int rc = launch_pair_fused(a, groups_bound, qbox, s0)) return rc;
+            if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0)) return rc;
     } else {
         const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
             constexpr int T = decltype(tc)::value;

@@ -106,6 +106,7 @@ int generic_max_rows(void);
 int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q, int rows_c, hipStream_t stream);
 
 // fused.hip: cost + Sinkhorn solve in one launch for documents of <= 8 rows (CSR inputs, CROSS or MAPPED pairing)
+bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm);
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
 

@@ -15,6 +15,7 @@ struct Tuning {
                              // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch
     int fused_valu = 0;      // ASPIRE_HIP_FUSED_VALU=1: the fused kernel's dot products as VALU FMAs instead of MFMA (A/B, parity tests)
     int fused_nosolve = 0;   // ASPIRE_HIP_FUSED_NOSOLVE=1: the fused kernel's cost phase alone (timing experiments)
+    int fused_noself = 0;    // ASPIRE_HIP_FUSED_NOSELF=1: batches of <= 64 jobs also take the tables launch + the table-driven kernel (A/B)
     int fused_waves = 0;     // ASPIRE_HIP_FUSED_WAVES: cap on the fused kernel's resident waves (0 = default; grid experiments)
 };
 

@@ -116,6 +116,25 @@ def test_throughput_forms_and_single_jobs(amd):
         np.testing.assert_allclose(dflt[0][j].numpy()[pick], want, atol=TOL, rtol=0)
 
 
+def test_fused_in_wave_tables_equal_the_tables_launch(amd):
+    """batches of <= 64 jobs: the fused kernel derives an item's documents and the query's box itself (no tables launch);
+    pinned back to the tables launch + table-driven kernel it gives the same bits -- ragged jobs, empty jobs in front,
+    in the middle and at the end, exactly 64 jobs; 65 jobs take the tables launch by themselves"""
+    for seed, sizes in ((51, [0, 801, 2, 0, 0, 1203, 5, 640, 0]), (52, [37] * 63 + [41]), (53, [33] * 65)):
+        queries, pools = _jobs(seed, sizes, 8)
+        with amd.pinned(OT_FORM='fused'):
+            a = _batch(amd, queries, pools, 50)
+        with amd.pinned(OT_FORM='fused', FUSED_NOSELF=1):
+            b = _batch(amd, queries, pools, 50)
+        _check_rank(*a, 50)
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        j = 1 if seed == 51 else 7
+        want = np.array([orc.get_similarity(queries[j], c) for c in pools[j][:8]], dtype=np.float32)
+        np.testing.assert_allclose(a[0][j].numpy()[:8], want, atol=TOL, rtol=0)
+
+
 def test_batch_hparams_and_wants(amd):
     queries, pools = _jobs(41, [40, 25], 8)
     for want, sign in ((amd.lib.OT_DISTANCE, -1.0), (amd.lib.OT_SIMILARITY, 1.0)):

@@ -88,6 +88,26 @@ def bench(J, NC, S, k=100):
             t_host = time.perf_counter() - t0
             torch.cuda.synchronize()
             e2e[chunks] = (1e6 * (time.perf_counter() - t0) / n, 1e6 * t_host / n)
+    # the same call without its first launch (tables + query boxes left over from the last full call: same layout in every
+    # set, boxes of another set's queries) -- what folding that launch into the scoring kernel could save at most
+    with _lib.pinned(OT_FORM='fused'):
+        full(0)
+        for i in range(4):
+            stage(i, 14)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(40):
+            stage(i, 14)
+        torch.cuda.synchronize()
+        e2e['fused-noprep'] = (1e6 * (time.perf_counter() - t0) / 40, 0.0)
+        for i in range(4):
+            stage(i, 6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(40):
+            stage(i, 6)
+        torch.cuda.synchronize()
+        e2e['fused-alone'] = (1e6 * (time.perf_counter() - t0) / 40, 0.0)
     print(f'J={J} NC={NC} S={S}: ' + ' '.join(f'{k_}={v:.1f}us' for k_, v in out.items() if k_ != 'cost_TBs') +
           f' score={out["cost_TBs"]:.2f}TB/s | e2e(us)/host(us): ' +
           ' '.join(f'{c}={a:.0f}/{h:.0f}' for c, (a, h) in e2e.items()) +
