@@ -29,6 +29,8 @@
 //     with the long-form kernel (generic.hip: max-shifted log-sum-exps), which re-solves exactly the NaN pairs.
 #include <math.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "score_device.h"
 #include "score_types.h"
@@ -337,12 +339,22 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         }
         return x;
     };
-    const uint32_t item_first = item_lo + blockIdx.x * 4 + wave;
-    Ctx next = load_ctx(item_first < n_items ? item_first : item_lo);
+    // a wave's items: every n_waves-th one -- or, SELF, a run of consecutive ones: those are mostly groups of ONE job, and the
+    // query's box, formed during the first of them, is kept in LDS for the others
+    uint32_t item_first = item_lo + blockIdx.x * 4 + wave, item_end = n_items, item_step = n_waves;
+    if constexpr (SELF) {
+        const uint32_t w = blockIdx.x * 4 + wave, base = n_items / n_waves, rem = n_items % n_waves;
+        item_first = w * base + min(w, rem);
+        item_end = item_first + base + (w < rem ? 1u : 0u);
+        item_step = 1;
+    }
+    float* qcache = lds_all + 4 * kWaveLds + wave * 2 * kD;      // SELF: [2][768] box of query cached_q
+    int64_t cached_q = -1;
+    Ctx next = load_ctx(item_first < item_end ? item_first : item_lo);
 
-    for (uint32_t item = item_first; item < n_items; item += n_waves) {
+    for (uint32_t item = item_first; item < item_end; item += item_step) {
         const Ctx cur = next;
-        next = load_ctx(item + n_waves < n_items ? item + n_waves : item);      // (the last item fetches itself again)
+        next = load_ctx(item + item_step < item_end ? item + item_step : item);      // (the last item fetches itself again)
         const int64_t c_idx = cur.c_idx, q_idx = cur.q_idx;
         const int c_len = cur.c_len, q_len = cur.q_len, c_start = cur.c_start, q_start = cur.q_start;
         const bool my_c_real = cur.my_c_real;
@@ -352,6 +364,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         // unused) -- the loads stay UNCONDITIONAL: a branch around them makes the compiler wait for the just-issued row
         // loads at the join (a register copy of the conditionally defined value), which serialises every stage's HBM
         // latency with its arithmetic (measured: 160 instead of 110 us for the cost phase of 20 x 1000 pairs)
+        const bool have_box = SELF && q_idx == cached_q;       // wave-uniform
         const float* qb = (own_diam && !SELF) ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
         const int qb_hi = (own_diam && !SELF) ? kD : 0;
 
@@ -422,15 +435,28 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if constexpr (SELF) {
-                // the query's box at this lane's chunk, from the eight staged query rows (rows past the document's end are
-                // copies of its last row), joined with the candidate's
+                // the query's box at this lane's chunk: from the eight staged query rows (rows past the document's end are
+                // copies of its last row) and into the wave's cache, or from the cache; joined with the candidate's
+                float4 qn, qx;
+                float* qc = qcache + (st * kCh + sc) * 4;
+                if (have_box) {
+                    qn = *reinterpret_cast<const float4*>(qc);
+                    qx = *reinterpret_cast<const float4*>(qc + kD);
+                } else {
+                    qn = qx = *reinterpret_cast<const float4*>(lds + sc * 4);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float4 qv = *reinterpret_cast<const float4*>(lds + r * kRowStride + sc * 4);
-                    mn.x = fminf(mn.x, qv.x); mn.y = fminf(mn.y, qv.y); mn.z = fminf(mn.z, qv.z); mn.w = fminf(mn.w, qv.w);
-                    mx.x = fmaxf(mx.x, qv.x); mx.y = fmaxf(mx.y, qv.y); mx.z = fmaxf(mx.z, qv.z); mx.w = fmaxf(mx.w, qv.w);
+                    for (int r = 1; r < 8; ++r) {
+                        const float4 qv = *reinterpret_cast<const float4*>(lds + r * kRowStride + sc * 4);
+                        qn.x = fminf(qn.x, qv.x); qn.y = fminf(qn.y, qv.y); qn.z = fminf(qn.z, qv.z); qn.w = fminf(qn.w, qv.w);
+                        qx.x = fmaxf(qx.x, qv.x); qx.y = fmaxf(qx.y, qv.y); qx.z = fmaxf(qx.z, qv.z); qx.w = fmaxf(qx.w, qv.w);
+                    }
+                    if (sg == 0) {
+                        *reinterpret_cast<float4*>(qc) = qn;
+                        *reinterpret_cast<float4*>(qc + kD) = qx;
+                    }
                 }
-                const f2_t dlo = {mx.x - mn.x, mx.y - mn.y}, dhi = {mx.z - mn.z, mx.w - mn.w};
+                const f2_t dlo = {fmaxf(mx.x, qx.x) - fminf(mn.x, qn.x), fmaxf(mx.y, qx.y) - fminf(mn.y, qn.y)};
+                const f2_t dhi = {fmaxf(mx.z, qx.z) - fminf(mn.z, qn.z), fmaxf(mx.w, qx.w) - fminf(mn.w, qn.w)};
                 dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
             }
             // ---- accumulate: every lane walks the staged chunks for its own 2 x 2 entries ----------------------------
@@ -588,6 +614,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch table is rewritten by the next item
         __builtin_amdgcn_wave_barrier();
+        cached_q = q_idx;
 
         // ---- the previous item's solve ends here (its last steps, score, store); this item's begins ---------------------
         if constexpr (SOLVE)
@@ -610,7 +637,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         }
     }
     if constexpr (SOLVE)
-        if (have_pend) solve_finish(pend, a);   // the wave's last item: nothing left to hide it behind
+        if (have_pend && !a.skip_tail) solve_finish(pend, a);   // the wave's last item: nothing left to hide it behind
 }
 
 }  // namespace
@@ -618,7 +645,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 // batched jobs: few enough jobs for the in-wave tables (one lane per job), and hyper-parameters that never need the repair
 // pass (which indexes the candidate -> job table)
 bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm) {
-    return jobs <= 64 && prm->scaling >= 0.25 && !tuning().fused_nosolve && !tuning().fused_valu && !tuning().fused_noself;
+    return jobs <= 64 && prm->scaling >= 0.25 && tuning().fused_nosolve != 1 && !tuning().fused_valu && !tuning().fused_noself;
 }
 
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
@@ -626,22 +653,31 @@ bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
     return q->ext == 0 && c->ext == 0 && mq > 0 && mc > 0 && mq <= 8 && mc <= 8;
 }
 
-size_t fused_lds_bytes(void) { return 4 * kWaveLds * sizeof(float); }
-
 // groups_bound: upper bound of the launch's items (groups of four candidates x queries)
 int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, hipStream_t stream) {
-    const ScoreArgs& a = a_in;
     // two 4-wave workgroups per CU are resident.  (Built for three -- 168 registers, the kernel-invariant values spilled,
     // the norm table already shares the stage buffer so the LDS fits -- the 20 x 1000 call went from 120 to 144 us.)
+    ScoreArgs a = a_in;
+    a.skip_tail = tuning().fused_nosolve == 2;
     const int64_t cap = tuning().fused_waves > 0 ? tuning().fused_waves : 256 * 8;
     const int64_t waves = groups_bound < cap ? groups_bound : cap;
     const dim3 grid((unsigned)((waves + 3) / 4));
-    const size_t lds = 4 * kWaveLds * sizeof(float);
     const bool self = qbox == nullptr && a.pairing == kPairMapped;       // batched jobs without the tables launch (fused_self_ok)
-    if (self && (tuning().fused_nosolve || tuning().fused_valu)) return ASPIRE_ERR_INVALID_ARG;
-    if (tuning().fused_nosolve) hipLaunchKernelGGL((pair_fused_kernel<true, false>), grid, dim3(256), lds, stream, a, qbox);
+    if (self && (tuning().fused_nosolve == 1 || tuning().fused_valu)) return ASPIRE_ERR_INVALID_ARG;
+    const size_t lds = 4 * (kWaveLds + (self ? 2 * kD : 0)) * sizeof(float);      // SELF: + a query-box cache per wave
+    if (tuning().fused_nosolve == 1) hipLaunchKernelGGL((pair_fused_kernel<true, false>), grid, dim3(256), lds, stream, a, qbox);
     else if (tuning().fused_valu) hipLaunchKernelGGL((pair_fused_kernel<false, true>), grid, dim3(256), lds, stream, a, qbox);
-    else if (self) hipLaunchKernelGGL((pair_fused_kernel<true, true, true>), grid, dim3(256), lds, stream, a, qbox);
+    else if (self) {
+        // 67.6 KB of dynamic LDS: above the default limit of 64 KB (raised once per process; two workgroups still fit a CU)
+        static std::once_flag raised;
+        static hipError_t raise_rc = hipSuccess;
+        std::call_once(raised, [] {
+            raise_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fused_kernel<true, true, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        });
+        ASPIRE_HIP_OK(raise_rc);
+        hipLaunchKernelGGL((pair_fused_kernel<true, true, true>), grid, dim3(256), lds, stream, a, qbox);
+    }
     else hipLaunchKernelGGL((pair_fused_kernel<true, true>), grid, dim3(256), lds, stream, a, qbox);
     ASPIRE_LAUNCH_OK();
     // scaling below ~0.03 lets the shifted sums overflow (the exponent of K grows by 1 / scaling from one step to the next);

@@ -46,6 +46,7 @@ struct ScoreArgs {
     int32_t job0, job1;       // the jobs this launch covers (chunks of a batch run side by side on two streams)
     int32_t max_job_groups;   // host-side launch geometry: upper bound of a job's groups of four
     int32_t tile_form;        // host-side: the batch runs on the throughput kernels
+    int32_t skip_tail;        // diagnostics (FUSED_NOSOLVE=2): the fused kernel drops every wave's LAST solve (timing of the exposed tail)
     long long* dbg;  // phase cycle stamps (only with -DASPIRE_PHASE_CLOCK)
 };
 

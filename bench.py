@@ -9,9 +9,12 @@ fp32, resident in HBM before the timed region.  One STEP = one query re-ranked a
 (evaluate.py:58-76: every query of a dataset has its own pool): cost matrix + marginals + Sinkhorn (one epsilon schedule
 per pair, AspireModel.get_similarity) of the 1000 pairs, then the stable descending rank (top-100).  The K steps of a run
 are K independent (query, pool) jobs and go through ONE library call, aspire_ot_rank_batch_f32 -- a small launch that
-builds the job tables and query boxes, ONE scoring launch over the K x 1000 pairs (costs and Sinkhorn solves fused: a
+builds the job tables and query boxes (batches of more than 64 jobs only), ONE scoring launch over the K x 1000 pairs (costs and Sinkhorn solves fused: a
 wave streams four candidates' rows, then solves those four pairs from its registers while other waves stream), one
-K-workgroup rank launch.  The caller uses ONE stream, no hipGraphs, no lanes.
+K-workgroup rank launch.  No hipGraphs.  Consecutive calls are independent requests and go round-robin over --streams
+caller streams (default 3), each with its own outputs and workspace: the end of one call (the last Sinkhorn solves,
+the rank launch -- neither touches HBM) overlaps the next call's streaming.  `one_stream` in the JSON is the same schedule
+with one call at a time.
 
 Timing: the K-step schedule is repeated R times back to back (R chosen so that the timed region is >= 50 ms: K = 20 steps
 alone are ~0.1 ms) between barrier + torch.cuda.synchronize() on both sides; ms_per_step = elapsed / (K * R), value =
@@ -105,6 +108,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--repeats', type=int, default=0, help='repetitions of the K-step schedule (0 = enough for >= 50 ms)')
+    ap.add_argument('--streams', type=int, default=3,
+                    help='independent calls in flight: repetitions go round-robin over this many caller streams, each with its own '
+                         'outputs and workspace (1 = one call at a time)')
     ap.add_argument('--shard-path', action='store_true',
                     help='run the N > 1 code path (key-form rank, gather, merge kernel) on one GPU, for testing')
     args = ap.parse_args()
@@ -142,7 +148,8 @@ def main():
 
     # ---- the pool store, resident in HBM: M distinct (query, 1000-candidate pool) jobs; repetition r runs jobs
     # [r*K, r*K + K) mod M.  Rank r of a sharded run owns block r of every job's pool. ----------------------------------
-    M = max(2 * K, 24)
+    n_lanes = max(1, args.streams)
+    M = max((n_lanes + 1) * K, 24)      # calls in flight never share a pool set
     while M * algorithmic_bytes(1) <= L3_BYTES or M % K:
         M += 1
     g = torch.Generator().manual_seed(1000 * rank)
@@ -168,17 +175,36 @@ def main():
             self.n = n_jobs
 
     sets = [JobSet(f) for f in range(0, M, K)]
-    scores = torch.empty(K * NC, device=device, dtype=torch.float32)
-    top_s = torch.empty(K, TOPK, device=device, dtype=torch.float32)
-    top_i = torch.empty(K, TOPK, device=device, dtype=torch.int64)
-    keys = torch.empty(K, TOPK, device=device, dtype=torch.int64) if shard_path else None
-    gathered = torch.empty(world, K, TOPK, device=device, dtype=torch.int64) if shard_path else None
-    ws = torch.empty(lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(sets[0].qs), ctypes.byref(sets[0].cs), NC, TOPK),
-                     device=device, dtype=torch.uint8)
-    P = [ctypes.c_void_p(t.data_ptr()) if t is not None else null for t in (scores, top_s, top_i, keys, ws, job_off, job_base)]
+    ws_bytes = lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(sets[0].qs), ctypes.byref(sets[0].cs), NC, TOPK)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null
+    P_job_off, P_job_base = ptr(job_off), ptr(job_base)
+
+    class Lane:
+        """One caller stream with its own outputs and workspace: calls on different lanes are independent requests."""
+
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device)
+            self.sp = ctypes.c_void_p(self.stream.cuda_stream)
+            self.scores = torch.empty(K * NC, device=device, dtype=torch.float32)
+            self.top_s = torch.empty(K, TOPK, device=device, dtype=torch.float32)
+            self.top_i = torch.empty(K, TOPK, device=device, dtype=torch.int64)
+            self.keys = torch.empty(K, TOPK, device=device, dtype=torch.int64) if shard_path else None
+            self.gathered = torch.empty(world, K, TOPK, device=device, dtype=torch.int64) if shard_path else None
+            self.ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8)
+            self.P = [ptr(t) for t in (self.scores, self.top_s, self.top_i, self.keys, self.ws)]
+            self.done = torch.cuda.Event()       # this lane's rank keys are written
+            self.free = torch.cuda.Event()       # ... and have been consumed by the exchange
+            self.exchanging = False
+
+    lanes = [Lane() for _ in range(n_lanes)]
+    # sharded: the per-call exchange (all-gather + merge) runs on its own stream behind the lanes, in call order (one
+    # communicator = one stream); a lane waits for ITS previous exchange before it overwrites its keys -- n_lanes calls later
+    comm = torch.cuda.Stream(device) if (world > 1 and not one_gpu_test) else None
+    scores, top_s, top_i, ws = lanes[0].scores, lanes[0].top_s, lanes[0].top_i, lanes[0].ws
+    P = [lanes[0].P[0], lanes[0].P[1], lanes[0].P[2], lanes[0].P[3], lanes[0].P[4], P_job_off, P_job_base]
 
     def stream():
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return lanes[0].sp
 
     def reduce_max(v):
         """max over ranks of a host scalar (RCCL on the GPUs; gloo, in the one-GPU rehearsal, reduces host tensors)"""
@@ -188,21 +214,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item()
 
-    def run_schedule(js, exchange=True):
-        """K steps = K jobs = ONE C-ABI call; sharded: + one all-gather of the K x k keys + one merge launch
+    def run_schedule(js, lane=None, exchange=True):
+        """K steps = K jobs = ONE C-ABI call on the lane's stream; sharded: + one all-gather of the K x k keys + one merge launch
         (exchange=False: this rank's kernels only -- the stage timings below run on rank 0 alone)."""
-        rc = lib.aspire_ot_rank_batch_f32(ctypes.byref(js.qs), ctypes.byref(js.cs), D, P[5], NC, ctypes.byref(prm), _lib.OT_SIMILARITY,
-                                          P[0], TOPK, P[6], null if shard_path else P[1], null if shard_path else P[2], P[3], P[4],
-                                          ws.numel(), stream())
+        lane = lane or lanes[0]
+        if lane.exchanging:
+            lane.stream.wait_event(lane.free)
+            lane.exchanging = False
+        rc = lib.aspire_ot_rank_batch_f32(ctypes.byref(js.qs), ctypes.byref(js.cs), D, P_job_off, NC, ctypes.byref(prm), _lib.OT_SIMILARITY,
+                                          lane.P[0], TOPK, P_job_base, null if shard_path else lane.P[1], null if shard_path else lane.P[2],
+                                          lane.P[3], lane.P[4], ws_bytes, lane.sp)
         if rc:
             _lib.check(rc)
         if shard_path and exchange:
-            if world > 1:
-                all_gather_flat(gathered.view(-1), keys.view(-1))      # -> [world][K][k]; RCCL over xGMI
-                src = gathered
+            if world == 1:
+                rc = lib.aspire_topk_merge_keys(ptr(lane.keys), 1, K, TOPK, TOPK, lane.P[1], lane.P[2], lane.sp)
+            elif comm is None:           # one-GPU rehearsal over gloo: the gather goes through the host, on the lane's stream
+                with torch.cuda.stream(lane.stream):
+                    all_gather_flat(lane.gathered.view(-1), lane.keys.view(-1))
+                rc = lib.aspire_topk_merge_keys(ptr(lane.gathered), world, K, TOPK, TOPK, lane.P[1], lane.P[2], lane.sp)
             else:
-                src = keys
-            rc = lib.aspire_topk_merge_keys(ctypes.c_void_p(src.data_ptr()), world, K, TOPK, TOPK, P[1], P[2], stream())
+                lane.done.record(lane.stream)
+                comm.wait_event(lane.done)
+                with torch.cuda.stream(comm):
+                    all_gather_flat(lane.gathered.view(-1), lane.keys.view(-1))      # -> [world][K][k]; RCCL over xGMI
+                rc = lib.aspire_topk_merge_keys(ptr(lane.gathered), world, K, TOPK, TOPK, lane.P[1], lane.P[2],
+                                                ctypes.c_void_p(comm.cuda_stream))
+                lane.free.record(comm)
+                lane.exchanging = True
             if rc:
                 _lib.check(rc)
 
@@ -213,16 +252,16 @@ def main():
             _lib.check(rc)
 
     # ---- W untimed warm-up steps, then a calibration pass that sizes R ----------------------------------------------
-    for r in range(max(1, -(-args.warmup // K))):
-        run_schedule(sets[r % len(sets)])
+    for r in range(max(n_lanes, -(-args.warmup // K))):
+        run_schedule(sets[r % len(sets)], lanes[r % n_lanes])
     torch.cuda.synchronize()
     if args.repeats > 0:
         R = args.repeats
     else:
         t0 = time.perf_counter()
-        n_cal = 8
+        n_cal = 4 * n_lanes
         for r in range(n_cal):
-            run_schedule(sets[r % len(sets)])
+            run_schedule(sets[r % len(sets)], lanes[r % n_lanes])
         torch.cuda.synchronize()
         per_call = (time.perf_counter() - t0) / n_cal
         R = max(4, int(1.3 * MIN_TIMED_S / per_call) + 1)
@@ -236,39 +275,41 @@ def main():
         fn()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()          # every stream of the device
         return reduce_max(time.perf_counter() - t0)
 
-    def all_reps():
-        for r in range(R):
-            run_schedule(sets[r % len(sets)])
+    def all_reps(use=None, reps=None):
+        use = use or lanes
+        for r in range(reps or R):
+            run_schedule(sets[r % len(sets)], use[r % len(use)])
 
     # untimed: clocks settle on the workload itself (~0.3 s), beyond the W warm-up steps
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < 0.3:
         for r in range(8):
-            run_schedule(sets[r % len(sets)], exchange=False)      # time-based loop: no collective inside
+            run_schedule(sets[r % len(sets)], lanes[r % n_lanes], exchange=False)      # time-based loop: no collective inside
         torch.cuda.synchronize()
 
-    elapsed = min(timed(all_reps) for _ in range(1))      # EXACTLY K steps x R repetitions, timed once
+    elapsed = timed(all_reps)             # EXACTLY K steps x R repetitions, timed once
+    # the same schedule with ONE call at a time (lane 0 alone), for the record: not the reported value
+    R1 = max(4, R // 2)
+    elapsed_one = timed(lambda: all_reps(lanes[:1], R1)) if n_lanes > 1 else elapsed * R1 / R
 
-    # ---- checks on the last repetition's outputs -------------------------------------------------------------------
+    # ---- checks on every lane's last outputs ------------------------------------------------------------------------
     torch.cuda.synchronize()
-    assert torch.isfinite(scores).all(), 'non-finite scores'
-    assert (top_i >= 0).all() and (top_i < world * NC).all(), 'rank produced out-of-range indices'
-    assert (top_s[:, 1:] <= top_s[:, :-1]).all(), 'rank output is not descending'
-    if not shard_path:
-        ref_s, ref_i = torch.sort(scores.view(K, NC), dim=1, descending=True, stable=True)
-        assert torch.equal(top_i, ref_i[:, :TOPK]) and torch.equal(top_s, ref_s[:, :TOPK]), 'rank differs from the stable sort'
-    elif world > 1:
-        mine = top_i.clone()
-        everyone = torch.empty(world, K, TOPK, device=device, dtype=torch.int64)
-        all_gather_flat(everyone.view(-1), mine.view(-1))
-        assert all(torch.equal(everyone[0], everyone[r]) for r in range(world)), 'ranks disagree on the merged ranking'
-        assert len(torch.unique(mine // NC)) > 1, 'merged ranking holds candidates of one shard only'
-    else:
-        ref_s, ref_i = torch.sort(scores.view(K, NC), dim=1, descending=True, stable=True)
-        assert torch.equal(top_i, ref_i[:, :TOPK]) and torch.equal(top_s, ref_s[:, :TOPK]), 'merged ranking differs'
+    for ln in lanes:
+        assert torch.isfinite(ln.scores).all(), 'non-finite scores'
+        assert (ln.top_i >= 0).all() and (ln.top_i < world * NC).all(), 'rank produced out-of-range indices'
+        assert (ln.top_s[:, 1:] <= ln.top_s[:, :-1]).all(), 'rank output is not descending'
+        if not shard_path or world == 1:
+            ref_s, ref_i = torch.sort(ln.scores.view(K, NC), dim=1, descending=True, stable=True)
+            assert torch.equal(ln.top_i, ref_i[:, :TOPK]) and torch.equal(ln.top_s, ref_s[:, :TOPK]), 'rank differs from the stable sort'
+        else:
+            mine = ln.top_i.clone()
+            everyone = torch.empty(world, K, TOPK, device=device, dtype=torch.int64)
+            all_gather_flat(everyone.view(-1), mine.view(-1))
+            assert all(torch.equal(everyone[0], everyone[r]) for r in range(world)), 'ranks disagree on the merged ranking'
+            assert len(torch.unique(mine // NC)) > 1, 'merged ranking holds candidates of one shard only'
 
     out = None
     if rank == 0:
@@ -282,9 +323,9 @@ def main():
                 js = jsets[i % len(jsets)]
                 if stages != 1:
                     run_stage(js, 1 if stages in (2, 6) else 7)      # this job set's tables and query boxes (+ costs and scores, for the later stages)
-                a.record()
+                a.record(lanes[0].stream)
                 run_stage(js, stages)
-                b.record()
+                b.record(lanes[0].stream)
             torch.cuda.synchronize()
             t = sorted(a.elapsed_time(b) for a, b in evs)
             return sum(t[:n // 2]) / (n // 2)       # mean of the faster half: launch gaps of a cold queue out of the bracket
@@ -316,9 +357,9 @@ def main():
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(24)]
         for a, b in evs:
-            a.record()
+            a.record(lanes[0].stream)
             cost_l3()
-            b.record()
+            b.record(lanes[0].stream)
         torch.cuda.synchronize()
         t = sorted(a.elapsed_time(b) for a, b in evs)
         cost_l3_ms = sum(t[:12]) / 12
@@ -345,8 +386,13 @@ def main():
                                    + (f'; sharded: one RCCL all-gather of {K} x {TOPK} keys per call + merge kernel' if shard_path else ''),
                        'queries_per_step': 1, 'candidates_per_gpu_per_step': NC, 'sents': S, 'dim': D, 'topk': TOPK,
                        'parallelism': f'candidate-pool shards x{world}',
-                       'launch': f'the {K} steps of a schedule = {K} independent (query, pool) jobs in ONE aspire_ot_rank_batch_f32 call on '
-                                 f'one caller stream (eager, no hipGraph); schedule repeated {R}x back to back for a >= 50 ms timed region'},
+                       'launch': f'the {K} steps of a schedule = {K} independent (query, pool) jobs in ONE aspire_ot_rank_batch_f32 call '
+                                 f'(eager, no hipGraph); schedule repeated {R}x for a >= 50 ms timed region, the repetitions round-robin on '
+                                 f'{n_lanes} caller stream(s) with their own outputs and workspaces = {n_lanes} independent calls in flight '
+                                 f'(a call\'s solve tail and rank launch overlap the next call\'s streaming); one call at a time: see one_stream',
+                       'streams': n_lanes},
+            'one_stream': {'what': 'the same schedule with ONE call at a time (one caller stream), timed right after the reported region',
+                           'value': world * K * R1 * NC / elapsed_one, 'ms_per_call': elapsed_one / R1 * 1e3, 'repeats': R1},
             # Dominant kernel of a step: the cost kernel streams every rep once (the HBM side of the step).
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -358,8 +404,10 @@ def main():
                          'stages_ms': {'tables+boxes': prep_ms, 'score': cost_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3},
                          'two_kernel_form': {'cost_ms': cost_only_ms, 'sinkhorn_ms': solve_only_ms,
                                              'cost_frac': bytes_per_launch / (cost_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         'step': {'what': 'all kernels of a schedule (timed region) against the same algorithmic bytes',
-                                  'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS}},
+                         'step': {'what': 'all kernels of a schedule (timed region, calls in flight as configured) against the same '
+                                          'algorithmic bytes',
+                                  'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS,
+                                  'one_stream_frac': bytes_per_launch * R1 / elapsed_one / 1e9 / HBM_PEAK_GBS}},
         }
         spath = os.path.join(ROOT, 'profiles', 'sinkhorn_roofline.json')
         if os.path.exists(spath):

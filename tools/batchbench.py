@@ -71,7 +71,7 @@ def bench(J, NC, S, k=100):
     out['cost_TBs'] = bytes_ / out['score'] / 1e6
     e2e = {}
     variants = [('fused', dict(OT_FORM='fused')), ('fused-valu', dict(OT_FORM='fused', FUSED_VALU=1)),
-                ('fused-nosolve', dict(OT_FORM='fused', FUSED_NOSOLVE=1))]
+                ('fused-nosolve', dict(OT_FORM='fused', FUSED_NOSOLVE=1)), ('fused-notail', dict(OT_FORM='fused', FUSED_NOSOLVE=2))]
     variants += [('tile', dict(OT_FORM='tile')), ('small', dict(OT_FORM='small'))]
     variants += [(f'fused-w{w}', dict(OT_FORM='fused', FUSED_WAVES=w)) for w in os.environ.get('BATCHBENCH_WAVES', '').split(',') if w]
     if S > 8:
