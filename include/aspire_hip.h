@@ -256,8 +256,10 @@ int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D
  * Job j scores the candidates [job_off[j], job_off[j+1]) of `c` -- query j's own pool (evaluate.py:60-62), all pools
  * laid back to back in one CSR rep set -- against query j of `q`, one epsilon schedule per pair
  * (AspireModel.get_similarity, src/evaluation/utils/models.py:190-197), and ranks each pool on its own (stable
- * descending, evaluate.py:76).  Three launches on `stream`: job tables + query boxes, ONE scoring launch over all pairs
- * (costs and Sinkhorn solves fused once the batch fills the chip), one rank launch with a workgroup per job.
+ * descending, evaluate.py:76).  Launches on `stream`: ONE scoring launch over all pairs (costs and Sinkhorn solves fused
+ * once the batch fills the chip) and one rank launch with a workgroup per job; batches of more than 64 jobs, and the
+ * small-batch kernel forms, put a launch in front that builds the job tables and the query boxes.  Everything runs on the
+ * caller's stream: independent calls on different streams (each with its own outputs and workspace) overlap.
  *   q          J query documents (q->n == J), CSR (ext == 0)
  *   c          every job's candidates (c->n == C == job_off[J]), CSR (ext == 0)
  *   job_off    DEVICE int32 [J + 1], non-decreasing, job_off[0] == 0, job_off[J] == C
@@ -297,12 +299,14 @@ int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (tests, bench.py, tuning) -- not part of the surface that replaces reference code.
  *   aspire_debug_set   pin a kernel form / grid: key = "SINKHORN" (wave | block | block-norepair | block16), "COST_PATH"
- *                      (mfma | valu), "OT_FORM" (small | tile | fused), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM_TILE" (96);
+ *                      (mfma | valu), "OT_FORM" (small | tile | fused), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM_TILE" (96), "FUSED_VALU" (1),
+ *                      "FUSED_NOSELF" (1), "FUSED_WAVES" (n), "FUSED_NOSOLVE" (1 | 2: timing only, invalid scores);
  *                      value NULL or "" restores the default.  The same switches are read
  *                      ONCE from the environment (ASPIRE_HIP_<key>) when the library is first used; nothing on the
  *                      launch path reads the environment.
  *   aspire_debug_ot_cost_stage_f32         the cost stage of aspire_ot_sinkhorn_f32 alone (no solve, scores untouched)
- *   aspire_debug_ot_rank_batch_stages_f32  chosen stages of aspire_ot_rank_batch_f32 alone: 1 tables + query boxes,
+ *   aspire_debug_ot_rank_batch_stages_f32  chosen stages of aspire_ot_rank_batch_f32 alone: 1 tables + query boxes (nothing
+ *                      for a batch whose scoring kernel derives them itself),
  *                      2 costs, 4 Sinkhorn solves (2 and 4 are ONE kernel in the fused form: either bit launches it),
  *                      8 rank (bench.py times the stages of a pass one by one this way, after a full call has filled
  *                      the workspace)

@@ -29,9 +29,9 @@ traffic = int(2 * fetch_kb * 1024 + write_kb * 1024)
 json.dump({
     'round': 2,
     'command': 'rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python bench.py --steps 20 --warmup 5 '
-               '--repeats 6 --no-cpu-baseline   (tools/profile_r2.sh; summed per kernel by tools/pmcsum.py)',
+               '--repeats 6 --streams 1 --no-cpu-baseline   (tools/profile_r2.sh; summed per kernel by tools/pmcsum.py)',
     'workload': 'bench.py: 20 jobs x (1 query x 1000 candidates x 8 sents x 768 d) per aspire_ot_rank_batch_f32 call; the scoring launch = '
-                'pair_fused_kernel<true, true> (costs + Sinkhorn solves), rotating cold pools',
+                'pair_fused_kernel<true, true, true> (costs + Sinkhorn solves, in-wave tables), rotating cold pools, one call at a time',
     'jobs_per_launch': K,
     'FETCH_SIZE_KB_per_launch': fetch_kb, 'WRITE_SIZE_KB_per_launch': write_kb,
     'correction': 'MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced (16 B/lane) '
@@ -40,6 +40,6 @@ json.dump({
     'cost_kernel_hbm_bytes_per_launch': traffic,
     'algorithmic_bytes_per_launch': alg,
     'ratio': traffic / alg,
-    'kernel_stats': {'source': stats_csv + ' (rocprofv3 --kernel-trace --stats on bench.py --steps 20 --warmup 5 --repeats 60)', **stats},
+    'kernel_stats': {'source': stats_csv + ' (rocprofv3 --kernel-trace --stats on bench.py --steps 20 --warmup 5 --repeats 60 --streams 1)', **stats},
 }, open('profiles/traffic.json', 'w'), indent=1)
 print(traffic, alg, traffic / alg, stats)
