@@ -1541,6 +1541,8 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
 // A sum that leaves fp32 range (extreme scaling) poisons the score with NaN; sinkhorn_repair_kernel then redoes
 // such pairs with the max-shifted solver.
 // ---------------------------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));     // a register pair for the packed fp32 instructions
+
 template <int LD>
 __device__ __forceinline__ float blk_sum_j(float v) {   // all-reduce over the LD lanes that share li
     v += lane_xor<1>(v);
@@ -1670,13 +1672,10 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
     // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = exp(ld + (k-1) lsc), n_mid+1 = blur, n_mid+2 = blur (final)
     float ldf;
     const int n_mid = schedule_mid_steps(a, diam, ldf);
-    const float lscf = a.log2_scaling;
     const int n_steps = n_mid + 3;
     int max_steps = n_steps;
 #pragma unroll
     for (int m = NL; m < 64; m <<= 1) max_steps = max(max_steps, __shfl_xor(max_steps, m));
-    const float c_r2 = 0.5287663729448977f - ldf;      // log2(log2 e) - log2(diam):  r2_k = exp2(c_r2 - (k-1) lscf)
-    const float c_h = -1.5287663729448977f + ldf;      // log2(ln2 / 2) + log2(diam): h_k  = exp2(c_h  + (k-1) lscf)
     const float r2_first = kLog2e * rcp_refined(diam), h_first = 0.5f * kLn2 * diam;
     const float eb = (float)a.blur;
     const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
@@ -1703,33 +1702,95 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
         }
     }
     // ---- the annealing loop ---------------------------------------------------------------------------------
-    for (int k = 0; k < max_steps; ++k) {
-        const float kf = (float)(k - 1);
-        float r2 = __builtin_amdgcn_exp2f(fmaf(-kf, lscf, c_r2));
-        float h = __builtin_amdgcn_exp2f(fmaf(kf, lscf, c_h));
-        if (k == 0) { r2 = r2_first; h = h_first; }
-        if (k > n_mid) { r2 = r2_blur; h = k == n_mid + 1 ? h_blur : (k == n_mid + 2 ? 2.f * h_blur : 0.f); }
-        float f2[R], g2[R], rs[R], cs[R];
+    // One step on register PAIRS (v_pk_mul / v_pk_fma_f32 work on two entries at once): the entries of a row as R / 2 column
+    // pairs (+ a single for odd R).  R = 4: 76 issue slots per step instead of 122, R = 3: 62 instead of 90 -- the kernel
+    // runs at its VALU-issue roof (profiles/sinkhorn_roofline.json), so only fewer instructions make it faster.  The
+    // per-step constants follow from the previous step's by one multiply each through the annealed part of the schedule
+    // (steps 2 .. n_mid: eps *= scaling), with a select-free loop while all of the wave's pairs anneal.
+    constexpr int RP = R / 2;
+    constexpr bool ODD = (R & 1) != 0;
+    f2v cp[R][RP > 0 ? RP : 1], wbp[RP > 0 ? RP : 1], gp[RP > 0 ? RP : 1];
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            f2[t] = f[t] * r2;
-            g2[t] = g[t] * r2;
-            rs[t] = cs[t] = 0.f;
-        }
+    for (int j = 0; j < RP; ++j) {
+        wbp[j] = f2v{wb[2 * j], wb[2 * j + 1]};
+        gp[j] = f2v{g[2 * j], g[2 * j + 1]};
 #pragma unroll
-        for (int x = 0; x < R; ++x)
-#pragma unroll
-            for (int y = 0; y < R; ++y) {
-                const float kxy = __builtin_amdgcn_exp2f(fmaf(-cost[x][y], r2, f2[x] + g2[y]));
-                rs[x] = fmaf(wb[y], kxy, rs[x]);
-                cs[y] = fmaf(wa[x], kxy, cs[y]);
-            }
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            f[t] = fmaf(-h, __builtin_amdgcn_logf(blk_sum_j<LD>(rs[t])), f[t]);
-            g[t] = fmaf(-h, __builtin_amdgcn_logf(blk_sum_i<LD>(cs[t])), g[t]);
-        }
+        for (int x = 0; x < R; ++x) cp[x][j] = f2v{cost[x][2 * j], cost[x][2 * j + 1]};
     }
+    float go = ODD ? g[R - 1] : 0.f;
+    auto step = [&](float r2, float h) {
+        f2v g2p[RP > 0 ? RP : 1], csp[RP > 0 ? RP : 1];
+        float rs[R], cso = 0.f;
+        const float g2o = go * r2;
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            g2p[j] = gp[j] * r2;
+            csp[j] = f2v{0.f, 0.f};
+        }
+#pragma unroll
+        for (int x = 0; x < R; ++x) {
+            const float fx = f[x] * r2;
+            f2v racc = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const f2v arg = __builtin_elementwise_fma(cp[x][j], f2v{-r2, -r2}, f2v{fx, fx} + g2p[j]);
+                const f2v kk = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                racc = __builtin_elementwise_fma(kk, wbp[j], racc);
+                csp[j] = __builtin_elementwise_fma(kk, f2v{wa[x], wa[x]}, csp[j]);
+            }
+            rs[x] = racc.x + racc.y;
+            if constexpr (ODD) {
+                const float ko = __builtin_amdgcn_exp2f(fmaf(-cost[x][R - 1], r2, fx + g2o));
+                rs[x] = fmaf(wb[R - 1], ko, rs[x]);
+                cso = fmaf(wa[x], ko, cso);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < R; ++x) f[x] = fmaf(-h, __builtin_amdgcn_logf(blk_sum_j<LD>(rs[x])), f[x]);
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const f2v lc = {__builtin_amdgcn_logf(blk_sum_i<LD>(csp[j].x)), __builtin_amdgcn_logf(blk_sum_i<LD>(csp[j].y))};
+            gp[j] = __builtin_elementwise_fma(f2v{-h, -h}, lc, gp[j]);
+        }
+        if constexpr (ODD) go = fmaf(-h, __builtin_amdgcn_logf(blk_sum_i<LD>(cso)), go);
+    };
+    {
+        const float scal = (float)a.scaling, inv_scal = (float)(1.0 / a.scaling);
+        int n_mid_lo = n_mid;
+#pragma unroll
+        for (int m = NL; m < 64; m <<= 1) n_mid_lo = min(n_mid_lo, __shfl_xor(n_mid_lo, m));
+        n_mid_lo = __builtin_amdgcn_readfirstlane(n_mid_lo);
+        max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+        float r2 = r2_first, h = h_first;
+        int k = 0;
+        // eps_k: diam at k = 0 and 1, diam scaling^(k-1) up to k = n_mid, then blur (averaged), blur (final, h doubled), and
+        // nothing (h = 0) while a wave mate with a longer schedule is still annealing
+        auto general = [&](int upto) {
+#pragma unroll 1
+            for (; k < upto; ++k) {
+                const bool anneal = k >= 2 && k <= n_mid;
+                r2 = anneal ? r2 * inv_scal : r2;
+                h = anneal ? h * scal : h;
+                if (k > n_mid) { r2 = r2_blur; h = k == n_mid + 1 ? h_blur : (k == n_mid + 2 ? 2.f * h_blur : 0.f); }
+                step(r2, h);
+            }
+        };
+        general(min(max_steps, 2));
+        const int fast_end = min(max_steps, n_mid_lo + 1);
+#pragma unroll 1
+        for (; k < fast_end; ++k) {
+            r2 *= inv_scal;
+            h *= scal;
+            step(r2, h);
+        }
+        general(max_steps);
+    }
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        g[2 * j] = gp[j].x;
+        g[2 * j + 1] = gp[j].y;
+    }
+    if constexpr (ODD) g[R - 1] = go;
     // ---- outputs ---------------------------------------------------------------------------------------------
     float score;
     if (a.want != ASPIRE_OT_PLAN_SIM) {
