@@ -251,7 +251,9 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 // SELF (batches of <= 64 jobs): no tables, no query boxes from a launch in front of this one -- every wave derives an item's
 // documents from job_off itself (a 64-lane scan, once) and forms the query's box per stage from the query rows it has just
 // staged (+32 min/max and 8 LDS reads per stage, against ~7 us for the extra launch in a 115 us call).
-template <bool MFMA, bool SOLVE = true, bool SELF = false>
+// L2MAX (with SOLVE = false): tsAspire on the same streaming phase -- the score is the maximum of -cdist over the valid
+// block (allpair_masked_dist_l2max, pair_distances.py:167-176); no boxes, no solve.
+template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false>
 __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -383,7 +385,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
-            if constexpr (!SELF) {
+            if constexpr (!SELF && !L2MAX) {
                 qmn = ld4(qb + dofs);
                 qmx = ld4(qb + qb_hi + dofs);
             }
@@ -405,13 +407,13 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     ny[j] = sq_acc(ny[j], vy[j]);
-                    if (j > 0) {
+                    if (j > 0 && !L2MAX) {
                         mn.x = fminf(mn.x, vy[j].x); mn.y = fminf(mn.y, vy[j].y); mn.z = fminf(mn.z, vy[j].z); mn.w = fminf(mn.w, vy[j].w);
                         mx.x = fmaxf(mx.x, vy[j].x); mx.y = fmaxf(mx.y, vy[j].y); mx.z = fmaxf(mx.z, vy[j].z); mx.w = fmaxf(mx.w, vy[j].w);
                     }
                     *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
                 }
-                if constexpr (!SELF) {
+                if constexpr (!SELF && !L2MAX) {
                     const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
                     const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
                     dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
@@ -632,6 +634,15 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             if (q_len > 8 || c_len > 8) pend.valid |= 16u;
             slice = (pend.max_steps + kStages - 1) / kStages;
             have_pend = true;
+        } else if constexpr (L2MAX) {
+            float m = kNegBig;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) m = fmaxf(m, (2 * li + x < q_len && 2 * lj + y < c_len) ? neg[x][y] : kNegBig);
+            m = max_li(max_lj(m));
+            if (q_len > 8 || c_len > 8) m = __builtin_nanf("");          // longer than the tile: never truncated silently
+            if (my_c_real && lp == 0) a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = m;
         } else if (my_c_real && lp == 0) {
             a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = diam2;
         }
@@ -651,6 +662,15 @@ bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm) {
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
     const int mq = q->max_len, mc = c->max_len;
     return q->ext == 0 && c->ext == 0 && mq > 0 && mc > 0 && mq <= 8 && mc <= 8;
+}
+
+// tsAspire (max-sim) of every (query, candidate) pair, CROSS, documents of <= 8 rows: the fused kernel's streaming phase
+int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream) {
+    const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;
+    hipLaunchKernelGGL((pair_fused_kernel<true, false, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float),
+                       stream, a, (const float*)nullptr);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
 }
 
 // groups_bound: upper bound of the launch's items (groups of four candidates x queries)

@@ -110,5 +110,6 @@ int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q
 bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm);
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
+int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream);
 
 }  // namespace aspire

@@ -140,3 +140,26 @@ def test_fused_repeated_launches_on_one_workspace(amd):
         out = torch.full((9000,), float('nan'), device='cuda')
         amd.ops.ot_sinkhorn(q, c, out=out, workspace=ws)
         assert torch.equal(out, first)
+
+
+@pytest.mark.parametrize('nq,nc', [(1, 8203), (3, 2735)])
+def test_fused_l2max_matches_the_per_candidate_kernel_and_torch(amd, nq, nc):
+    """tsAspire on the fused kernel's streaming phase (few queries x a big CSR pool of short documents): against
+    l2max_kernel<1> (pinned: OT_FORM=small) and against -min cdist of the valid block in torch; candidates that repeat a query
+    sentence give exactly 0 (torch.cdist's direct formula), ragged documents, a tail group of fewer than four candidates"""
+    cands = _pool(300 + nc, nc)
+    queries = _pool(11, nq, 2, 8)
+    cands[5] = torch.cat([queries[0][1:2], cands[5][:3]])                 # shares a sentence with query 0
+    cands[nc - 1] = queries[nq - 1].clone()                              # a copy of the last query
+    q, c = amd.ops.DeviceRepSet.from_list(queries), amd.ops.DeviceRepSet.from_list(cands)
+    dflt = amd.ops.l2max_scores(q, c).view(nq, nc).cpu().numpy()
+    with amd.pinned(OT_FORM='fused'):
+        fused = amd.ops.l2max_scores(q, c).view(nq, nc).cpu().numpy()
+    with amd.pinned(OT_FORM='small'):
+        small = amd.ops.l2max_scores(q, c).view(nq, nc).cpu().numpy()
+    assert np.array_equal(dflt, fused) and np.isfinite(fused).all()
+    np.testing.assert_allclose(fused, small, atol=4e-5, rtol=0)
+    assert fused[0, 5] == 0.0 and fused[nq - 1, nc - 1] == 0.0
+    idx = [0, 1, 5, nc // 2, nc - 2, nc - 1]
+    ref = np.array([[-torch.cdist(x, cands[i]).min().item() for i in idx] for x in queries], dtype=np.float32)
+    np.testing.assert_allclose(fused[:, idx], ref, atol=4e-5, rtol=0)
