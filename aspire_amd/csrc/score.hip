@@ -1443,34 +1443,49 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
             }
         if (my_c_real && own_diam && lp == 0) ws.diam2[slot] = diam2;
         if constexpr (R == 2 && DS == 1) {
-            // direct-formula redo, the 16 lanes of a candidate together: 48 coordinates per lane, 4-step DPP-row sum
-            const float* crow = a.c.rows + (size_t)a.c.start[c_idx] * kD + 4 * lp;
-            const float* qrow = qdoc + 4 * lp;
+            // direct-formula redo, the whole wave on one entry (12 coordinates per lane), four entries per memory round trip
+            // (see pair_fused_kernel: one entry per trip makes a wave with a duplicate document fall behind by 8 trips)
+            const int c_start_v = a.c.start[c_idx];
 #pragma unroll
             for (int x = 0; x < R; ++x)
 #pragma unroll
                 for (int y = 0; y < R; ++y) {
                     unsigned long long wm = __ballot(redo[x][y]);
-                    unsigned gm = (unsigned)(wm >> (16 * p)) & 0xFFFFu;        // flagged lanes of this candidate's group
-                    while (__any(gm != 0)) {
-                        const bool act = gm != 0;
-                        const int b16 = act ? __builtin_ctz(gm) : 0;
-                        gm &= gm - 1;
-                        const int i = R * (b16 >> 2) + x, j = R * (b16 & 3) + y;
-                        float p0 = 0.f;
-                        if (act) {
+                    while (wm != 0) {
+                        int owner[4];
+                        float4 u[4][3], v[4][3];
 #pragma unroll
-                            for (int cc = 0; cc < 12; ++cc) {
-                                const float4 u = ld4(qrow + (size_t)i * kD + 64 * cc), v = ld4(crow + (size_t)j * kD + 64 * cc);
-                                const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
-                                p0 = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, p0))));
+                        for (int e = 0; e < 4; ++e) {
+                            owner[e] = wm != 0 ? (int)__builtin_ctzll(wm) : -1;
+                            wm = wm != 0 ? wm & (wm - 1) : 0;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {            // all 24 loads go out before the first is consumed
+                            const int o = owner[e] >= 0 ? owner[e] : owner[0];
+                            const int ol = o & 15, i = R * (ol >> 2) + x, j = R * (ol & 3) + y;
+                            const int cs_e = __builtin_amdgcn_readlane(c_start_v, o);
+                            const float* qrow = qdoc + (size_t)i * kD + 4 * lane;
+                            const float* crow = a.c.rows + ((size_t)cs_e + j) * kD + 4 * lane;
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                u[e][t] = ld4(qrow + 256 * t);
+                                v[e][t] = ld4(crow + 256 * t);
                             }
                         }
-                        p0 += lane_xor<1>(p0);
-                        p0 += lane_xor<2>(p0);
-                        p0 += lane_xor<4>(p0);
-                        p0 += lane_xor<8>(p0);
-                        if (act && lp == b16) ws.neg[slot * 64 + i * 8 + j] = -sqrtf(p0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float part = 0.f;
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                const float d0 = u[e][t].x - v[e][t].x, d1 = u[e][t].y - v[e][t].y, d2 = u[e][t].z - v[e][t].z, d3 = u[e][t].w - v[e][t].w;
+                                part = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, part))));
+                            }
+                            if (owner[e] >= 0) {
+                                const float tot = wave_sum(part);
+                                const int ol = owner[e] & 15, i = R * (ol >> 2) + x, j = R * (ol & 3) + y;
+                                if (lane == owner[e]) ws.neg[slot * 64 + i * 8 + j] = -sqrtf(tot);
+                            }
+                        }
                     }
                 }
         } else {
