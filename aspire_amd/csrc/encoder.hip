@@ -188,6 +188,181 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix pipe at fp32 accuracy ("bf16x3"): every fp32 operand is split into three bf16 planes,
+// x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits, the two subtractions are
+// exact), and a product a.b is accumulated as the six terms of order >= 2^-16: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1
+// (the three dropped terms are <= 2^-24 |a||b|, fp32's own rounding).  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of
+// the fp32-input MFMA, so six of them cost 3/8 of the fp32 form's matrix-pipe time; accumulation is fp32 in both.
+// Operands are split ONCE, when a tile is staged (registers -> three bf16 planes in LDS, rows k-contiguous and padded to
+// 48 bytes so that the 16-byte fragment reads are conflict free); A [M, K] and B [N, K] both k-contiguous (nn.Linear).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// two fp32 -> the three bf16 planes, each as one packed dword (low half = first value)
+__device__ __forceinline__ void split3(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const f32x2_t v = {x, y};
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t r1 = v - f32x2_t{__builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2_t));
+    const f32x2_t r2 = r1 - f32x2_t{__builtin_bit_cast(float, p2 << 16), __builtin_bit_cast(float, p2 & 0xffff0000u)};
+    p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2_t));
+}
+
+template <int BM, int BN, int WAVES_N = 2>
+__global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
+    constexpr int kBK = 16;
+    constexpr int LDW = (kBK + 8) / 2;         // dwords per LDS row: 16 bf16 + 8 of padding = 48 bytes
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int A_F4 = BM * kBK / 4 / 256;   // float4 loads per thread per tile
+    constexpr int B_F4 = (BN * kBK / 4 + 255) / 256;
+    constexpr bool B_EXACT = BN * kBK / 4 % 256 == 0;
+    static_assert(A_F4 >= 1 && WM % 32 == 0 && WN % 32 == 0, "tile / wave layout");
+    __shared__ __attribute__((aligned(16))) uint32_t As[2][3][BM][LDW];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[2][3][BN][LDW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    uint32_t bx, by, bz;       // XCD-aware tile order, as gemm_f32_kernel
+    {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+        const uint32_t b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t x = b & 7, q8 = nb >> 3, r8 = nb & 7;
+        const uint32_t L = x * q8 + (x < r8 ? x : r8) + (b >> 3);
+        bx = L % gx;
+        by = (L / gx) % gy;
+        bz = L / (gx * gy);
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int z1 = bz / g.nz2, z2 = bz % g.nz2;
+    const float* A = g.A + z1 * g.sa1 + z2 * g.sa2;
+    const float* B = g.B + z1 * g.sb1 + z2 * g.sb2;
+    float* C = g.C + z1 * g.sc1 + z2 * g.sc2;
+
+    // Pipeline (tile t is multiplied in iteration t): global loads run TWO tiles ahead (their latency is longer than one tile's
+    // MFMAs), the split + LDS stores of tile t + 1 are threaded between the MFMAs of tile t (the matrix pipe takes 32
+    // cycles per instruction on a SIMD: ~5 VALU issue slots per MFMA are free), one barrier per tile.
+    struct Stage {
+        float4 a[A_F4], b[B_F4];
+    };
+    // (rows past M / N are clamped, not predicated: they only feed output rows / columns that are never stored, and a
+    // branch-free body lets the MFMAs and the staging arithmetic of a tile be scheduled as one block; K % 16 == 0)
+    auto load_tiles = [&](Stage& r, int k0) {
+#pragma unroll
+        for (int p = 0; p < A_F4; ++p) {
+            const int idx = tid + 256 * p, row = idx / (kBK / 4), k4 = idx % (kBK / 4);
+            r.a[p] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + row, g.M - 1) * g.lda + k0 + 4 * k4);
+        }
+#pragma unroll
+        for (int p = 0; p < B_F4; ++p) {
+            const int idx = tid + 256 * p, row = idx / (kBK / 4), k4 = idx % (kBK / 4);
+            r.b[p] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + row, g.N - 1) * g.ldb + k0 + 4 * k4);
+        }
+    };
+    auto store_tiles = [&](const Stage& r, int buf) {
+#pragma unroll
+        for (int p = 0; p < A_F4; ++p) {
+            const int idx = tid + 256 * p, row = idx / (kBK / 4), k4 = idx % (kBK / 4);
+            uint32_t a1, a2, a3, b1, b2, b3;
+            split3(r.a[p].x, r.a[p].y, a1, a2, a3);
+            split3(r.a[p].z, r.a[p].w, b1, b2, b3);
+            *reinterpret_cast<uint2*>(&As[buf][0][row][2 * k4]) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(&As[buf][1][row][2 * k4]) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(&As[buf][2][row][2 * k4]) = make_uint2(a3, b3);
+        }
+#pragma unroll
+        for (int p = 0; p < B_F4; ++p) {
+            const int idx = tid + 256 * p, row = idx / (kBK / 4), k4 = idx % (kBK / 4);
+            if (B_EXACT || row < BN) {
+                uint32_t a1, a2, a3, b1, b2, b3;
+                split3(r.b[p].x, r.b[p].y, a1, a2, a3);
+                split3(r.b[p].z, r.b[p].w, b1, b2, b3);
+                *reinterpret_cast<uint2*>(&Bs[buf][0][row][2 * k4]) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(&Bs[buf][1][row][2 * k4]) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2*>(&Bs[buf][2][row][2 * k4]) = make_uint2(a3, b3);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (g.K + kBK - 1) / kBK;
+    const int lr = lane & 31, lk = lane >> 5;
+    Stage st0, st1;
+    load_tiles(st0, 0);
+    store_tiles(st0, 0);
+    load_tiles(st0, min(1, nk - 1) * kBK);       // tile 1 -> st0, tile 2 -> st1, tile 3 -> st0, ...
+    __syncthreads();
+    auto tile_step = [&](int t, Stage& cur, Stage& nxt) {
+        // cur holds tile t + 1 (loaded one iteration ago); tile t + 2 goes into nxt
+        const int buf = t & 1;
+        load_tiles(nxt, min(t + 2, nk - 1) * kBK);        // (past the end: the last tile again, unused)
+        // fragments: lane = (row lr, k half lk): eight consecutive k of one row = one 16-byte read per plane; A and B use
+        // the same (lane half, element) -> k map, which is all the instruction's sum over k needs
+        bf16x8_t af[TM][3], bfr[TN][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&As[buf][pl][wr * WM + 32 * i + lr][4 * lk]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bs[buf][pl][wc * WN + 32 * j + lr][4 * lk]));
+        }
+        store_tiles(cur, buf ^ 1);                        // (after the last tile: into the idle buffer, unread)
+        // the six products, smallest terms first; the TM x TN accumulators take turns inside each term
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[term]], bfr[j][PB[term]], acc[i][j], 0, 0, 0);
+        // issue order: one MFMA, then the VALU / LDS-store work that fits its shadow
+        __builtin_amdgcn_sched_group_barrier(0x020, A_F4 + B_F4, 0);      // the global loads first: they have two tiles to land
+#pragma unroll
+        for (int m = 0; m < 6 * TM * TN; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __syncthreads();
+    };
+    for (int t = 0; t < nk; t += 2) {
+        tile_step(t, st0, st1);
+        if (t + 1 < nk) tile_step(t + 1, st1, st0);
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * WN + 32 * j + lr;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] * g.alpha + bv;
+                if (g.gelu) v = gelu_erf(v);
+                if (g.res) v += g.res[(size_t)m * g.ldr + n];
+                C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+}
+
 // One wave per row of 768: lane holds 3 float4 (d = 4*lane + 256*c).
 __device__ __forceinline__ void layernorm_row(float4 (&v)[3], const float* gamma, const float* beta, float eps,
                                               float* out, int lane) {
@@ -450,6 +625,22 @@ int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     // resident workgroups where 128-column tiles leave half a round idle (QKV, N = 2304: 1152 -> 1536 workgroups).
     const long long b12896 = (long long)((g.M + 127) / 128) * (g.N / 96) * batch;
     const bool force96 = tuning().gemm_tile96 && g.N % 96 == 0;   // tuning only
+    // nn.Linear shapes (both operands k-contiguous, K a multiple of the 16-wide bf16 MFMA step): the bf16x3 form
+    if constexpr (!B_KN) {
+        if (tuning().gemm_form == 2 && g.K % 16 == 0) {
+            if (g.N % 96 == 0 && (force96 || (b12896 >= 768 && gemm_rounds_waste(b12896) + 0.05 < gemm_rounds_waste(b128)))) {
+                hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 96, 1>), dim3(g.N / 96, (g.M + 127) / 128, batch), dim3(256), 0, st, g);
+            } else if (b128 >= 512 && g.N >= 128) {
+                hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128>), dim3((g.N + 127) / 128, (g.M + 127) / 128, batch), dim3(256), 0, st, g);
+            } else if (b12864 >= 512) {
+                hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 64>), dim3((g.N + 63) / 64, (g.M + 127) / 128, batch), dim3(256), 0, st, g);
+            } else {
+                hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64>), dim3((g.N + 63) / 64, (g.M + 63) / 64, batch), dim3(256), 0, st, g);
+            }
+            ASPIRE_LAUNCH_OK();
+            return ASPIRE_OK;
+        }
+    }
     if (!B_KN && g.N % 96 == 0 && (force96 || (b12896 >= 768 && gemm_rounds_waste(b12896) + 0.05 < gemm_rounds_waste(b128)))) {
         dim3 grid(g.N / 96, (g.M + 127) / 128, batch);
         hipLaunchKernelGGL((gemm_f32_kernel<128, 96, 16, false, 1>), grid, dim3(256), 0, st, g);

@@ -31,6 +31,10 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "ATTN")) {
         if (!unset && strcmp(v, "gemm")) return false;
         t.attn_gemm = unset ? 0 : 1;
+    } else if (!strcmp(key, "GEMM")) {
+        const int f = unset ? 0 : !strcmp(v, "f32") ? 1 : !strcmp(v, "bf16x3") ? 2 : -1;
+        if (f < 0) return false;
+        t.gemm_form = f;
     } else if (!strcmp(key, "GEMM_TILE")) {
         if (!unset && strcmp(v, "96")) return false;
         t.gemm_tile96 = unset ? 0 : 1;
@@ -53,7 +57,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

@@ -10,6 +10,7 @@ struct Tuning {
     int cost_path = 0;       // ASPIRE_HIP_COST_PATH: 0 by shape, 1 mfma (Gram kernel), 2 valu
     int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
+    int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default, 1 f32 = fp32-input MFMA, 2 bf16x3 = three-way bf16 split on the bf16 matrix pipe
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
     int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
                              // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch

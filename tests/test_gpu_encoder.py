@@ -122,3 +122,33 @@ def test_readme_example_shapes(tmp_path, golden_dir):
     sims, extras = AllPairMaskedWasserstein({}).compute_distance(q, c, return_pair_sims=True)
     assert sims.shape == (1,) and extras[3].shape == (1, sent.shape[1], sent.shape[1])
     assert np.isfinite(sims.numpy()).all()
+
+
+def test_gemm_bf16x3_form_is_fp32_accurate():
+    """the three-way bf16 split on the bf16 matrix pipe against float64 and against the fp32-input MFMA form: same error
+    level (the dropped cross terms are 2^-24 relative); odd M / N edges, bias; asymmetric operands (a transposed or
+    mis-paired fragment cannot pass)"""
+    import ctypes
+    from aspire_amd import _lib
+    f = _lib.lib.aspire_debug_gemm_f32
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    g = torch.Generator().manual_seed(5)
+    for M, N, K in ((8192, 2304, 768), (1000, 768, 3072), (130, 70, 768), (4096, 3072, 768)):
+        A = (torch.randn(M, K, generator=g) * torch.linspace(0.1, 3.0, K)).cuda()
+        B = (torch.randn(N, K, generator=g) + 0.5).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        ref = A[:256].double() @ B.double().T + bias.double()
+        out = {}
+        for form in ('f32', 'bf16x3'):
+            C = torch.empty(M, N, device='cuda')
+            with _lib.pinned(GEMM=form):
+                assert f(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K,
+                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+            torch.cuda.synchronize()
+            out[form] = C
+        e32 = (out['f32'][:256].double() - ref).abs().max().item()
+        e3 = (out['bf16x3'][:256].double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert e3 <= max(2.0 * e32, 3e-7 * scale), (M, N, K, e32, e3, scale)
+        assert (out['f32'] - out['bf16x3']).abs().max().item() <= 4e-6 * scale

@@ -16,19 +16,23 @@ def main():
     torch.cuda.synchronize()
     for M, N, K in shapes:
         A = torch.randn(M, K, device='cuda'); B = torch.randn(N, K, device='cuda'); C = torch.empty(M, N, device='cuda')
+        ref = (A[:64].double() @ B.double().T)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         run = lambda: f(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, st)
-        for _ in range(3): assert run() == 0
-        torch.cuda.synchronize()
-        n, us = 20, 1e30
-        for _ in range(3):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(n): run()
-            b.record(); torch.cuda.synchronize()
-            us = min(us, a.elapsed_time(b) / n * 1e3)
-        err = (C[:64] - A[:64] @ B.T).abs().max().item()
-        print(f'M={M} N={N} K={K}: {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}%)  max|err| vs torch {err:.2e}')
+        for form in ('f32', 'bf16x3'):
+            with _lib.pinned(GEMM=form):
+                for _ in range(3): assert run() == 0
+                torch.cuda.synchronize()
+                n, us = 20, 1e30
+                for _ in range(3):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(n): run()
+                    b.record(); torch.cuda.synchronize()
+                    us = min(us, a.elapsed_time(b) / n * 1e3)
+            err = (C[:64].double() - ref).abs().max().item()
+            print(f'M={M} N={N} K={K} {form:7s}: {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}% of the fp32-MFMA peak)  '
+                  f'max|err| vs float64 {err:.2e}', flush=True)
 
 if __name__ == '__main__':
     main()
