@@ -36,8 +36,10 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         if (f < 0) return false;
         t.gemm_form = f;
     } else if (!strcmp(key, "GEMM_TILE")) {
-        if (!unset && strcmp(v, "96")) return false;
-        t.gemm_tile96 = unset ? 0 : 1;
+        const int f = unset ? 0 : atoi(v);
+        if (f != 0 && f != 96 && f != 128 && f != 64) return false;
+        t.gemm_tile96 = f == 96;
+        t.gemm_tile = f;
     } else if (!strcmp(key, "FUSED_VALU")) {
         t.fused_valu = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {

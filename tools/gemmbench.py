@@ -19,8 +19,10 @@ def main():
         ref = (A[:64].double() @ B.double().T)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         run = lambda: f(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, st)
-        for form in ('f32', 'bf16x3'):
-            with _lib.pinned(GEMM=form):
+        for form, tile in (('f32', ''), ('bf16x3', ''), ('bf16x3', '128'), ('bf16x3', '96'), ('bf16x3', '64')):
+            if tile == '96' and N % 96:
+                continue
+            with _lib.pinned(GEMM=form, GEMM_TILE=tile):
                 for _ in range(3): assert run() == 0
                 torch.cuda.synchronize()
                 n, us = 20, 1e30
@@ -31,7 +33,7 @@ def main():
                     b.record(); torch.cuda.synchronize()
                     us = min(us, a.elapsed_time(b) / n * 1e3)
             err = (C[:64].double() - ref).abs().max().item()
-            print(f'M={M} N={N} K={K} {form:7s}: {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}% of the fp32-MFMA peak)  '
+            print(f'M={M} N={N} K={K} {form:7s} tile {tile or "auto":4s}: {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}% of the fp32-MFMA peak)  '
                   f'max|err| vs float64 {err:.2e}', flush=True)
 
 if __name__ == '__main__':
