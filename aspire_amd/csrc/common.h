@@ -166,6 +166,20 @@ __device__ __forceinline__ float col8_sum(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return col8_sum(row8_sum(v)); }
 __device__ __forceinline__ float wave_max(float v) { return col8_max(row8_max(v)); }
+
+// fp32 -> three bf16 planes, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (24 mantissa bits;
+// both subtractions are exact): two values at a time, each plane as one packed dword (low half = first value).  The operand
+// split of the bf16x3 matrix products (encoder.hip: gemm_bf16x3_kernel, gram.hip: pair_gram_kernel<..., X3>).
+__device__ __forceinline__ void split3_bf16(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {x, y};
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+    const f2 r1 = v - f2{__builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf2));
+    const f2 r2 = r1 - f2{__builtin_bit_cast(float, p2 << 16), __builtin_bit_cast(float, p2 & 0xffff0000u)};
+    p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf2));
+}
 #endif  // __HIPCC__
 
 }  // namespace aspire

@@ -201,19 +201,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 // Operands are split ONCE, when a tile is staged (registers -> three bf16 planes in LDS, rows k-contiguous and padded to
 // 48 bytes so that the 16-byte fragment reads are conflict free); A [M, K] and B [N, K] both k-contiguous (nn.Linear).
 // ---------------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// two fp32 -> the three bf16 planes, each as one packed dword (low half = first value)
-__device__ __forceinline__ void split3(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    const f32x2_t v = {x, y};
-    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-    const f32x2_t r1 = v - f32x2_t{__builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
-    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2_t));
-    const f32x2_t r2 = r1 - f32x2_t{__builtin_bit_cast(float, p2 << 16), __builtin_bit_cast(float, p2 & 0xffff0000u)};
-    p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2_t));
-}
 
 template <int BM, int BN, int WAVES_N = 2>
 __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
@@ -271,8 +259,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
         for (int p = 0; p < A_F4; ++p) {
             const int idx = tid + 256 * p, row = idx / (kBK / 4), k4 = idx % (kBK / 4);
             uint32_t a1, a2, a3, b1, b2, b3;
-            split3(r.a[p].x, r.a[p].y, a1, a2, a3);
-            split3(r.a[p].z, r.a[p].w, b1, b2, b3);
+            split3_bf16(r.a[p].x, r.a[p].y, a1, a2, a3);
+            split3_bf16(r.a[p].z, r.a[p].w, b1, b2, b3);
             *reinterpret_cast<uint2*>(&As[buf][0][row][2 * k4]) = make_uint2(a1, b1);
             *reinterpret_cast<uint2*>(&As[buf][1][row][2 * k4]) = make_uint2(a2, b2);
             *reinterpret_cast<uint2*>(&As[buf][2][row][2 * k4]) = make_uint2(a3, b3);
@@ -282,8 +270,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
             const int idx = tid + 256 * p, row = idx / (kBK / 4), k4 = idx % (kBK / 4);
             if (B_EXACT || row < BN) {
                 uint32_t a1, a2, a3, b1, b2, b3;
-                split3(r.b[p].x, r.b[p].y, a1, a2, a3);
-                split3(r.b[p].z, r.b[p].w, b1, b2, b3);
+                split3_bf16(r.b[p].x, r.b[p].y, a1, a2, a3);
+                split3_bf16(r.b[p].z, r.b[p].w, b1, b2, b3);
                 *reinterpret_cast<uint2*>(&Bs[buf][0][row][2 * k4]) = make_uint2(a1, b1);
                 *reinterpret_cast<uint2*>(&Bs[buf][1][row][2 * k4]) = make_uint2(a2, b2);
                 *reinterpret_cast<uint2*>(&Bs[buf][2][row][2 * k4]) = make_uint2(a3, b3);

@@ -35,6 +35,7 @@ namespace aspire {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int kBM = 128;   // candidate rows per tile
 constexpr int kBK = 16;    // coordinates per LDS stage
@@ -101,17 +102,27 @@ __device__ __noinline__ float direct_d2(unsigned long long x, unsigned long long
 // Two workgroups per CU for every form: at three (168 registers) the 32- / 64-column forms spilled 80 / 144 bytes; without
 // spills (178 / 194 registers) 1 x 20 000 x 12 is 8 % slower (371 vs 340 us) and 2 x 10 000 x 12 4 - 20 % faster (240 vs 248 us
 // otAspire, 103 vs 126 us max-sim).
-template <int BN, bool L2MAX, bool BOX>
+// X3 (the 128-column forms): the Gram tile on the bf16 matrix pipe at fp32 accuracy -- operands split into three bf16 planes
+// when a tile is staged, six v_mfma_f32_32x32x16_bf16 products per term (see gemm_bf16x3_kernel in encoder.hip: same error
+// against float64 as the fp32-input MFMA at 3/8 of its matrix-pipe time).
+template <int BN, bool L2MAX, bool BOX, bool X3 = false>
 __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     static_assert(!BOX || (!L2MAX && BN <= 64), "the fused diameter serves the few-query otAspire tiles");
+    static_assert(!X3 || (BN == 128 && !BOX), "the bf16x3 form is built for the 128-column tiles");
     constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int WM = kBM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int LDA = kBM + 4, LDB = BN + 4;
     constexpr int A_F4 = kBM * kBK / 4 / 256;                        // 2
     constexpr int B_F4 = (BN * kBK / 4 + 255) / 256;                 // 2, 1, 1 (half the threads at BN = 32)
     constexpr bool B_ALL = BN * kBK / 4 >= 256;
-    __shared__ __attribute__((aligned(16))) float As[2][kBK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][kBK][LDB];
+    constexpr int kLdw = (kBK + 8) / 2;                               // X3: dwords per LDS row (16 bf16 + 8 of padding = 48 bytes)
+    constexpr int A_WORDS = X3 ? 2 * 3 * kBM * kLdw : 2 * kBK * LDA, B_WORDS = X3 ? 2 * 3 * BN * kLdw : 2 * kBK * LDB;
+    __shared__ __attribute__((aligned(16))) uint32_t As_raw[A_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs_raw[B_WORDS];
+    float (*As)[kBK][LDA] = reinterpret_cast<float (*)[kBK][LDA]>(As_raw);             // fp32 form: [buf][k][row]
+    float (*Bs)[kBK][LDB] = reinterpret_cast<float (*)[kBK][LDB]>(Bs_raw);
+    uint32_t (*As3)[3][kBM][kLdw] = reinterpret_cast<uint32_t (*)[3][kBM][kLdw]>(As_raw);   // X3: [buf][plane][row][k pairs]
+    uint32_t (*Bs3)[3][BN][kLdw] = reinterpret_cast<uint32_t (*)[3][BN][kLdw]>(Bs_raw);
     __shared__ unsigned long long c_ptr[kBM];   // global addresses of the tile's rows (zero row where there is none)
     __shared__ unsigned long long q_ptr[BN];
     __shared__ long long c_off[kBM];
@@ -195,6 +206,29 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
         for (int p = 0; p < B_F4; ++p) rb[S][p] = ldg4(pb[p], k0 + 4 * lk4);
     };
     // one float4 piece (A piece p < A_F4, B piece p - A_F4 otherwise) of a register set -> LDS, k-major
+    auto split_store = [&](uint32_t (*dst)[kLdw], uint32_t (*dst1)[kLdw], uint32_t (*dst2)[kLdw], int row, const float4& v) {
+        uint32_t a1, a2, a3, b1, b2, b3;
+        split3_bf16(v.x, v.y, a1, a2, a3);
+        split3_bf16(v.z, v.w, b1, b2, b3);
+        *reinterpret_cast<uint2*>(&dst[row][2 * lk4]) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(&dst1[row][2 * lk4]) = make_uint2(a2, b2);
+        *reinterpret_cast<uint2*>(&dst2[row][2 * lk4]) = make_uint2(a3, b3);
+    };
+    // X3: one register set -> the three bf16 planes of LDS buffer `buf`; `count` = 1.f the first time a tile is stored
+    // (its squared norms are accumulated), 0.f for the unread repeat after the last tile
+    auto store_set3 = [&](auto setc, int buf, float count) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int p = 0; p < A_F4; ++p) {
+            split_store(As3[buf][0], As3[buf][1], As3[buf][2], lrow + 64 * p, ra[S][p]);
+            na[p] = fmaf(count, sq4f(ra[S][p]), na[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < B_F4; ++p) {
+            split_store(Bs3[buf][0], Bs3[buf][1], Bs3[buf][2], lrow + 64 * p, rb[S][p]);
+            nb[p] = fmaf(count, sq4f(rb[S][p]), nb[p]);
+        }
+    };
     auto store_piece = [&](auto setc, int piece, int buf) {
         constexpr int S = decltype(setc)::value;
         if (piece < A_F4) {
@@ -304,6 +338,39 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // X3: one tile = 12 fragment reads (lane = row lr, k half lk: eight consecutive k of a row per plane; A and B use the same
+    // (lane half, element) -> k map) and 6 x TM x TN MFMAs, smallest terms first, the accumulators taking turns inside a term;
+    // the next-but-one tile's loads go out first, the split + LDS stores of the next tile ride in the MFMAs' shadow.  The
+    // body is branch free (past the end the last tile is loaded / stored again, unread) so that it schedules as one block.
+    auto tile_step3 = [&](auto load_set, auto store_set, int buf, int k_load, float count) {
+        load_tiles(load_set, k_load);
+        bf16x8_t af[TM][3], bfr[TN][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&As3[buf][pl][wr * WM + 32 * i + lr][4 * lk]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bs3[buf][pl][wc * WN + 32 * j + lr][4 * lk]));
+        }
+        store_set3(store_set, buf ^ 1, count);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[term]], bfr[j][PB[term]], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, A_F4 + B_F4, 0);
+#pragma unroll
+        for (int m = 0; m < 6 * TM * TN; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     constexpr int nk = kD / kBK;
@@ -311,6 +378,19 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     static_assert(A_F4 + B_F4 <= 4, "four store slots per tile step");
     load_tiles(S0{}, 0);
     load_tiles(S1{}, kBK);
+    if constexpr (X3) {
+        store_set3(S0{}, 0, 1.f);
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < nk; t += 2) {
+            // LDS buffer 0 = tile t, set 1 = tile t+1 (stored into buffer 1 here), set 0 free (tile t+2 loads into it)
+            tile_step3(S0{}, S1{}, 0, min(t + 2, nk - 1) * kBK, 1.f);
+            __syncthreads();
+            // LDS buffer 1 = tile t+1, set 0 = tile t+2, set 1 free
+            tile_step3(S1{}, S0{}, 1, min(t + 3, nk - 1) * kBK, t + 2 < nk ? 1.f : 0.f);
+            __syncthreads();
+        }
+    } else {
 #pragma unroll
     for (int piece = 0; piece < A_F4 + B_F4; ++piece) store_piece(S0{}, piece, 0);
     __syncthreads();
@@ -322,6 +402,7 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
         // LDS buffer 1 = tile t+1, set 0 = tile t+2, set 1 free
         tile_step(S1{}, S0{}, 1, t + 3 < nk, (t + 3) * kBK, t + 2 < nk, (t + 1) * kBK);
         __syncthreads();
+    }
     }
 
     if constexpr (BOX) {
@@ -359,8 +440,8 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     // recomputed afterwards by WHOLE WAVES, one entry at a time, 12 coordinates per lane.  A lane-local recompute
     // would serialise 768 coordinates per flagged entry while its 63 wave mates wait: with real sentence vectors,
     // where a few percent of the pairs are that close, that was several times the cost of the tile's MFMAs.
-    uint32_t* wlist = reinterpret_cast<uint32_t*>(&As[0][0][0]);
-    constexpr int kCap = 2 * kBK * LDA;                                 // (row << 16 | column) entries in As's footprint
+    uint32_t* wlist = As_raw;
+    constexpr int kCap = A_WORDS;                                 // (row << 16 | column) entries in As's footprint
     __shared__ uint32_t wl_count;
     if (tid == 0) wl_count = 0;
     __syncthreads();
@@ -557,13 +638,15 @@ int launch_gram(const GramArgs& g, int bn, hipStream_t stream) {
     if constexpr (L2MAX) {
         if (bn == 32) hipLaunchKernelGGL((pair_gram_kernel<32, true, false>), grid, dim3(256), 0, stream, g);
         else if (bn == 64) hipLaunchKernelGGL((pair_gram_kernel<64, true, false>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((pair_gram_kernel<128, true, false>), grid, dim3(256), 0, stream, g);
+        else if (tuning().gemm_form == 1) hipLaunchKernelGGL((pair_gram_kernel<128, true, false>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((pair_gram_kernel<128, true, false, true>), grid, dim3(256), 0, stream, g);
     } else {
         if (bn == 32 && box) hipLaunchKernelGGL((pair_gram_kernel<32, false, true>), grid, dim3(256), 0, stream, g);
         else if (bn == 32) hipLaunchKernelGGL((pair_gram_kernel<32, false, false>), grid, dim3(256), 0, stream, g);
         else if (bn == 64 && box) hipLaunchKernelGGL((pair_gram_kernel<64, false, true>), grid, dim3(256), 0, stream, g);
         else if (bn == 64) hipLaunchKernelGGL((pair_gram_kernel<64, false, false>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((pair_gram_kernel<128, false, false>), grid, dim3(256), 0, stream, g);
+        else if (tuning().gemm_form == 1) hipLaunchKernelGGL((pair_gram_kernel<128, false, false>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((pair_gram_kernel<128, false, false, true>), grid, dim3(256), 0, stream, g);
     }
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
