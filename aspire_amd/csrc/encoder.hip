@@ -198,23 +198,24 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 // exact), and a product a.b is accumulated as the six terms of order >= 2^-16: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1
 // (the three dropped terms are <= 2^-24 |a||b|, fp32's own rounding).  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of
 // the fp32-input MFMA, so six of them cost 3/8 of the fp32 form's matrix-pipe time; accumulation is fp32 in both.
-// Operands are split ONCE, when a tile is staged (registers -> three bf16 planes in LDS, rows k-contiguous and padded to
-// 48 bytes so that the 16-byte fragment reads are conflict free); A [M, K] and B [N, K] both k-contiguous (nn.Linear).
+// Operands are split ONCE, when a tile is staged (registers -> three bf16 planes in LDS, each plane as two k halves of
+// [row][8 bf16]: the 16-byte fragment reads are conflict free); A [M, K] and B [N, K] both k-contiguous (nn.Linear).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 template <int BM, int BN, int WAVES_N = 2>
 __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int kBK = 16;
-    constexpr int LDW = (kBK + 8) / 2;         // dwords per LDS row: 16 bf16 + 8 of padding = 48 bytes
     constexpr int WAVES_M = 4 / WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * kBK / 4 / 256;   // float4 loads per thread per tile
     constexpr int B_F4 = (BN * kBK / 4 + 255) / 256;
     constexpr bool B_EXACT = BN * kBK / 4 % 256 == 0;
     static_assert(A_F4 >= 1 && WM % 32 == 0 && WN % 32 == 0, "tile / wave layout");
-    __shared__ __attribute__((aligned(16))) uint32_t As[2][3][BM][LDW];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[2][3][BN][LDW];
+    // [buffer][plane][k half][row][8 bf16]: a fragment read (lane = row, k half) walks 512 contiguous bytes per half-wave
+    // -- conflict free without padding (32 bytes of LDS per row and plane: three workgroups fit a CU)
+    __shared__ __attribute__((aligned(16))) uint32_t As[2][3][2][BM][4];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[2][3][2][BN][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
@@ -261,9 +262,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
             uint32_t a1, a2, a3, b1, b2, b3;
             split3_bf16(r.a[p].x, r.a[p].y, a1, a2, a3);
             split3_bf16(r.a[p].z, r.a[p].w, b1, b2, b3);
-            *reinterpret_cast<uint2*>(&As[buf][0][row][2 * k4]) = make_uint2(a1, b1);
-            *reinterpret_cast<uint2*>(&As[buf][1][row][2 * k4]) = make_uint2(a2, b2);
-            *reinterpret_cast<uint2*>(&As[buf][2][row][2 * k4]) = make_uint2(a3, b3);
+            *reinterpret_cast<uint2*>(&As[buf][0][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(&As[buf][1][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(&As[buf][2][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a3, b3);
         }
 #pragma unroll
         for (int p = 0; p < B_F4; ++p) {
@@ -272,9 +273,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
                 uint32_t a1, a2, a3, b1, b2, b3;
                 split3_bf16(r.b[p].x, r.b[p].y, a1, a2, a3);
                 split3_bf16(r.b[p].z, r.b[p].w, b1, b2, b3);
-                *reinterpret_cast<uint2*>(&Bs[buf][0][row][2 * k4]) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2*>(&Bs[buf][1][row][2 * k4]) = make_uint2(a2, b2);
-                *reinterpret_cast<uint2*>(&Bs[buf][2][row][2 * k4]) = make_uint2(a3, b3);
+                *reinterpret_cast<uint2*>(&Bs[buf][0][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(&Bs[buf][1][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2*>(&Bs[buf][2][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a3, b3);
             }
         }
     };
@@ -305,10 +306,10 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&As[buf][pl][wr * WM + 32 * i + lr][4 * lk]));
+                af[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&As[buf][pl][lk][wr * WM + 32 * i + lr][0]));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bs[buf][pl][wc * WN + 32 * j + lr][4 * lk]));
+                bfr[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bs[buf][pl][lk][wc * WN + 32 * j + lr][0]));
         }
         store_tiles(cur, buf ^ 1);                        // (after the last tile: into the idle buffer, unread)
         // the six products, smallest terms first; the TM x TN accumulators take turns inside each term
