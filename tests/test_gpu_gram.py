@@ -114,6 +114,31 @@ def test_gram_matches_valu_at_size(amd, nq, nc, s):
         assert np.array_equal(dflt[k], out['mfma'][k]) or np.array_equal(dflt[k], out['valu'][k])
 
 
+def test_gram_bf16x3_and_fp32_input_forms_agree(amd):
+    """the 128-column Gram tiles on the bf16 matrix pipe (three-way operand split, six products: the default) against the
+    same tiles on the fp32-input MFMA (pinned GEMM=f32): max-sim to 2e-5 (both are fp32-accurate expansions), otAspire to
+    5e-5, and both against -min cdist in float64 on a sample"""
+    from aspire_amd._lib import pinned
+    nq, nc, s = 32, 4000, 8
+    g = torch.Generator().manual_seed(77)
+    qrows = (torch.randn(nq * s, 768, generator=g) * torch.linspace(0.3, 2.0, 768)).cuda()
+    crows = (torch.randn(nc * s, 768, generator=g) + 0.25).cuda()
+    mk = lambda rows, n: amd.ops.DeviceRepSet(rows, (torch.arange(n, device='cuda', dtype=torch.int32) * s).contiguous(),
+                                              torch.full((n,), s, device='cuda', dtype=torch.int32), ext=0, max_len=s)
+    q, c = mk(qrows, nq), mk(crows, nc)
+    out = {}
+    for form in ('bf16x3', 'f32'):
+        with pinned(COST_PATH='mfma', GEMM=form):
+            out[form] = (amd.ops.l2max_scores(q, c).view(nq, nc).cpu().numpy(), amd.ops.ot_sinkhorn(q, c).view(nq, nc).cpu().numpy())
+    np.testing.assert_allclose(out['bf16x3'][0], out['f32'][0], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out['bf16x3'][1], out['f32'][1], atol=5e-5, rtol=0)
+    qd, cd = qrows.double().cpu().view(nq, s, 768), crows.double().cpu().view(nc, s, 768)
+    for qi, ci in ((0, 0), (5, 123), (31, 3999), (17, 2048)):
+        want = -torch.cdist(qd[qi], cd[ci]).min().item()
+        for form in out:
+            assert abs(out[form][0][qi, ci] - want) < 3e-5, (form, qi, ci)
+
+
 def test_gram_workspace_chunking(amd):
     """A workspace smaller than the pool's slots + boxes: candidates run in chunks, results unchanged."""
     q, c = _docs(41, [8] * 6), _docs(42, [8] * 300)
