@@ -12,14 +12,16 @@
 //
 // Work decomposition (gfx950, wave = 64 lanes), documents of <= 8 sentence rows, CSR inputs:
 //   * item = four consecutive candidates of ONE query (groups never straddle two jobs of a batch); a wave owns an item and
-//     walks the items with a static stride.  (Claiming items dynamically -- one atomicAdd on a shared counter per item --
-//     was measured and dropped: 2048 waves finishing an item together queue 2048 same-address atomics, ~40 us per round;
-//     and it buys nothing here: the kernel is bandwidth bound, so a last partial round of fewer waves simply runs each
-//     of them faster.)
-//   * cost phase = pair_tile_kernel<2,1> of score.hip: 16 lanes per candidate, lane (li, lj) owns the 2 x 2 entries
-//     (2 li + x, 2 lj + y) and walks all 768 coordinates itself; rows are staged 64 coordinates at a time (coalesced
-//     global_load_dwordx4 -> ds_write_b128 -> conflict-free broadcast ds_read_b128), next stage's loads in flight under
-//     this stage's arithmetic; row norms and the bounding-box term (geomloss's diameter) fall out of the staging.
+//     walks the items with a static stride (SELF: a run of consecutive items).  (Claiming items dynamically -- one atomicAdd
+//     on a shared counter per item -- was measured and dropped: 2048 waves finishing an item together queue 2048
+//     same-address atomics, ~40 us per round; and it buys nothing here: the kernel is bandwidth bound, so a last partial
+//     round of fewer waves simply runs each of them faster.)
+//   * cost phase: 16 lanes per candidate stage its 8 rows 64 coordinates at a time (coalesced global_load_dwordx4 ->
+//     ds_write_b128 into padded rows), the row norms and the bounding-box term (geomloss's diameter) fall out of the
+//     registers before they go to LDS, the NEXT stage's loads then go out into the same registers; the dot products run on
+//     the matrix pipe (v_mfma_f32_4x4x1: 16 blocks of 4 x 4 = the 64 entries of each of the wave's four pairs; conflict-free
+//     ds_read_b128 operands) and are transposed through LDS into the solve's layout: lane (li, lj) of a candidate's 16
+//     lanes owns the 2 x 2 entries (2 li + x, 2 lj + y).
 //   * solve phase: the same 16 lanes x (2 x 2) layout IS a Sinkhorn layout: row sums are two quad_perm DPP adds, column sums
 //     two row_ror DPP adds, both inside a DPP row of 16 lanes; four solves per wave, every pair on its own epsilon schedule
 //     (the loop runs to the longest of the four, finished pairs idle with h = 0).  One exponential per entry and step,
@@ -70,7 +72,7 @@ __device__ __forceinline__ float sum16(float v) { return sum_li(sum_lj(v)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The Sinkhorn solve of the four pairs of a wave as a resumable state machine.  A solve is ~80 dependent epsilon steps of
-// ~50 instructions each -- latency bound for a lone wave (two resident per SIMD here), ~18 us per item when run in one
+// 31 issue slots each -- latency bound for a lone wave (two resident per SIMD here), ~8 us per item when run in one
 // piece.  So the solve of item i is cut into slices that run INSIDE the cost stages of item i + 1, each slice in the
 // shadow of that stage's HBM loads: the wave was going to wait there anyway.
 // ---------------------------------------------------------------------------------------------------------------------

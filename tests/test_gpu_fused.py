@@ -1,5 +1,5 @@
-"""The fused otAspire kernel (fused.hip: costs + Sinkhorn solves of four pairs per wave in one launch, items claimed
-dynamically) against the oracle and against the two-kernel forms, for single big pools (CROSS) and batched jobs."""
+"""The fused otAspire kernel (fused.hip: costs + Sinkhorn solves of four pairs per wave in one launch) against the oracle
+and against the two-kernel forms, for single big pools (CROSS) and batched jobs; its max-sim (tsAspire) form."""
 import numpy as np
 import pytest
 import torch
