@@ -255,8 +255,11 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 // staged (+32 min/max and 8 LDS reads per stage, against ~7 us for the extra launch in a 115 us call).
 // L2MAX (with SOLVE = false): tsAspire on the same streaming phase -- the score is the maximum of -cdist over the valid
 // block (allpair_masked_dist_l2max, pair_distances.py:167-176); no boxes, no solve.
-template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false>
+// QBOX (one query against a big pool): the in-wave query box of SELF without its tables -- every item has the same query, so
+// the box is formed during a wave's first item and read from the LDS cache afterwards; no doc_box launch in front.
+template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false, bool QBOX = false>
 __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
+    constexpr bool INBOX = SELF || QBOX;        // the query's box comes from the staged query rows
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         item_end = item_first + base + (w < rem ? 1u : 0u);
         item_step = 1;
     }
-    float* qcache = lds_all + 4 * kWaveLds + wave * 2 * kD;      // SELF: [2][768] box of query cached_q
+    float* qcache = lds_all + 4 * kWaveLds + wave * 2 * kD;      // INBOX: [2][768] box of query cached_q
     int64_t cached_q = -1;
     Ctx next = load_ctx(item_first < item_end ? item_first : item_lo);
 
@@ -368,9 +371,9 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         // unused) -- the loads stay UNCONDITIONAL: a branch around them makes the compiler wait for the just-issued row
         // loads at the join (a register copy of the conditionally defined value), which serialises every stage's HBM
         // latency with its arithmetic (measured: 160 instead of 110 us for the cost phase of 20 x 1000 pairs)
-        const bool have_box = SELF && q_idx == cached_q;       // wave-uniform
-        const float* qb = (own_diam && !SELF) ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
-        const int qb_hi = (own_diam && !SELF) ? kD : 0;
+        const bool have_box = INBOX && q_idx == cached_q;       // wave-uniform
+        const float* qb = (own_diam && !INBOX) ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
+        const int qb_hi = (own_diam && !INBOX) ? kD : 0;
 
         float accg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         mfma4_t macc[4];
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
-            if constexpr (!SELF && !L2MAX) {
+            if constexpr (!INBOX && !L2MAX) {
                 qmn = ld4(qb + dofs);
                 qmx = ld4(qb + qb_hi + dofs);
             }
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                     }
                     *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
                 }
-                if constexpr (!SELF && !L2MAX) {
+                if constexpr (!INBOX && !L2MAX) {
                     const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
                     const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
                     dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
@@ -427,7 +430,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                 }
             }
             // pin the side products HERE (the optimiser otherwise sinks these loop-carried sums below the loads)
-            if constexpr (SELF)
+            if constexpr (INBOX)
                 asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
                                   "+v"(nx[0]), "+v"(nx[1]), "+v"(mn.x), "+v"(mn.y), "+v"(mn.z), "+v"(mn.w), "+v"(mx.x), "+v"(mx.y),
                                   "+v"(mx.z), "+v"(mx.w) : : "memory");
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if constexpr (SELF) {
+            if constexpr (INBOX) {
                 // the query's box at this lane's chunk: from the eight staged query rows (rows past the document's end are
                 // copies of its last row) and into the wave's cache, or from the cache; joined with the candidate's
                 float4 qn, qx;
@@ -661,6 +664,11 @@ bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm) {
     return jobs <= 64 && prm->scaling >= 0.25 && tuning().fused_nosolve != 1 && !tuning().fused_valu && !tuning().fused_noself;
 }
 
+// one query against a pool with its own per-pair diameters: the box comes from the staged query rows (no box launch)
+bool fused_inbox_ok(const aspire_repset* q, const float* diameter) {
+    return q->n == 1 && diameter == nullptr && tuning().fused_nosolve != 1 && !tuning().fused_valu && !tuning().fused_noself;
+}
+
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
     const int mq = q->max_len, mc = c->max_len;
     return q->ext == 0 && c->ext == 0 && mq > 0 && mc > 0 && mq <= 8 && mc <= 8;
@@ -685,8 +693,9 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     const int64_t waves = groups_bound < cap ? groups_bound : cap;
     const dim3 grid((unsigned)((waves + 3) / 4));
     const bool self = qbox == nullptr && a.pairing == kPairMapped;       // batched jobs without the tables launch (fused_self_ok)
-    if (self && (tuning().fused_nosolve == 1 || tuning().fused_valu)) return ASPIRE_ERR_INVALID_ARG;
-    const size_t lds = 4 * (kWaveLds + (self ? 2 * kD : 0)) * sizeof(float);      // SELF: + a query-box cache per wave
+    const bool inbox1 = qbox == nullptr && a.pairing == ASPIRE_PAIR_CROSS;      // one query, box in-wave (fused_inbox_ok)
+    if ((self || inbox1) && (tuning().fused_nosolve == 1 || tuning().fused_valu)) return ASPIRE_ERR_INVALID_ARG;
+    const size_t lds = 4 * (kWaveLds + (self || inbox1 ? 2 * kD : 0)) * sizeof(float);      // + a query-box cache per wave
     if (tuning().fused_nosolve == 1) hipLaunchKernelGGL((pair_fused_kernel<true, false>), grid, dim3(256), lds, stream, a, qbox);
     else if (tuning().fused_valu) hipLaunchKernelGGL((pair_fused_kernel<false, true>), grid, dim3(256), lds, stream, a, qbox);
     else if (self) {
@@ -699,6 +708,16 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
         });
         ASPIRE_HIP_OK(raise_rc);
         hipLaunchKernelGGL((pair_fused_kernel<true, true, true>), grid, dim3(256), lds, stream, a, qbox);
+    }
+    else if (inbox1) {
+        static std::once_flag raised1;
+        static hipError_t raise1_rc = hipSuccess;
+        std::call_once(raised1, [] {
+            raise1_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fused_kernel<true, true, false, false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        });
+        ASPIRE_HIP_OK(raise1_rc);
+        hipLaunchKernelGGL((pair_fused_kernel<true, true, false, false, true>), grid, dim3(256), lds, stream, a, qbox);
     }
     else hipLaunchKernelGGL((pair_fused_kernel<true, true>), grid, dim3(256), lds, stream, a, qbox);
     ASPIRE_LAUNCH_OK();

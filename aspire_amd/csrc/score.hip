@@ -2306,11 +2306,12 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     if (fused) {
         a.cand0 = 0;
         a.cand1 = c->n;
-        if (!diameter) {   // per-coordinate boxes of the queries (the kernel adds each candidate's rows)
+        const bool inbox = fused_inbox_ok(q, diameter);      // ONE query: the kernel forms its box itself
+        if (!diameter && !inbox) {   // per-coordinate boxes of the queries (the kernel adds each candidate's rows)
             hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, (hipStream_t)stream, a.q, qbox);
             ASPIRE_LAUNCH_OK();
         }
-        if (int rc = launch_pair_fused(a, groups4_all, qbox, (hipStream_t)stream)) return rc;
+        if (int rc = launch_pair_fused(a, groups4_all, inbox ? nullptr : qbox, (hipStream_t)stream)) return rc;
     }
     const int rc_run = fused ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;

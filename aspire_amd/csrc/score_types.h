@@ -108,6 +108,7 @@ int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q
 
 // fused.hip: cost + Sinkhorn solve in one launch for documents of <= 8 rows (CSR inputs, CROSS or MAPPED pairing)
 bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm);
+bool fused_inbox_ok(const aspire_repset* q, const float* diameter);
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
 int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream);

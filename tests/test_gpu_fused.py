@@ -36,6 +36,10 @@ def test_fused_single_pool_matches_oracle_and_tile_form(amd, nq, nc, want):
     with amd.pinned(OT_FORM='tile'):
         tile = amd.ops.ot_sinkhorn(q, c, want=w).view(nq, nc).cpu().numpy()
     assert np.array_equal(dflt, fused) and np.isfinite(fused).all()
+    if nq == 1:      # one query: the kernel forms the query's box itself; with the box launch in front (pinned) the same bits
+        with amd.pinned(OT_FORM='fused', FUSED_NOSELF=1):
+            boxed = amd.ops.ot_sinkhorn(q, c, want=w).view(nq, nc).cpu().numpy()
+        assert np.array_equal(boxed, fused)
     # plan-weighted similarity: exp((f + g - d) / 0.05) with |f|, |g|, |d| ~ 38 -- the reference's own fp32 value is off by up
     # to 1.6e-2 from a float64 evaluation
     np.testing.assert_allclose(fused, tile, atol=5e-5 if want != 'plan' else 2e-2, rtol=0)
