@@ -151,22 +151,18 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
     return [[(pool.pids[i], float(s)) for s, i in zip(rs, ri) if i >= 0] for rs, ri in zip(top_s, top_i)]
 
 
-def rank_pools(query_reps_list, pools, k=None, hparams=None):
-    """The whole per-query loop of evaluate.py:58-76 in ONE library call: query j is scored against ITS OWN pool
-    pools[j] (every query of a dataset has its own candidate pool, evaluate.py:60-62) with otAspire, one epsilon schedule
-    per pair (AspireModel.get_similarity, models.py:190-197), and each pool is ranked on its own (stable descending,
-    evaluate.py:76).  pools: list of CandidatePool or lists of [S_i, 768] arrays.  Returns per query [(pid, score), ...]."""
+def _launch_rank_pools(query_reps_list, pools, k, hparams):
+    """Uploads + the one library call of rank_pools on the CURRENT stream; returns (pools, top_scores, top_idx) GPU tensors
+    (None for the tensors when every pool is empty)."""
     hparams = hparams or {}
     if hparams.get('geoml_reach', None) is not None:
         raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
     assert len(query_reps_list) == len(pools), 'one pool per query'
-    if not pools:
-        return []
     pools = [_as_pool(p) for p in pools]
     sizes = [len(p) for p in pools]
-    max_job = max(sizes)
+    max_job = max(sizes) if sizes else 0
     if max_job == 0:
-        return [[] for _ in pools]
+        return pools, None, None
     k = max_job if k is None else min(k, max_job)
     dev = ops.require_gpu()
     q = ops.DeviceRepSet.from_list(query_reps_list)
@@ -179,8 +175,59 @@ def rank_pools(query_reps_list, pools, k=None, hparams=None):
     _, top_s, top_i = ops.ot_rank_batch(q, c, job_off, max_job, k, blur=hparams.get('geoml_blur', 0.05),
                                         scaling=hparams.get('geoml_scaling', 0.9), sent_sm_temp=hparams.get('sent_sm_temp', 1.0),
                                         want=_lib.OT_SIMILARITY)
+    return pools, top_s, top_i
+
+
+def _ranked_lists(pools, top_s, top_i):
+    if top_s is None:
+        return [[] for _ in pools]
     top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
     return [[(p.pids[i], float(sc)) for sc, i in zip(rs, ri) if i >= 0] for p, rs, ri in zip(pools, top_s, top_i)]
+
+
+def rank_pools(query_reps_list, pools, k=None, hparams=None):
+    """The whole per-query loop of evaluate.py:58-76 in ONE library call: query j is scored against ITS OWN pool
+    pools[j] (every query of a dataset has its own candidate pool, evaluate.py:60-62) with otAspire, one epsilon schedule
+    per pair (AspireModel.get_similarity, models.py:190-197), and each pool is ranked on its own (stable descending,
+    evaluate.py:76).  pools: list of CandidatePool or lists of [S_i, 768] arrays.  Returns per query [(pid, score), ...]."""
+    if not pools:
+        return []
+    return _ranked_lists(*_launch_rank_pools(query_reps_list, pools, k, hparams))
+
+
+class InFlightRanker:
+    """rank_pools for a process that serves independent requests: up to `n_lanes` calls in flight, each on its own stream
+    with its own buffers.  The library queues everything on the caller's stream and keeps no state between calls, so calls on
+    different streams overlap -- the end of one call (last Sinkhorn solves, rank launch: no HBM traffic) runs beside the next
+    call's streaming (bench.py: 96 instead of 111 us per 20-query call).
+
+        ranker = InFlightRanker()
+        tickets = [ranker.submit(queries_b, pools_b) for queries_b, pools_b in requests]
+        ranked = [ranker.result(t) for t in tickets]          # same lists as rank_pools(queries_b, pools_b)
+    """
+
+    def __init__(self, n_lanes=3, k=None, hparams=None):
+        dev = ops.require_gpu()
+        self.k, self.hparams = k, hparams
+        self.lanes = [torch.cuda.Stream(dev) for _ in range(max(1, int(n_lanes)))]
+        self.busy = [None] * len(self.lanes)          # the lane's last ticket (its stream runs calls in order)
+        self.turn = 0
+
+    def submit(self, query_reps_list, pools):
+        lane = self.turn % len(self.lanes)
+        self.turn += 1
+        with torch.cuda.stream(self.lanes[lane]):
+            out = _launch_rank_pools(query_reps_list, pools, self.k, self.hparams) if pools else ([], None, None)
+            done = torch.cuda.Event()
+            done.record()
+        ticket = {'lane': lane, 'out': out, 'done': done}
+        self.busy[lane] = ticket
+        return ticket
+
+    def result(self, ticket):
+        ticket['done'].synchronize()
+        with torch.cuda.stream(self.lanes[ticket['lane']]):
+            return _ranked_lists(*ticket['out'])
 
 
 def get_similarity(x, y, hparams=None):

@@ -240,3 +240,19 @@ def test_config2_batch_of_twenty_full_size(amd):
         want = np.array([orc.get_similarity(qrows[j * S:(j + 1) * S].cpu(), crows[(j * n + i) * S:(j * n + i + 1) * S].cpu())
                          for i in (0, 499, 999)], dtype=np.float32)
         np.testing.assert_allclose(sj[j].numpy()[[0, 499, 999]], want, atol=TOL, rtol=0)
+
+
+def test_in_flight_ranker_equals_rank_pools(amd):
+    """independent rank_pools calls in flight on three streams (own buffers each): the same ranked lists, whatever the
+    order in which the results are collected; an empty request and a request of empty pools among them"""
+    reqs = []
+    for seed, sizes in ((71, [300, 5, 0, 1200]), (72, [2500] * 3), (73, [17]), (74, [0, 0]), (75, [900, 901, 902, 903, 904])):
+        reqs.append(_jobs(seed, sizes, 8))
+    reqs.insert(2, ([], []))
+    want = [amd.scorer.rank_pools(q, p, k=50) for q, p in reqs]
+    ranker = amd.scorer.InFlightRanker(n_lanes=3, k=50)
+    for rounds in range(2):
+        tickets = [ranker.submit(q, p) for q, p in reqs]
+        order = range(len(tickets)) if rounds == 0 else reversed(range(len(tickets)))
+        for i in order:
+            assert ranker.result(tickets[i]) == want[i], i
