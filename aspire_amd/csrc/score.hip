@@ -2155,6 +2155,18 @@ int launch_cost_stage(const ScoreArgs& a, const aspire_repset* q, const aspire_r
             hipLaunchKernelGGL(pair_cost1_kernel, dim3((unsigned)blocks), dim3(kBlock), Lds<1>::kTotal * sizeof(float), stream, a,
                                ws1, 1u);
         }
+    } else if (T == 2 && tile16_path_ok(q, c, a.pairing) && (a.pairing != kPairMapped || a.grp_off != nullptr) &&
+               tuning().ot_form != 1 &&
+               (tuning().ot_form == 2 || (a.pairing == kPairMapped ? 2 * (int64_t)(a.job1 - a.job0) * a.max_job_groups
+                                                                      : (a.cand1 - a.cand0 + 1) / 2 * q->n) >= 2048)) {
+        // documents of 9 .. 16 rows, enough pairs of candidates to fill the chip: the streaming kernel (tile16.hip)
+        if (!a.diameter && first_chunk && a.pairing != kPairMapped) {   // per-coordinate boxes of the queries, once per call
+            hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, stream, a.q, qbox);
+            ASPIRE_LAUNCH_OK();
+        }
+        const int64_t items = a.pairing == kPairMapped ? 2 * (int64_t)(a.job1 - a.job0) * a.max_job_groups
+                                                       : (a.cand1 - a.cand0 + 1) / 2 * q->n;
+        return launch_pair_tile16(a, ws.cost, ws.neg, ws.diam2, items, qbox, stream);
     } else if (csr && n_slots < 512) {
         // CSR documents of more than 8 rows: every 8 x 8 sub-tile of every pair is an item of the small-pool kernel
         // while the pairs alone would not fill the chip (1 x 125 x 20: 125 workgroups walking 9 tiles each -> 1024
@@ -2281,7 +2293,12 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     ASPIRE_REQUIRE(!diameter || diam_group > 0, ASPIRE_ERR_INVALID_ARG, "diam_group must be positive");
     const int max_rows = max_rows_of(q, c);
     const size_t per_cand = per_cand_bytes(q, c, pairing);
-    const bool gram = gram_path_wanted(q, c, pairing);
+    // ONE query against a big pool of 9 .. 16-row documents: the streaming kernel (tile16.hip) beats the 32-column Gram tiles,
+    // whose 12 .. 16 real query rows fill a third to a half of the MFMA tile (1 x 20 000 x 12 otAspire: 247 vs 363 us; at two
+    // queries they tie, from three the Gram tiles win: 623 vs 565 us)
+    const bool stream16 = q->n == 1 && c->n >= 4096 && tile16_path_ok(q, c, pairing) && tuning().cost_path != 1 &&
+                          tuning().ot_form != 1;
+    const bool gram = gram_path_wanted(q, c, pairing) && !stream16;
     ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + kWsSlack, ASPIRE_ERR_INVALID_ARG,
                    "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
                    workspace_bytes, per_cand, aspire_ot_workspace_bytes(q, c, pairing));

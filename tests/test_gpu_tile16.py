@@ -1,0 +1,93 @@
+"""The streaming cost kernel for documents of 9 .. 16 sentence rows (tile16.hip: two candidates of one query per wave, dot
+products on the matrix pipe) against the per-pair tile-loop kernel it replaces at scale, the oracle, and torch.cdist --
+single pools (CROSS) and batched jobs (MAPPED)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def amd():
+    from aspire_amd import ops, scorer, _lib
+    assert torch.cuda.is_available()
+    return type('NS', (), dict(ops=ops, scorer=scorer, lib=_lib, pinned=_lib.pinned))
+
+
+def _pool(seed, n, smin, smax):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(smin, smax + 1, (n,), generator=g).tolist()
+    return [torch.randn(l, 768, generator=g) for l in lens]
+
+
+@pytest.mark.parametrize('nq,nc,smax', [(1, 4501, 16), (2, 2300, 12), (1, 4400, 9)])
+def test_tile16_single_pool_matches_small_form_and_oracle(amd, nq, nc, smax):
+    cands = _pool(500 + nc, nc, 1, smax)
+    queries = _pool(13, nq, max(2, smax - 6), smax)
+    cands[7] = torch.cat([queries[0][3:5], cands[7][:9]])               # shares two sentences with query 0: direct-formula redo
+    cands[nc - 1] = queries[nq - 1].clone()                              # a copy of the last query (odd pool size: lone last item)
+    q, c = amd.ops.DeviceRepSet.from_list(queries), amd.ops.DeviceRepSet.from_list(cands)
+    with amd.pinned(COST_PATH='valu'):
+        new = amd.ops.ot_sinkhorn(q, c).view(nq, nc).cpu().numpy()
+    with amd.pinned(COST_PATH='valu', OT_FORM='small'):
+        old = amd.ops.ot_sinkhorn(q, c).view(nq, nc).cpu().numpy()
+    assert np.isfinite(new).all()
+    # duplicate sentences: the solver side carries geomloss's cancellation noise
+    noisy = np.zeros_like(new, dtype=bool)
+    noisy[0, 7] = noisy[nq - 1, nc - 1] = True
+    np.testing.assert_allclose(new[~noisy], old[~noisy], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(new[noisy], old[noisy], atol=5e-2, rtol=0)
+    idx = [0, 1, 2, nc // 2, nc - 2]
+    ref = np.array([[-orc.get_similarity(x, cands[i]) for i in idx] for x in queries], dtype=np.float32)
+    np.testing.assert_allclose(new[:, idx], ref, atol=TOL, rtol=0)
+
+
+def test_tile16_marginals_see_the_direct_formula(amd):
+    """pair outputs come from the same workspace slots: -cdist of a shared sentence is exactly 0 (torch.cdist's direct
+    formula), the marginals match the oracle"""
+    g = torch.Generator().manual_seed(3)
+    query = torch.randn(11, 768, generator=g)
+    cands = _pool(9, 4200, 3, 14)
+    cands[0] = torch.cat([cands[0][:4], query[2:3], cands[0][4:9]])
+    qd = {'sent_reps': query.numpy()}
+    with amd.pinned(COST_PATH='valu'):
+        ret = amd.scorer.caching_score(qd, [{'sent_reps': x.numpy()} for x in cands[:64]])
+        q, c = amd.ops.DeviceRepSet.from_list([query]), amd.ops.DeviceRepSet.from_list(cands)
+        big = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+    want = np.array([-orc.get_similarity(query, x) for x in cands[:6]], dtype=np.float32)
+    np.testing.assert_allclose(big[1:6], want[1:6], atol=TOL, rtol=0)
+    np.testing.assert_allclose(big[0], want[0], atol=5e-2, rtol=0)
+    assert ret['batch_scores'].shape == (64,)
+
+
+def test_tile16_batched_jobs(amd):
+    """aspire_ot_rank_batch_f32 on jobs of long documents: the mapped form of the kernel (items = halves of the job tables'
+    groups of four; job sizes that are not multiples of two or four, single-candidate and empty jobs) against the small form
+    and the oracle"""
+    g = torch.Generator().manual_seed(21)
+    sizes = [1203, 1, 0, 998, 2, 1501, 3, 700]
+    queries = [torch.randn(int(torch.randint(5, 15, (1,), generator=g)), 768, generator=g) for _ in sizes]
+    pools = [[torch.randn(int(n), 768, generator=g) for n in torch.randint(1, 15, (sz,), generator=g)] for sz in sizes]
+    q = amd.ops.DeviceRepSet.from_list(queries)
+    c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
+    job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).cuda()
+    out = {}
+    for form in ('', 'small'):
+        with amd.pinned(OT_FORM=form):
+            s, ts, ti = amd.ops.ot_rank_batch(q, c, job_off, max(sizes), 20)
+            torch.cuda.synchronize()
+            out[form] = (s.cpu().numpy(), ts.cpu().numpy(), ti.cpu().numpy())
+    np.testing.assert_allclose(out[''][0], out['small'][0], atol=5e-5, rtol=0)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for j in (0, 1, 3, 6):
+        pick = list(range(min(4, sizes[j])))
+        want = np.array([orc.get_similarity(queries[j], pools[j][i]) for i in pick], dtype=np.float32)
+        np.testing.assert_allclose(out[''][0][off[j]:off[j + 1]][pick], want, atol=TOL, rtol=0)
+        sc = out[''][0][off[j]:off[j + 1]]
+        order = np.argsort(-sc.astype(np.float64), kind='stable')[:20]
+        kk = min(20, sizes[j])
+        assert out[''][2][j, :kk].tolist() == order.tolist()
