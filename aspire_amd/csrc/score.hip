@@ -2008,6 +2008,13 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     a.scores = scores;
     a.out_pairsims = pair_sims;
     a.out_plan = pair_softmax;
+    // ONE query against a big pool of 9 .. 16-row documents: the streaming kernel's max-sim form (tile16.hip)
+    if (agg == ASPIRE_AGG_MAX && !pair_sims && q->n == 1 && c->n >= 4096 && tile16_path_ok(q, c, pairing) &&
+        pairing == ASPIRE_PAIR_CROSS && tuning().cost_path != 1 && tuning().ot_form != 1) {
+        a.cand0 = 0;
+        a.cand1 = c->n;
+        return launch_pair_tile16_l2max(a, (c->n + 1) / 2, (hipStream_t)stream);
+    }
     if (agg == ASPIRE_AGG_MAX && !pair_sims && gram_path_wanted(q, c, pairing))
         return launch_pair_gram_l2max(a, q->max_len, c->max_len, (hipStream_t)stream);
     // Few queries against a big pool of short documents (CSR): the fused kernel's streaming phase with a max epilogue --

@@ -113,6 +113,7 @@ bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
 int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream);
 bool tile16_path_ok(const aspire_repset* q, const aspire_repset* c, int pairing);
+int launch_pair_tile16_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);
 int launch_pair_tile16(const ScoreArgs& a, float* cost, float* neg, float* diam2, int64_t items_bound, const float* qbox,
                        hipStream_t stream);
 

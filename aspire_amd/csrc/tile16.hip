@@ -37,6 +37,9 @@ static_assert(12 * kNormLd <= kWaveLds, "norm table must fit the idle stage buff
 typedef float mfma4_t __attribute__((ext_vector_type(4)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
+// L2MAX: tsAspire on the same streaming phase -- the score is the maximum of -cdist over the valid block
+// (allpair_masked_dist_l2max, pair_distances.py:167-176); no boxes, nothing goes to the workspace.
+template <bool L2MAX>
 __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs<2> ws, const float* __restrict__ qbox) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -50,7 +53,7 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
     const uint32_t g4_lo = mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
     const uint32_t n_items = mapped ? 2u * ((uint32_t)a.grp_off[a.job1] - g4_lo) : ((ncand + 1) / 2) * nq;   // CROSS: (pair of candidates, query), group-major
     const uint32_t n_waves = gridDim.x * 4;
-    const bool own_diam = a.diameter == nullptr;
+    const bool own_diam = a.diameter == nullptr && !L2MAX;
 
     const int p = lane >> 4, lp = lane & 15, cs = p >> 1, hp = p & 1, sc = lp;
     const int mb = lane >> 2, mt = lane & 3, miq = (mb >> 1) & 1, mjq = mb & 1;
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
         const float* sy_doc = a.c.rows + (size_t)c_start * kD;
         // the query's per-coordinate box; with caller-supplied diameters the candidate's rows stand in (term unused): the
         // loads stay unconditional (fused.hip)
-        const float* qb = own_diam ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
+        const float* qb = (own_diam && !L2MAX) ? qbox + (size_t)q_idx * 2 * kD : sy_doc;
         const int qb_hi = own_diam ? kD : 0;
 
         mfma4_t macc[2][2];
@@ -116,8 +119,10 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
             const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(8 * hp + j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
-            qmn = ld4(qb + dofs);
-            qmx = ld4(qb + qb_hi + dofs);
+            if constexpr (!L2MAX) {
+                qmn = ld4(qb + dofs);
+                qmx = ld4(qb + qb_hi + dofs);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) vx[k] = ld4(qdoc + (size_t)min(4 * p + k, q_len - 1) * kD + dofs);
         };
@@ -134,21 +139,23 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     ny[j] = sq_acc(ny[j], vy[j]);
-                    if (j > 0) {
+                    if (j > 0 && !L2MAX) {
                         mn.x = fminf(mn.x, vy[j].x); mn.y = fminf(mn.y, vy[j].y); mn.z = fminf(mn.z, vy[j].z); mn.w = fminf(mn.w, vy[j].w);
                         mx.x = fmaxf(mx.x, vy[j].x); mx.y = fmaxf(mx.y, vy[j].y); mx.z = fmaxf(mx.z, vy[j].z); mx.w = fmaxf(mx.w, vy[j].w);
                     }
                     *reinterpret_cast<float4*>(lds + (16 + p * 8 + j) * kRowStride + sc * 4) = vy[j];
                 }
-                // the candidate's other half sits in the neighbouring lane group (a half past the document's end repeats its
-                // last row: box neutral)
-                mn.x = fminf(mn.x, lane_xor<16>(mn.x)); mn.y = fminf(mn.y, lane_xor<16>(mn.y));
-                mn.z = fminf(mn.z, lane_xor<16>(mn.z)); mn.w = fminf(mn.w, lane_xor<16>(mn.w));
-                mx.x = fmaxf(mx.x, lane_xor<16>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<16>(mx.y));
-                mx.z = fmaxf(mx.z, lane_xor<16>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<16>(mx.w));
-                const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
-                const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
-                dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
+                if constexpr (!L2MAX) {
+                    // the candidate's other half sits in the neighbouring lane group (a half past the document's end repeats its
+                    // last row: box neutral)
+                    mn.x = fminf(mn.x, lane_xor<16>(mn.x)); mn.y = fminf(mn.y, lane_xor<16>(mn.y));
+                    mn.z = fminf(mn.z, lane_xor<16>(mn.z)); mn.w = fminf(mn.w, lane_xor<16>(mn.w));
+                    mx.x = fmaxf(mx.x, lane_xor<16>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<16>(mx.y));
+                    mx.z = fmaxf(mx.z, lane_xor<16>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<16>(mx.w));
+                    const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
+                    const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
+                    dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     nx[k] = sq_acc(nx[k], vx[k]);
@@ -215,10 +222,11 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the table is the next item's stage buffer
         __builtin_amdgcn_wave_barrier();
 
-        // ---- the pair's entries (i = 8 s + 4 iq + r, j = 8 hp + 4 jq + t) -> workspace ---------------------------------
+        // ---- the pair's entries (i = 8 s + 4 iq + r, j = 8 hp + 4 jq + t) ---------------------------------------------
         const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
         const int j = 8 * hp + 4 * mjq + mt;
         bool redo[2][4];
+        float negv[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -228,12 +236,12 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
                 const float sq = fmaf(-2.f, dot, xx[s][r]) + yy;
                 const float ns = xx[s][r] + yy;
                 redo[s][r] = my_c_real && !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
-                if (my_c_real) {
-                    ws.cost[slot * 256 + i * 16 + j] = sqrtf(fmaxf(sq, 1e-8f));
-                    if (!redo[s][r]) ws.neg[slot * 256 + i * 16 + j] = -sqrtf(fmaxf(sq, 0.f));
-                }
+                negv[s][r] = -sqrtf(fmaxf(sq, 0.f));
+                if constexpr (!L2MAX)
+                    if (my_c_real) ws.cost[slot * 256 + i * 16 + j] = sqrtf(fmaxf(sq, 1e-8f));
             }
-        if (my_c_real && own_diam && lp == 0 && hp == 0) ws.diam2[slot] = diam2;
+        if constexpr (!L2MAX)
+            if (my_c_real && own_diam && lp == 0 && hp == 0) ws.diam2[slot] = diam2;
         // direct-formula redo, the whole wave on one entry (12 coordinates per lane), four entries per memory round trip
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -273,11 +281,28 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
                             const float tot = wave_sum(part);
                             const int o = owner[e], ob = o >> 2;
                             const int oi = 8 * s + 4 * ((ob >> 1) & 1) + r, oj = 8 * ((ob >> 2) & 1) + 4 * (ob & 1) + (o & 3);
-                            if (lane == o) ws.neg[slot * 256 + oi * 16 + oj] = -sqrtf(tot);
+                            (void)oi; (void)oj;
+                            if (lane == o) negv[s][r] = -sqrtf(tot);
                         }
                     }
                 }
             }
+        if constexpr (L2MAX) {
+            float m = kNegBig;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, (8 * s + 4 * miq + r < q_len && j < c_len) ? negv[s][r] : kNegBig);
+            m = fmaxf(m, lane_xor<1>(m)); m = fmaxf(m, lane_xor<2>(m)); m = fmaxf(m, lane_xor<4>(m)); m = fmaxf(m, lane_xor<8>(m));
+            m = fmaxf(m, lane_xor<16>(m));                                    // the candidate's two halves
+            if (q_len > 16 || c_len > 16) m = __builtin_nanf("");          // longer than the tile: never truncated silently
+            if (my_c_real && lp == 0 && hp == 0) a.scores[mapped ? cur.c_idx : q_idx * a.c.n + cur.c_idx] = m;
+        } else if (my_c_real) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ws.neg[slot * 256 + (8 * s + 4 * miq + r) * 16 + j] = negv[s][r];
+        }
     }
 }
 
@@ -295,7 +320,18 @@ int launch_pair_tile16(const ScoreArgs& a, float* cost, float* neg, float* diam2
                        hipStream_t stream) {
     PairWs<2> ws{cost, neg, diam2};
     const int64_t waves = items_bound < 256 * 8 ? items_bound : 256 * 8;
-    hipLaunchKernelGGL(pair_tile16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws, qbox);
+    hipLaunchKernelGGL(pair_tile16_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws,
+                       qbox);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+// tsAspire (max-sim) of every (query, candidate) pair, CROSS
+int launch_pair_tile16_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream) {
+    PairWs<2> ws{nullptr, nullptr, nullptr};
+    const int64_t waves = items_bound < 256 * 8 ? items_bound : 256 * 8;
+    hipLaunchKernelGGL(pair_tile16_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws,
+                       (const float*)nullptr);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

@@ -91,3 +91,25 @@ def test_tile16_batched_jobs(amd):
         order = np.argsort(-sc.astype(np.float64), kind='stable')[:20]
         kk = min(20, sizes[j])
         assert out[''][2][j, :kk].tolist() == order.tolist()
+
+
+def test_tile16_l2max_matches_the_tile_loop_kernel_and_torch(amd):
+    """tsAspire for one query against a big pool of 9 .. 16-row documents on the streaming kernel: against l2max_kernel<2>
+    (pinned OT_FORM=small), the Gram form, and -min cdist in torch; shared sentences give exactly 0"""
+    nc = 4601
+    cands = _pool(900, nc, 1, 16)
+    query = _pool(17, 1, 13, 13)[0]
+    cands[3] = torch.cat([cands[3][:5], query[12:13]])
+    cands[nc - 1] = query.clone()
+    q, c = amd.ops.DeviceRepSet.from_list([query]), amd.ops.DeviceRepSet.from_list(cands)
+    new = amd.ops.l2max_scores(q, c).cpu().numpy()
+    with amd.pinned(OT_FORM='small', COST_PATH='valu'):
+        old = amd.ops.l2max_scores(q, c).cpu().numpy()
+    with amd.pinned(COST_PATH='mfma'):
+        gram = amd.ops.l2max_scores(q, c).cpu().numpy()
+    np.testing.assert_allclose(new, old, atol=4e-5, rtol=0)
+    np.testing.assert_allclose(new, gram, atol=4e-5, rtol=0)
+    assert new[3] == 0.0 and new[nc - 1] == 0.0
+    idx = [0, 1, 2, 3, nc // 2, nc - 2, nc - 1]
+    ref = np.array([-torch.cdist(query, cands[i]).min().item() for i in idx], dtype=np.float32)
+    np.testing.assert_allclose(new[idx], ref, atol=4e-5, rtol=0)
