@@ -15,7 +15,7 @@ worst_ot = worst_l2 = 0.0
 for case in range(n_cases):
     nq = int(rng.choice([1, 1, 1, 2, 3, 5]))
     nc = int(rng.choice(sizes))
-    smax = int(rng.choice([8, 8, 8, 12, 20, 32]))
+    smax = int(rng.choice([8, 8, 8, 12, 16, 20, 32]))
     if nq * nc * (smax // 8 + (smax % 8 > 0)) ** 2 > 120000:
         nc = max(1, nc // 8)
     g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
