@@ -192,14 +192,8 @@ def main():
             self.gathered = torch.empty(world, K, TOPK, device=device, dtype=torch.int64) if shard_path else None
             self.ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8)
             self.P = [ptr(t) for t in (self.scores, self.top_s, self.top_i, self.keys, self.ws)]
-            self.done = torch.cuda.Event()       # this lane's rank keys are written
-            self.free = torch.cuda.Event()       # ... and have been consumed by the exchange
-            self.exchanging = False
 
     lanes = [Lane() for _ in range(n_lanes)]
-    # sharded: the per-call exchange (all-gather + merge) runs on its own stream behind the lanes, in call order (one
-    # communicator = one stream); a lane waits for ITS previous exchange before it overwrites its keys -- n_lanes calls later
-    comm = torch.cuda.Stream(device) if (world > 1 and not one_gpu_test) else None
     scores, top_s, top_i, ws = lanes[0].scores, lanes[0].top_s, lanes[0].top_i, lanes[0].ws
     P = [lanes[0].P[0], lanes[0].P[1], lanes[0].P[2], lanes[0].P[3], lanes[0].P[4], P_job_off, P_job_base]
 
@@ -218,30 +212,23 @@ def main():
         """K steps = K jobs = ONE C-ABI call on the lane's stream; sharded: + one all-gather of the K x k keys + one merge launch
         (exchange=False: this rank's kernels only -- the stage timings below run on rank 0 alone)."""
         lane = lane or lanes[0]
-        if lane.exchanging:
-            lane.stream.wait_event(lane.free)
-            lane.exchanging = False
         rc = lib.aspire_ot_rank_batch_f32(ctypes.byref(js.qs), ctypes.byref(js.cs), D, P_job_off, NC, ctypes.byref(prm), _lib.OT_SIMILARITY,
                                           lane.P[0], TOPK, P_job_base, null if shard_path else lane.P[1], null if shard_path else lane.P[2],
                                           lane.P[3], lane.P[4], ws_bytes, lane.sp)
         if rc:
             _lib.check(rc)
         if shard_path and exchange:
-            if world == 1:
-                rc = lib.aspire_topk_merge_keys(ptr(lane.keys), 1, K, TOPK, TOPK, lane.P[1], lane.P[2], lane.sp)
-            elif comm is None:           # one-GPU rehearsal over gloo: the gather goes through the host, on the lane's stream
+            # on the lane's own stream: torch.distributed orders the collective behind the lane's kernels and the merge behind
+            # the collective; collectives of different lanes go out in call order on every rank.  (A separate exchange
+            # stream tied to the lanes by events was measured on one GPU, the gather replaced by a copy: 152 instead of 121 us
+            # per call -- cross-stream event waits cost more than they hide on this runtime.)
+            if world > 1:
                 with torch.cuda.stream(lane.stream):
-                    all_gather_flat(lane.gathered.view(-1), lane.keys.view(-1))
-                rc = lib.aspire_topk_merge_keys(ptr(lane.gathered), world, K, TOPK, TOPK, lane.P[1], lane.P[2], lane.sp)
-            else:
-                lane.done.record(lane.stream)
-                comm.wait_event(lane.done)
-                with torch.cuda.stream(comm):
                     all_gather_flat(lane.gathered.view(-1), lane.keys.view(-1))      # -> [world][K][k]; RCCL over xGMI
-                rc = lib.aspire_topk_merge_keys(ptr(lane.gathered), world, K, TOPK, TOPK, lane.P[1], lane.P[2],
-                                                ctypes.c_void_p(comm.cuda_stream))
-                lane.free.record(comm)
-                lane.exchanging = True
+                src = lane.gathered
+            else:
+                src = lane.keys
+            rc = lib.aspire_topk_merge_keys(ptr(src), world, K, TOPK, TOPK, lane.P[1], lane.P[2], lane.sp)
             if rc:
                 _lib.check(rc)
 
