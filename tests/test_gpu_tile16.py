@@ -113,3 +113,29 @@ def test_tile16_l2max_matches_the_tile_loop_kernel_and_torch(amd):
     idx = [0, 1, 2, 3, nc // 2, nc - 2, nc - 1]
     ref = np.array([-torch.cdist(query, cands[i]).min().item() for i in idx], dtype=np.float32)
     np.testing.assert_allclose(new[idx], ref, atol=4e-5, rtol=0)
+
+
+def test_tile16_other_entry_modes(amd):
+    """the same kernel behind the other ways of calling the path: plan-weighted similarity (want = PLAN_SIM), caller-supplied
+    group diameters (schedule='batch': caching_score's one schedule per group of 64 -- the kernel's own box term unused),
+    a workspace smaller than the pool's slots (candidate chunks: slots relative to the chunk)"""
+    nc = 9001
+    cands = _pool(700, nc, 2, 15)
+    query = _pool(19, 1, 12, 12)[0]
+    q, c = amd.ops.DeviceRepSet.from_list([query]), amd.ops.DeviceRepSet.from_list(cands)
+    res = {}
+    for form in ('', 'small'):
+        with amd.pinned(COST_PATH='valu', OT_FORM=form):
+            plan = amd.ops.ot_sinkhorn(q, c, want=amd.lib.OT_PLAN_SIM).cpu().numpy()
+            batch = amd.scorer.score_pool([query], cands, method='ot', schedule='batch').cpu().numpy()[0]
+            small_ws = torch.empty(4600 * (2 * 256 + 1) * 4 + 2 * 768 * 4 + 64, dtype=torch.uint8, device='cuda')      # two chunks, both big enough for the streaming kernel
+            chunked = amd.ops.ot_sinkhorn(q, c, workspace=small_ws).cpu().numpy()
+            full = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+        res[form] = (plan, batch, chunked, full)
+    np.testing.assert_array_equal(res[''][2], res[''][3])                       # chunks do not change a bit
+    np.testing.assert_allclose(res[''][3], res['small'][3], atol=5e-5, rtol=0)
+    # plan-weighted similarity: fp32 conditioning of exp((f + g - d) / 0.05) (DESIGN.md section 6)
+    np.testing.assert_allclose(res[''][0], res['small'][0], atol=2e-2, rtol=0)
+    np.testing.assert_allclose(res[''][1], res['small'][1], atol=2e-2, rtol=0)
+    want = np.array(orc.rank_pool_caching(query.numpy(), [x.numpy() for x in cands[:64]]), dtype=np.float32)
+    np.testing.assert_allclose(res[''][1][:64], want, atol=2e-2, rtol=0)
