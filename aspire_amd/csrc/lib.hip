@@ -19,7 +19,7 @@ std::once_flag g_tuning_once;
 bool apply_tuning(Tuning& t, const char* key, const char* v) {
     const bool unset = !v || !*v;
     if (!strcmp(key, "SINKHORN")) {
-        const int f = unset ? 0 : !strcmp(v, "wave") ? 1 : !strcmp(v, "block") ? 3 : !strcmp(v, "block-norepair") ? 4 : !strcmp(v, "block16") ? 5 : -1;
+        const int f = unset ? 0 : !strcmp(v, "wave") ? 1 : !strcmp(v, "block") ? 3 : !strcmp(v, "block-norepair") ? 4 : !strcmp(v, "block16") ? 5 : !strcmp(v, "block-dense") ? 6 : !strcmp(v, "block-wide") ? 7 : -1;
         if (f < 0) return false;
         t.sinkhorn_form = f;
     } else if (!strcmp(key, "COST_PATH")) {

@@ -1542,7 +1542,8 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
 // ---------------------------------------------------------------------------------------------
 // Kernel 2, block form (throughput form for big grids, any T): a pair occupies LD x LD lanes of one DPP row and
 // lane (li, lj) owns the R x R block of entries (R li + x, R lj + y), LD * R = 8 T:
-//     T = 1: LD 2, R 4 (16 solves per wave)      T = 2, 3, 4: LD 4, R 4 / 6 / 8 (4 solves per wave)
+//     T = 1: LD 2, R 4 (16 solves per wave) or LD 1, R 8 (64);  T = 2: LD 4, R 3 / 4 (4 solves per wave) or LD 2, R 6 / 8 (16);
+//     T = 3, 4: LD 4, R 5 .. 8 (4 solves per wave)
 // so most of a reduction is in-register adds and the cross-lane part is 1-2 DPP levels per direction.  The update
 // is written around ONE exponential per entry, K_ij = exp2((f_i + g_j - C_ij) * log2(e)/eps):
 //     sum_j b_j K_ij = exp((f_i - ft_i)/eps)   =>   ft_i = f_i - eps ln2 log2(sum_j b_j K_ij)
@@ -1560,19 +1561,21 @@ typedef float f2v __attribute__((ext_vector_type(2)));     // a register pair fo
 
 template <int LD>
 __device__ __forceinline__ float blk_sum_j(float v) {   // all-reduce over the LD lanes that share li
-    v += lane_xor<1>(v);
+    if constexpr (LD >= 2) v += lane_xor<1>(v);
     if constexpr (LD == 4) v += lane_xor<2>(v);
     return v;
 }
 template <int LD>
 __device__ __forceinline__ float blk_max_j(float v) {
-    v = fmaxf(v, lane_xor<1>(v));
+    if constexpr (LD >= 2) v = fmaxf(v, lane_xor<1>(v));
     if constexpr (LD == 4) v = fmaxf(v, lane_xor<2>(v));
     return v;
 }
 template <int LD>
 __device__ __forceinline__ float blk_sum_i(float v) {   // all-reduce over the LD lanes that share lj
-    if constexpr (LD == 2) {
+    if constexpr (LD == 1) {
+        return v;
+    } else if constexpr (LD == 2) {
         return v + lane_xor<2>(v);
     } else {
         v += dpp_mov<0x124>(v, v);       // row_ror:4
@@ -1581,7 +1584,9 @@ __device__ __forceinline__ float blk_sum_i(float v) {   // all-reduce over the L
 }
 template <int LD>
 __device__ __forceinline__ float blk_max_i(float v) {
-    if constexpr (LD == 2) {
+    if constexpr (LD == 1) {
+        return v;
+    } else if constexpr (LD == 2) {
         return fmaxf(v, lane_xor<2>(v));
     } else {
         v = fmaxf(v, dpp_mov<0x124>(v, v));
@@ -2217,8 +2222,16 @@ int launch_sinkhorn_stage(const ScoreArgs& a, const PairWs<T>& ws, int64_t n_slo
         using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>;
         const int r4 = (max_rows + 3) / 4;
+        // Lanes per pair.  The dense layouts (documents of <= 8 rows: ONE lane per pair, 8 x 8 entries, no cross-lane step at
+        // all; 9 .. 16 rows: 2 x 2 lanes of 6 x 6 / 8 x 8 entries) need a third fewer issue slots per pair than the wide ones
+        // (2 x 2 lanes of 4 x 4; 4 x 4 lanes of 3 x 3 / 4 x 4): 32 x 50 000 x 8 0.90 -> 0.74 ms per launch, 128 x 8192 x 12
+        // 1.10 -> 0.76, x 16 1.59 -> 1.27 -- but hold 64 / 16 pairs per wave, so only grids that still fill the chip take them.
+        const bool dense = form == 6 || (form != 7 && n_slots >= (T == 1 ? 196608 : 49152));
         if (T == 1 && form == 5) launch_block(I4{}, I2{});
+        else if (T == 1 && dense) launch_block(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
         else if (T == 1) launch_block(I2{}, I4{});
+        else if (r4 == 3 && dense) launch_block(I2{}, std::integral_constant<int, 6>{});
+        else if (r4 == 4 && dense) launch_block(I2{}, std::integral_constant<int, 8>{});
         else if (r4 == 3) launch_block(I4{}, std::integral_constant<int, 3>{});
         else if (r4 == 4) launch_block(I4{}, I4{});
         else if (r4 == 5) launch_block(I4{}, std::integral_constant<int, 5>{});

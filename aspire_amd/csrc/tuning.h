@@ -6,7 +6,7 @@
 namespace aspire {
 
 struct Tuning {
-    int sinkhorn_form = 0;   // ASPIRE_HIP_SINKHORN: 0 by grid size, 1 wave, 3 block, 4 block-norepair, 5 block16
+    int sinkhorn_form = 0;   // ASPIRE_HIP_SINKHORN: 0 by grid size, 1 wave, 3 block, 4 block-norepair, 5 block16, 6 block-dense, 7 block-wide (lanes per pair of the block form)
     int cost_path = 0;       // ASPIRE_HIP_COST_PATH: 0 by shape, 1 mfma (Gram kernel), 2 valu
     int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel

@@ -80,7 +80,8 @@ def test_forms_agree_at_size(amd, nq, nc, s, want):
     c = amd.ops.DeviceRepSet.from_list([torch.randn(int(n), 768, generator=g) for n in lens_c])
     w = amd.lib.OT_DISTANCE if want == 'distance' else amd.lib.OT_PLAN_SIM
     out = {}
-    forms = ['wave', 'block'] + (['block16'] if s <= 8 else [])
+    # block-dense / block-wide pin the lanes-per-pair layout of the block form (by default the grid size picks it)
+    forms = ['wave', 'block'] + (['block16'] if s <= 8 else []) + (['block-dense', 'block-wide'] if s <= 16 else [])
     # documents of <= 8 rows at this size run costs + solves fused in one launch by default: OT_FORM='tile' is the two-kernel
     # form whose Sinkhorn kernel SINKHORN= pins
     for form in forms:
