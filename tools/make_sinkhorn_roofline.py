@@ -7,22 +7,24 @@ import csv, json, re
 SIMDS, CLOCK_GHZ = 1024, 2.4
 out = {}
 for shape, pairs, label in (('32x50000x8', 32 * 50000, 'config 3 shape'), ('128x8192x12', 128 * 8192, 'config 5 slice')):
-    cnt, cur = {}, None
+    cnt, cur, disp = {}, None, 0
     for line in open(f'profiles/r02_sinkhorn_{shape}_sq_counters.txt'):
         if 'dispatches' in line:
             cur = 'sinkhorn_block_kernel' in line
-            n_disp = int(line.split('dispatches')[1]) if cur else None
             if cur:
-                disp = n_disp
+                disp += int(line.split('dispatches')[1])
         elif cur:
             k, v = line.split()[0], float(line.split()[1])
-            cnt[k] = v          # summed over the dispatches of ONE scoring call (the call runs in candidate chunks)
+            cnt[k] = cnt.get(k, 0.0) + v          # summed over the dispatches of ONE scoring call (the call runs in candidate
+                                                  # chunks; a small last chunk may take another lanes-per-pair layout)
     total_ns = calls = 0
-    name = None
+    names = []
     for r in csv.DictReader(open(f'profiles/r02_ot_l2max_{shape}_kernel_stats.csv')):
         if 'sinkhorn_block_kernel' in r['Name']:
-            total_ns, calls = float(r['TotalDurationNs']), int(r['Calls'])
-            name = re.search(r'sinkhorn_block_kernel<[^>]*>', r['Name']).group(0)
+            total_ns += float(r['TotalDurationNs'])
+            calls += int(r['Calls'])
+            names.append((float(r['TotalDurationNs']), re.search(r'sinkhorn_block_kernel<[^>]*>', r['Name']).group(0)))
+    name = ' + '.join(n for _, n in sorted(names, reverse=True))
     reps = calls // disp                      # the stats run repeats the call
     kernel_us = total_ns / reps / 1e3         # all chunks of one call
     valu_cycles = cnt['SQ_ACTIVE_INST_VALU'] * 4
