@@ -139,3 +139,30 @@ def test_tile16_other_entry_modes(amd):
     np.testing.assert_allclose(res[''][1], res['small'][1], atol=2e-2, rtol=0)
     want = np.array(orc.rank_pool_caching(query.numpy(), [x.numpy() for x in cands[:64]]), dtype=np.float32)
     np.testing.assert_allclose(res[''][1][:64], want, atol=2e-2, rtol=0)
+
+
+@pytest.mark.parametrize('mode', ['CDIST_DIRECT', 'CDIST_MM'])
+def test_streaming_kernels_follow_the_cdist_mode(amd, mode):
+    """torch.cdist's two formulas as the caller pins them (scorer._cdist_runs does, per padded group): the direct formula
+    gives exactly 0 for a shared sentence (the kernels redo cancelled entries), the matmul expansion keeps its cancellation
+    noise -- fused kernel (<= 8 rows) and tile16 (9 .. 16 rows) against the small forms, tsAspire"""
+    cm = getattr(amd.lib, mode)
+    for smax, nc in ((8, 8300), (14, 4400)):
+        cands = _pool(40 + smax, nc, 2, smax)
+        query = _pool(41, 1, smax, smax)[0]
+        cands[2] = torch.cat([query[1:2], cands[2][:smax - 1]])
+        q, c = amd.ops.DeviceRepSet.from_list([query]), amd.ops.DeviceRepSet.from_list(cands)
+        new = amd.ops.l2max_scores(q, c, cdist_mode=cm).cpu().numpy()
+        with amd.pinned(OT_FORM='small', COST_PATH='valu'):
+            old = amd.ops.l2max_scores(q, c, cdist_mode=cm).cpu().numpy()
+        keep = np.ones(nc, dtype=bool)
+        keep[2] = False
+        np.testing.assert_allclose(new[keep], old[keep], atol=4e-5, rtol=0)
+        if mode == 'CDIST_DIRECT':
+            assert new[2] == 0.0 and old[2] == 0.0
+        else:
+            assert abs(new[2]) < 5e-2 and abs(old[2]) < 5e-2          # sqrt(clamp(cancellation noise)): 0 or ~1e-2 by rounding luck
+        ot_new = amd.ops.ot_sinkhorn(q, c, cdist_mode=cm).cpu().numpy()
+        with amd.pinned(OT_FORM='small', COST_PATH='valu'):
+            ot_old = amd.ops.ot_sinkhorn(q, c, cdist_mode=cm).cpu().numpy()
+        np.testing.assert_allclose(ot_new[keep], ot_old[keep], atol=5e-5, rtol=0)
