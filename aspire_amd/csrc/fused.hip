@@ -261,6 +261,7 @@ template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false, b
 __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
     constexpr bool INBOX = SELF || QBOX;        // the query's box comes from the staged query rows
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    if (a.gate != nullptr && !gate_few_long(a)) return;      // hybrid (score_types.h): mostly long pairs -- the 16-row kernels take them all
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* lds = lds_all + wave * kWaveLds;

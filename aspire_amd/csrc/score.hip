@@ -1205,6 +1205,19 @@ __global__ void __launch_bounds__(192) doc_box_kernel(RepSet d, float* __restric
     *reinterpret_cast<float4*>(box + k * 2 * kD + kD + threadIdx.x * 4) = mx;
 }
 
+// gate[0] += pairs of this launch that hold a document of more than 8 rows (MAPPED: candidate p against query qmap[p]; CROSS:
+// one query).  The counter is zeroed on the stream in front of it.
+__global__ void __launch_bounds__(256) long_pair_census_kernel(ScoreArgs a, int32_t* gate) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int is_long = 0;
+    if (p < a.c.n) {
+        const int64_t q_idx = a.pairing == kPairMapped ? (int64_t)a.qmap[p] : 0;
+        is_long = a.c.len[p] > 8 || a.q.len[q_idx] > 8;
+    }
+    const int n = __popcll(__ballot(is_long));
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(gate, n);
+}
+
 // DS = 1: every wave of the 4-wave workgroup takes its own items (throughput form).  DS > 1: the DS waves of a
 // workgroup share one item and each walks every DS-th stage, then wave 0 adds the partial results (latency form
 // for small grids).
@@ -1607,11 +1620,25 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
         n_slots = a.job_off[a.job1];
     }
     if (slot0 >= n_slots) return;
-    const bool real = slot0 + pp < n_slots;                  // tail wave: surplus groups redo the last pair, store nothing
-    const int64_t slot = real ? slot0 + pp : n_slots - 1;
-    const PairIdx ix = pair_of_slot(a, slot);
+    bool real = slot0 + pp < n_slots;                        // tail wave: surplus groups redo the last pair, store nothing
+    int64_t slot = real ? slot0 + pp : n_slots - 1;
+    PairIdx ix = pair_of_slot(a, slot);
+    int q_len = a.q.len[ix.q_idx], c_len = a.c.len[ix.c_idx];
+    if (gate_few_long(a)) {
+        // hybrid (score_types.h): only the pairs the fused kernel left to the 16-row kernels have slots.  The other lane
+        // groups of the wave mirror its first such pair (their own slots hold nothing: a garbage diameter could mean any
+        // number of steps) and store nothing.
+        real = real && (q_len > 8 || c_len > 8);
+        const unsigned long long todo = __ballot(real);
+        if (todo == 0) return;
+        const int lead = (int)__builtin_ctzll(todo);
+        const int lo = __builtin_amdgcn_readlane((int)(uint32_t)slot, lead), hi = __builtin_amdgcn_readlane((int)(slot >> 32), lead);
+        if (!real) slot = ((int64_t)hi << 32) | (uint32_t)lo;
+        ix = pair_of_slot(a, slot);
+        q_len = a.q.len[ix.q_idx];
+        c_len = a.c.len[ix.c_idx];
+    }
     const int64_t p = ix.p;
-    const int q_len = a.q.len[ix.q_idx], c_len = a.c.len[ix.c_idx];
 
     float cost[R][R];
     bool rv[R], cv[R];
@@ -2350,6 +2377,21 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         }
         if (int rc = launch_pair_fused(a, groups4_all, inbox ? nullptr : qbox, (hipStream_t)stream)) return rc;
     }
+    // ONE short query against a big pool whose documents reach 9 .. 16 rows: the hybrid of ot_rank_batch -- the fused kernel in
+    // front of the 16-row kernels, a census of the long pairs on the device decides who scores what (ScoreArgs::gate).  The
+    // counter lives in the 32 spare bytes in front of the query boxes.
+    if (stream16 && !gram && !fused && !extra && !cost_only && !diameter && q->max_len <= 8 && form_t == 0 && prm->scaling >= 0.25 &&
+        want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu) {
+        int32_t* gate = (int32_t*)((char*)qbox - 16);
+        a.cand0 = 0;
+        a.cand1 = c->n;
+        ASPIRE_HIP_OK(hipMemsetAsync(gate, 0, sizeof(int32_t), (hipStream_t)stream));
+        hipLaunchKernelGGL(long_pair_census_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, gate);
+        ASPIRE_LAUNCH_OK();
+        a.gate = gate;
+        a.gate_limit = (int32_t)(c->n / 24);
+        if (int rc = launch_pair_fused(a, groups4_all, nullptr, (hipStream_t)stream)) return rc;
+    }
     const int rc_run = fused ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         for (int64_t c0 = 0; c0 < c->n; c0 += cand_per_chunk) {
@@ -2477,7 +2519,7 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
 }
 
 struct BatchLayout {
-    size_t slots, qbox, cand_job, grp_job, grp_off, grp_rec, topk, total;
+    size_t slots, qbox, cand_job, grp_job, grp_off, grp_rec, gate, topk, total;
 };
 BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, int64_t k) {
     BatchLayout L{};
@@ -2488,6 +2530,7 @@ BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, in
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
     L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
     L.grp_rec = o; o = align16(o + (size_t)(C / 4 + J + 1) * 16 * sizeof(int32_t));
+    L.gate = o; o = align16(o + 16);
     L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
     L.total = o;
     return L;
@@ -2556,6 +2599,13 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const bool big = max_rows <= 8 && groups_bound >= 2048 && C >= 6000;
     const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
     a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
+    // Documents of up to 16 rows in a batch that fills the chip: usually pools of mostly short abstracts with a few longer
+    // ones.  The fused kernel is queued in front of the 16-row streaming kernel + block Sinkhorn, and a census of the long
+    // pairs, taken on the device, decides how they work (score_types.h: ScoreArgs::gate): few long pairs -- the fused kernel
+    // scores the short ones, the 16-row kernels only the long ones; many -- the fused kernel returns at once.  No host round
+    // trip, and ONE long document no longer moves 20 000 pairs onto kernels 2.5 x slower.
+    const bool hybrid = max_rows > 8 && max_rows <= 16 && form_t == 0 && groups_bound >= 2048 && C >= 6000 && stages == kStageAll &&
+                        prm->scaling >= 0.25 && want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu;
     // batches of <= 64 jobs on the fused kernel need no tables launch: the kernel's waves derive them (fused.hip, SELF)
     const bool self = fused && fused_self_ok(J, prm);
     if ((stages & kStagePrep) && !self) {
@@ -2569,6 +2619,15 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
         ASPIRE_LAUNCH_OK();
     }
     const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
+    if (hybrid) {
+        int32_t* gate = (int32_t*)(wsb + L.gate);
+        ASPIRE_HIP_OK(hipMemsetAsync(gate, 0, sizeof(int32_t), s0));
+        hipLaunchKernelGGL(long_pair_census_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s0, a, gate);
+        ASPIRE_LAUNCH_OK();
+        a.gate = gate;
+        a.gate_limit = (int32_t)(C / 24);     // up to ~4 % long pairs (measured crossover at 20 x 1000: 5 %): fused kernel + the 16-row kernels on the long pairs only
+        if (int rc = launch_pair_fused(a, groups_bound, qbox, s0)) return rc;
+    }
     if (fused) {
         if (stages & (kStageCost | kStageSolve))
             if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0)) return rc;

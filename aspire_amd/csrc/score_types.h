@@ -47,11 +47,20 @@ struct ScoreArgs {
     int32_t max_job_groups;   // host-side launch geometry: upper bound of a job's groups of four
     int32_t tile_form;        // host-side: the batch runs on the throughput kernels
     int32_t skip_tail;        // diagnostics (FUSED_NOSOLVE=2): the fused kernel drops every wave's LAST solve (timing of the exposed tail)
+    // Hybrid for pools of mostly short documents with a few of 9 .. 16 rows: a census of the long pairs (gate[0], written by
+    // long_pair_census_kernel earlier on the stream) decides ON THE DEVICE how the queued kernels work.  Few long pairs
+    // (gate[0] <= gate_limit): the fused kernel scores the short pairs and poisons the long ones, the 16-row streaming kernel
+    // and the block Sinkhorn kernel then touch ONLY the long pairs.  Many: the fused kernel returns at once, the other two
+    // take every pair.
+    const int32_t* gate;
+    int32_t gate_limit;
     long long* dbg;  // phase cycle stamps (only with -DASPIRE_PHASE_CLOCK)
 };
 
 // Internal third pairing next to ASPIRE_PAIR_CROSS / ASPIRE_PAIR_PAIRED (see ScoreArgs::qmap).
 constexpr int kPairMapped = 2;
+
+__device__ __forceinline__ bool gate_few_long(const ScoreArgs& a) { return a.gate != nullptr && *a.gate <= a.gate_limit; }
 
 // (query, candidate, output index) of workspace slot `slot` of the current candidate chunk.
 struct PairIdx {

@@ -42,6 +42,7 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 template <bool L2MAX>
 __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs<2> ws, const float* __restrict__ qbox) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const bool selective = gate_few_long(a);                // hybrid: only the pairs that hold a document of more than 8 rows
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* lds = lds_all + wave * kWaveLds;
@@ -96,7 +97,8 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
         next = load_ctx(item + n_waves < n_items ? item + n_waves : item);      // one item ahead (fused.hip)
         const int64_t q_idx = cur.q_idx, slot = cur.slot;
         const int c_len = cur.c_len, q_len = cur.q_len, c_start = cur.c_start;
-        const bool my_c_real = cur.my_c_real;
+        if (selective && !__any(cur.my_c_real && (cur.q_len > 8 || cur.c_len > 8))) continue;      // the fused kernel scored this item
+        const bool my_c_real = cur.my_c_real && (!selective || cur.q_len > 8 || cur.c_len > 8);
         const float* qdoc = a.q.rows + (size_t)cur.q_start * kD;
         const float* sy_doc = a.c.rows + (size_t)c_start * kD;
         // the query's per-coordinate box; with caller-supplied diameters the candidate's rows stand in (term unused): the

@@ -166,3 +166,76 @@ def test_streaming_kernels_follow_the_cdist_mode(amd, mode):
         with amd.pinned(OT_FORM='small', COST_PATH='valu'):
             ot_old = amd.ops.ot_sinkhorn(q, c, cdist_mode=cm).cpu().numpy()
         np.testing.assert_allclose(ot_new[keep], ot_old[keep], atol=5e-5, rtol=0)
+
+
+def _batch16(amd, queries, pools, k, **pins):
+    q = amd.ops.DeviceRepSet.from_list(queries)
+    c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
+    sizes = [len(p) for p in pools]
+    job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).cuda()
+    with amd.pinned(**pins):
+        s, ts, ti = amd.ops.ot_rank_batch(q, c, job_off, max(sizes), k)
+        torch.cuda.synchronize()
+    return s.cpu().numpy(), ts.cpu().numpy(), ti.cpu().numpy()
+
+
+@pytest.mark.parametrize('p_long', [0.004, 0.6])
+def test_batch_hybrid_short_pools_with_a_few_long_documents(amd, p_long):
+    """batches whose documents reach 9 .. 16 rows: a census on the device picks the kernel family.  Few long pairs (0.4 %):
+    the fused kernel scores the short pairs, the long-form kernel exactly the poisoned ones -- every score against the
+    16-row streaming path (pinned OT_FORM=tile) and the oracle.  Many long pairs (60 %): the census sends the whole batch
+    to the streaming path -- bit for bit the pinned result (the short-document kernels returned at once, wrote nothing)."""
+    g = torch.Generator().manual_seed(int(p_long * 1000) + 5)
+    sizes = [1500, 1203, 2, 998, 1777, 1501, 3, 700]
+    def doc():
+        long = torch.rand(1, generator=g).item() < p_long
+        n = int(torch.randint(9, 17, (1,), generator=g)) if long else int(torch.randint(1, 9, (1,), generator=g))
+        return torch.randn(n, 768, generator=g)
+    queries = [torch.randn(int(torch.randint(3, 9, (1,), generator=g)), 768, generator=g) for _ in sizes]
+    if p_long > 0.5:
+        queries[3] = torch.randn(13, 768, generator=g)           # a long query: every pair of its job is long
+    pools = [[doc() for _ in range(sz)] for sz in sizes]
+    pools[0][5] = torch.randn(16, 768, generator=g)              # at least one long document in any case
+    pools[4][1776] = torch.randn(9, 768, generator=g)
+    hyb = _batch16(amd, queries, pools, 25)
+    ref = _batch16(amd, queries, pools, 25, OT_FORM='tile')
+    assert np.isfinite(hyb[0]).all()
+    if p_long > 0.5:
+        assert np.array_equal(hyb[0], ref[0]) and np.array_equal(hyb[2], ref[2])
+    else:
+        np.testing.assert_allclose(hyb[0], ref[0], atol=5e-5, rtol=0)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for j, i in ((0, 5), (4, 1776), (0, 0), (3, 10), (7, 699)):
+        want = orc.get_similarity(queries[j], pools[j][i])
+        assert abs(hyb[0][off[j] + i] - want) < TOL, (j, i)
+    for j in range(len(sizes)):                                   # every job's list = the stable sort of its own scores
+        sc = hyb[0][off[j]:off[j + 1]]
+        kk = min(25, sizes[j])
+        assert hyb[2][j, :kk].tolist() == np.argsort(-sc.astype(np.float64), kind='stable')[:kk].tolist()
+
+
+@pytest.mark.parametrize('p_long', [0.003, 0.5])
+def test_single_pool_hybrid(amd, p_long):
+    """one short query against a big pool with a share of 9 .. 16-row documents (aspire_ot_sinkhorn_f32 / aspire_ot_rank_f32):
+    the same device-side hybrid as the batch entry, against the 16-row streaming path pinned and the oracle"""
+    g = torch.Generator().manual_seed(77)
+    nc = 9100
+    lens = torch.where(torch.rand(nc, generator=g) < p_long, torch.randint(9, 17, (nc,), generator=g), torch.randint(1, 9, (nc,), generator=g))
+    lens[11] = 15
+    cands = [torch.randn(int(n), 768, generator=g) for n in lens]
+    query = torch.randn(7, 768, generator=g)
+    q, c = amd.ops.DeviceRepSet.from_list([query]), amd.ops.DeviceRepSet.from_list(cands)
+    hyb = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+    with amd.pinned(OT_FORM='tile'):
+        ref = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+    assert np.isfinite(hyb).all()
+    if p_long > 0.4:
+        assert np.array_equal(hyb, ref)
+    else:
+        np.testing.assert_allclose(hyb, ref, atol=5e-5, rtol=0)
+    idx = [0, 11, 12, nc - 1] + [int(i) for i in np.nonzero(lens.numpy() > 8)[0][:3]]
+    want = np.array([-orc.get_similarity(query, cands[i]) for i in idx], dtype=np.float32)
+    np.testing.assert_allclose(hyb[idx], want, atol=TOL, rtol=0)
+    sc, ts, ti = amd.ops.ot_rank(q, c, 50, want=amd.lib.OT_SIMILARITY)
+    order = np.argsort(-sc.cpu().numpy()[0].astype(np.float64), kind='stable')[:50]
+    assert ti.cpu().numpy()[0].tolist() == order.tolist()
