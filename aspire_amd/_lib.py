@@ -90,6 +90,9 @@ SIGNATURES = {
     'aspire_ot_rank_batch_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_void_p, c_int64,
                                          ctypes.POINTER(OtParams), c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    'aspire_l2max_rank_batch_workspace_bytes': (c_size_t, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int64]),
+    'aspire_l2max_rank_batch_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_void_p, c_int64, c_int,
+                                            c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'aspire_debug_set': (c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     'aspire_debug_ot_cost_stage_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int,
                                                ctypes.POINTER(OtParams), c_void_p, c_void_p, c_size_t, c_void_p]),

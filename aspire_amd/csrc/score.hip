@@ -2661,6 +2661,105 @@ extern "C" int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_rep
                          workspace_bytes, stream, kStageAll);
 }
 
+// ---- tsAspire over batched jobs ------------------------------------------------------------------------------------------
+namespace {
+struct L2BatchLayout {
+    size_t cand_job, grp_job, grp_off, grp_rec, qbox, topk, total;
+};
+L2BatchLayout l2_batch_layout(int64_t J, int64_t C, int64_t max_job, int64_t k) {
+    L2BatchLayout L{};
+    size_t o = 0;
+    L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
+    L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
+    L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
+    L.grp_rec = o; o = align16(o + (size_t)(C / 4 + J + 1) * 16 * sizeof(int32_t));
+    L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));      // (written by the tables kernel, unused by max-sim)
+    L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t aspire_l2max_rank_batch_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t max_job, int64_t k) {
+    if (!q || !c || q->n <= 0 || c->n <= 0) return 0;
+    return l2_batch_layout(q->n, c->n, max_job, k).total;
+}
+
+extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,
+                                           int64_t max_job, int cdist_mode, float* scores, int64_t k, const int32_t* job_base,
+                                           float* top_scores, int64_t* top_idx, uint64_t* keys, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (int rc = check_repsets(q, c, D, ASPIRE_PAIR_CROSS)) return rc;
+    const int64_t J = q->n, C = c->n;
+    ASPIRE_REQUIRE(q->ext == 0 && c->ext == 0, ASPIRE_ERR_INVALID_ARG, "batched jobs take CSR rep sets (ext == 0)");
+    ASPIRE_REQUIRE(k >= 0 && (k == 0 || (top_scores && top_idx) || keys), ASPIRE_ERR_INVALID_ARG,
+                   "k > 0 needs (top_scores, top_idx) or keys");
+    if (J == 0) return ASPIRE_OK;
+    ASPIRE_REQUIRE(job_off && max_job >= 0 && max_job <= C, ASPIRE_ERR_INVALID_ARG, "need job_off and 0 <= max_job <= C");
+    ASPIRE_REQUIRE(J < ((int64_t)1 << 30) && C < ((int64_t)1 << 31) - 8, ASPIRE_ERR_UNSUPPORTED, "batch too large for 32-bit offsets");
+    hipStream_t s0 = (hipStream_t)stream;
+    if (C == 0) {
+        const float* unread = reinterpret_cast<const float*>(job_off);     // every segment is empty: never dereferenced
+        if (k > 0) return topk_run(unread, J, 0, k, 0, top_scores, top_idx, keys, nullptr, 0, stream, job_off, job_base);
+        return ASPIRE_OK;
+    }
+    ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "null scores");
+    const int max_rows = max_rows_of(q, c);
+    ASPIRE_REQUIRE(max_rows <= generic_max_rows(), ASPIRE_ERR_UNSUPPORTED, "documents with more than %d sentence rows are not supported (got %d)",
+                   generic_max_rows(), max_rows);
+    const L2BatchLayout L = l2_batch_layout(J, C, max_job, k);
+    ASPIRE_REQUIRE(workspace && workspace_bytes >= L.total, ASPIRE_ERR_INVALID_ARG,
+                   "workspace too small: %zu bytes given, aspire_l2max_rank_batch_workspace_bytes says %zu", workspace_bytes, L.total);
+    ASPIRE_REQUIRE(((uintptr_t)workspace & 15) == 0, ASPIRE_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
+    char* wsb = (char*)workspace;
+    ScoreArgs a{};
+    a.q = to_dev(q);
+    a.c = to_dev(c);
+    a.pairing = kPairMapped;
+    a.cdist_mode = cdist_mode;
+    a.agg = ASPIRE_AGG_MAX;
+    a.temp = 1.0;
+    a.scores = scores;
+    a.cand0 = 0;
+    a.cand1 = C;
+    a.qmap = (int32_t*)(wsb + L.cand_job);
+    a.job_off = job_off;
+    a.grp_off = (int32_t*)(wsb + L.grp_off);
+    a.grp_job = (int32_t*)(wsb + L.grp_job);
+    a.grp_rec = (int32_t*)(wsb + L.grp_rec);
+    a.job0 = 0;
+    a.job1 = (int32_t)J;
+    a.max_job_groups = (int32_t)((max_job + 3) / 4);
+    {
+        const int64_t work = ((max_job + 3) / 4) * 16;
+        int64_t parts = (work + 2 * 192 - 1) / (2 * 192);
+        parts = parts < 1 ? 1 : parts > 64 ? 64 : parts;
+        while (parts > 1 && J * parts > 4096) parts /= 2;
+        hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)J, (unsigned)parts + 1), dim3(192), 0, s0, a.q, a.c, job_off, (int)J,
+                           (float*)(wsb + L.qbox), (int32_t*)(wsb + L.cand_job), (int32_t*)(wsb + L.grp_off), (int32_t*)(wsb + L.grp_job),
+                           (int32_t*)(wsb + L.grp_rec));
+        ASPIRE_LAUNCH_OK();
+    }
+    // Forms: the streaming kernels once the batch fills the chip (documents of <= 8 rows: fused.hip's max-sim form, four
+    // candidates of a job per wave; 9 .. 16 rows: tile16.hip, two), else -- small batches, longer documents -- the
+    // one-workgroup-per-pair kernel (generic.hip).
+    const int64_t groups_bound = J * ((max_job + 3) / 4);
+    const int form_t = tuning().ot_form;
+    const bool big = groups_bound >= 2048 && C >= 6000 && form_t != 1;
+    if (big && max_rows <= 8) {
+        if (int rc = launch_pair_fused_l2max(a, groups_bound, s0)) return rc;
+    } else if (big && max_rows <= 16) {
+        if (int rc = launch_pair_tile16_l2max(a, 2 * groups_bound, s0)) return rc;
+    } else {
+        if (int rc = launch_pair_generic(a, 1, 0, q->max_len, c->max_len, s0)) return rc;
+    }
+    const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
+    if (k > 0)
+        return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
+                        topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);
+    return ASPIRE_OK;
+}
+
 // Diagnostics: chosen stages of aspire_ot_rank_batch_f32 on the caller's stream alone (1 tables + query boxes, 2 cost
 // kernel, 4 Sinkhorn kernel, 8 rank) -- bench.py times each stage of a pass this way, after a full call has filled the
 // workspace.

@@ -239,6 +239,33 @@ def ot_rank_batch(q, c, job_off, max_job, k, blur=0.05, scaling=0.9, sent_sm_tem
     return (scores, keys) if key_form else (scores, top_s, top_i)
 
 
+def l2max_rank_batch(q, c, job_off, max_job, k, cdist_mode=_lib.CDIST_AUTO, out=None, workspace=None, job_base=None, key_form=False):
+    """tsAspire over J independent (query, pool) jobs in ONE call (include/aspire_hip.h: aspire_l2max_rank_batch_f32); arguments
+    and returns as ot_rank_batch: (scores [C], top_scores [J, k], top_idx [J, k]) or (scores, keys [J, k]) with key_form."""
+    dev = q.rows.device
+    _i32(job_off, 'job_off')
+    assert job_off.numel() == q.n + 1, 'job_off must have one entry per job plus one'
+    keys = None
+    if out is not None and key_form:
+        scores, keys = out
+        top_s = top_i = None
+    elif out is not None:
+        scores, top_s, top_i = out
+    else:
+        scores = torch.empty(c.n, device=dev, dtype=torch.float32)
+        top_s = torch.empty(q.n, k, device=dev, dtype=torch.float32) if k > 0 and not key_form else None
+        top_i = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and not key_form else None
+        keys = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and key_form else None
+    qs, cs = q.struct(), c.struct()
+    if workspace is None:
+        nbytes = lib.aspire_l2max_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), max_job, k)
+        workspace = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+    check(lib.aspire_l2max_rank_batch_f32(ctypes.byref(qs), ctypes.byref(cs), D, _ptr(job_off), max_job, cdist_mode, _ptr(scores), k,
+                                          _ptr(job_base), _ptr(top_s), _ptr(top_i), _ptr(keys), _ptr(workspace), workspace.numel(),
+                                          _stream()))
+    return (scores, keys) if key_form else (scores, top_s, top_i)
+
+
 def topk_desc(scores, k, idx_base=0):
     """A12 (evaluate.py:76): scores [Q, C] -> (top_scores [Q,k], top_idx [Q,k] int64), stable descending."""
     _f32(scores, 'scores')

@@ -151,10 +151,12 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
     return [[(pool.pids[i], float(s)) for s, i in zip(rs, ri) if i >= 0] for rs, ri in zip(top_s, top_i)]
 
 
-def _launch_rank_pools(query_reps_list, pools, k, hparams):
+def _launch_rank_pools(query_reps_list, pools, k, hparams, method='ot'):
     """Uploads + the one library call of rank_pools on the CURRENT stream; returns (pools, top_scores, top_idx) GPU tensors
     (None for the tensors when every pool is empty)."""
     hparams = hparams or {}
+    if method not in ('ot', 'l2max'):
+        raise ValueError(f'Unknown aggregation: {method}')
     if hparams.get('geoml_reach', None) is not None:
         raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
     assert len(query_reps_list) == len(pools), 'one pool per query'
@@ -172,6 +174,9 @@ def _launch_rank_pools(query_reps_list, pools, k, hparams):
                          torch.cat([r.start + int(b) for r, b in zip(nonempty, row_base)]).to(torch.int32).contiguous(),
                          torch.cat([r.len for r in nonempty]).contiguous(), ext=0, max_len=max(r.max_len for r in nonempty))
     job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    if method == 'l2max':
+        _, top_s, top_i = ops.l2max_rank_batch(q, c, job_off, max_job, k)
+        return pools, top_s, top_i
     _, top_s, top_i = ops.ot_rank_batch(q, c, job_off, max_job, k, blur=hparams.get('geoml_blur', 0.05),
                                         scaling=hparams.get('geoml_scaling', 0.9), sent_sm_temp=hparams.get('sent_sm_temp', 1.0),
                                         want=_lib.OT_SIMILARITY)
@@ -185,14 +190,15 @@ def _ranked_lists(pools, top_s, top_i):
     return [[(p.pids[i], float(sc)) for sc, i in zip(rs, ri) if i >= 0] for p, rs, ri in zip(pools, top_s, top_i)]
 
 
-def rank_pools(query_reps_list, pools, k=None, hparams=None):
+def rank_pools(query_reps_list, pools, k=None, hparams=None, method='ot'):
     """The whole per-query loop of evaluate.py:58-76 in ONE library call: query j is scored against ITS OWN pool
     pools[j] (every query of a dataset has its own candidate pool, evaluate.py:60-62) with otAspire, one epsilon schedule
-    per pair (AspireModel.get_similarity, models.py:190-197), and each pool is ranked on its own (stable descending,
-    evaluate.py:76).  pools: list of CandidatePool or lists of [S_i, 768] arrays.  Returns per query [(pid, score), ...]."""
+    per pair (AspireModel.get_similarity, models.py:190-197) -- or, method='l2max', tsAspire's max-sim -- and each pool is
+    ranked on its own (stable descending, evaluate.py:76).  pools: list of CandidatePool or lists of [S_i, 768] arrays.
+    Returns per query [(pid, score), ...]."""
     if not pools:
         return []
-    return _ranked_lists(*_launch_rank_pools(query_reps_list, pools, k, hparams))
+    return _ranked_lists(*_launch_rank_pools(query_reps_list, pools, k, hparams, method))
 
 
 class InFlightRanker:
@@ -206,9 +212,9 @@ class InFlightRanker:
         ranked = [ranker.result(t) for t in tickets]          # same lists as rank_pools(queries_b, pools_b)
     """
 
-    def __init__(self, n_lanes=3, k=None, hparams=None):
+    def __init__(self, n_lanes=3, k=None, hparams=None, method='ot'):
         dev = ops.require_gpu()
-        self.k, self.hparams = k, hparams
+        self.k, self.hparams, self.method = k, hparams, method
         self.lanes = [torch.cuda.Stream(dev) for _ in range(max(1, int(n_lanes)))]
         self.busy = [None] * len(self.lanes)          # the lane's last ticket (its stream runs calls in order)
         self.turn = 0
@@ -217,7 +223,7 @@ class InFlightRanker:
         lane = self.turn % len(self.lanes)
         self.turn += 1
         with torch.cuda.stream(self.lanes[lane]):
-            out = _launch_rank_pools(query_reps_list, pools, self.k, self.hparams) if pools else ([], None, None)
+            out = _launch_rank_pools(query_reps_list, pools, self.k, self.hparams, self.method) if pools else ([], None, None)
             done = torch.cuda.Event()
             done.record()
         ticket = {'lane': lane, 'out': out, 'done': done}

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASPIRE_ABI_VERSION 2
+#define ASPIRE_ABI_VERSION 3
 
 typedef enum {
     ASPIRE_OK = 0,
@@ -279,6 +279,18 @@ int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int
                              int64_t max_job, const aspire_ot_params* prm, int want, float* scores, int64_t k,
                              const int32_t* job_base, float* top_scores, int64_t* top_idx, uint64_t* keys, void* workspace,
                              size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The same per-query loop for tsAspire (allpair_masked_dist_l2max, pair_distances.py:138-186; caching_score's 'l2lse'
+ * branch, disent_models.py:294-295): J independent (query, pool) re-ranks by max-sim in ONE call.  Arguments as
+ * aspire_ot_rank_batch_f32 (no OT parameters; cdist_mode as aspire_l2max_scores_f32); scores [C] = -min L2 over the valid
+ * sentence pairs of candidate p and its job's query.  Documents of up to 128 rows.
+ * ------------------------------------------------------------------------------------------- */
+size_t aspire_l2max_rank_batch_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t max_job, int64_t k);
+int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,
+                                int64_t max_job, int cdist_mode, float* scores, int64_t k, const int32_t* job_base,
+                                float* top_scores, int64_t* top_idx, uint64_t* keys, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SURVEY.md 8(e)  shard merge.  The same rank in KEY form for the candidate-pool shards of a multi-GPU job:

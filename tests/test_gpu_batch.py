@@ -256,3 +256,32 @@ def test_in_flight_ranker_equals_rank_pools(amd):
         order = range(len(tickets)) if rounds == 0 else reversed(range(len(tickets)))
         for i in order:
             assert ranker.result(tickets[i]) == want[i], i
+
+
+@pytest.mark.parametrize('smax,sizes', [(8, [1503, 2, 0, 997, 1250, 3, 2048, 1, 1100]),      # fused max-sim form
+                                        (14, [1203, 1, 998, 2, 1501, 700, 0, 1600]),       # 16-row streaming kernel
+                                        (8, [40, 0, 25, 3]), (23, [300, 1, 77])])           # small / long: one workgroup per pair
+def test_l2max_rank_batch(amd, smax, sizes):
+    """tsAspire over batched jobs (aspire_l2max_rank_batch_f32, rank_pools(method='l2max')): every job's scores = the
+    per-pool call's, = -min cdist in torch on a sample; every list = the stable descending sort of its own scores"""
+    queries, pools = _jobs(90 + smax, sizes, smax)
+    q = amd.ops.DeviceRepSet.from_list(queries)
+    c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
+    job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).cuda()
+    k = 30
+    s, ts, ti = amd.ops.l2max_rank_batch(q, c, job_off, max(sizes), k)
+    torch.cuda.synchronize()
+    off = job_off.cpu().numpy()
+    sc = [s[off[j]:off[j + 1]].cpu() for j in range(len(sizes))]
+    _check_rank(sc, ts.cpu(), ti.cpu(), k)
+    for j, n in enumerate(sizes):
+        if n == 0:
+            continue
+        one = amd.scorer.score_pool([queries[j]], pools[j], method='l2max')[0].cpu().numpy()
+        np.testing.assert_allclose(sc[j].numpy(), one, atol=4e-5, rtol=0)
+        for i in (0, n - 1):
+            want = -torch.cdist(queries[j], pools[j][i]).min().item()
+            assert abs(sc[j][i].item() - want) < 4e-5, (j, i)
+    ranked = amd.scorer.rank_pools(queries, pools, k=k, method='l2max')
+    for j, n in enumerate(sizes):
+        assert [i for i, _ in ranked[j]] == ti.cpu()[j, :min(k, n)].tolist()
