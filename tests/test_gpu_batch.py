@@ -145,10 +145,14 @@ def test_batch_hparams_and_wants(amd):
         np.testing.assert_allclose(sign * sc[1].numpy(), ref, atol=TOL, rtol=0)
 
 
-def test_batch_under_graph_capture(amd):
-    """the call is capturable into a hipGraph (everything runs on the caller's stream) and replays to the same bits"""
+@pytest.mark.parametrize('long_doc', [False, True])
+def test_batch_under_graph_capture(amd, long_doc):
+    """the call is capturable into a hipGraph (everything runs on the caller's stream) and replays to the same bits -- also
+    the device-side hybrid (a 13-row document among the pools: counter reset, census, gated kernels are all stream work)"""
     sizes = [1200] * 8
     queries, pools = _jobs(51, sizes, 8, smin=8)
+    if long_doc:
+        pools[3][17] = torch.randn(13, 768, generator=torch.Generator().manual_seed(1))
     q = amd.ops.DeviceRepSet.from_list(queries)
     c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
     job_off = torch.arange(0, 9601, 1200, dtype=torch.int32).cuda()
