@@ -2664,7 +2664,7 @@ extern "C" int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_rep
 // ---- tsAspire over batched jobs ------------------------------------------------------------------------------------------
 namespace {
 struct L2BatchLayout {
-    size_t cand_job, grp_job, grp_off, grp_rec, qbox, topk, total;
+    size_t cand_job, grp_job, grp_off, grp_rec, qbox, gate, topk, total;
 };
 L2BatchLayout l2_batch_layout(int64_t J, int64_t C, int64_t max_job, int64_t k) {
     L2BatchLayout L{};
@@ -2674,6 +2674,7 @@ L2BatchLayout l2_batch_layout(int64_t J, int64_t C, int64_t max_job, int64_t k) 
     L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
     L.grp_rec = o; o = align16(o + (size_t)(C / 4 + J + 1) * 16 * sizeof(int32_t));
     L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));      // (written by the tables kernel, unused by max-sim)
+    L.gate = o; o = align16(o + 16);
     L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
     L.total = o;
     return L;
@@ -2749,6 +2750,16 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     if (big && max_rows <= 8) {
         if (int rc = launch_pair_fused_l2max(a, groups_bound, s0)) return rc;
     } else if (big && max_rows <= 16) {
+        // mostly short documents with a few of 9 .. 16 rows: the hybrid of ot_rank_batch (ScoreArgs::gate)
+        if (form_t == 0) {
+            int32_t* gate = (int32_t*)(wsb + L.gate);
+            ASPIRE_HIP_OK(hipMemsetAsync(gate, 0, sizeof(int32_t), s0));
+            hipLaunchKernelGGL(long_pair_census_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s0, a, gate);
+            ASPIRE_LAUNCH_OK();
+            a.gate = gate;
+            a.gate_limit = (int32_t)(C / 24);
+            if (int rc = launch_pair_fused_l2max(a, groups_bound, s0)) return rc;
+        }
         if (int rc = launch_pair_tile16_l2max(a, 2 * groups_bound, s0)) return rc;
     } else {
         if (int rc = launch_pair_generic(a, 1, 0, q->max_len, c->max_len, s0)) return rc;

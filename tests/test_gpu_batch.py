@@ -263,7 +263,7 @@ def test_in_flight_ranker_equals_rank_pools(amd):
 
 
 @pytest.mark.parametrize('smax,sizes', [(8, [1503, 2, 0, 997, 1250, 3, 2048, 1, 1100]),      # fused max-sim form
-                                        (14, [1203, 1, 998, 2, 1501, 700, 0, 1600]),       # 16-row streaming kernel
+                                        (14, [1203, 1, 998, 2, 1501, 700, 0, 1600]),       # 16-row streaming kernel (most pairs long)
                                         (8, [40, 0, 25, 3]), (23, [300, 1, 77])])           # small / long: one workgroup per pair
 def test_l2max_rank_batch(amd, smax, sizes):
     """tsAspire over batched jobs (aspire_l2max_rank_batch_f32, rank_pools(method='l2max')): every job's scores = the
@@ -289,3 +289,27 @@ def test_l2max_rank_batch(amd, smax, sizes):
     ranked = amd.scorer.rank_pools(queries, pools, k=k, method='l2max')
     for j, n in enumerate(sizes):
         assert [i for i, _ in ranked[j]] == ti.cpu()[j, :min(k, n)].tolist()
+
+
+def test_l2max_rank_batch_hybrid(amd):
+    """tsAspire batch with a handful of 9 .. 16-row documents among short ones: the fused max-sim kernel scores the short pairs,
+    the 16-row kernel only the long ones (census on the device) -- against the 16-row path pinned and torch"""
+    sizes = [1500, 1203, 2, 998, 1777, 1501, 3, 700]
+    queries, pools = _jobs(123, sizes, 8)
+    g = torch.Generator().manual_seed(9)
+    for j, i, n in ((0, 5, 16), (4, 1776, 9), (5, 0, 12), (7, 350, 11)):
+        pools[j][i] = torch.randn(n, 768, generator=g)
+    q = amd.ops.DeviceRepSet.from_list(queries)
+    c = amd.ops.DeviceRepSet.from_list([d for p in pools for d in p])
+    job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).cuda()
+    hyb = amd.ops.l2max_rank_batch(q, c, job_off, max(sizes), 20)
+    with amd.pinned(OT_FORM='tile'):
+        ref = amd.ops.l2max_rank_batch(q, c, job_off, max(sizes), 20)
+    torch.cuda.synchronize()
+    assert torch.isfinite(hyb[0]).all()
+    np.testing.assert_allclose(hyb[0].cpu().numpy(), ref[0].cpu().numpy(), atol=4e-5, rtol=0)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for j, i in ((0, 5), (4, 1776), (5, 0), (7, 350), (0, 0), (3, 997)):
+        want = -torch.cdist(queries[j], pools[j][i]).min().item()
+        assert abs(hyb[0][off[j] + i].item() - want) < 4e-5, (j, i)
+    _check_rank([hyb[0][off[j]:off[j + 1]].cpu() for j in range(len(sizes))], hyb[1].cpu(), hyb[2].cpu(), 20)
