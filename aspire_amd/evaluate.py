@@ -7,8 +7,8 @@
             utils/utils.py:59-82                  (`query-evaluations[-facet].csv`) and their means per (facet, split)
                                                   (`aggregated-evaluations[-facet].csv`)
 
-The per-pair Python loop of the reference (one get_similarity call per candidate) becomes one rank_pool call per query
-against sentence reps resident in HBM.  File names and layouts are the reference's, so its own `evaluate` step can read
+The per-pair Python loop of the reference (one get_similarity call per candidate) becomes one rank_pools call per 32 queries
+(each against its own pool) on sentence reps resident in HBM.  File names and layouts are the reference's, so its own `evaluate` step can read
 what `score` writes here and vice versa.
 """
 import codecs
@@ -30,18 +30,35 @@ def get_evaluations_filename(results_dir, facet, aggregated):   # utils/utils.py
     return os.path.join(results_dir, f'{kind}-evaluations.csv' if facet is None else f'{kind}-evaluations-{facet}.csv')
 
 
-def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, method='ot', schedule='pair', hparams=None):
+def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, method='ot', schedule='pair', hparams=None,
+          queries_per_call=32):
     """evaluate.py:36-82.  test_pool: {query_id: {'cands': [cand_id, ...]}} (the dataset's test-pid json);
     rep_store: aspire_amd.repstore.RepStore of sentence reps.  A faceted query keeps only the sentence rows whose
     predicted label matches the facet (models.py:127-163; pred_labels: {paper_id: [label per sentence]}).
-    Writes and returns {query_id: [(cand_id, -sim), ...]}."""
+    Writes and returns {query_id: [(cand_id, -sim), ...]}.
+
+    With the per-pair schedule (the reference's own: one get_similarity call per candidate, evaluate.py:68-72) the queries go
+    through scorer.rank_pools `queries_per_call` at a time -- every query against ITS OWN pool in one library call; any other
+    schedule / aggregation keeps one rank_pool call per query."""
     from . import scorer
     results = {}
-    for query_id, pool in test_pool.items():
-        cand_ids = list(pool['cands'])
-        q = rep_store.faceted(query_id, facet, pred_labels[query_id]) if facet is not None else rep_store.get(query_id)
-        ranked = scorer.rank_pool([q], rep_store.pool(cand_ids), method=method, schedule=schedule, hparams=hparams)[0]
-        results[query_id] = [(cid, -1 * sim) for cid, sim in ranked]     # evaluate.py:77
+    query_ids = list(test_pool.keys())
+
+    def query_reps(query_id):
+        return rep_store.faceted(query_id, facet, pred_labels[query_id]) if facet is not None else rep_store.get(query_id)
+
+    if schedule == 'pair' and method in ('ot', 'l2max') and queries_per_call > 1:
+        for lo in range(0, len(query_ids), queries_per_call):
+            ids = query_ids[lo:lo + queries_per_call]
+            pools = [rep_store.pool(list(test_pool[i]['cands'])) for i in ids]
+            ranked = scorer.rank_pools([query_reps(i) for i in ids], pools, method=method, hparams=hparams)
+            for query_id, r in zip(ids, ranked):
+                results[query_id] = [(cid, -1 * sim) for cid, sim in r]     # evaluate.py:77
+    else:
+        for query_id in query_ids:
+            pool = rep_store.pool(list(test_pool[query_id]['cands']))
+            ranked = scorer.rank_pool([query_reps(query_id)], pool, method=method, schedule=schedule, hparams=hparams)[0]
+            results[query_id] = [(cid, -1 * sim) for cid, sim in ranked]     # evaluate.py:77
     os.makedirs(results_dir, exist_ok=True)
     with codecs.open(get_scores_filename(results_dir, facet), 'w', 'utf-8') as fp:
         json.dump(results, fp)

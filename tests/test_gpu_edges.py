@@ -157,6 +157,30 @@ def test_score_and_evaluate_steps_close_the_map_loop(amd, tmp_path):
     assert agg[0]['av_precision'] == pytest.approx(round(float(want_map), 4))
 
 
+@pytest.mark.parametrize('method', ['ot', 'l2max'])
+def test_score_step_batched_over_queries_equals_the_per_query_loop(amd, tmp_path, method):
+    """evaluate.score sends the queries through rank_pools several at a time (each against its own pool, pools of different
+    sizes, one of them empty): the same json as one rank_pool call per query."""
+    from aspire_amd import evaluate as ev
+    from aspire_amd.repstore import RepStore
+    g = torch.Generator().manual_seed(62)
+    pids = [f'p{i}' for i in range(90)]
+    store = RepStore({p: torch.randn(int(n), 768, generator=g).numpy()
+                      for p, n in zip(pids, torch.randint(1, 14, (90,), generator=g))})
+    test_pool = {pids[j]: {'cands': pids[10 + j:10 + j + size]} for j, size in enumerate([40, 7, 0, 61, 1, 33, 80])}
+    one = ev.score(str(tmp_path / 'one'), test_pool, store, method=method, schedule='pair', queries_per_call=1)
+    for per_call in (3, 32):
+        got = ev.score(str(tmp_path / f'b{per_call}'), test_pool, store, method=method, schedule='pair', queries_per_call=per_call)
+        assert list(got) == list(one)
+        for q in test_pool:
+            assert [c for c, _ in got[q]] == [c for c, _ in one[q]]
+            np.testing.assert_allclose([s for _, s in got[q]], [s for _, s in one[q]], atol=TOL, rtol=0)
+    for q, d in test_pool.items():
+        if d['cands'] and method == 'ot':
+            want = [orc.get_similarity(torch.from_numpy(store.get(q)), torch.from_numpy(store.get(c))) for c in d['cands']]
+            np.testing.assert_allclose(sorted(-s for _, s in one[q]), sorted(want), atol=TOL)
+
+
 def test_small_pool_with_coincident_sentences(amd):
     """The small-pool cost kernel accumulates only x.y and takes -cdist from the expansion; entries where that
     cancels (a candidate sentence equal, or nearly equal, to a query sentence) are redone with the direct formula,

@@ -1,0 +1,65 @@
+"""BASELINE config 4's shape on one GPU: the CSFCube re-rank -- 50 (query, facet) jobs, every query against its own pool of
+~125 candidates, ragged abstracts of 3 .. 20 sentences, facet-selected query rows (1 .. 8), full ranking (k = pool size).
+Times the batched call (aspire_ot_rank_batch_f32 / aspire_l2max_rank_batch_f32, reps resident) against the per-query loop
+(aspire_ot_rank_f32 per query) and prints the launches' share.   python tools/csfbench.py [J NC SMAX]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aspire_amd import _lib, ops
+
+J, NC, SMAX = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (50, 125, 20)
+dev = torch.device('cuda')
+g = torch.Generator().manual_seed(4)
+
+
+def repset(lens):
+    start = torch.cumsum(lens, 0) - lens
+    rows = torch.randn(int(lens.sum()), 768, generator=g).to(dev)
+    return ops.DeviceRepSet(rows, start.to(torch.int32).to(dev), lens.to(torch.int32).to(dev), ext=0, max_len=int(lens.max()))
+
+
+def timed(fn, n=50):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return 1e6 * (time.perf_counter() - t0) / n
+
+
+c_lens = torch.randint(3, SMAX + 1, (J * NC,), generator=g)
+q_lens = torch.randint(1, min(SMAX, 8) + 1, (J,), generator=g)
+c, q = repset(c_lens), repset(q_lens)
+job_off = (torch.arange(J + 1, dtype=torch.int32) * NC).to(dev)
+pairs = J * NC
+out = ops.ot_rank_batch(q, c, job_off, NC, NC)
+t = timed(lambda: ops.ot_rank_batch(q, c, job_off, NC, NC, out=out))
+print(f'otAspire {J} x {NC} (rows 3..{SMAX}), one batched call: {t:8.1f} us = {pairs / t:6.2f} M pairs/s', flush=True)
+out2 = ops.l2max_rank_batch(q, c, job_off, NC, NC)
+t = timed(lambda: ops.l2max_rank_batch(q, c, job_off, NC, NC, out=out2))
+print(f'tsAspire {J} x {NC}, one batched call:               {t:8.1f} us = {pairs / t:6.2f} M pairs/s', flush=True)
+
+# the per-query loop: one aspire_ot_rank_f32 call per query on its own pool
+qs = [ops.DeviceRepSet(q.rows, q.start[j:j + 1].contiguous(), q.len[j:j + 1].contiguous(), ext=0, max_len=int(q_lens[j])) for j in range(J)]
+cs = [ops.DeviceRepSet(c.rows, c.start[j * NC:(j + 1) * NC].contiguous(), c.len[j * NC:(j + 1) * NC].contiguous(), ext=0,
+                       max_len=int(c_lens[j * NC:(j + 1) * NC].max())) for j in range(J)]
+
+
+def loop():
+    for j in range(J):
+        ops.ot_rank(qs[j], cs[j], NC)
+
+
+t = timed(loop, n=10)
+print(f'otAspire, one call per query:                        {t:8.1f} us = {pairs / t:6.2f} M pairs/s', flush=True)
+same = all(torch.equal(ops.ot_rank(qs[j], cs[j], NC)[2][0], out[2][j]) for j in range(J))
+print('batched ranking == per-query ranking:', same)
+for form in ('small', 'tile'):
+    try:
+        with _lib.pinned(OT_FORM=form):
+            t = timed(lambda: ops.ot_rank_batch(q, c, job_off, NC, NC, out=out))
+        print(f'otAspire batched, OT_FORM={form}: {t:8.1f} us')
+    except Exception as e:          # a form that does not take this shape
+        print(f'OT_FORM={form}: {type(e).__name__}: {e}')
