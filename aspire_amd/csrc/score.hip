@@ -212,8 +212,11 @@ __global__ void __launch_bounds__(kBlock, 3) l2max_kernel(ScoreArgs a) {
     const int c_len = a.c.len[c_idx];
     const int c_avail = a.c.ext > 0 ? a.c.ext : c_len;
     const float* cdoc = a.c.rows + (size_t)a.c.start[c_idx] * kD;
-    const int64_t q_begin = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx : (int64_t)blockIdx.y * a.q_per_block;
-    const int64_t q_end = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx + 1 : min(a.q.n, q_begin + a.q_per_block);
+    // one query per candidate (PAIRED: the candidate's own index; MAPPED: its job's) or a block of queries (CROSS)
+    const bool one_q = a.pairing != ASPIRE_PAIR_CROSS;
+    const int64_t q_begin = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx : a.pairing == kPairMapped ? (int64_t)a.qmap[c_idx]
+                                                                                                : (int64_t)blockIdx.y * a.q_per_block;
+    const int64_t q_end = one_q ? q_begin + 1 : min(a.q.n, q_begin + a.q_per_block);
     const int li = lane >> 3, lj = lane & 7;
     for (int64_t q_idx = q_begin; q_idx < q_end; ++q_idx) {
         const int q_len = a.q.len[q_idx];
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(kBlock, 3) l2max_kernel(ScoreArgs a) {
         }
         __syncthreads();
         if (wave == 0) {
-            const int64_t p = a.pairing == ASPIRE_PAIR_PAIRED ? c_idx : q_idx * a.c.n + c_idx;
+            const int64_t p = one_q ? c_idx : q_idx * a.c.n + c_idx;
             float negv[T][T];
             bool val[T][T];
 #pragma unroll
@@ -2663,6 +2666,8 @@ extern "C" int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_rep
 
 // ---- tsAspire over batched jobs ------------------------------------------------------------------------------------------
 namespace {
+// groups of four candidates from which aspire_l2max_rank_batch_f32 takes the streaming kernels (measured, tools/l2batchbench.py)
+constexpr int64_t kL2StreamMinGroups = 384;
 struct L2BatchLayout {
     size_t cand_job, grp_job, grp_off, grp_rec, qbox, gate, topk, total;
 };
@@ -2747,11 +2752,13 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     const int64_t groups_bound = J * ((max_job + 3) / 4);
     const int form_t = tuning().ot_form;
     const bool big = groups_bound >= 2048 && C >= 6000 && form_t != 1;
-    if (big && max_rows <= 8) {
+    // (small batches too: a wave walks an item's twelve stages in ~15 us, what a one-workgroup-per-pair launch takes anyway)
+    const bool streaming = form_t != 1 && (big || form_t >= 2 || groups_bound >= kL2StreamMinGroups);
+    if (streaming && max_rows <= 8) {
         if (int rc = launch_pair_fused_l2max(a, groups_bound, s0)) return rc;
-    } else if (big && max_rows <= 16) {
+    } else if (streaming && max_rows <= 16) {
         // mostly short documents with a few of 9 .. 16 rows: the hybrid of ot_rank_batch (ScoreArgs::gate)
-        if (form_t == 0) {
+        if (big && form_t == 0) {
             int32_t* gate = (int32_t*)(wsb + L.gate);
             ASPIRE_HIP_OK(hipMemsetAsync(gate, 0, sizeof(int32_t), s0));
             hipLaunchKernelGGL(long_pair_census_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s0, a, gate);
@@ -2761,6 +2768,15 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
             if (int rc = launch_pair_fused_l2max(a, groups_bound, s0)) return rc;
         }
         if (int rc = launch_pair_tile16_l2max(a, 2 * groups_bound, s0)) return rc;
+    } else if (max_rows <= 8 * kMaxT) {
+        // one workgroup per candidate against its job's query (small batches, documents of 17 .. 32 rows)
+        const int rc_tiles = dispatch_T(max_rows, [&](auto tc) -> int {
+            constexpr int T = decltype(tc)::value;
+            hipLaunchKernelGGL(l2max_kernel<T>, dim3((unsigned)C, 1, 1), dim3(kBlock), Lds<T>::kTotal * sizeof(float), s0, a);
+            ASPIRE_LAUNCH_OK();
+            return (int)ASPIRE_OK;
+        });
+        if (rc_tiles) return rc_tiles;
     } else {
         if (int rc = launch_pair_generic(a, 1, 0, q->max_len, c->max_len, s0)) return rc;
     }

@@ -284,7 +284,9 @@ int aspire_ot_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int
  * The same per-query loop for tsAspire (allpair_masked_dist_l2max, pair_distances.py:138-186; caching_score's 'l2lse'
  * branch, disent_models.py:294-295): J independent (query, pool) re-ranks by max-sim in ONE call.  Arguments as
  * aspire_ot_rank_batch_f32 (no OT parameters; cdist_mode as aspire_l2max_scores_f32); scores [C] = -min L2 over the valid
- * sentence pairs of candidate p and its job's query.  Documents of up to 128 rows.
+ * sentence pairs of candidate p and its job's query.  Documents of up to 128 rows.  Launches: tables, then the streaming
+ * max-sim kernels (documents of <= 16 rows, from 384 groups of four candidates) or one workgroup per candidate, then the
+ * segmented rank.
  * ------------------------------------------------------------------------------------------- */
 size_t aspire_l2max_rank_batch_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t max_job, int64_t k);
 int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, const int32_t* job_off,

@@ -264,7 +264,9 @@ def test_in_flight_ranker_equals_rank_pools(amd):
 
 @pytest.mark.parametrize('smax,sizes', [(8, [1503, 2, 0, 997, 1250, 3, 2048, 1, 1100]),      # fused max-sim form
                                         (14, [1203, 1, 998, 2, 1501, 700, 0, 1600]),       # 16-row streaming kernel (most pairs long)
-                                        (8, [40, 0, 25, 3]), (23, [300, 1, 77])])           # small / long: one workgroup per pair
+                                        (8, [40, 0, 25, 3]),                                # tiny: one workgroup per candidate
+                                        (8, [340, 0, 325, 3, 297, 310]), (15, [330, 2, 0, 325, 301]),  # >= 384 groups of four: the streaming kernels again
+                                        (23, [300, 1, 77]), (32, [150, 0, 61])])            # 17 .. 32 rows: one workgroup per candidate
 def test_l2max_rank_batch(amd, smax, sizes):
     """tsAspire over batched jobs (aspire_l2max_rank_batch_f32, rank_pools(method='l2max')): every job's scores = the
     per-pool call's, = -min cdist in torch on a sample; every list = the stable descending sort of its own scores"""
@@ -289,6 +291,11 @@ def test_l2max_rank_batch(amd, smax, sizes):
     ranked = amd.scorer.rank_pools(queries, pools, k=k, method='l2max')
     for j, n in enumerate(sizes):
         assert [i for i, _ in ranked[j]] == ti.cpu()[j, :min(k, n)].tolist()
+    # the other form of the same batch (streaming kernels <-> one workgroup per candidate), pinned
+    for form in (['small'] + (['fused'] if smax <= 8 else ['tile'] if smax <= 16 else [])):
+        with amd.pinned(OT_FORM=form):
+            s2 = amd.ops.l2max_rank_batch(q, c, job_off, max(sizes), k)[0]
+        np.testing.assert_allclose(s2.cpu().numpy(), s.cpu().numpy(), atol=4e-5, rtol=0)
 
 
 def test_l2max_rank_batch_hybrid(amd):
