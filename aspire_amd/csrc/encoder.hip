@@ -212,10 +212,13 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int B_F4 = (BN * kBK / 4 + 255) / 256;
     constexpr bool B_EXACT = BN * kBK / 4 % 256 == 0;
     static_assert(A_F4 >= 1 && WM % 32 == 0 && WN % 32 == 0, "tile / wave layout");
-    // [buffer][plane][k half][row][8 bf16]: a fragment read (lane = row, k half) walks 512 contiguous bytes per half-wave
-    // -- conflict free without padding (32 bytes of LDS per row and plane: three workgroups fit a CU)
-    __shared__ __attribute__((aligned(16))) uint32_t As[2][3][2][BM][4];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[2][3][2][BN][4];
+    // [buffer][plane][k half][row][8 bf16]: a fragment read (lane = row, k half) is conflict free (ds_read_b128's lane groups
+    // each cover 16 distinct rows = 256 bytes).  The staging stores (ds_write_b64: groups of 16 lanes = 4 rows x both k halves,
+    // 32 store banks of 4 bytes) need the two k halves 64 bytes apart modulo 128: 64 bytes of padding behind each half (rows
+    // x 16 B is a multiple of 128; unpadded every store was a 2-way conflict -- a third of the kernel's LDS cycles,
+    // SQ_LDS_BANK_CONFLICT).  49.5 KB per workgroup: three still fit a CU.
+    __shared__ __attribute__((aligned(16))) uint32_t As[2][3][2][BM * 4 + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[2][3][2][BN * 4 + 16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
@@ -262,9 +265,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
             uint32_t a1, a2, a3, b1, b2, b3;
             split3_bf16(r.a[p].x, r.a[p].y, a1, a2, a3);
             split3_bf16(r.a[p].z, r.a[p].w, b1, b2, b3);
-            *reinterpret_cast<uint2*>(&As[buf][0][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a1, b1);
-            *reinterpret_cast<uint2*>(&As[buf][1][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a2, b2);
-            *reinterpret_cast<uint2*>(&As[buf][2][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a3, b3);
+            *reinterpret_cast<uint2*>(&As[buf][0][k4 >> 1][4 * row + 2 * (k4 & 1)]) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(&As[buf][1][k4 >> 1][4 * row + 2 * (k4 & 1)]) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(&As[buf][2][k4 >> 1][4 * row + 2 * (k4 & 1)]) = make_uint2(a3, b3);
         }
 #pragma unroll
         for (int p = 0; p < B_F4; ++p) {
@@ -273,9 +276,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
                 uint32_t a1, a2, a3, b1, b2, b3;
                 split3_bf16(r.b[p].x, r.b[p].y, a1, a2, a3);
                 split3_bf16(r.b[p].z, r.b[p].w, b1, b2, b3);
-                *reinterpret_cast<uint2*>(&Bs[buf][0][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2*>(&Bs[buf][1][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a2, b2);
-                *reinterpret_cast<uint2*>(&Bs[buf][2][k4 >> 1][row][2 * (k4 & 1)]) = make_uint2(a3, b3);
+                *reinterpret_cast<uint2*>(&Bs[buf][0][k4 >> 1][4 * row + 2 * (k4 & 1)]) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(&Bs[buf][1][k4 >> 1][4 * row + 2 * (k4 & 1)]) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2*>(&Bs[buf][2][k4 >> 1][4 * row + 2 * (k4 & 1)]) = make_uint2(a3, b3);
             }
         }
     };
@@ -306,10 +309,10 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&As[buf][pl][lk][wr * WM + 32 * i + lr][0]));
+                af[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&As[buf][pl][lk][4 * (wr * WM + 32 * i + lr)]));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bs[buf][pl][lk][wc * WN + 32 * j + lr][0]));
+                bfr[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bs[buf][pl][lk][4 * (wc * WN + 32 * j + lr)]));
         }
         store_tiles(cur, buf ^ 1);                        // (after the last tile: into the idle buffer, unread)
         // the six products, smallest terms first; the TM x TN accumulators take turns inside each term
