@@ -117,3 +117,58 @@ for case in range(n2):
                 assert e_gpu <= max(3 * e_cpu, 3e-3), (case, b, qlen, e_gpu, e_cpu)
     print(f'caching case {case}: B={b} qlen={qlen} S<={smax} ok', flush=True)
 print(f'{n2} caching_score cases ok; worst errors {worst}')
+
+# ---- part 3: batched jobs (aspire_ot_rank_batch_f32 / aspire_l2max_rank_batch_f32): every query against its own pool ----------
+n3 = max(4, n_cases // 2)
+worst_b = {'ot': 0.0, 'l2max': 0.0}
+for case in range(n3):
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    smax = int(rng.choice([8, 8, 8, 12, 16, 20, 32]))
+    J = int(rng.choice([1, 2, 5, 20, 50, 70]))
+    pool_sizes = [int(rng.choice([0, 1, 3, 50, 125, 400, 1000, 1503])) for _ in range(J)]
+    budget = 24000 // (smax // 8 + (smax % 8 > 0)) ** 2              # pairs
+    while sum(pool_sizes) > budget:
+        pool_sizes = [n // 2 for n in pool_sizes]
+    few_long = smax > 8 and smax <= 16 and rng.random() < 0.5           # mostly short documents, a few long ones (the hybrid)
+    def doc_len():
+        if few_long and rng.random() > 0.01:
+            return int(rng.integers(1, 9))
+        return int(rng.integers(1, smax + 1))
+    queries = [torch.randn(int(rng.integers(1, min(smax, 8) + 1)) if rng.random() < 0.5 else doc_len(), 768, generator=g) for _ in range(J)]
+    pools = [[torch.randn(doc_len(), 768, generator=g) for _ in range(n)] for n in pool_sizes]
+    k = int(rng.choice([1, 10, 100, 2000]))
+    for method in ('ot', 'l2max'):
+        pls, top_s, top_i = scorer._launch_rank_pools(queries, pools, k, None, method)
+        if top_s is None:
+            continue
+        top_s, top_i = top_s.cpu(), top_i.cpu()
+        ranked = scorer.rank_pools(queries, pools, k=k, method=method)
+        for j, n in enumerate(pool_sizes):
+            assert len(ranked[j]) == min(k, n), (case, method, j)
+            if n == 0:
+                continue
+            one = scorer.score_pool([queries[j]], pools[j], method=method, schedule='pair')[0].cpu()
+            got = dict(ranked[j])
+            # the list = stable descending order of the job's own scores (scores of a batch and of a one-pool call may differ
+            # in the last bits -- other kernels --, so the order is checked against the listed scores, the values against both)
+            vals = [s for _, s in ranked[j]]
+            assert all(vals[t] >= vals[t + 1] for t in range(len(vals) - 1)), (case, method, j)
+            for i, s in ranked[j]:
+                assert abs(s - float(one[i])) <= 2e-4, (case, method, j, i, s, float(one[i]))
+            if len(vals) < n:                   # nothing outside the list beats its last entry
+                rest = [float(one[i]) for i in range(n) if i not in got]
+                assert max(rest) <= vals[-1] + 2e-4, (case, method, j)
+            for _ in range(2):                  # sampled pairs against the oracle
+                i = int(rng.integers(n))
+                if i not in got:
+                    continue
+                if method == 'ot':
+                    w = orc.get_similarity(queries[j], pools[j][i])
+                else:
+                    w = -orc.allpair_masked_dist_l2max(orc.RepLen(queries[j][None].permute(0, 2, 1), [len(queries[j])]),
+                                                       orc.RepLen(pools[j][i][None].permute(0, 2, 1), [len(pools[j][i])])).item()
+                e = abs(got[i] - w)
+                assert e <= 1e-4, (case, method, j, i, got[i], w)
+                worst_b[method] = max(worst_b[method], e)
+    print(f'batched case {case}: J={J} pools={pool_sizes[:8]}{"..." if J > 8 else ""} S<={smax} few_long={few_long} k={k} ok', flush=True)
+print(f'{n3} batched cases ok; worst errors {worst_b}')
