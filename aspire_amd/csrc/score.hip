@@ -161,19 +161,24 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
             if ((lane & 3) == 0) rednorm[lane >> 2] = r;
         }
     } else {
+    // whole 8 x 8 tiles past a document's rows are skipped (CSR documents: `avail` = the document's own length; consumers
+    // never read those tiles' sums -- finish_pair, l2max_kernel).  Row norms: the query tile's with the first candidate tile,
+    // the candidate tile's with the first query tile.
+    const int Tq = min(T, max(1, (q_avail + 7) >> 3)), Tc = min(T, max(1, (c_avail + 7) >> 3));
 #pragma unroll 1
-    for (int tj = 0; tj < T; ++tj) {
+    for (int tj = 0; tj < Tc; ++tj) {
         float4 y[8];
         load_rows<8, BBOX>(y, cdoc, tj * 8, c_avail, dofs, c_box, mn, mx);
 #pragma unroll 1
-        for (int ti = 0; ti < T; ++ti) {
-            float nrm[16];  // |x_i|^2 of the 8 query rows, |y_j|^2 of the 8 candidate rows (diagonal tiles only)
+        for (int ti = 0; ti < Tq; ++ti) {
+            float nrm[16];  // |x_i|^2 of the 8 query rows, |y_j|^2 of the 8 candidate rows (first row / column of tiles only)
+            const bool want_norms = NEED_G && (ti == 0 || tj == 0);
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
                 float4 x[4];
                 load_rows<4, BBOX>(x, qdoc, ti * 8 + half * 4, q_avail, dofs, q_box, mn, mx);  // min/max idempotent
                 half_tile_partials<NEED_G, NEED_D2>(x, y, red + (ti * T + tj) * 128 + half * 32, xp, lane);
-                if (NEED_G && ti == tj) {
+                if (want_norms) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (half == 0) {
@@ -186,9 +191,10 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
                     }
                 }
             }
-            if (NEED_G && ti == tj) {
+            if (want_norms) {
                 const float r = lds_wave_reduce<16>(nrm, xp, lane);
-                if ((lane & 3) == 0) rednorm[ti * 16 + (lane >> 2)] = r;
+                const int e = lane >> 2;                  // 0 .. 7: query rows of tile ti, 8 .. 15: candidate rows of tile tj
+                if ((lane & 3) == 0 && (e < 8 ? tj == 0 : ti == 0)) rednorm[(e < 8 ? ti : tj) * 16 + e] = r;
             }
         }
     }
@@ -240,7 +246,9 @@ __global__ void __launch_bounds__(kBlock, 3) l2max_kernel(ScoreArgs a) {
                     const int i = ta * 8 + li, j = tb * 8 + lj;
                     const float* r = lds + (ta * T + tb) * 128;
                     float d2;
-                    if (mm) {
+                    if (T > 1 && (ta * 8 >= q_avail || tb * 8 >= c_avail)) {
+                        d2 = 0.f;                       // a tile pair_partials skipped: no sums in LDS, no valid entry
+                    } else if (mm) {
                         float g = 0.f, xx = 0.f, yy = 0.f;
 #pragma unroll
                         for (int w = 0; w < kWaves; ++w) {
@@ -343,10 +351,18 @@ struct PairState {
 // (sum of partials, both L2 formulas) and store them to the pair's workspace slot.
 template <int T, bool DIRECT = true>
 __device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want_diam, const PairWs<T>& ws, int64_t slot,
-                                            const float* qdoc = nullptr, const float* cdoc = nullptr, int q_len = 0, int c_len = 0) {
+                                            const float* qdoc = nullptr, const float* cdoc = nullptr, int q_len = 0, int c_len = 0,
+                                            int q_avail = 8 * T, int c_avail = 8 * T) {
     for (int e = threadIdx.x; e < 64 * T * T; e += kBlock) {
         const int tile = e >> 6, l = e & 63, ta = tile / T, tb = tile % T, li = l >> 3, lj = l & 7;
         const float* r = lds + tile * 128;
+        if (T > 1 && (ta * 8 >= q_avail || tb * 8 >= c_avail)) {
+            // pair_partials skipped this tile (no row of one side reaches it); the solvers mask it
+            const int64_t o = slot * (64 * T * T) + (ta * 8 + li) * (8 * T) + tb * 8 + lj;
+            ws.cost[o] = 1.f;
+            ws.neg[o] = -1.f;
+            continue;
+        }
         float g = 0.f, d2 = 0.f, xx = 0.f, yy = 0.f;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
@@ -897,7 +913,8 @@ __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairW
         }
         __syncthreads();
         const int64_t slot = paired ? (c_idx - a.cand0) : q_idx * ncand + (c_idx - a.cand0);
-        finish_pair<T, DIRECT>(lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), own_diam, ws, slot, qdoc, cdoc, q_len, c_len);
+        finish_pair<T, DIRECT>(lds, use_mm_formula(a.cdist_mode, q_avail, c_avail), own_diam, ws, slot, qdoc, cdoc, q_len, c_len, q_avail,
+                               c_avail);
         __syncthreads();
     }
 }

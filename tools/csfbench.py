@@ -54,8 +54,13 @@ def loop():
 
 t = timed(loop, n=10)
 print(f'otAspire, one call per query:                        {t:8.1f} us = {pairs / t:6.2f} M pairs/s', flush=True)
-same = all(torch.equal(ops.ot_rank(qs[j], cs[j], NC)[2][0], out[2][j]) for j in range(J))
-print('batched ranking == per-query ranking:', same)
+# batched and per-query calls run different kernels (another summation order): scores agree to a few 1e-5, so near-ties may swap
+diff, moved = 0.0, 0
+for j in range(J):
+    s1, _, i1 = ops.ot_rank(qs[j], cs[j], NC)
+    diff = max(diff, float((s1[0] - out[0][j * NC:(j + 1) * NC]).abs().max()))
+    moved += int((i1[0] != out[2][j]).sum())
+print(f'batched vs per-query: max |score difference| {diff:.1e}, {moved} of {pairs} list positions differ (near-ties)')
 for form in ('small', 'tile'):
     try:
         with _lib.pinned(OT_FORM=form):
