@@ -31,7 +31,7 @@ def get_evaluations_filename(results_dir, facet, aggregated):   # utils/utils.py
 
 
 def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, method='ot', schedule='pair', hparams=None,
-          queries_per_call=32):
+          queries_per_call=32, resident=True):
     """evaluate.py:36-82.  test_pool: {query_id: {'cands': [cand_id, ...]}} (the dataset's test-pid json);
     rep_store: aspire_amd.repstore.RepStore of sentence reps.  A faceted query keeps only the sentence rows whose
     predicted label matches the facet (models.py:127-163; pred_labels: {paper_id: [label per sentence]}).
@@ -39,10 +39,15 @@ def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, metho
 
     With the per-pair schedule (the reference's own: one get_similarity call per candidate, evaluate.py:68-72) the queries go
     through scorer.rank_pools `queries_per_call` at a time -- every query against ITS OWN pool in one library call; any other
-    schedule / aggregation keeps one rank_pool call per query."""
+    schedule / aggregation keeps one rank_pool call per query.  resident: the candidates of all pools are uploaded once
+    (RepStore.to_device: a paper in many pools is stored once) and the pools are index lists into that matrix."""
     from . import scorer
     results = {}
     query_ids = list(test_pool.keys())
+    if resident:
+        wanted = [c for pool in test_pool.values() for c in pool['cands']]
+        if wanted and not rep_store.resident(wanted):
+            rep_store.to_device(wanted)
 
     def query_reps(query_id):
         return rep_store.faceted(query_id, facet, pred_labels[query_id]) if facet is not None else rep_store.get(query_id)
@@ -61,7 +66,7 @@ def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, metho
             results[query_id] = [(cid, -1 * sim) for cid, sim in ranked]     # evaluate.py:77
     os.makedirs(results_dir, exist_ok=True)
     with codecs.open(get_scores_filename(results_dir, facet), 'w', 'utf-8') as fp:
-        json.dump(results, fp)
+        fp.write(json.dumps(results))      # the same text as json.dump(results, fp) (evaluate.py:80), encoded in one piece
     return results
 
 

@@ -72,7 +72,39 @@ class RepStore:
         idxs = [i for i, lab in enumerate(labs) if lab == f'{facet}_label']
         return reps[idxs, :]
 
+    def to_device(self, pids=None):
+        """Upload the reps of `pids` (default: the whole store) ONCE as one [sum S, 768] matrix and keep it resident: pools
+        built afterwards (`pool`) are index lists into it -- a paper that sits in many queries' pools is uploaded and stored
+        once, and a pool costs two small int32 uploads.  Papers added later are uploaded per pool as before."""
+        import torch
+        from . import ops
+        dev = ops.require_gpu()
+        pids = list(self.pid2reps) if pids is None else [p for p in dict.fromkeys(pids)]
+        lens = [int(self.pid2reps[p].shape[0]) for p in pids]
+        rows = np.concatenate([self.pid2reps[p] for p in pids], 0).astype(np.float32, copy=False) if pids \
+            else np.zeros((0, 768), np.float32)
+        self._dev_rows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+        starts = np.concatenate([[0], np.cumsum(lens)])[:-1] if pids else []
+        self._dev_index = {p: (int(s), n) for p, s, n in zip(pids, starts, lens)}
+        return self
+
+    def resident(self, pids):
+        idx = getattr(self, '_dev_index', None)
+        return idx is not None and all(p in idx for p in pids)
+
     def pool(self, pids):
-        """Upload the reps of `pids` (in this order = pool order) to the GPU."""
+        """The reps of `pids` (in this order = pool order) as a CandidatePool on the GPU: index lists into the resident matrix
+        when `to_device` holds all of them, else uploaded now."""
         from .scorer import CandidatePool
-        return CandidatePool([self.pid2reps[p] for p in pids], pids=list(pids))
+        pids = list(pids)
+        if pids and self.resident(pids):
+            import torch
+            from . import ops
+            dev = self._dev_rows.device
+            where = [self._dev_index[p] for p in pids]
+            lens = [n for _, n in where]
+            start = torch.tensor([s for s, _ in where], dtype=torch.int32).to(dev)
+            repset = ops.DeviceRepSet(self._dev_rows, start, torch.tensor(lens, dtype=torch.int32).to(dev), ext=0,
+                                      max_len=max(lens), lens_host=lens)
+            return CandidatePool.from_repset(repset, pids=pids)
+        return CandidatePool([self.pid2reps[p] for p in pids], pids=pids)

@@ -169,10 +169,15 @@ def _launch_rank_pools(query_reps_list, pools, k, hparams, method='ot'):
     dev = ops.require_gpu()
     q = ops.DeviceRepSet.from_list(query_reps_list)
     nonempty = [p.repset for p in pools if len(p)]
-    row_base = np.cumsum([0] + [int(r.rows.shape[0]) for r in nonempty])[:-1]
-    c = ops.DeviceRepSet(torch.cat([r.rows for r in nonempty], 0),
-                         torch.cat([r.start + int(b) for r, b in zip(nonempty, row_base)]).to(torch.int32).contiguous(),
-                         torch.cat([r.len for r in nonempty]).contiguous(), ext=0, max_len=max(r.max_len for r in nonempty))
+    if all(r.rows.data_ptr() == nonempty[0].rows.data_ptr() and r.rows.shape == nonempty[0].rows.shape for r in nonempty):
+        # every pool indexes ONE resident matrix (RepStore.to_device): the jobs' candidates are its index lists back to back
+        c = ops.DeviceRepSet(nonempty[0].rows, torch.cat([r.start for r in nonempty]).contiguous(),
+                             torch.cat([r.len for r in nonempty]).contiguous(), ext=0, max_len=max(r.max_len for r in nonempty))
+    else:
+        row_base = np.cumsum([0] + [int(r.rows.shape[0]) for r in nonempty])[:-1]
+        c = ops.DeviceRepSet(torch.cat([r.rows for r in nonempty], 0),
+                             torch.cat([r.start + int(b) for r, b in zip(nonempty, row_base)]).to(torch.int32).contiguous(),
+                             torch.cat([r.len for r in nonempty]).contiguous(), ext=0, max_len=max(r.max_len for r in nonempty))
     job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
     if method == 'l2max':
         _, top_s, top_i = ops.l2max_rank_batch(q, c, job_off, max_job, k)

@@ -168,7 +168,11 @@ def test_score_step_batched_over_queries_equals_the_per_query_loop(amd, tmp_path
     store = RepStore({p: torch.randn(int(n), 768, generator=g).numpy()
                       for p, n in zip(pids, torch.randint(1, 14, (90,), generator=g))})
     test_pool = {pids[j]: {'cands': pids[10 + j:10 + j + size]} for j, size in enumerate([40, 7, 0, 61, 1, 33, 80])}
-    one = ev.score(str(tmp_path / 'one'), test_pool, store, method=method, schedule='pair', queries_per_call=1)
+    one = ev.score(str(tmp_path / 'one'), test_pool, store, method=method, schedule='pair', queries_per_call=1, resident=False)
+    assert not store.resident(pids[10:12])
+    # pools as index lists into ONE resident matrix (a paper of several pools is stored once): the same scores, bit for bit
+    res = ev.score(str(tmp_path / 'res'), test_pool, store, method=method, schedule='pair', queries_per_call=1)
+    assert store.resident(pids[10:90]) and res == one
     for per_call in (3, 32):
         got = ev.score(str(tmp_path / f'b{per_call}'), test_pool, store, method=method, schedule='pair', queries_per_call=per_call)
         assert list(got) == list(one)
