@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         auto issue_loads = [&](int st) {
             const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
+            for (int j = 0; j < 8; ++j) vy[j] = ld4_stream(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
             if constexpr (!INBOX && !L2MAX) {
                 qmn = ld4(qb + dofs);
                 qmx = ld4(qb + qb_hi + dofs);

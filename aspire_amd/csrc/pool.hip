@@ -31,17 +31,17 @@ __global__ void __launch_bounds__(192) span_mean_pool_kernel(const float* __rest
     int k = lo;
     // 4 rows in flight per thread to cover HBM latency.
     for (; k + 4 <= hi; k += 4) {
-        const float4 v0 = *reinterpret_cast<const float4*>(doc + (size_t)tok_idx[k] * kD + d);
-        const float4 v1 = *reinterpret_cast<const float4*>(doc + (size_t)tok_idx[k + 1] * kD + d);
-        const float4 v2 = *reinterpret_cast<const float4*>(doc + (size_t)tok_idx[k + 2] * kD + d);
-        const float4 v3 = *reinterpret_cast<const float4*>(doc + (size_t)tok_idx[k + 3] * kD + d);
+        const float4 v0 = ld4_stream(doc + (size_t)tok_idx[k] * kD + d);
+        const float4 v1 = ld4_stream(doc + (size_t)tok_idx[k + 1] * kD + d);
+        const float4 v2 = ld4_stream(doc + (size_t)tok_idx[k + 2] * kD + d);
+        const float4 v3 = ld4_stream(doc + (size_t)tok_idx[k + 3] * kD + d);
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
         acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
         acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
     }
     for (; k < hi; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(doc + (size_t)tok_idx[k] * kD + d);
+        const float4 v = ld4_stream(doc + (size_t)tok_idx[k] * kD + d);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     // torch.count_nonzero(mask).clamp(min=1): an empty slot stays exactly zero.

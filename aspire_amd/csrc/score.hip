@@ -967,7 +967,7 @@ __device__ __forceinline__ void load_item(RowSet& r, const ScoreArgs& a, uint32_
         r.x1[i] = ld4(qdoc + (size_t)min(i0 + 4 + i, q_len - 1) * kD);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.y[j] = ld4(cdoc + (size_t)min(j0 + j, c_len - 1) * kD);
+    for (int j = 0; j < 8; ++j) r.y[j] = ld4_stream(cdoc + (size_t)min(j0 + j, c_len - 1) * kD);
 }
 
 __device__ __forceinline__ float box_partial(const RowSet& r) {
@@ -1310,7 +1310,7 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
             const int dofs = (st * C::kCh + sc) * 4;
             if (stages_y) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vy[j] = ld4(sy_doc + (size_t)min(j, sy_len - 1) * kD + dofs);
+                for (int j = 0; j < 8; ++j) vy[j] = ld4_stream(sy_doc + (size_t)min(j, sy_len - 1) * kD + dofs);
                 // UNCONDITIONAL (with caller-supplied diameters the candidate's first row stands in and the box term
                 // is unused): a branch around these two loads made the compiler wait for the row loads just issued
                 // at the join -- every stage's HBM latency in series with its arithmetic (see fused.hip)

@@ -87,7 +87,6 @@ __device__ __forceinline__ float group_diameter_of(const ScoreArgs& a, const Pai
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
 // Per-pair intermediates between the two kernels of the otAspire path, one slot per pair of the current
 // chunk: cost [8T x 8T] row-major, neg [8T x 8T], diam2 (sum over coordinates of (max-min)^2).
 template <int T>
