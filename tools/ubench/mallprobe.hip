@@ -11,6 +11,8 @@
 
 constexpr size_t kItemF = 32 * 768;
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT>      // NT: the loads carry the non-temporal hint (__builtin_nontemporal_load)
 __global__ void __launch_bounds__(256) read_kernel(const float* __restrict__ base, unsigned n_items, float* out) {
     const int lane = threadIdx.x & 63;
     const unsigned n_waves = gridDim.x * 4;
@@ -20,7 +22,15 @@ __global__ void __launch_bounds__(256) read_kernel(const float* __restrict__ bas
         for (int k0 = 0; k0 < 96; k0 += 8) {
             float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(it + (size_t)(k0 + j) * 256 + lane * 4);
+            for (int j = 0; j < 8; ++j) {
+                const float* src = it + (size_t)(k0 + j) * 256 + lane * 4;
+                if constexpr (NT) {
+                    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
+                    v[j] = make_float4(t.x, t.y, t.z, t.w);
+                } else {
+                    v[j] = *reinterpret_cast<const float4*>(src);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
         }
@@ -49,7 +59,7 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < reps; ++rep) {
             const float* src = buf + (size_t)(rep % n_bufs) * buf_f;
             CK(hipEventRecord(a, 0));
-            hipLaunchKernelGGL(read_kernel, dim3(512), dim3(256), 0, 0, src, n_items, out);
+            hipLaunchKernelGGL(read_kernel<false>, dim3(512), dim3(256), 0, 0, src, n_items, out);
             CK(hipEventRecord(b, 0));
             CK(hipEventSynchronize(b));
             CK(hipEventElapsedTime(&t[rep], a, b));
@@ -59,20 +69,21 @@ int main(int argc, char** argv) {
         printf("\n");
     }
     // back-to-back without host syncs (the bench's regime): 2 buffers alternating, 200 launches, events per launch
-    {
+    for (int nt = 0; nt < 2; ++nt) {
         const int n = 200;
         std::vector<hipEvent_t> ev(n + 1);
         for (size_t i = 0; i < ev.size(); ++i) CK(hipEventCreate(&ev[i]));
         CK(hipEventRecord(ev[0], 0));
         for (int i = 0; i < n; ++i) {
-            hipLaunchKernelGGL(read_kernel, dim3(512), dim3(256), 0, 0, buf + (size_t)(i % 2) * buf_f, n_items, out);
+            if (nt) hipLaunchKernelGGL(read_kernel<true>, dim3(512), dim3(256), 0, 0, buf + (size_t)(i % 2) * buf_f, n_items, out);
+            else hipLaunchKernelGGL(read_kernel<false>, dim3(512), dim3(256), 0, 0, buf + (size_t)(i % 2) * buf_f, n_items, out);
             CK(hipEventRecord(ev[i + 1], 0));
         }
         CK(hipDeviceSynchronize());
         double s[2] = {0, 0};
         for (int i = 100; i < n; ++i) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); s[i % 2] += ms; }
-        printf("back-to-back, 2 buffers alternating: buffer 0 %.1f us, buffer 1 %.1f us per launch (%.2f / %.2f TB/s)\n", s[0] / 50 * 1e3, s[1] / 50 * 1e3,
-               buf_f * 4 / (s[0] / 50 * 1e-3) / 1e12, buf_f * 4 / (s[1] / 50 * 1e-3) / 1e12);
+        printf("back-to-back, 2 buffers alternating, %s loads: buffer 0 %.1f us, buffer 1 %.1f us per launch (%.2f / %.2f TB/s)\n", nt ? "non-temporal" : "plain",
+               s[0] / 50 * 1e3, s[1] / 50 * 1e3, buf_f * 4 / (s[0] / 50 * 1e-3) / 1e12, buf_f * 4 / (s[1] / 50 * 1e-3) / 1e12);
     }
     return 0;
 }
