@@ -210,7 +210,7 @@ class InFlightRanker:
     """rank_pools for a process that serves independent requests: up to `n_lanes` calls in flight, each on its own stream
     with its own buffers.  The library queues everything on the caller's stream and keeps no state between calls, so calls on
     different streams overlap -- the end of one call (last Sinkhorn solves, rank launch: no HBM traffic) runs beside the next
-    call's streaming (bench.py: 96 instead of 111 us per 20-query call).
+    call's streaming (bench.py: 93 instead of 105 us per 20-query call).
 
         ranker = InFlightRanker()
         tickets = [ranker.submit(queries_b, pools_b) for queries_b, pools_b in requests]
