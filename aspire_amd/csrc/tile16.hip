@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
             {
                 const float* xm = lds + (4 * miq + mt) * kRowStride;
                 const float* ym = lds + (16 + p * 8 + 4 * mjq + mt) * kRowStride;
-#pragma unroll 2
+#pragma unroll 4
                 for (int c = 0; c < kCh; ++c) {
                     const float4 x0 = *reinterpret_cast<const float4*>(xm + c * 4);
                     const float4 x1 = *reinterpret_cast<const float4*>(xm + 8 * kRowStride + c * 4);
