@@ -259,7 +259,7 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 // the box is formed during a wave's first item and read from the LDS cache afterwards; no doc_box launch in front.
 template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false, bool QBOX = false>
 __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
-    constexpr bool INBOX = SELF || QBOX;        // the query's box comes from the staged query rows
+    constexpr bool INBOX = (SELF || QBOX) && !L2MAX;        // the query's box comes from the staged query rows (max-sim needs none)
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     if (a.gate != nullptr && !gate_few_long(a)) return;      // hybrid (score_types.h): mostly long pairs -- the 16-row kernels take them all
     const int lane = threadIdx.x & 63;
@@ -676,10 +676,16 @@ bool fused_path_ok(const aspire_repset* q, const aspire_repset* c) {
 }
 
 // tsAspire (max-sim) of every (query, candidate) pair, CROSS, documents of <= 8 rows: the fused kernel's streaming phase
-int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream) {
+// self (batched jobs, <= 64 of them): no tables in front of the launch -- the waves derive an item's job from job_off (SELF)
+int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream, bool self) {
     const int64_t waves = groups_bound < 256 * 8 ? groups_bound : 256 * 8;
-    hipLaunchKernelGGL((pair_fused_kernel<true, false, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float),
-                       stream, a, (const float*)nullptr);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (self)
+        hipLaunchKernelGGL((pair_fused_kernel<true, false, true, true>), grid, dim3(256), 4 * kWaveLds * sizeof(float), stream, a,
+                           (const float*)nullptr);
+    else
+        hipLaunchKernelGGL((pair_fused_kernel<true, false, false, true>), grid, dim3(256), 4 * kWaveLds * sizeof(float), stream, a,
+                           (const float*)nullptr);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

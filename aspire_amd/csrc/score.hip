@@ -2753,7 +2753,15 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     a.job0 = 0;
     a.job1 = (int32_t)J;
     a.max_job_groups = (int32_t)((max_job + 3) / 4);
-    {
+    const int64_t groups_bound = J * ((max_job + 3) / 4);
+    const int form_t = tuning().ot_form;
+    const bool big = groups_bound >= 2048 && C >= 6000 && form_t != 1;
+    // (small batches too: a wave walks an item's twelve stages in ~15 us, what a one-workgroup-per-pair launch takes anyway)
+    // batches of <= 64 jobs of short documents: the streaming kernel's waves derive the tables themselves (fused.hip, SELF) --
+    // one launch in front of the rank, at any size (2 x 20: 19 us either way)
+    const bool self = form_t != 1 && max_rows <= 8 && J <= 64 && !tuning().fused_noself;
+    const bool streaming = form_t != 1 && (self || big || form_t >= 2 || groups_bound >= kL2StreamMinGroups);
+    if (!self) {
         const int64_t work = ((max_job + 3) / 4) * 16;
         int64_t parts = (work + 2 * 192 - 1) / (2 * 192);
         parts = parts < 1 ? 1 : parts > 64 ? 64 : parts;
@@ -2766,13 +2774,8 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     // Forms: the streaming kernels once the batch fills the chip (documents of <= 8 rows: fused.hip's max-sim form, four
     // candidates of a job per wave; 9 .. 16 rows: tile16.hip, two), else -- small batches, longer documents -- the
     // one-workgroup-per-pair kernel (generic.hip).
-    const int64_t groups_bound = J * ((max_job + 3) / 4);
-    const int form_t = tuning().ot_form;
-    const bool big = groups_bound >= 2048 && C >= 6000 && form_t != 1;
-    // (small batches too: a wave walks an item's twelve stages in ~15 us, what a one-workgroup-per-pair launch takes anyway)
-    const bool streaming = form_t != 1 && (big || form_t >= 2 || groups_bound >= kL2StreamMinGroups);
     if (streaming && max_rows <= 8) {
-        if (int rc = launch_pair_fused_l2max(a, groups_bound, s0)) return rc;
+        if (int rc = launch_pair_fused_l2max(a, groups_bound, s0, self)) return rc;
     } else if (streaming && max_rows <= 16) {
         // mostly short documents with a few of 9 .. 16 rows: the hybrid of ot_rank_batch (ScoreArgs::gate)
         if (big && form_t == 0) {

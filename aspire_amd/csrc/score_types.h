@@ -119,7 +119,7 @@ bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm);
 bool fused_inbox_ok(const aspire_repset* q, const float* diameter);
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
-int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream);
+int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream, bool self = false);
 bool tile16_path_ok(const aspire_repset* q, const aspire_repset* c, int pairing);
 int launch_pair_tile16_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);
 int launch_pair_tile16(const ScoreArgs& a, float* cost, float* neg, float* diam2, int64_t items_bound, const float* qbox,

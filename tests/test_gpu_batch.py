@@ -264,7 +264,7 @@ def test_in_flight_ranker_equals_rank_pools(amd):
 
 @pytest.mark.parametrize('smax,sizes', [(8, [1503, 2, 0, 997, 1250, 3, 2048, 1, 1100]),      # fused max-sim form
                                         (14, [1203, 1, 998, 2, 1501, 700, 0, 1600]),       # 16-row streaming kernel (most pairs long)
-                                        (8, [40, 0, 25, 3]),                                # tiny: one workgroup per candidate
+                                        (8, [40, 0, 25, 3]),                                # tiny (<= 64 jobs: still the streaming kernel, in-wave tables)
                                         (8, [340, 0, 325, 3, 297, 310]), (15, [330, 2, 0, 325, 301]),  # >= 384 groups of four: the streaming kernels again
                                         (23, [300, 1, 77]), (32, [150, 0, 61])])            # 17 .. 32 rows: one workgroup per candidate
 def test_l2max_rank_batch(amd, smax, sizes):
@@ -296,6 +296,12 @@ def test_l2max_rank_batch(amd, smax, sizes):
         with amd.pinned(OT_FORM=form):
             s2 = amd.ops.l2max_rank_batch(q, c, job_off, max(sizes), k)[0]
         np.testing.assert_allclose(s2.cpu().numpy(), s.cpu().numpy(), atol=4e-5, rtol=0)
+    if smax <= 8:
+        # <= 64 jobs: the streaming kernel derives the job tables itself (no tables launch); pinned back to the tables launch +
+        # table-driven kernel: the same bits
+        with amd.pinned(FUSED_NOSELF=1, OT_FORM='fused'):
+            s3 = amd.ops.l2max_rank_batch(q, c, job_off, max(sizes), k)[0]
+        assert torch.equal(s3, s)
 
 
 def test_l2max_rank_batch_hybrid(amd):

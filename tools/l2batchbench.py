@@ -27,7 +27,7 @@ def timed(fn, n=40):
 
 
 for smax in (8, 16, 20):
-    for J, NC in ((2, 20), (5, 20), (5, 50), (10, 50), (20, 100), (50, 125), (100, 200), (50, 1000)):
+    for J, NC in ((2, 20), (5, 20), (5, 50), (10, 50), (20, 100), (50, 125), (100, 200), (20, 1000), (50, 1000)):
         c = repset(torch.randint(3, smax + 1, (J * NC,), generator=g))
         q = repset(torch.randint(1, min(smax, 8) + 1, (J,), generator=g))
         job_off = (torch.arange(J + 1, dtype=torch.int32) * NC).to(dev)
