@@ -32,6 +32,10 @@ namespace {
 constexpr int kWaves = 3;
 constexpr int kBlock = 64 * kWaves;
 constexpr int kMaxT = 4;  // sentence rows per document <= 8 * kMaxT
+// Groups of four candidates from which the fused streaming kernel (fused.hip) is ahead of the small-pool kernels, documents of
+// <= 8 rows (tools/otbatchcross.py: one query x one pool 750 groups 39 against 46 us, 2000 groups 59 / 94; batched jobs 500
+// groups 33 / 37, 1600 groups 45 / 79).  Below, a call is latency bound and the small-pool kernels' shorter chains win.
+constexpr int64_t kStreamMinGroups1 = 640, kStreamMinGroupsBatch = 512;
 
 // LDS carve (floats): red[kWaves][T*T][128] | rednorm[kWaves][T][16] | reddiam[4] | redo_mask (8 B) + pad | xpose[kWaves][32][68]
 constexpr int kXpLd = 68;                 // row stride of the transpose scratch: 64 lanes + 4 (keeps b128 reads
@@ -2076,7 +2080,7 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
         const int form_t = tuning().ot_form;
         const int64_t groups4 = (c->n + 3) / 4 * q->n;
         if (agg == ASPIRE_AGG_MAX && !pair_sims && pairing == ASPIRE_PAIR_CROSS && fused_path_ok(q, c) &&
-            (form_t == 3 || (form_t == 0 && groups4 >= 2048))) {
+            (form_t == 3 || (form_t == 0 && groups4 >= (q->n == 1 ? kStreamMinGroups1 : 2048)))) {
             a.cand0 = 0;
             a.cand1 = c->n;
             return launch_pair_fused_l2max(a, groups4, (hipStream_t)stream);
@@ -2386,7 +2390,7 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     const int form_t = tuning().ot_form;
     const int64_t groups4_all = (c->n + 3) / 4 * q->n;
     const bool fused = pairing == ASPIRE_PAIR_CROSS && !extra && !gram && !cost_only && fused_path_ok(q, c) &&
-                       (form_t == 3 || (form_t == 0 && groups4_all >= 2048));
+                       (form_t == 3 || (form_t == 0 && groups4_all >= (q->n == 1 ? kStreamMinGroups1 : 2048)));
     if (fused) {
         a.cand0 = 0;
         a.cand1 = c->n;
@@ -2616,7 +2620,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     // 20 x 1000: 169 us on one stream, 213 / 266 / 403 us in 2 / 4 / 8 chunks -- cross-stream waits cost more than they hide.)
     const int64_t groups_bound = J * ((max_job + 3) / 4);
     const int form_t = tuning().ot_form;
-    const bool big = max_rows <= 8 && groups_bound >= 2048 && C >= 6000;
+    const bool big = max_rows <= 8 && groups_bound >= kStreamMinGroupsBatch;
     const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
     a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
     // Documents of up to 16 rows in a batch that fills the chip: usually pools of mostly short abstracts with a few longer
