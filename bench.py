@@ -107,6 +107,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-probes', action='store_true',
+                    help='skip the side measurements that launch the scoring kernel at OTHER sizes / forms (Infinity-Cache-resident job set, '
+                         'two-kernel form): for counter passes, whose per-kernel sums should hold the 20-job launches only')
     ap.add_argument('--repeats', type=int, default=0, help='repetitions of the K-step schedule (0 = enough for >= 50 ms)')
     ap.add_argument('--streams', type=int, default=3,
                     help='independent calls in flight: repetitions go round-robin over this many caller streams, each with its own '
@@ -317,13 +320,15 @@ def main():
             t = sorted(a.elapsed_time(b) for a, b in evs)
             return sum(t[:n // 2]) / (n // 2)       # mean of the faster half: launch gaps of a cold queue out of the bracket
 
-        fused_form = K * NC >= 6000 and K * ((NC + 3) // 4) >= 2048      # the library's own rule (score.hip: ot_rank_batch)
+        fused_form = K * ((NC + 3) // 4) >= 512      # the library's own rule (score.hip: ot_rank_batch, kStreamMinGroupsBatch)
         prep_ms = stage_ms(1, sets)
         cost_ms = stage_ms(6, sets)              # the scoring launch (fused form: costs + solves in one kernel)
         rank_ms = stage_ms(8, sets)
-        with _lib.pinned(OT_FORM='tile' if fused_form else 'small'):
-            cost_only_ms = stage_ms(2, sets)
-            solve_only_ms = stage_ms(4, sets)
+        cost_only_ms = solve_only_ms = None
+        if not args.no_probes:
+            with _lib.pinned(OT_FORM='tile' if fused_form else 'small'):
+                cost_only_ms = stage_ms(2, sets)
+                solve_only_ms = stage_ms(4, sets)
         run_schedule(sets[0], exchange=False)   # the workspace tables back in the default form's state
         torch.cuda.synchronize()
         # Infinity-Cache-resident variant: ONE small job set (<= 8 jobs, < 200 MB) scored again and again
@@ -339,17 +344,19 @@ def main():
             if rc:
                 _lib.check(rc)
         i_l3 = [0]
-        for _ in range(4):
-            cost_l3()
-        torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(24)]
-        for a, b in evs:
-            a.record(lanes[0].stream)
-            cost_l3()
-            b.record(lanes[0].stream)
-        torch.cuda.synchronize()
-        t = sorted(a.elapsed_time(b) for a, b in evs)
-        cost_l3_ms = sum(t[:12]) / 12
+        cost_l3_ms = None
+        if not args.no_probes:
+            for _ in range(4):
+                cost_l3()
+            torch.cuda.synchronize()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(24)]
+            for a, b in evs:
+                a.record(lanes[0].stream)
+                cost_l3()
+                b.record(lanes[0].stream)
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(b) for a, b in evs)
+            cost_l3_ms = sum(t[:12]) / 12
 
         bytes_per_launch = algorithmic_bytes(K)
         achieved = bytes_per_launch / (cost_ms * 1e-3) / 1e9
@@ -386,11 +393,11 @@ def main():
                          'kernel': 'pair_fused_kernel (costs + Sinkhorn solves)' if fused_form else 'pair_cost1_kernel + sinkhorn_kernel<1>',
                          'kernel_ms': cost_ms,
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'jobs_per_launch': K, 'data': 'cold (rotating pools, > L3)',
-                         'l3_resident_frac': algorithmic_bytes(n_l3) / (cost_l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'l3_resident_frac': algorithmic_bytes(n_l3) / (cost_l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cost_l3_ms else None,
                          'l3_resident': {'jobs': n_l3, 'kernel_ms': cost_l3_ms, 'bytes': algorithmic_bytes(n_l3)},
                          'stages_ms': {'tables+boxes': prep_ms, 'score': cost_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3},
                          'two_kernel_form': {'cost_ms': cost_only_ms, 'sinkhorn_ms': solve_only_ms,
-                                             'cost_frac': bytes_per_launch / (cost_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                             'cost_frac': bytes_per_launch / (cost_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cost_only_ms else None},
                          'step': {'what': 'all kernels of a schedule (timed region, calls in flight as configured) against the same '
                                           'algorithmic bytes',
                                   'achieved': step_achieved, 'frac': step_achieved / HBM_PEAK_GBS,

@@ -29,7 +29,7 @@ traffic = int(2 * fetch_kb * 1024 + write_kb * 1024)
 json.dump({
     'round': 2,
     'command': 'rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python bench.py --steps 20 --warmup 5 '
-               '--repeats 6 --streams 1 --no-cpu-baseline   (tools/profile_r2.sh; summed per kernel by tools/pmcsum.py)',
+               '--repeats 6 --streams 1 --no-cpu-baseline --no-probes   (tools/profile_r2.sh; summed per kernel by tools/pmcsum.py)',
     'workload': 'bench.py: 20 jobs x (1 query x 1000 candidates x 8 sents x 768 d) per aspire_ot_rank_batch_f32 call; the scoring launch = '
                 'pair_fused_kernel<true, true, true> (costs + Sinkhorn solves, in-wave tables), rotating cold pools, one call at a time',
     'jobs_per_launch': K,
