@@ -175,19 +175,33 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
             {
                 const float* xm = lds + (4 * miq + mt) * kRowStride;
                 const float* ym = lds + (16 + p * 8 + 4 * mjq + mt) * kRowStride;
+                if (q_len > 8) {
 #pragma unroll 4
-                for (int c = 0; c < kCh; ++c) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(xm + c * 4);
-                    const float4 x1 = *reinterpret_cast<const float4*>(xm + 8 * kRowStride + c * 4);
-                    const float4 yb = *reinterpret_cast<const float4*>(ym + c * 4);
-                    macc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.x, yb.x, macc[0][0], 0, 0, 0);
-                    macc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.x, yb.x, macc[1][0], 0, 0, 0);
-                    macc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.y, yb.y, macc[0][1], 0, 0, 0);
-                    macc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.y, yb.y, macc[1][1], 0, 0, 0);
-                    macc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.z, yb.z, macc[0][0], 0, 0, 0);
-                    macc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.z, yb.z, macc[1][0], 0, 0, 0);
-                    macc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.w, yb.w, macc[0][1], 0, 0, 0);
-                    macc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.w, yb.w, macc[1][1], 0, 0, 0);
+                    for (int c = 0; c < kCh; ++c) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(xm + c * 4);
+                        const float4 x1 = *reinterpret_cast<const float4*>(xm + 8 * kRowStride + c * 4);
+                        const float4 yb = *reinterpret_cast<const float4*>(ym + c * 4);
+                        macc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.x, yb.x, macc[0][0], 0, 0, 0);
+                        macc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.x, yb.x, macc[1][0], 0, 0, 0);
+                        macc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.y, yb.y, macc[0][1], 0, 0, 0);
+                        macc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.y, yb.y, macc[1][1], 0, 0, 0);
+                        macc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.z, yb.z, macc[0][0], 0, 0, 0);
+                        macc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.z, yb.z, macc[1][0], 0, 0, 0);
+                        macc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.w, yb.w, macc[0][1], 0, 0, 0);
+                        macc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.w, yb.w, macc[1][1], 0, 0, 0);
+                    }
+                } else {
+                    // a short query (facet-selected rows) against longer candidates: query rows 8 .. 15 do not exist -- their
+                    // entries are masked downstream and their sums stay zero
+#pragma unroll 4
+                    for (int c = 0; c < kCh; ++c) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(xm + c * 4);
+                        const float4 yb = *reinterpret_cast<const float4*>(ym + c * 4);
+                        macc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.x, yb.x, macc[0][0], 0, 0, 0);
+                        macc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.y, yb.y, macc[0][1], 0, 0, 0);
+                        macc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.z, yb.z, macc[0][0], 0, 0, 0);
+                        macc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.w, yb.w, macc[0][1], 0, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
