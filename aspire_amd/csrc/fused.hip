@@ -242,6 +242,9 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
     // the score: the pair is poisoned with NaN and solved again by the long-form kernel that follows (launch_pair_fused);
     // so is a document longer than the tile -- never truncated silently.
     if (!(fabsf(score) < 1e30f) || (s.valid & 16u)) score = __builtin_nanf("");
+    // ... and a clearly NEGATIVE transport cost (an entropic OT value is >= 0 up to rounding): sums that left fp32 range on the
+    // way and came back finite (seen with a sentence shared by query and candidate on large vectors)
+    if (a.want != ASPIRE_OT_PLAN_SIM && (a.want == ASPIRE_OT_SIMILARITY ? score : -score) > 1e-2f) score = __builtin_nanf("");
     if (s.out >= 0 && (threadIdx.x & 15) == 0) a.scores[s.out] = score;
 }
 
@@ -691,7 +694,7 @@ int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_
 }
 
 // groups_bound: upper bound of the launch's items (groups of four candidates x queries)
-int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, hipStream_t stream) {
+int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, hipStream_t stream, bool repair) {
     // two 4-wave workgroups per CU are resident.  (Built for three -- 168 registers, the kernel-invariant values spilled,
     // the norm table already shares the stage buffer so the LDS fits -- the 20 x 1000 call went from 120 to 144 us.)
     ScoreArgs a = a_in;
@@ -728,10 +731,20 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     }
     else hipLaunchKernelGGL((pair_fused_kernel<true, true>), grid, dim3(256), lds, stream, a, qbox);
     ASPIRE_LAUNCH_OK();
-    // scaling below ~0.03 lets the shifted sums overflow (the exponent of K grows by 1 / scaling from one step to the next);
-    // far above that they cannot.  Below 0.25: re-solve the NaN pairs with geomloss's own max-shifted formulation.
-    if (a.scaling < 0.25) return launch_pair_generic(a, 2, 0, 8, 8, stream);
+    if (repair) return launch_fused_repair(a, self, 8, stream);
     return ASPIRE_OK;
+}
+
+// The fused kernel's shifted sums can leave fp32 range -- scaling below ~0.03 (the exponent of K grows by 1 / scaling from one
+// step to the next), or, at ANY scaling, a candidate that shares a sentence with the query when the vectors are large (a zero
+// cost next to costs of ~80: found by the fuzz sweep at 2 x N(0,1)) -- and poison the pair's score with NaN: this launch
+// re-solves exactly those pairs with geomloss's own max-shifted formulation (one workgroup per pair, all but the NaN ones
+// return at once).  self: the launch had no candidate -> job table (the kernel searches job_off).
+int launch_fused_repair(const ScoreArgs& a_in, bool self, int max_rows, hipStream_t stream) {
+    ScoreArgs a = a_in;
+    if (self) a.qmap = nullptr;
+    a.gate = nullptr;
+    return launch_pair_generic(a, 2, 0, max_rows, max_rows, stream);
 }
 
 }  // namespace aspire

@@ -73,7 +73,16 @@ __global__ void __launch_bounds__(kGenThreads) pair_generic_kernel(ScoreArgs a, 
         mode = 0;
     }
     const int64_t c_idx = paired ? p : p % a.c.n;
-    const int64_t q_idx = a.pairing == ASPIRE_PAIR_PAIRED ? p : a.pairing == kPairMapped ? (int64_t)a.qmap[p] : p / a.c.n;
+    int64_t q_idx = a.pairing == ASPIRE_PAIR_PAIRED ? p : p / a.c.n;
+    if (a.pairing == kPairMapped) {
+        if (a.qmap != nullptr) {
+            q_idx = (int64_t)a.qmap[p];
+        } else {                                                       // no candidate -> job table (the fused kernel's SELF form): search job_off
+            int j = a.job0;
+            while (j + 1 < a.job1 && (int64_t)a.job_off[j + 1] <= p) ++j;
+            q_idx = j;
+        }
+    }
     const int q_len = a.q.len[q_idx], c_len = a.c.len[c_idx];
     if (q_len <= skip_up_to && c_len <= skip_up_to) return;          // the tile kernels scored this pair
     if (q_len > rows_q || c_len > rows_c) {                            // longer than the host-known bound: poison

@@ -1906,8 +1906,12 @@ __global__ void __launch_bounds__(256) sinkhorn_repair_kernel(ScoreArgs a, PairW
     if (base >= n_slots) return;
     bool bad = false;
     if (base + lane < n_slots) {
-        const float s = a.scores[pair_of_slot(a, base + lane).p];
+        const PairIdx ix = pair_of_slot(a, base + lane);
+        const float s = a.scores[ix.p];
         bad = !(fabsf(s) < 1e30f);
+        // hybrid, few long pairs: only those have slots in the workspace -- a short pair the fused kernel poisoned (overflow)
+        // waits for the long-form repair behind this launch (launch_fused_repair)
+        if (gate_few_long(a) && a.q.len[ix.q_idx] <= 8 && a.c.len[ix.c_idx] <= 8) bad = false;
     }
     unsigned long long todo = __ballot(bad);
     while (todo) {
@@ -2401,6 +2405,7 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         }
         if (int rc = launch_pair_fused(a, groups4_all, inbox ? nullptr : qbox, (hipStream_t)stream)) return rc;
     }
+    bool hybrid1 = false;
     // ONE short query against a big pool whose documents reach 9 .. 16 rows: the hybrid of ot_rank_batch -- the fused kernel in
     // front of the 16-row kernels, a census of the long pairs on the device decides who scores what (ScoreArgs::gate).  The
     // counter lives in the 32 spare bytes in front of the query boxes.
@@ -2414,7 +2419,8 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         ASPIRE_LAUNCH_OK();
         a.gate = gate;
         a.gate_limit = (int32_t)(c->n / 24);
-        if (int rc = launch_pair_fused(a, groups4_all, nullptr, (hipStream_t)stream)) return rc;
+        if (int rc = launch_pair_fused(a, groups4_all, nullptr, (hipStream_t)stream, false)) return rc;
+        hybrid1 = true;
     }
     const int rc_run = fused ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
@@ -2434,6 +2440,11 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         return (int)ASPIRE_OK;
     });
     if (rc_run) return rc_run;
+    if (hybrid1) {      // the fused kernel's overflowed short pairs, behind the kernels that rewrote the long ones
+        a.cand0 = 0;
+        a.cand1 = c->n;
+        if (int rc = launch_fused_repair(a, false, 16, (hipStream_t)stream)) return rc;
+    }
     if (rank.k > 0) {
         // the rank kernels follow the scores on the same stream (their scratch sits behind the OT workspace proper,
         // which aspire_ot_workspace_bytes keeps a multiple of 16 bytes)
@@ -2650,11 +2661,11 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
         ASPIRE_LAUNCH_OK();
         a.gate = gate;
         a.gate_limit = (int32_t)(C / 24);     // up to ~4 % long pairs (measured crossover at 20 x 1000: 5 %): fused kernel + the 16-row kernels on the long pairs only
-        if (int rc = launch_pair_fused(a, groups_bound, qbox, s0)) return rc;
+        if (int rc = launch_pair_fused(a, groups_bound, qbox, s0, false)) return rc;
     }
     if (fused) {
         if (stages & (kStageCost | kStageSolve))
-            if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0)) return rc;
+            if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0, false)) return rc;
     } else {
         const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
             constexpr int T = decltype(tc)::value;
@@ -2670,6 +2681,10 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
         });
         if (rc_run) return rc_run;
     }
+    // the fused kernel's overflowed pairs (NaN) re-solved in the max-shifted form: behind the kernels that rewrite the long
+    // pairs (hybrid), in front of the rank; counted with the rank stage by the stage-timing entry
+    if ((fused || hybrid) && (stages & kStageRank))
+        if (int rc = launch_fused_repair(a, self, hybrid ? 16 : 8, s0)) return rc;
     if (k > 0 && (stages & kStageRank))
         return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
                         topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);

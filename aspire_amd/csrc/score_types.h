@@ -118,7 +118,10 @@ int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q
 bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm);
 bool fused_inbox_ok(const aspire_repset* q, const float* diameter);
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
-int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
+// repair: follow up with launch_fused_repair (callers that time the kernel alone, or queue other kernels that rewrite poisoned
+// pairs first, pass false and launch it themselves)
+int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream, bool repair = true);
+int launch_fused_repair(const ScoreArgs& a, bool self, int max_rows, hipStream_t stream);
 int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream, bool self = false);
 bool tile16_path_ok(const aspire_repset* q, const aspire_repset* c, int pairing);
 int launch_pair_tile16_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);

@@ -167,3 +167,37 @@ def test_fused_l2max_matches_the_per_candidate_kernel_and_torch(amd, nq, nc):
     idx = [0, 1, 5, nc // 2, nc - 2, nc - 1]
     ref = np.array([[-torch.cdist(x, cands[i]).min().item() for i in idx] for x in queries], dtype=np.float32)
     np.testing.assert_allclose(fused[:, idx], ref, atol=4e-5, rtol=0)
+
+
+@pytest.mark.parametrize('scale', [2.0, 3.0])
+def test_fused_kernel_overflowed_pairs_are_resolved(amd, scale):
+    """A candidate that shares a sentence with the query, on vectors 2 - 3 x N(0, 1): a zero cost next to costs of ~80 - 120
+    takes the fused kernel's shifted sums out of fp32 range.  The poisoned pairs are re-solved in the max-shifted form (found by
+    the fuzz sweep: they came back NaN) -- one pool (two queries), batched jobs without tables (SELF: the repair searches
+    job_off), and the hybrid with a long document in the pool."""
+    g = torch.Generator().manual_seed(int(scale * 10))
+    mk = lambda n: scale * torch.randn(n, 768, generator=g)
+    q = [mk(8), mk(5)]
+    c = [mk(int(torch.randint(1, 9, (1,), generator=g))) for _ in range(4100)]
+    c[1] = torch.cat([q[0][:1], mk(1)])
+    c[2] = torch.cat([q[0][:1], mk(7)])
+    c[3] = q[0][:1].clone()
+    want = [orc.get_similarity(q[0], c[j]) for j in (1, 2, 3)]
+    tol = 5e-2 * scale                      # coincident sentences: geomloss's own cancellation noise (test_gpu_scoring)
+    got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[0, 1:4], want, atol=tol, rtol=0)
+    # batched jobs, <= 64 of them: no candidate -> job table for the repair
+    pools = [c[:1500], c[1500:2900], [c[3], c[1]] + c[2900:4100]]
+    queries = [q[1], q[1], q[0]]
+    ranked = amd.scorer.rank_pools(queries, pools, k=None)
+    scores = dict(ranked[2])
+    assert all(np.isfinite(s) for r in ranked for _, s in r)
+    np.testing.assert_allclose([scores[1], scores[0]], [want[0], want[2]], atol=tol, rtol=0)
+    # one long document in the pool: the hybrid (fused kernel on the short pairs, 16-row kernels on the long ones)
+    c_long = list(c)
+    c_long[10] = mk(13)
+    got = amd.scorer.score_pool([q[0]], c_long, method='ot', schedule='pair').cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[0, 1:4], want, atol=tol, rtol=0)
+    assert abs(got[0, 10] - orc.get_similarity(q[0], c_long[10])) < 1e-4 * scale

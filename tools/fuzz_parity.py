@@ -28,7 +28,10 @@ for case in range(n_cases):
         c[1] = torch.cat([q[0][:1], c[1]])[:smax]
     ot = scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
     l2 = scorer.score_pool(q, c, method='l2max').cpu().numpy()
-    assert np.isfinite(ot).all() and np.isfinite(l2).all(), (case, nq, nc, smax)
+    if not (np.isfinite(ot).all() and np.isfinite(l2).all()):
+        bad_ot, bad_l2 = np.argwhere(~np.isfinite(ot)), np.argwhere(~np.isfinite(l2))
+        raise AssertionError(('non-finite scores', case, nq, nc, smax, scale, ragged, 'ot', bad_ot[:6].tolist(), len(bad_ot), 'l2max', bad_l2[:6].tolist(),
+                              len(bad_l2), 'lens', [(len(q[i]), len(c[j])) for i, j in (bad_ot[:6].tolist() + bad_l2[:6].tolist())]))
     for _ in range(12):
         i, j = int(rng.integers(nq)), int(rng.integers(nc))
         if nc > 2 and rng.random() < 0.2:
