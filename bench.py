@@ -395,7 +395,8 @@ def main():
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'jobs_per_launch': K, 'data': 'cold (rotating pools, > L3)',
                          'l3_resident_frac': algorithmic_bytes(n_l3) / (cost_l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cost_l3_ms else None,
                          'l3_resident': {'jobs': n_l3, 'kernel_ms': cost_l3_ms, 'bytes': algorithmic_bytes(n_l3)},
-                         'stages_ms': {'tables+boxes': prep_ms, 'score': cost_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3},
+                         'stages_ms': {'tables+boxes': prep_ms, 'score': cost_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3,
+                                       'note': 'rank = the overflow-repair scan behind the scoring kernel (~5 us, usually finds nothing) + the rank launch'},
                          'two_kernel_form': {'cost_ms': cost_only_ms, 'sinkhorn_ms': solve_only_ms,
                                              'cost_frac': bytes_per_launch / (cost_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cost_only_ms else None},
                          'step': {'what': 'all kernels of a schedule (timed region, calls in flight as configured) against the same '
