@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                 rv[t] = 2 * li + t < q_len;
                 cv[t] = 2 * lj + t < c_len;
             }
-            const float diam = own_diam ? sqrtf(diam2) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
+            const float diam = own_diam ? fmaxf(sqrtf(diam2), kMinDiameter) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
             solve_begin(pend, a, cost, neg, rv, cv, diam);
             pend.out = my_c_real ? (mapped ? c_idx : q_idx * a.c.n + c_idx) : (int64_t)-1;
             if (q_len > 8 || c_len > 8) pend.valid |= 16u;

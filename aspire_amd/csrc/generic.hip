@@ -153,6 +153,9 @@ __device__ __forceinline__ void pair_generic_body(const ScoreArgs& a, int mode, 
         }
         diam = sqrtf(block_reduce(acc, lds + L.red, false));
     }
+    // two documents that are one and the same point (a one-sentence candidate equal to a one-sentence query): diameter 0,
+    // where geomloss's schedule (log diam) is undefined -- a tiny diameter gives the obvious answer, the cost of that one entry
+    diam = fmaxf(diam, kMinDiameter);
     // ---- marginals (pair_distances.py:57-60): softmax over sentences of the best match / temp ----------------------------
     const float temp = (float)a.temp;
     if (tid < q_len) {

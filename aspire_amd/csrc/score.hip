@@ -1571,7 +1571,7 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
         const PairIdx ix = pair_of_slot(a, slot);
         PairState<T> st;
         load_pair<T>(st, ws, slot, lane);
-        const float diam = a.diameter == nullptr ? sqrtf(ws.diam2[slot]) : group_diameter_of(a, ix);
+        const float diam = a.diameter == nullptr ? fmaxf(sqrtf(ws.diam2[slot]), kMinDiameter) : group_diameter_of(a, ix);
         sinkhorn_pair<T>(a, st, a.q.len[ix.q_idx], a.c.len[ix.c_idx], diam, ix.p, lane);
     }
 }
@@ -1739,7 +1739,7 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
         }
     }
     load_block(ws.cost, cost);
-    const float diam = a.diameter == nullptr ? sqrtf(ws.diam2[slot]) : group_diameter_of(a, ix);
+    const float diam = a.diameter == nullptr ? fmaxf(sqrtf(ws.diam2[slot]), kMinDiameter) : group_diameter_of(a, ix);
     // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = exp(ld + (k-1) lsc), n_mid+1 = blur, n_mid+2 = blur (final)
     float ldf;
     const int n_mid = schedule_mid_steps(a, diam, ldf);
@@ -1921,7 +1921,7 @@ __global__ void __launch_bounds__(256) sinkhorn_repair_kernel(ScoreArgs a, PairW
         const PairIdx ix = pair_of_slot(a, slot);
         PairState<T> st;
         load_pair<T>(st, ws, slot, lane);
-        const float diam = a.diameter == nullptr ? sqrtf(ws.diam2[slot]) : group_diameter_of(a, ix);
+        const float diam = a.diameter == nullptr ? fmaxf(sqrtf(ws.diam2[slot]), kMinDiameter) : group_diameter_of(a, ix);
         sinkhorn_pair<T>(a, st, a.q.len[ix.q_idx], a.c.len[ix.c_idx], diam, ix.p, lane);
     }
 }

@@ -59,6 +59,10 @@ struct ScoreArgs {
 
 // Internal third pairing next to ASPIRE_PAIR_CROSS / ASPIRE_PAIR_PAIRED (see ScoreArgs::qmap).
 constexpr int kPairMapped = 2;
+// Floor of a pair's bounding-box diameter in the Sinkhorn solvers: two documents that are one and the same point (a
+// one-sentence candidate equal to a one-sentence query) have diameter 0, where geomloss's schedule (log diam) is undefined --
+// with a tiny diameter every solver gives the obvious answer, the cost of that one entry.
+constexpr float kMinDiameter = 1e-6f;
 
 __device__ __forceinline__ bool gate_few_long(const ScoreArgs& a) { return a.gate != nullptr && *a.gate <= a.gate_limit; }
 

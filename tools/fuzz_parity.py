@@ -137,8 +137,14 @@ for case in range(n3):
         if few_long and rng.random() > 0.01:
             return int(rng.integers(1, 9))
         return int(rng.integers(1, smax + 1))
-    queries = [torch.randn(int(rng.integers(1, min(smax, 8) + 1)) if rng.random() < 0.5 else doc_len(), 768, generator=g) for _ in range(J)]
-    pools = [[torch.randn(doc_len(), 768, generator=g) for _ in range(n)] for n in pool_sizes]
+    bscale = float(rng.choice([1.0, 1.0, 2.0, 3.0]))       # large vectors + a shared sentence: the fused kernel's sums overflow, the repair re-solves
+    queries = [bscale * torch.randn(int(rng.integers(1, min(smax, 8) + 1)) if rng.random() < 0.5 else doc_len(), 768, generator=g) for _ in range(J)]
+    pools = [[bscale * torch.randn(doc_len(), 768, generator=g) for _ in range(n)] for n in pool_sizes]
+    shared = set()
+    for j, n in enumerate(pool_sizes):
+        if n > 0 and rng.random() < 0.4:                    # candidate 0 of this pool shares a sentence with its query
+            pools[j][0] = torch.cat([queries[j][:1], pools[j][0]])[:max(1, min(smax, len(pools[j][0])))]
+            shared.add(j)
     k = int(rng.choice([1, 10, 100, 2000]))
     for method in ('ot', 'l2max'):
         pls, top_s, top_i = scorer._launch_rank_pools(queries, pools, k, None, method)
@@ -147,7 +153,7 @@ for case in range(n3):
         top_s, top_i = top_s.cpu(), top_i.cpu()
         ranked = scorer.rank_pools(queries, pools, k=k, method=method)
         for j, n in enumerate(pool_sizes):
-            assert len(ranked[j]) == min(k, n), (case, method, j)
+            assert len(ranked[j]) == min(k, n), ('length', case, method, j, len(ranked[j]), k, n)
             if n == 0:
                 continue
             one = scorer.score_pool([queries[j]], pools[j], method=method, schedule='pair')[0].cpu()
@@ -155,23 +161,29 @@ for case in range(n3):
             # the list = stable descending order of the job's own scores (scores of a batch and of a one-pool call may differ
             # in the last bits -- other kernels --, so the order is checked against the listed scores, the values against both)
             vals = [s for _, s in ranked[j]]
-            assert all(vals[t] >= vals[t + 1] for t in range(len(vals) - 1)), (case, method, j)
+            assert all(vals[t] >= vals[t + 1] for t in range(len(vals) - 1)), ('order', case, method, j, vals[:6])
+            assert all(np.isfinite(v) for v in vals), ('non-finite', case, method, j, [(i, v) for i, v in ranked[j] if not np.isfinite(v)][:5], len(queries[j]), [len(pools[j][i]) for i, v in ranked[j] if not np.isfinite(v)][:5], smax, bscale, pool_sizes[j])
+            # a shared sentence: geomloss's own cancellation noise (otAspire), torch.cdist's matmul formula beyond 25 rows (tsAspire)
+            noisy = lambda i: j in shared and i == 0 and (method == 'ot' or max(len(queries[j]), len(pools[j][0])) > 25)
             for i, s in ranked[j]:
-                assert abs(s - float(one[i])) <= 2e-4, (case, method, j, i, s, float(one[i]))
+                assert abs(s - float(one[i])) <= (5e-2 * bscale if noisy(i) else 2e-4 * bscale), (case, method, j, i, s, float(one[i]))
             if len(vals) < n:                   # nothing outside the list beats its last entry
                 rest = [float(one[i]) for i in range(n) if i not in got]
-                assert max(rest) <= vals[-1] + 2e-4, (case, method, j)
-            for _ in range(2):                  # sampled pairs against the oracle
-                i = int(rng.integers(n))
+                assert max(rest) <= vals[-1] + (5e-2 * bscale if j in shared else 2e-4 * bscale), ('rest', case, method, j, max(rest), vals[-1])
+            for i in ([0] if j in shared else []) + [int(rng.integers(n)) for _ in range(2)]:      # sampled pairs against the oracle
                 if i not in got:
                     continue
                 if method == 'ot':
-                    w = orc.get_similarity(queries[j], pools[j][i])
+                    try:
+                        w = orc.get_similarity(queries[j], pools[j][i])
+                    except ValueError:          # a one-sentence candidate equal to its one-sentence query: diameter 0, geomloss's
+                        continue                # schedule (arange from log 0) raises -- the GPU side gives the entry's cost (kMinDiameter)
                 else:
                     w = -orc.allpair_masked_dist_l2max(orc.RepLen(queries[j][None].permute(0, 2, 1), [len(queries[j])]),
                                                        orc.RepLen(pools[j][i][None].permute(0, 2, 1), [len(pools[j][i])])).item()
                 e = abs(got[i] - w)
-                assert e <= 1e-4, (case, method, j, i, got[i], w)
-                worst_b[method] = max(worst_b[method], e)
-    print(f'batched case {case}: J={J} pools={pool_sizes[:8]}{"..." if J > 8 else ""} S<={smax} few_long={few_long} k={k} ok', flush=True)
+                assert e <= (5e-2 * bscale if noisy(i) else 1e-4 * bscale), (case, method, j, i, got[i], w, bscale)
+                if not noisy(i):
+                    worst_b[method] = max(worst_b[method], e / bscale)
+    print(f'batched case {case}: J={J} pools={pool_sizes[:8]}{"..." if J > 8 else ""} S<={smax} few_long={few_long} k={k} scale={bscale} shared={len(shared)} ok', flush=True)
 print(f'{n3} batched cases ok; worst errors {worst_b}')
