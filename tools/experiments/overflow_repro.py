@@ -1,3 +1,5 @@
+"""A candidate sharing a sentence with the query at 1 - 3 x the N(0, 1) vector scale, per kernel form, against the oracle: the case the
+fuzz sweep found (fused kernel: NaN before the repair launch became unconditional).   python tools/experiments/overflow_repro.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
