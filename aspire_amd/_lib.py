@@ -20,6 +20,8 @@ c_void_p, c_int, c_int32, c_int64, c_double, c_size_t = (ctypes.c_void_p, ctypes
 
 ASPIRE_OK, ASPIRE_ERR_INVALID_ARG, ASPIRE_ERR_UNSUPPORTED, ASPIRE_ERR_HIP = 0, 1, 2, 3
 CDIST_AUTO, CDIST_DIRECT, CDIST_MM = 0, 1, 2
+CDIST_ONE_FORM = 0x100       # or'ed into cdist_mode of the max-sim entry points: one kernel form whatever the call's size
+OT_FLAG_ONE_FORM = 1         # aspire_ot_params.flags: the same for otAspire
 PAIR_CROSS, PAIR_PAIRED = 0, 1
 OT_DISTANCE, OT_PLAN_SIM, OT_SIMILARITY = 0, 1, 2
 AGG_MAX, AGG_TOP2, AGG_ATTENTION = 0, 1, 2
@@ -33,7 +35,8 @@ class RepSet(ctypes.Structure):
 
 class OtParams(ctypes.Structure):
     """struct aspire_ot_params"""
-    _fields_ = [('blur', c_double), ('scaling', c_double), ('sent_sm_temp', c_double), ('cdist_mode', c_int32)]
+    _fields_ = [('blur', c_double), ('scaling', c_double), ('sent_sm_temp', c_double), ('cdist_mode', c_int32),
+                ('flags', c_int32)]
 
 
 class BertLayer(ctypes.Structure):
@@ -94,6 +97,7 @@ SIGNATURES = {
     'aspire_l2max_rank_batch_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_void_p, c_int64, c_int,
                                             c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'aspire_debug_set': (c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    'aspire_debug_get': (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_size_t]),
     'aspire_debug_ot_cost_stage_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int,
                                                ctypes.POINTER(OtParams), c_void_p, c_void_p, c_size_t, c_void_p]),
     'aspire_debug_ot_rank_batch_stages_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_void_p, c_int64,
@@ -132,17 +136,23 @@ def check(status):
 
 class pinned:
     """Context manager over aspire_debug_set: pin diagnostic switches (kernel forms, grids) for a block of calls, e.g.
-    ``with pinned(SINKHORN='block', COST_PATH='valu'): ...``; the defaults come back on exit."""
+    ``with pinned(SINKHORN='block', COST_PATH='valu'): ...``; on exit every switch goes back to what it was before the
+    block (an enclosing pin, an ASPIRE_HIP_* environment setting, or the default)."""
 
     def __init__(self, **kv):
         self.kv = kv
+        self.before = {}
 
     def __enter__(self):
+        buf = ctypes.create_string_buffer(64)
         for k, v in self.kv.items():
+            check(lib.aspire_debug_get(k.encode(), buf, len(buf)))
+            self.before[k] = buf.value
             check(lib.aspire_debug_set(k.encode(), str(v).encode()))
         return self
 
     def __exit__(self, *exc):
-        for k in self.kv:
-            lib.aspire_debug_set(k.encode(), None)
+        for k, v in self.before.items():
+            lib.aspire_debug_set(k.encode(), v if v else None)
+        self.before = {}
         return False

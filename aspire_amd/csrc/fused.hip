@@ -69,6 +69,24 @@ __device__ __forceinline__ float max_li(float v) {
     return fmaxf(v, dpp_mov<0x128>(v, v));
 }
 __device__ __forceinline__ float sum16(float v) { return sum_li(sum_lj(v)); }
+// CHUNK: a candidate of up to 32 rows occupies w = 1, 2 or 4 of the wave's 16-lane groups (one per 8 of its rows: DPP rows
+// 2 k, 2 k + 1 or all four).  All-reduce across those groups: one v_permlane{16,32}_swap + add per level (common.h: swap_add).
+template <bool XG>
+__device__ __forceinline__ float xg_sum(float v, int w) {
+    if constexpr (XG) {
+        if (w >= 2) v = swap_add<16>(v, v);
+        if (w == 4) v = swap_add<32>(v, v);
+    }
+    return v;
+}
+template <bool XG>
+__device__ __forceinline__ float xg_max(float v, int w) {
+    if constexpr (XG) {
+        if (w >= 2) v = fmaxf(v, lane_xor<16>(v));
+        if (w == 4) v = fmaxf(v, lane_xor<32>(v));
+    }
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The Sinkhorn solve of the four pairs of a wave as a resumable state machine.  A solve is ~80 dependent epsilon steps of
@@ -89,26 +107,29 @@ struct Solve {
     int k, max_steps;      // wave-uniform: next step, steps of the longest of the wave's four schedules
     int n_mid_lo;          // wave-uniform: the shortest of the four schedules -- steps 2 .. n_mid_lo anneal in all four pairs
     unsigned valid;        // bit x: row x valid, bit 2 + y: column y valid, bit 4: a document longer than the tile (poison)
-    int64_t out;           // index into scores, < 0 = nothing to store (clamped tail candidate)
+    int w;                 // wave-uniform (CHUNK): lane groups per candidate, 1 otherwise
+    int64_t out;           // index into scores, < 0 = nothing to store (clamped tail candidate; CHUNK: not the candidate's first group)
 };
 
+template <bool XG = false>
 __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const float (&cost)[2][2], const float (&neg)[2][2],
-                                            const bool (&rv)[2], const bool (&cv)[2], float diam) {
+                                            const bool (&rv)[2], const bool (&cv)[2], float diam, int w = 1) {
+    s.w = w;
     // ---- marginals: soft-max over sentences of the best match / temp --------------------------------------------------
     const float temp = (float)a.temp;
     {
         float qm[2], cm[2];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
-            qm[x] = max_lj(fmaxf((rv[x] && cv[0]) ? neg[x][0] : kNegBig, (rv[x] && cv[1]) ? neg[x][1] : kNegBig)) / temp;
+            qm[x] = xg_max<XG>(max_lj(fmaxf((rv[x] && cv[0]) ? neg[x][0] : kNegBig, (rv[x] && cv[1]) ? neg[x][1] : kNegBig)), w) / temp;
 #pragma unroll
         for (int y = 0; y < 2; ++y)
             cm[y] = max_li(fmaxf((rv[0] && cv[y]) ? neg[0][y] : kNegBig, (rv[1] && cv[y]) ? neg[1][y] : kNegBig)) / temp;
         const float mq = max_li(fmaxf(rv[0] ? qm[0] : kNegBig, rv[1] ? qm[1] : kNegBig));
-        const float mc = max_lj(fmaxf(cv[0] ? cm[0] : kNegBig, cv[1] ? cm[1] : kNegBig));
+        const float mc = xg_max<XG>(max_lj(fmaxf(cv[0] ? cm[0] : kNegBig, cv[1] ? cm[1] : kNegBig)), w);
         const float sq = (rv[0] ? fast_exp(qm[0] - mq) : 0.f) + (rv[1] ? fast_exp(qm[1] - mq) : 0.f);
         const float sc = (cv[0] ? fast_exp(cm[0] - mc) : 0.f) + (cv[1] ? fast_exp(cm[1] - mc) : 0.f);
-        const float lsq = fast_log(sum_li(sq)), lsc = fast_log(sum_lj(sc));
+        const float lsq = fast_log(sum_li(sq)), lsc = fast_log(xg_sum<XG>(sum_lj(sc), w));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             s.wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;      // log_softmax(...).exp(); a zero weight is geomloss's
@@ -148,7 +169,7 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
         }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        s.f[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_lj(rs[t]));
+        s.f[t] = -2.f * h_first * __builtin_amdgcn_logf(xg_sum<XG>(sum_lj(rs[t]), w));
         s.g[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_li(cs[t]));
     }
 }
@@ -157,6 +178,7 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
 // the weights as factors, f -= h log2(row sums), g -= h log2(column sums) -- 32 issue slots, 8 of them transcendental
 // (as scalar code with per-step schedule selects it was 52: the solves are the kernel's largest VALU consumer and, with
 // two waves per SIMD, VALU issue is what the HBM stream competes with).
+template <bool XG = false>
 __device__ __forceinline__ void solve_step(Solve& s, float r2, float h) {
     const f2_t fr = s.f * r2, gr = s.g * r2;
     const f2_t a0 = __builtin_elementwise_fma(s.mc[0], f2_t{-r2, -r2}, f2_t{fr.x, fr.x} + gr);
@@ -165,13 +187,14 @@ __device__ __forceinline__ void solve_step(Solve& s, float r2, float h) {
     const f2_t k1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
     const f2_t t0 = k0 * s.wb, t1 = k1 * s.wb;
     const f2_t cs = __builtin_elementwise_fma(k1, f2_t{s.wa.y, s.wa.y}, k0 * f2_t{s.wa.x, s.wa.x});
-    const f2_t lr = {__builtin_amdgcn_logf(sum_lj(t0.x + t0.y)), __builtin_amdgcn_logf(sum_lj(t1.x + t1.y))};
+    const f2_t lr = {__builtin_amdgcn_logf(xg_sum<XG>(sum_lj(t0.x + t0.y), s.w)), __builtin_amdgcn_logf(xg_sum<XG>(sum_lj(t1.x + t1.y), s.w))};
     const f2_t lc = {__builtin_amdgcn_logf(sum_li(cs.x)), __builtin_amdgcn_logf(sum_li(cs.y))};
     s.f = __builtin_elementwise_fma(f2_t{-h, -h}, lr, s.f);
     s.g = __builtin_elementwise_fma(f2_t{-h, -h}, lc, s.g);
 }
 
 // up to `n` more annealing steps (all of the rest with n < 0)
+template <bool XG = false>
 __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n) {
     const float scal = (float)a.scaling, inv_scal = (float)(1.0 / a.scaling);
     const float eb = (float)a.blur;
@@ -190,7 +213,7 @@ __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n)
             if (k > s.n_mid) { r2 = r2_blur; h = k == s.n_mid + 1 ? h_blur : (k == s.n_mid + 2 ? 2.f * h_blur : 0.f); }
             s.r2 = r2;
             s.h = h;
-            solve_step(s, r2, h);
+            solve_step<XG>(s, r2, h);
         }
     };
     general(min(k_end, 2));
@@ -199,24 +222,27 @@ __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n)
     for (; k < fast_end; ++k) {
         s.r2 *= inv_scal;
         s.h *= scal;
-        solve_step(s, s.r2, s.h);
+        solve_step<XG>(s, s.r2, s.h);
     }
     general(k_end);
     s.k = k_end;
 }
 
+template <bool XG = false>
 __device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a, const f2_t f, const f2_t g) {
     const int lp = threadIdx.x & 15, li = lp >> 2, lj = lp & 3;
+    // CHUNK: the <a, f> terms are counted once per candidate, by the group of its first chunk
+    const bool first_grp = !XG || ((threadIdx.x >> 4) & (s.w - 1)) == 0;
     const bool rv[2] = {(s.valid & 1u) != 0, (s.valid & 2u) != 0}, cv[2] = {(s.valid & 4u) != 0, (s.valid & 8u) != 0};
     float score;
     if (a.want != ASPIRE_OT_PLAN_SIM) {
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            acc += (lj == 0 && rv[t]) ? s.wa[t] * f[t] : 0.f;
+            acc += (lj == 0 && rv[t] && first_grp) ? s.wa[t] * f[t] : 0.f;
             acc += (li == 0 && cv[t]) ? s.wb[t] * g[t] : 0.f;
         }
-        score = sum16(acc);
+        score = xg_sum<XG>(sum16(acc), s.w);
         if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
     } else {
         const float eb = (float)a.blur, rb = rcp_refined(eb);
@@ -229,15 +255,16 @@ __device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a
                 const float outer = valid ? f[x] + g[y] : 0.f;
                 acc += fast_exp(div_r(outer + s.neg[x][y], eb, rb)) * (s.wa[x] * s.wb[y]) * s.neg[x][y];
             }
-        score = sum16(acc);
+        score = xg_sum<XG>(sum16(acc), s.w);
     }
     return score;
 }
 
 // finish a solve: remaining steps, the score, the store
+template <bool XG = false>
 __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
-    solve_steps(s, a, -1);
-    float score = solve_output(s, a, s.f, s.g);
+    solve_steps<XG>(s, a, -1);
+    float score = solve_output<XG>(s, a, s.f, s.g);
     // An overflowed / vanished sum (extreme scaling) has turned into inf / nan that sticks to the potentials and reaches
     // the score: the pair is poisoned with NaN and solved again by the long-form kernel that follows (launch_pair_fused);
     // so is a document longer than the tile -- never truncated silently.
@@ -260,8 +287,15 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 // block (allpair_masked_dist_l2max, pair_distances.py:167-176); no boxes, no solve.
 // QBOX (one query against a big pool): the in-wave query box of SELF without its tables -- every item has the same query, so
 // the box is formed during a wave's first item and read from the LDS cache afterwards; no doc_box launch in front.
-template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false, bool QBOX = false>
+// CHUNK (batched jobs whose candidates reach 9 .. 32 rows, queries of <= 8: config 4's facet-selected queries against whole
+// abstracts -- pp_settings.py:2-3, models.py:127-163): an item's four 16-lane groups hold four 8-row CHUNKS instead of four
+// candidates -- four candidates of <= 8 rows, two of 9 .. 16 (two chunks each) or one of 17 .. 32 (four); chunk_prep_kernel
+// (score.hip) sorts a job's candidates into such items.  The streaming phase is the same (a group stages rows row0 .. row0 + 7
+// of its document; the candidate's per-coordinate box is joined across its groups), the solve's row sums and the marginals'
+// normalisations cross the candidate's groups (xg_sum / xg_max).
+template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false, bool QBOX = false, bool CHUNK = false>
 __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
+    static_assert(!CHUNK || (MFMA && !SELF && !QBOX), "CHUNK: table-driven items only");
     constexpr bool INBOX = (SELF || QBOX) && !L2MAX;        // the query's box comes from the staged query rows (max-sim needs none)
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     if (a.gate != nullptr && !gate_few_long(a)) return;      // hybrid (score_types.h): mostly long pairs -- the 16-row kernels take them all
@@ -286,8 +320,9 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             if (lane >= m) gend += t;
         }
     }
-    const uint32_t item_lo = SELF ? 0u : mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
+    const uint32_t item_lo = (SELF || CHUNK) ? 0u : mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
     const uint32_t n_items = SELF ? (uint32_t)__builtin_amdgcn_readlane(gend, 63)
+                                  : CHUNK ? (uint32_t)a.grp_off[0]          // the item counter chunk_prep_kernel has left
                                   : mapped ? (uint32_t)a.grp_off[a.job1] : ((ncand + 3) / 4) * nq;   // item = (candidate group, query), group-major
     const uint32_t n_waves = gridDim.x * 4;
     const bool own_diam = a.diameter == nullptr;            // else: the caller's per-group diameters (caching_score's batches)
@@ -307,10 +342,13 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     struct Ctx {
         int64_t c_idx, q_idx;
         int c_len, q_len, c_start, q_start;
+        int row0, w;           // CHUNK: first row of this group's chunk; groups per candidate (wave-uniform)
         bool my_c_real;
     };
     auto load_ctx = [&](uint32_t item) {
         Ctx x;
+        x.row0 = 0;
+        x.w = 1;
         if constexpr (SELF) {
             const int job = __popcll(__ballot(gend <= (int)item));          // jobs that end at or before this item (empty ones included)
             const int g0 = job > 0 ? __builtin_amdgcn_readlane(gend, job - 1) : 0;
@@ -331,7 +369,13 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             x.q_idx = hd.x;
             x.q_len = hd.y;
             x.q_start = hd.z;
-            x.my_c_real = p < hd.w;
+            if constexpr (CHUNK) {
+                x.w = __builtin_amdgcn_readfirstlane(hd.w >> 8);
+                x.row0 = 8 * (p & (x.w - 1));
+                x.my_c_real = p < (hd.w & 0xff);
+            } else {
+                x.my_c_real = p < hd.w;
+            }
             x.c_idx = rec[4 + p];
             x.c_len = rec[8 + p];
             x.c_start = rec[12 + p];
@@ -369,6 +413,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         const int64_t c_idx = cur.c_idx, q_idx = cur.q_idx;
         const int c_len = cur.c_len, q_len = cur.q_len, c_start = cur.c_start, q_start = cur.q_start;
         const bool my_c_real = cur.my_c_real;
+        const int row0 = cur.row0, cw = cur.w;
         const float* qdoc = a.q.rows + (size_t)q_start * kD;
         const float* sy_doc = a.c.rows + (size_t)c_start * kD;                 // staging group == compute group
         // the query's per-coordinate box; with caller-supplied diameters any readable row stands in (the box term is then
@@ -393,7 +438,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         auto issue_loads = [&](int st) {
             const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vy[j] = ld4_stream(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
+            for (int j = 0; j < 8; ++j) vy[j] = ld4_stream(sy_doc + (size_t)min(row0 + j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
             if constexpr (!INBOX && !L2MAX) {
                 qmn = ld4(qb + dofs);
                 qmx = ld4(qb + qb_hi + dofs);
@@ -421,6 +466,22 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                         mx.x = fmaxf(mx.x, vy[j].x); mx.y = fmaxf(mx.y, vy[j].y); mx.z = fmaxf(mx.z, vy[j].z); mx.w = fmaxf(mx.w, vy[j].w);
                     }
                     *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
+                }
+                if constexpr (CHUNK && !L2MAX) {
+                    // the candidate's other chunks sit in the neighbouring lane groups (a chunk past the document's end repeats
+                    // its last row: box neutral)
+                    if (cw >= 2) {
+                        mn.x = fminf(mn.x, lane_xor<16>(mn.x)); mn.y = fminf(mn.y, lane_xor<16>(mn.y));
+                        mn.z = fminf(mn.z, lane_xor<16>(mn.z)); mn.w = fminf(mn.w, lane_xor<16>(mn.w));
+                        mx.x = fmaxf(mx.x, lane_xor<16>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<16>(mx.y));
+                        mx.z = fmaxf(mx.z, lane_xor<16>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<16>(mx.w));
+                    }
+                    if (cw == 4) {
+                        mn.x = fminf(mn.x, lane_xor<32>(mn.x)); mn.y = fminf(mn.y, lane_xor<32>(mn.y));
+                        mn.z = fminf(mn.z, lane_xor<32>(mn.z)); mn.w = fminf(mn.w, lane_xor<32>(mn.w));
+                        mx.x = fmaxf(mx.x, lane_xor<32>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<32>(mx.y));
+                        mx.z = fmaxf(mx.z, lane_xor<32>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<32>(mx.w));
+                    }
                 }
                 if constexpr (!INBOX && !L2MAX) {
                     const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
@@ -508,7 +569,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             __builtin_amdgcn_wave_barrier();
             // ---- a slice of the PREVIOUS item's solve, in the shadow of the loads just issued ------------------------
             if constexpr (SOLVE)
-                if (have_pend) solve_steps(pend, a, slice);
+                if (have_pend) solve_steps<CHUNK>(pend, a, slice);
         }
 
         if constexpr (MFMA) {
@@ -564,7 +625,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
-                const int i = 2 * li + x, j = 2 * lj + y;
+                const int i = 2 * li + x, j = row0 + 2 * lj + y;
                 const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
                 const float ns = xx[x] + yy[y];
                 redo[x][y] = !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
@@ -595,7 +656,8 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int o = owner[e] >= 0 ? owner[e] : owner[0];
-                            const int ol = o & 15, i = 2 * (ol >> 2) + x, j = 2 * (ol & 3) + y;
+                            const int ol = o & 15, i = 2 * (ol >> 2) + x;
+                            const int j = (CHUNK ? __builtin_amdgcn_readlane(row0, o) : 0) + 2 * (ol & 3) + y;
                             const int cs_e = __builtin_amdgcn_readlane(c_start, o);
                             const float* qrow = qdoc + (size_t)i * kD + 4 * lane;
                             const float* crow = a.c.rows + ((size_t)cs_e + j) * kD + 4 * lane;
@@ -629,18 +691,18 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 
         // ---- the previous item's solve ends here (its last steps, score, store); this item's begins ---------------------
         if constexpr (SOLVE)
-            if (have_pend) solve_finish(pend, a);
+            if (have_pend) solve_finish<CHUNK>(pend, a);
         if constexpr (with_solve) {
             bool rv[2], cv[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 rv[t] = 2 * li + t < q_len;
-                cv[t] = 2 * lj + t < c_len;
+                cv[t] = row0 + 2 * lj + t < c_len;
             }
             const float diam = own_diam ? fmaxf(sqrtf(diam2), kMinDiameter) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
-            solve_begin(pend, a, cost, neg, rv, cv, diam);
-            pend.out = my_c_real ? (mapped ? c_idx : q_idx * a.c.n + c_idx) : (int64_t)-1;
-            if (q_len > 8 || c_len > 8) pend.valid |= 16u;
+            solve_begin<CHUNK>(pend, a, cost, neg, rv, cv, diam, cw);
+            pend.out = (my_c_real && row0 == 0) ? (mapped ? c_idx : q_idx * a.c.n + c_idx) : (int64_t)-1;
+            if (q_len > 8 || c_len > 8 * cw) pend.valid |= 16u;
             slice = (pend.max_steps + kStages - 1) / kStages;
             have_pend = true;
         } else if constexpr (L2MAX) {
@@ -648,16 +710,16 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int y = 0; y < 2; ++y) m = fmaxf(m, (2 * li + x < q_len && 2 * lj + y < c_len) ? neg[x][y] : kNegBig);
-            m = max_li(max_lj(m));
-            if (q_len > 8 || c_len > 8) m = __builtin_nanf("");          // longer than the tile: never truncated silently
-            if (my_c_real && lp == 0) a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = m;
+                for (int y = 0; y < 2; ++y) m = fmaxf(m, (2 * li + x < q_len && row0 + 2 * lj + y < c_len) ? neg[x][y] : kNegBig);
+            m = xg_max<CHUNK>(max_li(max_lj(m)), cw);
+            if (q_len > 8 || c_len > 8 * cw) m = __builtin_nanf("");          // longer than the tile: never truncated silently
+            if (my_c_real && lp == 0 && row0 == 0) a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = m;
         } else if (my_c_real && lp == 0) {
             a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = diam2;
         }
     }
     if constexpr (SOLVE)
-        if (have_pend && !a.skip_tail) solve_finish(pend, a);   // the wave's last item: nothing left to hide it behind
+        if (have_pend && !a.skip_tail) solve_finish<CHUNK>(pend, a);   // the wave's last item: nothing left to hide it behind
 }
 
 }  // namespace

@@ -58,6 +58,32 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     return true;
 }
 
+// the value apply_tuning would take to set the switch to what it is now ("" = default)
+bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
+    const char* v = nullptr;
+    char num[32] = "";
+    auto number = [&](int n) {
+        if (n != 0) snprintf(num, sizeof(num), "%d", n);
+        return (const char*)num;
+    };
+    if (!strcmp(key, "SINKHORN")) {
+        static const char* names[] = {"", "wave", "", "block", "block-norepair", "block16", "block-dense", "block-wide"};
+        v = names[t.sinkhorn_form];
+    } else if (!strcmp(key, "COST_PATH")) v = t.cost_path == 1 ? "mfma" : t.cost_path == 2 ? "valu" : "";
+    else if (!strcmp(key, "COST1_BLOCKS")) v = number(t.cost1_blocks);
+    else if (!strcmp(key, "ATTN")) v = t.attn_gemm ? "gemm" : "";
+    else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : "";
+    else if (!strcmp(key, "GEMM_TILE")) v = number(t.gemm_tile);
+    else if (!strcmp(key, "FUSED_VALU")) v = number(t.fused_valu);
+    else if (!strcmp(key, "FUSED_NOSOLVE")) v = number(t.fused_nosolve);
+    else if (!strcmp(key, "FUSED_NOSELF")) v = number(t.fused_noself);
+    else if (!strcmp(key, "FUSED_WAVES")) v = number(t.fused_waves);
+    else if (!strcmp(key, "OT_FORM")) v = t.ot_form == 1 ? "small" : t.ot_form == 2 ? "tile" : t.ot_form == 3 ? "fused" : "";
+    if (!v || strlen(v) + 1 > len) return false;
+    strcpy(buf, v);
+    return true;
+}
+
 void tuning_from_env() {
     static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
     for (const char* k : keys) {
@@ -75,6 +101,10 @@ const Tuning& tuning() {
 bool tuning_set(const char* key, const char* value) {
     std::call_once(g_tuning_once, tuning_from_env);
     return apply_tuning(g_tuning, key, value);
+}
+bool tuning_get(const char* key, char* buf, size_t len) {
+    std::call_once(g_tuning_once, tuning_from_env);
+    return render_tuning(g_tuning, key, buf, len);
 }
 
 namespace {
@@ -138,6 +168,11 @@ extern "C" int aspire_abi_version(void) { return ASPIRE_ABI_VERSION; }
 extern "C" int aspire_debug_set(const char* key, const char* value) {
     ASPIRE_REQUIRE(key, ASPIRE_ERR_INVALID_ARG, "null key");
     ASPIRE_REQUIRE(tuning_set(key, value), ASPIRE_ERR_INVALID_ARG, "unknown diagnostic switch %s=%s", key, value ? value : "");
+    return ASPIRE_OK;
+}
+extern "C" int aspire_debug_get(const char* key, char* buf, size_t len) {
+    ASPIRE_REQUIRE(key && buf && len > 0, ASPIRE_ERR_INVALID_ARG, "null key / buffer");
+    ASPIRE_REQUIRE(tuning_get(key, buf, len), ASPIRE_ERR_INVALID_ARG, "unknown diagnostic switch %s (or buffer too small)", key);
     return ASPIRE_OK;
 }
 extern "C" const char* aspire_last_error(void) { return g_err; }

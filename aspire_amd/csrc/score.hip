@@ -2058,6 +2058,9 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "scores is null");
     ASPIRE_REQUIRE((!pair_sims && !pair_softmax) || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
                    "pair outputs need padded extents (ext > 0)");
+    const bool one_form = (cdist_mode & ASPIRE_CDIST_ONE_FORM) != 0;
+    cdist_mode &= ~ASPIRE_CDIST_ONE_FORM;
+    ASPIRE_REQUIRE(!one_form || agg == ASPIRE_AGG_MAX, ASPIRE_ERR_UNSUPPORTED, "ASPIRE_CDIST_ONE_FORM is built for the max-sim score only");
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
@@ -2068,6 +2071,8 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     a.scores = scores;
     a.out_pairsims = pair_sims;
     a.out_plan = pair_softmax;
+    if (one_form)      // every pair through the long-form kernel, whatever the size of the call (include/aspire_hip.h)
+        return launch_pair_generic(a, 1, 0, q->ext > 0 ? q->ext : q->max_len, c->ext > 0 ? c->ext : c->max_len, (hipStream_t)stream);
     // ONE query against a big pool of 9 .. 16-row documents: the streaming kernel's max-sim form (tile16.hip)
     if (agg == ASPIRE_AGG_MAX && !pair_sims && q->n == 1 && c->n >= 4096 && tile16_path_ok(q, c, pairing) &&
         pairing == ASPIRE_PAIR_CROSS && tuning().cost_path != 1 && tuning().ot_form != 1) {
@@ -2179,6 +2184,13 @@ void fill_ot_args(ScoreArgs& a, const aspire_repset* q, const aspire_repset* c, 
     a.n_groups = diameter ? (c->n + diam_group - 1) / diam_group : 0;
     a.want = want;
     a.scores = scores;
+}
+
+// The hybrid forms (fused kernel in front of the 16-row kernels, ScoreArgs::gate) need a solve stage that leaves the short pairs'
+// scores alone: the block kernels and their repair kernel check the gate, the one-solve-per-wave kernel (SINKHORN=wave) does not.
+bool sinkhorn_form_honours_gate() {
+    const int f = tuning().sinkhorn_form;
+    return f == 0 || f == 3 || f == 5 || f == 6 || f == 7;
 }
 
 // ---- stage 1 of an otAspire pass: pairwise costs of the chunk [a.cand0, a.cand1) -> workspace slots ---------------------
@@ -2319,7 +2331,9 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
            bool cost_only = false) {
     if (int rc = check_repsets(q, c, D, pairing)) return rc;
     const int tile_max = 8 * kMaxT;
-    if (q->n == 0 || c->n == 0 || max_rows_of(q, c) <= tile_max)
+    // ONE_FORM (include/aspire_hip.h): every pair through the long-form kernel, whatever the size of the call
+    const bool one_form = prm && (prm->flags & ASPIRE_OT_FLAG_ONE_FORM) && !cost_only;
+    if (q->n == 0 || c->n == 0 || (max_rows_of(q, c) <= tile_max && !one_form))
         return ot_run_tiles(q, c, D, pairing, prm, diameter, diam_group, want, scores, out_qdistr, out_cdistr, out_pairsims, out_plan,
                             workspace, workspace_bytes, stream, rank, cost_only);
     if (int rc = check_ot_params(prm, want)) return rc;
@@ -2335,7 +2349,7 @@ int ot_run(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairin
     a.out_pairsims = out_pairsims;
     a.out_plan = out_plan;
     int skip = 0;
-    if (q->ext == 0 && c->ext == 0) {
+    if (q->ext == 0 && c->ext == 0 && !one_form) {
         aspire_repset q32 = *q, c32 = *c;
         q32.max_len = q->max_len < tile_max ? q->max_len : tile_max;
         c32.max_len = c->max_len < tile_max ? c->max_len : tile_max;
@@ -2410,7 +2424,7 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     // front of the 16-row kernels, a census of the long pairs on the device decides who scores what (ScoreArgs::gate).  The
     // counter lives in the 32 spare bytes in front of the query boxes.
     if (stream16 && !gram && !fused && !extra && !cost_only && !diameter && q->max_len <= 8 && form_t == 0 && prm->scaling >= 0.25 &&
-        want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu) {
+        want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu && sinkhorn_form_honours_gate()) {
         int32_t* gate = (int32_t*)((char*)qbox - 16);
         a.cand0 = 0;
         a.cand1 = c->n;
@@ -2575,7 +2589,8 @@ BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, in
 
 extern "C" size_t aspire_ot_rank_batch_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t max_job, int64_t k) {
     if (!q || !c || q->n <= 0 || c->n <= 0) return 0;
-    return batch_layout(q->n, c->n, max_rows_of(q, c), max_job, k).total;
+    const int mr = max_rows_of(q, c);
+    return batch_layout(q->n, c->n, mr < 8 * kMaxT ? mr : 8 * kMaxT, max_job, k).total;
 }
 
 namespace {
@@ -2600,7 +2615,13 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
         return ASPIRE_OK;
     }
     ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "null scores");
-    const int max_rows = max_rows_of(q, c);
+    // Documents beyond the tile kernels' 32 rows (AspireNER's appended entity rows, models.py:224-233), as in ot_run: the tile
+    // kernels run with their documents' bound clamped to 32 rows (a pair that holds a longer document gets NaN there) and the
+    // long-document kernel (generic.hip) then rewrites exactly those pairs, in front of the rank.
+    const int max_rows_all = max_rows_of(q, c);
+    ASPIRE_REQUIRE(max_rows_all <= generic_max_rows(), ASPIRE_ERR_UNSUPPORTED,
+                   "documents with more than %d sentence rows are not supported (got %d)", generic_max_rows(), max_rows_all);
+    const int max_rows = max_rows_all < 8 * kMaxT ? max_rows_all : 8 * kMaxT;
     const BatchLayout L = batch_layout(J, C, max_rows, max_job, k);
     ASPIRE_REQUIRE(workspace && workspace_bytes >= L.total, ASPIRE_ERR_INVALID_ARG,
                    "workspace too small: %zu bytes given, aspire_ot_rank_batch_workspace_bytes says %zu", workspace_bytes, L.total);
@@ -2629,6 +2650,17 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     // launch (fused.hip) -- or, pinned for A/B tests, the same cost kernel + the block Sinkhorn kernel as two launches.
     // (Chunks of jobs on two streams, Sinkhorn of chunk i beside the cost kernel of chunk i + 1, were measured and dropped:
     // 20 x 1000: 169 us on one stream, 213 / 266 / 403 us in 2 / 4 / 8 chunks -- cross-stream waits cost more than they hide.)
+    if (prm->flags & ASPIRE_OT_FLAG_ONE_FORM) {
+        // every pair through the long-form kernel (one workgroup per pair; it finds a candidate's job by searching job_off)
+        a.qmap = nullptr;
+        if (stages & kStageSolve)
+            if (int rc = launch_pair_generic(a, 0, 0, q->max_len, c->max_len, s0)) return rc;
+        const size_t need = aspire_topk_workspace_bytes(J, max_job, k);
+        if (k > 0 && (stages & kStageRank))
+            return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
+                            need ? wsb + L.topk : nullptr, need, stream, job_off, job_base);
+        return ASPIRE_OK;
+    }
     const int64_t groups_bound = J * ((max_job + 3) / 4);
     const int form_t = tuning().ot_form;
     const bool big = max_rows <= 8 && groups_bound >= kStreamMinGroupsBatch;
@@ -2640,7 +2672,8 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     // scores the short ones, the 16-row kernels only the long ones; many -- the fused kernel returns at once.  No host round
     // trip, and ONE long document no longer moves 20 000 pairs onto kernels 2.5 x slower.
     const bool hybrid = max_rows > 8 && max_rows <= 16 && form_t == 0 && groups_bound >= 2048 && C >= 6000 && stages == kStageAll &&
-                        prm->scaling >= 0.25 && want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu;
+                        prm->scaling >= 0.25 && want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu &&
+                        sinkhorn_form_honours_gate();
     // batches of <= 64 jobs on the fused kernel need no tables launch: the kernel's waves derive them (fused.hip, SELF)
     const bool self = fused && fused_self_ok(J, prm);
     if ((stages & kStagePrep) && !self) {
@@ -2680,6 +2713,8 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
             return (int)ASPIRE_OK;
         });
         if (rc_run) return rc_run;
+        if (max_rows_all > max_rows && (stages & kStageSolve))
+            if (int rc = launch_pair_generic(a, 0, max_rows, q->max_len, c->max_len, s0)) return rc;
     }
     // the fused kernel's overflowed pairs (NaN) re-solved in the max-shifted form: behind the kernels that rewrite the long
     // pairs (hybrid), in front of the rank; counted with the rank stage by the stage-timing entry
@@ -2754,6 +2789,8 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
                    "workspace too small: %zu bytes given, aspire_l2max_rank_batch_workspace_bytes says %zu", workspace_bytes, L.total);
     ASPIRE_REQUIRE(((uintptr_t)workspace & 15) == 0, ASPIRE_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
     char* wsb = (char*)workspace;
+    const bool one_form = (cdist_mode & ASPIRE_CDIST_ONE_FORM) != 0;
+    cdist_mode &= ~ASPIRE_CDIST_ONE_FORM;
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
@@ -2778,8 +2815,8 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     // (small batches too: a wave walks an item's twelve stages in ~15 us, what a one-workgroup-per-pair launch takes anyway)
     // batches of <= 64 jobs of short documents: the streaming kernel's waves derive the tables themselves (fused.hip, SELF) --
     // one launch in front of the rank, at any size (2 x 20: 19 us either way)
-    const bool self = form_t != 1 && max_rows <= 8 && J <= 64 && !tuning().fused_noself;
-    const bool streaming = form_t != 1 && (self || big || form_t >= 2 || groups_bound >= kL2StreamMinGroups);
+    const bool self = form_t != 1 && max_rows <= 8 && J <= 64 && !tuning().fused_noself && !one_form;
+    const bool streaming = form_t != 1 && (self || big || form_t >= 2 || groups_bound >= kL2StreamMinGroups) && !one_form;
     if (!self) {
         const int64_t work = ((max_job + 3) / 4) * 16;
         int64_t parts = (work + 2 * 192 - 1) / (2 * 192);
@@ -2807,7 +2844,7 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
             if (int rc = launch_pair_fused_l2max(a, groups_bound, s0)) return rc;
         }
         if (int rc = launch_pair_tile16_l2max(a, 2 * groups_bound, s0)) return rc;
-    } else if (max_rows <= 8 * kMaxT) {
+    } else if (max_rows <= 8 * kMaxT && !one_form) {
         // one workgroup per candidate against its job's query (small batches, documents of 17 .. 32 rows)
         const int rc_tiles = dispatch_T(max_rows, [&](auto tc) -> int {
             constexpr int T = decltype(tc)::value;

@@ -25,5 +25,7 @@ const Tuning& tuning();
 // key = the environment variable's name without the ASPIRE_HIP_ prefix (e.g. "SINKHORN"), value as in the environment;
 // value NULL or "" restores the default.  Returns false on an unknown key / value.
 bool tuning_set(const char* key, const char* value);
+// the switch's current value in the form tuning_set takes ("" = default); false on an unknown key / short buffer
+bool tuning_get(const char* key, char* buf, unsigned long len);
 
 }  // namespace aspire

@@ -49,6 +49,12 @@ class DeviceRepSet:
         assert lens.numel() == self.n
         self.ext = int(ext)
         self.max_len = int(max_len if max_len is not None else (ext if ext > 0 else (int(lens.max()) if self.n else 0)))
+        # A document without sentences: the reference raises (torch.max over an empty dimension, pair_distances.py:57 via
+        # models.py:190-197); scored here it would come back as OT distance 0 = the best possible similarity.  Checked
+        # wherever the lengths are known on the host (every constructor of the host layer passes them).
+        if self.lens_host is not None and any(n <= 0 for n in self.lens_host):
+            raise ValueError('a document without sentence rows cannot be scored (the reference raises on it: '
+                             'pair_distances.py:57); drop it from the pool')
 
     @classmethod
     def from_padded(cls, reps, abs_lens):
@@ -57,9 +63,10 @@ class DeviceRepSet:
         reps = reps.to(device=dev, dtype=torch.float32).contiguous()
         b, s, _ = reps.shape
         start = torch.arange(b, device=dev, dtype=torch.int32) * s
-        lens = torch.as_tensor(list(abs_lens), dtype=torch.int32).to(dev)
+        lens_host = [int(n) for n in abs_lens]
+        lens = torch.as_tensor(lens_host, dtype=torch.int32).to(dev)
         assert lens.numel() == b, 'abs_lens must have one entry per batch element'
-        return cls(reps.view(b * s, D), start, lens, ext=s)
+        return cls(reps.view(b * s, D), start, lens, ext=s, lens_host=lens_host)
 
     @classmethod
     def from_list(cls, reps_list):
@@ -122,8 +129,11 @@ def cls_l2(q_cls, c_cls, pairing=_lib.PAIR_PAIRED, eps=1e-6):
     return out
 
 
-def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want_pair_sims=False):
-    """A9 (pair_distances.py:138-186).  Returns sims [P] (and pair_sims [P, q.ext, c.ext])."""
+def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want_pair_sims=False, one_form=False):
+    """A9 (pair_distances.py:138-186).  Returns sims [P] (and pair_sims [P, q.ext, c.ext]).  one_form: see
+    include/aspire_hip.h, ASPIRE_CDIST_ONE_FORM."""
+    if one_form:
+        cdist_mode |= _lib.CDIST_ONE_FORM
     p = _npairs(q, c, pairing)
     dev = q.rows.device
     scores = torch.empty(p, device=dev, dtype=torch.float32)
@@ -162,7 +172,7 @@ def group_diameter(q, c, pairing, group):
 
 
 def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.CDIST_AUTO,
-                diameter=None, diam_group=0, want=_lib.OT_DISTANCE, want_extras=False, out=None, workspace=None):
+                diameter=None, diam_group=0, want=_lib.OT_DISTANCE, want_extras=False, out=None, workspace=None, one_form=False):
     """A5-A8 (pair_distances.py:21-92).  Returns scores [P]; with want_extras also
     (query_distr [P,q.ext], cand_distr [P,c.ext], pair_sims [P,q.ext,c.ext], plan [P,q.ext,c.ext])."""
     p = _npairs(q, c, pairing)
@@ -173,7 +183,7 @@ def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_t
     if want_extras:
         extras = [torch.empty(p, q.ext, device=dev), torch.empty(p, c.ext, device=dev),
                   torch.empty(p, q.ext, c.ext, device=dev), torch.empty(p, q.ext, c.ext, device=dev)]
-    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode)
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, _lib.OT_FLAG_ONE_FORM if one_form else 0)
     qs, cs = q.struct(), c.struct()
     nbytes = lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), pairing)
     ws = workspace if workspace is not None else torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
@@ -184,14 +194,14 @@ def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_t
 
 
 def ot_rank(q, c, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.CDIST_AUTO, diameter=None, diam_group=0,
-            want=_lib.OT_DISTANCE, idx_base=0, key_form=False):
+            want=_lib.OT_DISTANCE, idx_base=0, key_form=False, one_form=False):
     """The ranking step in one call (include/aspire_hip.h: aspire_ot_rank_f32): otAspire scores [Q, C] of every
     query against every candidate and their per-query stable descending rank.  Returns (scores [Q, C], top_scores
     [Q, k], top_idx [Q, k]) -- `scores` holds the raw kernel output (positive distances for OT_DISTANCE, so the rank
     is of the OUTPUT; pass want=OT_PLAN_SIM for similarities) -- or (scores, keys [Q, k]) with key_form."""
     dev = q.rows.device
     scores = torch.empty(q.n, c.n, device=dev, dtype=torch.float32)
-    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode)
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, _lib.OT_FLAG_ONE_FORM if one_form else 0)
     qs, cs = q.struct(), c.struct()
     nbytes = lib.aspire_ot_rank_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), k)
     ws = torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
@@ -207,7 +217,7 @@ def ot_rank(q, c, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.C
 
 
 def ot_rank_batch(q, c, job_off, max_job, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.CDIST_AUTO,
-                  want=_lib.OT_SIMILARITY, out=None, workspace=None, job_base=None, key_form=False):
+                  want=_lib.OT_SIMILARITY, out=None, workspace=None, job_base=None, key_form=False, one_form=False):
     """J independent (query, pool) re-ranks in ONE call (include/aspire_hip.h: aspire_ot_rank_batch_f32; the per-query
     loop of evaluate.py:58-76 batched over queries).  q: J queries; c: every job's candidates back to back; job_off int32
     GPU tensor [J + 1]; max_job: host-known bound of a pool's size.  Returns (scores [C], top_scores [J, k], top_idx [J, k])
@@ -228,7 +238,7 @@ def ot_rank_batch(q, c, job_off, max_job, k, blur=0.05, scaling=0.9, sent_sm_tem
         top_s = torch.empty(q.n, k, device=dev, dtype=torch.float32) if k > 0 and not key_form else None
         top_i = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and not key_form else None
         keys = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and key_form else None
-    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode)
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, _lib.OT_FLAG_ONE_FORM if one_form else 0)
     qs, cs = q.struct(), c.struct()
     if workspace is None:
         nbytes = lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), max_job, k)
@@ -239,10 +249,13 @@ def ot_rank_batch(q, c, job_off, max_job, k, blur=0.05, scaling=0.9, sent_sm_tem
     return (scores, keys) if key_form else (scores, top_s, top_i)
 
 
-def l2max_rank_batch(q, c, job_off, max_job, k, cdist_mode=_lib.CDIST_AUTO, out=None, workspace=None, job_base=None, key_form=False):
+def l2max_rank_batch(q, c, job_off, max_job, k, cdist_mode=_lib.CDIST_AUTO, out=None, workspace=None, job_base=None, key_form=False,
+                     one_form=False):
     """tsAspire over J independent (query, pool) jobs in ONE call (include/aspire_hip.h: aspire_l2max_rank_batch_f32); arguments
     and returns as ot_rank_batch: (scores [C], top_scores [J, k], top_idx [J, k]) or (scores, keys [J, k]) with key_form."""
     dev = q.rows.device
+    if one_form:
+        cdist_mode |= _lib.CDIST_ONE_FORM
     _i32(job_off, 'job_off')
     assert job_off.numel() == q.n + 1, 'job_off must have one entry per job plus one'
     keys = None

@@ -87,7 +87,8 @@ def all_gather_topk_keys(local_keys, k, group=None):
 class ShardedPoolRanker:
     """Holds this rank's block of a candidate pool resident in HBM and ranks queries against the whole
     pool.  `pool_reps` is the FULL pool (list of [S_i, 768] arrays) or, with `presharded=True`, only this
-    rank's block together with `global_offset`."""
+    rank's block together with `global_offset` (and `n_total` for rank_queries_full, which also requires the block to be
+    exactly shard_bounds(n_total, world, rank, multiple))."""
 
     def __init__(self, pool_reps, presharded=False, global_offset=0, multiple=64, group=None, n_total=None):
         from .scorer import CandidatePool
@@ -134,6 +135,11 @@ class ShardedPoolRanker:
         sizes = [shard_bounds(self.n_total, self.world, r, self.multiple) for r in range(self.world)] if self.n_total is not None else None
         assert sizes is not None, 'rank_queries_full needs the full pool size (construct without presharded=True or pass n_total)'
         lens = [hi - lo for lo, hi in sizes]
+        # a presharded caller must have cut the pool exactly as shard_bounds does (same `multiple`): the gathered [Q, C] matrix is
+        # assembled from those bounds, and a block cut elsewhere would silently misalign its columns
+        assert self.lo == sizes[self.rank][0] and len(self.pool) == lens[self.rank], (
+            f'rank {self.rank}: block [{self.lo}, {self.lo + len(self.pool)}) is not shard_bounds({self.n_total}, {self.world}, '
+            f'{self.rank}, {self.multiple}) = {sizes[self.rank]}')
         width = max(max(lens), 1)
         local = torch.full((qn, width), float('-inf'), device=dev)
         if len(self.pool) > 0:

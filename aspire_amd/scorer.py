@@ -66,8 +66,13 @@ def _cdist_runs(q, c, group):
     return runs
 
 
-def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None, score_batch_size=64):
+def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None, score_batch_size=64, deterministic=False):
     """Scores [Q, C] (GPU tensor, higher = more similar) of every query against every candidate.
+
+    deterministic ('ot' with the per-pair schedule, 'l2max'): every pair through ONE kernel form (include/aspire_hip.h:
+    ASPIRE_OT_FLAG_ONE_FORM), so that a pair's score -- and with it the order of near-ties -- does not depend on the size of
+    the call it is scored in: score_pool / rank_pool per query and rank_pools over all queries then agree bit for bit.
+    Several times slower than the default, which picks the kernel family by grid size (scores a few 1e-5 apart).
 
     method   'ot'     otAspire.  schedule 'pair': -OT_eps distance, one epsilon schedule per pair, exactly
                       AspireModel.get_similarity (models.py:190-197).  schedule 'batch': plan-weighted
@@ -89,17 +94,21 @@ def score_pool(query_reps_list, pool, method='ot', schedule='pair', hparams=None
     # group of score_batch_size candidates (caching_score) -> per group, see _cdist_runs.
     if schedule == 'batch' and q.n > 1 and q.max_len > 25 and c.n > 0:
         # the formula is per (query, group) and a launch takes one mode: long queries go one per call
-        return torch.cat([score_pool([qr], pool, method, schedule, hparams, score_batch_size) for qr in query_reps_list], dim=0)
+        return torch.cat([score_pool([qr], pool, method, schedule, hparams, score_batch_size, deterministic) for qr in query_reps_list],
+                         dim=0)
     runs = _cdist_runs(q, c, score_batch_size) if schedule == 'batch' and q.n > 0 and c.n > 0 else [(0, c.n, _lib.CDIST_AUTO)]
     if len(runs) > 1:
-        parts = [_score_run(q, c.slice(lo, hi), method, schedule, hparams, score_batch_size, mode) for lo, hi, mode in runs]
+        parts = [_score_run(q, c.slice(lo, hi), method, schedule, hparams, score_batch_size, mode, deterministic)
+                 for lo, hi, mode in runs]
         return torch.cat(parts, dim=1)
-    return _score_run(q, c, method, schedule, hparams, score_batch_size, runs[0][2])
+    return _score_run(q, c, method, schedule, hparams, score_batch_size, runs[0][2], deterministic)
 
 
-def _score_run(q, c, method, schedule, hparams, score_batch_size, cdist_mode):
+def _score_run(q, c, method, schedule, hparams, score_batch_size, cdist_mode, deterministic=False):
+    if deterministic and not (method == 'l2max' or (method == 'ot' and schedule == 'pair')):
+        raise ValueError("deterministic=True is built for method 'ot' with schedule 'pair' and for 'l2max'")
     if method == 'l2max':
-        return ops.l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=cdist_mode).view(q.n, c.n)
+        return ops.l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=cdist_mode, one_form=deterministic).view(q.n, c.n)
     if method == 'l2top2':
         return ops.l2agg_scores(q, c, _lib.AGG_TOP2, pairing=_lib.PAIR_CROSS, cdist_mode=cdist_mode).view(q.n, c.n)
     if method == 'l2attention':
@@ -110,7 +119,7 @@ def _score_run(q, c, method, schedule, hparams, score_batch_size, cdist_mode):
     if hparams.get('geoml_reach', None) is not None:
         raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
     if schedule == 'pair':
-        dist = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_DISTANCE, **kw)
+        dist = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_DISTANCE, one_form=deterministic, **kw)
         return (-dist).view(q.n, c.n)
     diam = ops.group_diameter(q, c, _lib.PAIR_CROSS, group=score_batch_size)
     sims = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_PLAN_SIM, diameter=diam,
@@ -118,9 +127,11 @@ def _score_run(q, c, method, schedule, hparams, score_batch_size, cdist_mode):
     return sims.view(q.n, c.n)
 
 
-def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hparams=None, score_batch_size=64):
+def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hparams=None, score_batch_size=64, deterministic=False):
     """Per query: [(pid, score), ...] best first, ties in pool order (evaluate.py:76).  otAspire goes through ONE
-    C-ABI call that scores and ranks (aspire_ot_rank_f32)."""
+    C-ABI call that scores and ranks (aspire_ot_rank_f32).  deterministic: see score_pool."""
+    if deterministic and not (method == 'l2max' or (method == 'ot' and schedule == 'pair')):
+        raise ValueError("deterministic=True is built for method 'ot' with schedule 'pair' and for 'l2max'")
     pool = _as_pool(pool)
     if len(pool) == 0:
         return [[] for _ in query_reps_list]
@@ -137,7 +148,7 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
         kw = dict(blur=hparams.get('geoml_blur', 0.05), scaling=hparams.get('geoml_scaling', 0.9),
                   sent_sm_temp=hparams.get('sent_sm_temp', 1.0))
         if schedule == 'pair':
-            _, top_s, top_i = ops.ot_rank(q, pool.repset, k, want=_lib.OT_SIMILARITY, **kw)
+            _, top_s, top_i = ops.ot_rank(q, pool.repset, k, want=_lib.OT_SIMILARITY, one_form=deterministic, **kw)
         else:
             diam = ops.group_diameter(q, pool.repset, _lib.PAIR_CROSS, group=score_batch_size)
             _, top_s, top_i = ops.ot_rank(q, pool.repset, k, want=_lib.OT_PLAN_SIM, diameter=diam,
@@ -145,13 +156,13 @@ def rank_pool(query_reps_list, pool, k=None, method='ot', schedule='pair', hpara
                                           cdist_mode=_cdist_runs(q, pool.repset, score_batch_size)[0][2], **kw)
     else:
         scores = score_pool(query_reps_list, pool, method=method, schedule=schedule, hparams=hparams,
-                            score_batch_size=score_batch_size)
+                            score_batch_size=score_batch_size, deterministic=deterministic)
         top_s, top_i = ops.topk_desc(scores.contiguous(), k)
     top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
     return [[(pool.pids[i], float(s)) for s, i in zip(rs, ri) if i >= 0] for rs, ri in zip(top_s, top_i)]
 
 
-def _launch_rank_pools(query_reps_list, pools, k, hparams, method='ot'):
+def _launch_rank_pools(query_reps_list, pools, k, hparams, method='ot', deterministic=False):
     """Uploads + the one library call of rank_pools on the CURRENT stream; returns (pools, top_scores, top_idx) GPU tensors
     (None for the tensors when every pool is empty)."""
     hparams = hparams or {}
@@ -174,17 +185,26 @@ def _launch_rank_pools(query_reps_list, pools, k, hparams, method='ot'):
         c = ops.DeviceRepSet(nonempty[0].rows, torch.cat([r.start for r in nonempty]).contiguous(),
                              torch.cat([r.len for r in nonempty]).contiguous(), ext=0, max_len=max(r.max_len for r in nonempty))
     else:
-        row_base = np.cumsum([0] + [int(r.rows.shape[0]) for r in nonempty])[:-1]
-        c = ops.DeviceRepSet(torch.cat([r.rows for r in nonempty], 0),
-                             torch.cat([r.start + int(b) for r, b in zip(nonempty, row_base)]).to(torch.int32).contiguous(),
+        # pools over several row matrices (some resident, some uploaded per pool): every DISTINCT matrix is concatenated once --
+        # a resident pool's `rows` is the whole store, and one copy of it per pool would be tens of GB for a real dataset
+        mats, base_of, total = [], {}, 0
+        for r in nonempty:
+            key = (r.rows.data_ptr(), tuple(r.rows.shape))
+            if key not in base_of:
+                base_of[key] = total
+                mats.append(r.rows)
+                total += int(r.rows.shape[0])
+        bases = [base_of[(r.rows.data_ptr(), tuple(r.rows.shape))] for r in nonempty]
+        c = ops.DeviceRepSet(torch.cat(mats, 0),
+                             torch.cat([r.start + int(b) for r, b in zip(nonempty, bases)]).to(torch.int32).contiguous(),
                              torch.cat([r.len for r in nonempty]).contiguous(), ext=0, max_len=max(r.max_len for r in nonempty))
     job_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
     if method == 'l2max':
-        _, top_s, top_i = ops.l2max_rank_batch(q, c, job_off, max_job, k)
+        _, top_s, top_i = ops.l2max_rank_batch(q, c, job_off, max_job, k, one_form=deterministic)
         return pools, top_s, top_i
     _, top_s, top_i = ops.ot_rank_batch(q, c, job_off, max_job, k, blur=hparams.get('geoml_blur', 0.05),
                                         scaling=hparams.get('geoml_scaling', 0.9), sent_sm_temp=hparams.get('sent_sm_temp', 1.0),
-                                        want=_lib.OT_SIMILARITY)
+                                        want=_lib.OT_SIMILARITY, one_form=deterministic)
     return pools, top_s, top_i
 
 
@@ -195,15 +215,16 @@ def _ranked_lists(pools, top_s, top_i):
     return [[(p.pids[i], float(sc)) for sc, i in zip(rs, ri) if i >= 0] for p, rs, ri in zip(pools, top_s, top_i)]
 
 
-def rank_pools(query_reps_list, pools, k=None, hparams=None, method='ot'):
+def rank_pools(query_reps_list, pools, k=None, hparams=None, method='ot', deterministic=False):
     """The whole per-query loop of evaluate.py:58-76 in ONE library call: query j is scored against ITS OWN pool
     pools[j] (every query of a dataset has its own candidate pool, evaluate.py:60-62) with otAspire, one epsilon schedule
     per pair (AspireModel.get_similarity, models.py:190-197) -- or, method='l2max', tsAspire's max-sim -- and each pool is
     ranked on its own (stable descending, evaluate.py:76).  pools: list of CandidatePool or lists of [S_i, 768] arrays.
-    Returns per query [(pid, score), ...]."""
+    Returns per query [(pid, score), ...].  deterministic: one kernel form whatever the batch's size -- the same bits and the
+    same order as rank_pool(..., deterministic=True) query by query (see score_pool)."""
     if not pools:
         return []
-    return _ranked_lists(*_launch_rank_pools(query_reps_list, pools, k, hparams, method))
+    return _ranked_lists(*_launch_rank_pools(query_reps_list, pools, k, hparams, method, deterministic))
 
 
 class InFlightRanker:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASPIRE_ABI_VERSION 3
+#define ASPIRE_ABI_VERSION 4
 
 typedef enum {
     ASPIRE_OK = 0,
@@ -131,7 +131,10 @@ typedef struct {
      * are laid out [.., ext, ..] with the reference's padding semantics; 0 = no padding (ext = len). */
     int32_t ext;
     /* Host-known upper bound of len[] (lens live on the device; the launcher needs the bound to size
-     * the tile).  Ignored when ext > 0.  A document longer than the bound yields a NaN score. */
+     * the tile).  Ignored when ext > 0.  A document longer than the bound yields a NaN score.
+     * Every document needs len >= 1: the reference raises on a document without sentences (torch.max over an
+     * empty dimension, pair_distances.py:57) -- lens live on the device, so the HOST layer rejects it
+     * (aspire_amd.ops.DeviceRepSet raises ValueError); the library does not look. */
     int32_t max_len;
 } aspire_repset;
 
@@ -181,7 +184,17 @@ typedef struct {
     double scaling;      /* geoml_scaling (default 0.9)  */
     double sent_sm_temp; /* sent_sm_temp  (default 1.0)  */
     int32_t cdist_mode;  /* ASPIRE_CDIST_*               */
+    int32_t flags;       /* ASPIRE_OT_FLAG_* (0 = default) */
 } aspire_ot_params;
+
+/* ONE_FORM: score every pair with ONE kernel (the one-workgroup-per-pair long form, documents of 1 .. 128 rows) whatever the
+ * size of the call.  By default the grid size selects among kernel families whose summation orders differ, so the same
+ * (query, candidate) pair can come back a few 1e-5 apart from a per-query call and from a batched one and near-ties of a
+ * ranking may swap; with this flag a pair's score depends on its two documents only -- aspire_ot_rank_f32 per query and
+ * aspire_ot_rank_batch_f32 over all queries return the same bits and the same order.  Several times slower.  The max-sim
+ * entry points take the same request as ASPIRE_CDIST_ONE_FORM or'ed into cdist_mode. */
+#define ASPIRE_OT_FLAG_ONE_FORM 1
+#define ASPIRE_CDIST_ONE_FORM 0x100
 
 #define ASPIRE_OT_DISTANCE 0 /* return_pair_sims=False: OT_eps = <a,f> + <b,g>  (positive)          */
 #define ASPIRE_OT_PLAN_SIM 1 /* return_pair_sims=True : sum_ij P_ij * neg_ij     (negative)         */
@@ -328,6 +341,9 @@ int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k
  *                      the workspace)
  * ------------------------------------------------------------------------------------------- */
 int aspire_debug_set(const char* key, const char* value);
+/* the switch's current value as aspire_debug_set takes it ("" = default) into buf[0 .. len); for scoped pins that restore
+ * what was set before them (an ASPIRE_HIP_* environment setting, an enclosing pin) */
+int aspire_debug_get(const char* key, char* buf, size_t len);
 int aspire_debug_ot_cost_stage_f32(const aspire_repset* q, const aspire_repset* c, int64_t D, int pairing,
                                    const aspire_ot_params* prm, float* scores, void* workspace, size_t workspace_bytes,
                                    void* stream);

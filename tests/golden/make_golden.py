@@ -37,7 +37,17 @@ sys.path.insert(0, '/root/reference/examples')
 
 from oracle import aspire_oracle as orc  # noqa: E402
 
-# ---- geomloss stand-in (solver = oracle restatement; records nothing else) -------------------
+# ---- geomloss: the real package when it is importable (tools/pin_geomloss.sh installs 0.2.4 into a venv and re-runs this
+# script: that PINS the solver), else a stand-in whose solver is the oracle's restatement (records nothing else) ----------
+try:
+    import geomloss as _real_geomloss  # noqa: F401
+    SOLVER = 'geomloss-' + getattr(_real_geomloss, '__version__', 'unknown')
+except ImportError:
+    _real_geomloss = None
+    SOLVER = 'oracle-restatement (parity unpinned)'
+if os.environ.get('ASPIRE_REQUIRE_GEOMLOSS') and _real_geomloss is None:
+    raise SystemExit('ASPIRE_REQUIRE_GEOMLOSS is set but geomloss is not importable')
+print('Sinkhorn solver behind the reference wrapper:', SOLVER)
 _geomloss = types.ModuleType('geomloss')
 
 
@@ -52,7 +62,8 @@ class _SamplesLoss:
 
 
 _geomloss.SamplesLoss = _SamplesLoss
-sys.modules['geomloss'] = _geomloss
+if _real_geomloss is None:
+    sys.modules['geomloss'] = _geomloss
 
 import ex_aspire_consent as ref_ex  # noqa: E402
 ref_pd = importlib.import_module('src.learning.facetid_models.pair_distances')
@@ -221,6 +232,7 @@ def make_scores():
                         f'{name}_{t}_maskedsims': ms.numpy(), f'{name}_{t}_wsims': ws.numpy(),
                         f'{name}_{t}_wdist': wd.numpy()})
         print(name, 'l2max', dists.numpy()[:3], 'wdist', out[f'{name}_t1_wdist'][:3], 'wsims', out[f'{name}_t1_wsims'][:3])
+    out['solver'] = np.array(SOLVER)      # which Sinkhorn solver sat behind the reference wrapper (tests/test_oracle_cpu.py reads it)
     np.savez_compressed(os.path.join(HERE, 'scores.npz'), **out)
 
 

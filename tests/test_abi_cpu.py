@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f'{name} declared in aspire_hip.h but not exported'
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature in aspire_amd/_lib.py'
     assert sorted(_lib.SIGNATURES) == declared
-    assert _lib.lib.aspire_abi_version() == 3
+    assert _lib.lib.aspire_abi_version() == 4
     assert _lib.lib.aspire_max_sents() == 128
 
 
@@ -67,6 +67,20 @@ def test_diagnostic_switches_without_gpu():
     with pytest.raises(AssertionError):
         with _lib.pinned(COST_PATH='bogus'):
             pass
+    # a pin restores what was set BEFORE it (an enclosing pin, an ASPIRE_HIP_* setting), not the library default
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+
+    def current(key):
+        assert _lib.lib.aspire_debug_get(key, buf, len(buf)) == _lib.ASPIRE_OK
+        return buf.value
+
+    with _lib.pinned(OT_FORM='small', FUSED_WAVES=1024):
+        with _lib.pinned(OT_FORM='fused'):
+            assert current(b'OT_FORM') == b'fused'
+        assert current(b'OT_FORM') == b'small' and current(b'FUSED_WAVES') == b'1024'
+    assert current(b'OT_FORM') == b'' and current(b'FUSED_WAVES') == b''
+    assert _lib.lib.aspire_debug_get(b'NO_SUCH_SWITCH', buf, len(buf)) == _lib.ASPIRE_ERR_INVALID_ARG
 
 
 def test_no_getenv_on_the_launch_path():

@@ -54,9 +54,22 @@ def test_ot_wrapper_matches_reference(scores, name, temp):
     ot = orc.AllPairMaskedWasserstein({'sent_sm_temp': temp})
     wd = ot.compute_distance(qt, ct)
     ws, (qd, cd, ps, plan, ms) = ot.compute_distance(qt, ct, return_pair_sims=True)
+    # fixtures regenerated with the real package (tools/pin_geomloss.sh) carry solver = 'geomloss-0.2.4': the solver-dependent
+    # outputs are then compared at north_star's 1e-4 (plan-weighted outputs at the fp32 conditioning bound of test_gpu_scoring)
+    pinned = 'solver' in scores.files and str(scores['solver']).startswith('geomloss')
     for got, key in ((qd, 'qdistr'), (cd, 'cdistr'), (ps, 'pairsims'), (plan, 'plan'), (ms, 'maskedsims'),
                      (ws, 'wsims'), (wd, 'wdist')):
-        assert np.array_equal(got.numpy(), scores[f'{name}_{t}_{key}']), key
+        if pinned and key in ('plan', 'maskedsims', 'wsims', 'wdist'):
+            tol = {'plan': 5e-4, 'maskedsims': 4e-3, 'wsims': 1e-2, 'wdist': 1e-4}[key]
+            np.testing.assert_allclose(got.numpy(), scores[f'{name}_{t}_{key}'], atol=tol, rtol=0, err_msg=key)
+        else:
+            assert np.array_equal(got.numpy(), scores[f'{name}_{t}_{key}']), key
+
+
+def test_report_whether_the_solver_is_pinned(scores):
+    """Not a gate: prints which solver produced the committed OT fixtures (the stand-in restatement = parity unpinned)."""
+    solver = str(scores['solver']) if 'solver' in scores.files else 'oracle-restatement (parity unpinned)'
+    print('tests/golden/scores.npz OT outputs were produced by:', solver)
 
 
 def test_metrics_kats(golden_dir):

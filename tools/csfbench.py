@@ -57,7 +57,7 @@ print(f'otAspire, one call per query:                        {t:8.1f} us = {pair
 # batched and per-query calls run different kernels (another summation order): scores agree to a few 1e-5, so near-ties may swap
 diff, moved = 0.0, 0
 for j in range(J):
-    s1, _, i1 = ops.ot_rank(qs[j], cs[j], NC)
+    s1, _, i1 = ops.ot_rank(qs[j], cs[j], NC, want=_lib.OT_SIMILARITY)
     diff = max(diff, float((s1[0] - out[0][j * NC:(j + 1) * NC]).abs().max()))
     moved += int((i1[0] != out[2][j]).sum())
 print(f'batched vs per-query: max |score difference| {diff:.1e}, {moved} of {pairs} list positions differ (near-ties)')
