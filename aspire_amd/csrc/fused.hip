@@ -797,6 +797,18 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     return ASPIRE_OK;
 }
 
+// batched jobs with candidates of up to 32 rows against queries of <= 8 (the CHUNK form; items from chunk_prep_kernel)
+int launch_pair_fused_chunk(const ScoreArgs& a_in, int64_t items_bound, const float* qbox, hipStream_t stream) {
+    ScoreArgs a = a_in;
+    a.skip_tail = 0;
+    const int64_t cap = tuning().fused_waves > 0 ? tuning().fused_waves : 256 * 8;
+    const int64_t waves = items_bound < cap ? items_bound : cap;
+    hipLaunchKernelGGL((pair_fused_kernel<true, true, false, false, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256),
+                       4 * kWaveLds * sizeof(float), stream, a, qbox);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
 // The fused kernel's shifted sums can leave fp32 range -- scaling below ~0.03 (the exponent of K grows by 1 / scaling from one
 // step to the next), or, at ANY scaling, a candidate that shares a sentence with the query when the vectors are large (a zero
 // cost next to costs of ~80: found by the fuzz sweep at 2 x N(0,1)) -- and poison the pair's score with NaN: this launch

@@ -49,7 +49,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "FUSED_WAVES")) {
         t.fused_waves = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "OT_FORM")) {
-        const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : !strcmp(v, "fused") ? 3 : -1;
+        const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : !strcmp(v, "fused") ? 3 : !strcmp(v, "chunk") ? 4 : -1;
         if (f < 0) return false;
         t.ot_form = f;
     } else {
@@ -78,7 +78,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "FUSED_NOSOLVE")) v = number(t.fused_nosolve);
     else if (!strcmp(key, "FUSED_NOSELF")) v = number(t.fused_noself);
     else if (!strcmp(key, "FUSED_WAVES")) v = number(t.fused_waves);
-    else if (!strcmp(key, "OT_FORM")) v = t.ot_form == 1 ? "small" : t.ot_form == 2 ? "tile" : t.ot_form == 3 ? "fused" : "";
+    else if (!strcmp(key, "OT_FORM")) v = t.ot_form == 1 ? "small" : t.ot_form == 2 ? "tile" : t.ot_form == 3 ? "fused" : t.ot_form == 4 ? "chunk" : "";
     if (!v || strlen(v) + 1 > len) return false;
     strcpy(buf, v);
     return true;

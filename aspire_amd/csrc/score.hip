@@ -2567,6 +2567,87 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
     }
 }
 
+// Items of the fused kernel's CHUNK form (fused.hip) for batched jobs whose candidates reach 9 .. 32 rows: an item = four 8-row
+// chunks of candidates of ONE job -- four candidates of <= 8 rows, two of 9 .. 16 or one of 17 .. 32.  Block (j, part) sorts its
+// slice of job j's candidates into those three classes (LDS counters), reserves its items with ONE atomicAdd on the launch's
+// item counter (items need not be contiguous per job: a score is stored by candidate index) and writes the 64-byte item
+// records: [0] query, [1] its len, [2] its first row, [3] real chunk slots | lane groups per candidate << 8, [4..7] the
+// slots' candidates, [8..11] their lens, [12..15] their first rows (a partial item's empty slots repeat its first candidate:
+// scored again, stored once).  Block (j, last) forms the query's box, as in batch_prep_kernel.
+constexpr int kChunkPrepPart = 384;      // candidates per classification block
+__global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, float* __restrict__ qbox,
+                                                         int32_t* __restrict__ cand_job, int32_t* __restrict__ counter,
+                                                         int32_t* __restrict__ grp_rec) {
+    __shared__ int cnt[3], base[3], pos[3];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (blockIdx.y == gridDim.y - 1) {
+        const int n = q.len[j];
+        const float* doc = q.rows + (size_t)q.start[j] * kD + tid * 4;
+        float4 mn, mx;
+        doc_box_chunk(doc, n, mn, mx);
+        *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + tid * 4) = mn;
+        *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + kD + tid * 4) = mx;
+        return;
+    }
+    const int c0 = job_off[j] + blockIdx.y * kChunkPrepPart, c1 = min(job_off[j + 1], c0 + kChunkPrepPart);
+    if (c0 >= c1) return;
+    if (tid < 3) cnt[tid] = pos[tid] = 0;
+    __syncthreads();
+    int len[2], start[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int cc = c0 + tid + 192 * r;
+        len[r] = cc < c1 ? c.len[cc] : 0;
+        start[r] = cc < c1 ? c.start[cc] : 0;
+        if (cc < c1) {
+            atomicAdd(&cnt[len[r] <= 8 ? 0 : len[r] <= 16 ? 1 : 2], 1);
+            cand_job[cc] = j;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int i0 = (cnt[0] + 3) >> 2, i1 = (cnt[1] + 1) >> 1, i2 = cnt[2];
+        const int b = atomicAdd(counter, i0 + i1 + i2);
+        base[0] = b;
+        base[1] = b + i0;
+        base[2] = b + i0 + i1;
+    }
+    __syncthreads();
+    const int q_len = q.len[j], q_start = q.start[j];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int cc = c0 + tid + 192 * r;
+        if (cc >= c1) continue;
+        const int cls = len[r] <= 8 ? 0 : len[r] <= 16 ? 1 : 2;
+        const int w = 1 << cls, per = 4 >> cls;            // lane groups per candidate, candidates per item
+        const int ps = atomicAdd(&pos[cls], 1);
+        const int it = ps >> (2 - cls), sub = ps & (per - 1);
+        int32_t* rec = grp_rec + (size_t)(base[cls] + it) * 16;
+        const int in_item = min(per, cnt[cls] - it * per);   // real candidates of this item
+        for (int t = 0; t < w; ++t) {
+            rec[4 + sub * w + t] = cc;
+            rec[8 + sub * w + t] = len[r];
+            rec[12 + sub * w + t] = start[r];
+        }
+        if (sub == 0) {
+            rec[0] = j;
+            rec[1] = q_len;
+            rec[2] = q_start;
+            rec[3] = (in_item * w) | (w << 8);
+            for (int t = in_item * w; t < 4; ++t) {
+                rec[4 + t] = cc;
+                rec[8 + t] = len[r];
+                rec[12 + t] = start[r];
+            }
+        }
+    }
+}
+// parts (classification blocks) per job, and the bound on the items the launch can make
+int64_t chunk_parts(int64_t max_job) { return max_job > 0 ? (max_job + kChunkPrepPart - 1) / kChunkPrepPart : 1; }
+int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job) { return C + 3 * J * chunk_parts(max_job); }
+// smallest batch (candidates) that takes the CHUNK form (below: the small-batch kernels; tools/csfbench.py sweeps)
+constexpr int64_t kChunkMinCands = 256;
+
 struct BatchLayout {
     size_t slots, qbox, cand_job, grp_job, grp_off, grp_rec, gate, topk, total;
 };
@@ -2578,7 +2659,9 @@ BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, in
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
     L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
-    L.grp_rec = o; o = align16(o + (size_t)(C / 4 + J + 1) * 16 * sizeof(int32_t));
+    // (documents of more than 8 rows: room for the CHUNK form's items, up to one per candidate)
+    const size_t n_rec = max_rows > 8 ? (size_t)chunk_items_bound(J, C, max_job) + 1 : (size_t)(C / 4 + J + 1);
+    L.grp_rec = o; o = align16(o + n_rec * 16 * sizeof(int32_t));
     L.gate = o; o = align16(o + 16);
     L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
     L.total = o;
@@ -2663,6 +2746,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     }
     const int64_t groups_bound = J * ((max_job + 3) / 4);
     const int form_t = tuning().ot_form;
+    const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
     const bool big = max_rows <= 8 && groups_bound >= kStreamMinGroupsBatch;
     const bool fused = max_rows <= 8 && (form_t == 3 || (form_t == 0 && big));
     a.tile_form = max_rows <= 8 && (form_t == 2 || fused);
@@ -2674,6 +2758,22 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const bool hybrid = max_rows > 8 && max_rows <= 16 && form_t == 0 && groups_bound >= 2048 && C >= 6000 && stages == kStageAll &&
                         prm->scaling >= 0.25 && want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu &&
                         sinkhorn_form_honours_gate();
+    // Short queries (facet-selected rows, models.py:127-163) against abstracts of up to 32 rows -- config 4's shape: the fused
+    // kernel's CHUNK form, costs and solves of every pair in one launch behind a launch that sorts the candidates into items.
+    const bool chunked = q->max_len <= 8 && max_rows > 8 && max_rows_all <= 8 * kMaxT && (form_t == 4 || (form_t == 0 && C >= kChunkMinCands)) &&
+                         stages == kStageAll && prm->scaling >= 0.25 && !tuning().fused_nosolve && !tuning().fused_valu;
+    if (chunked) {
+        ASPIRE_HIP_OK(hipMemsetAsync(grp_off, 0, sizeof(int32_t), s0));
+        hipLaunchKernelGGL(chunk_prep_kernel, dim3((unsigned)J, (unsigned)chunk_parts(max_job) + 1), dim3(192), 0, s0, a.q, a.c, job_off, qbox,
+                           cand_job, grp_off, grp_rec);
+        ASPIRE_LAUNCH_OK();
+        if (int rc = launch_pair_fused_chunk(a, chunk_items_bound(J, C, max_job), qbox, s0)) return rc;
+        if (int rc = launch_fused_repair(a, false, 8 * kMaxT, s0)) return rc;
+        if (k > 0)
+            return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
+                            topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);
+        return ASPIRE_OK;
+    }
     // batches of <= 64 jobs on the fused kernel need no tables launch: the kernel's waves derive them (fused.hip, SELF)
     const bool self = fused && fused_self_ok(J, prm);
     if ((stages & kStagePrep) && !self) {
@@ -2686,7 +2786,6 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
                            grp_off, grp_job, grp_rec);
         ASPIRE_LAUNCH_OK();
     }
-    const size_t topk_need = aspire_topk_workspace_bytes(J, max_job, k);
     if (hybrid) {
         int32_t* gate = (int32_t*)(wsb + L.gate);
         ASPIRE_HIP_OK(hipMemsetAsync(gate, 0, sizeof(int32_t), s0));
