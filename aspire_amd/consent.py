@@ -120,6 +120,13 @@ class AspireConSent:
         start_t = (torch.cumsum(lens_t, 0) - lens_t).to(torch.int32)
         rows = torch.empty(max(total, 1), 768, device=dev, dtype=torch.float32)[:total]
         cls_all = torch.empty(n_docs, 768, device=dev, dtype=torch.float32) if want_cls else None
+        # token ids of every batch validated with ONE device round trip (nn.Embedding raises IndexError on the reference path);
+        # per batch that check is a host sync in front of every encoder call
+        if batches:
+            lo_hi = torch.stack([torch.stack([bb['tokid_tt'].min(), bb['tokid_tt'].max()]).to(dev) for bb, _, _ in batches])
+            if int(lo_hi[:, 0].min()) < 0 or int(lo_hi[:, 1].max()) >= self.bert_encoder.config.vocab_size:
+                raise IndexError('token id out of range')
+        start_np = start_t.numpy()
         doc0 = 0
         for bert_batch, abs_lens, sent_tok_idxs in batches:
             b = len(abs_lens)
@@ -128,17 +135,15 @@ class AspireConSent:
             max_seq_len = max(seq_lens)
             tokid_tt = bert_batch['tokid_tt']
             assert tokid_tt.shape == (b, max_seq_len)
-            for doc in sent_tok_idxs:
-                for span in doc:
-                    if span and (min(span) < 0 or max(span) >= max_seq_len):
-                        raise IndexError('sentence token index out of range')
-            hidden = self.bert_encoder.forward_hidden(tokid_tt, token_type_ids=bert_batch['seg_tt'],
-                                                      attention_mask=bert_batch['attnmask_tt'])
             tok_idx, span_off = spans_to_csr(sent_tok_idxs, max_sents)
+            if tok_idx.numel() and (int(tok_idx.min()) < 0 or int(tok_idx.max()) >= max_seq_len):
+                raise IndexError('sentence token index out of range')
+            hidden = self.bert_encoder.forward_hidden(tokid_tt, token_type_ids=bert_batch['seg_tt'],
+                                                      attention_mask=bert_batch['attnmask_tt'], check_ids=False)
             # slot (b, s) -> row of the store, -1 beyond the document's sentence count
-            out_row = np.full((b, max_sents), -1, dtype=np.int32)
-            for i, n in enumerate(abs_lens):
-                out_row[i, :n] = int(start_t[doc0 + i]) + np.arange(n, dtype=np.int32)
+            lens_b = np.asarray(abs_lens, dtype=np.int32)[:, None]
+            slot = np.arange(max_sents, dtype=np.int32)[None, :]
+            out_row = np.where(slot < lens_b, start_np[doc0:doc0 + b, None] + slot, -1).astype(np.int32)
             ops.span_mean_pool_rows(hidden, tok_idx.to(dev), span_off.to(dev), max_sents, torch.from_numpy(out_row.reshape(-1)).to(dev),
                                     rows, cls_all[doc0:doc0 + b] if want_cls else None)
             doc0 += b

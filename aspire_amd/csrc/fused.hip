@@ -52,6 +52,21 @@ static_assert(kNormOfs + 16 * kNormLd <= kWaveLds, "norm table must fit the idle
 
 typedef float mfma4_t __attribute__((ext_vector_type(4)));
 
+#ifdef ASPIRE_PHASE_CLOCK
+// debug build only (tools/chunkphases.py): per-wave time stamps (100 MHz wall clock) into the buffer set by
+// aspire_debug_fused_buffer: [wave][8] = start, then per item (end of its streaming phase, its solve set up), ..., [6] the
+// wave's last solve begins, [7] end
+static __device__ long long* g_fdbg = nullptr;
+#define F_STAMP(k)                                                                                                   \
+    do {                                                                                                             \
+        if (g_fdbg && lane == 0 && (k) < 8) g_fdbg[(size_t)(blockIdx.x * 4 + wave) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define F_STAMP(k) \
+    do {           \
+    } while (0)
+#endif
+
 __device__ __forceinline__ float sum_lj(float v) {       // all-reduce over the 4 lanes that share li (lane bits 0, 1)
     v += lane_xor<1>(v);
     return v + lane_xor<2>(v);
@@ -178,7 +193,16 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
 // the weights as factors, f -= h log2(row sums), g -= h log2(column sums) -- 32 issue slots, 8 of them transcendental
 // (as scalar code with per-step schedule selects it was 52: the solves are the kernel's largest VALU consumer and, with
 // two waves per SIMD, VALU issue is what the HBM stream competes with).
-template <bool XG = false>
+// W: lane groups per candidate, a compile-time constant here -- with a run-time W the branches around the cross-group exchanges
+// cut the step into basic blocks and the two row chains and the column chain, which otherwise interleave level by level, run
+// one after the other (measured on the config-4 shape: every wave's last solve 26 us).
+template <int W>
+__device__ __forceinline__ float xg_sum_w(float v) {
+    if constexpr (W >= 2) v = swap_add<16>(v, v);
+    if constexpr (W == 4) v = swap_add<32>(v, v);
+    return v;
+}
+template <int W = 1>
 __device__ __forceinline__ void solve_step(Solve& s, float r2, float h) {
     const f2_t fr = s.f * r2, gr = s.g * r2;
     const f2_t a0 = __builtin_elementwise_fma(s.mc[0], f2_t{-r2, -r2}, f2_t{fr.x, fr.x} + gr);
@@ -187,15 +211,15 @@ __device__ __forceinline__ void solve_step(Solve& s, float r2, float h) {
     const f2_t k1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
     const f2_t t0 = k0 * s.wb, t1 = k1 * s.wb;
     const f2_t cs = __builtin_elementwise_fma(k1, f2_t{s.wa.y, s.wa.y}, k0 * f2_t{s.wa.x, s.wa.x});
-    const f2_t lr = {__builtin_amdgcn_logf(xg_sum<XG>(sum_lj(t0.x + t0.y), s.w)), __builtin_amdgcn_logf(xg_sum<XG>(sum_lj(t1.x + t1.y), s.w))};
+    const f2_t lr = {__builtin_amdgcn_logf(xg_sum_w<W>(sum_lj(t0.x + t0.y))), __builtin_amdgcn_logf(xg_sum_w<W>(sum_lj(t1.x + t1.y)))};
     const f2_t lc = {__builtin_amdgcn_logf(sum_li(cs.x)), __builtin_amdgcn_logf(sum_li(cs.y))};
     s.f = __builtin_elementwise_fma(f2_t{-h, -h}, lr, s.f);
     s.g = __builtin_elementwise_fma(f2_t{-h, -h}, lc, s.g);
 }
 
 // up to `n` more annealing steps (all of the rest with n < 0)
-template <bool XG = false>
-__device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n) {
+template <int W>
+__device__ __forceinline__ void solve_steps_w(Solve& s, const ScoreArgs& a, int n) {
     const float scal = (float)a.scaling, inv_scal = (float)(1.0 / a.scaling);
     const float eb = (float)a.blur;
     const float r2_blur = kLog2e * rcp_refined(eb), h_blur = 0.5f * kLn2 * eb;
@@ -213,7 +237,7 @@ __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n)
             if (k > s.n_mid) { r2 = r2_blur; h = k == s.n_mid + 1 ? h_blur : (k == s.n_mid + 2 ? 2.f * h_blur : 0.f); }
             s.r2 = r2;
             s.h = h;
-            solve_step<XG>(s, r2, h);
+            solve_step<W>(s, r2, h);
         }
     };
     general(min(k_end, 2));
@@ -222,10 +246,20 @@ __device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n)
     for (; k < fast_end; ++k) {
         s.r2 *= inv_scal;
         s.h *= scal;
-        solve_step<XG>(s, s.r2, s.h);
+        solve_step<W>(s, s.r2, s.h);
     }
     general(k_end);
     s.k = k_end;
+}
+template <bool XG = false>
+__device__ __forceinline__ void solve_steps(Solve& s, const ScoreArgs& a, int n) {
+    if constexpr (!XG) {
+        solve_steps_w<1>(s, a, n);
+    } else {
+        if (s.w == 1) solve_steps_w<1>(s, a, n);
+        else if (s.w == 2) solve_steps_w<2>(s, a, n);
+        else solve_steps_w<4>(s, a, n);
+    }
 }
 
 template <bool XG = false>
@@ -406,6 +440,9 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     float* qcache = lds_all + 4 * kWaveLds + wave * 2 * kD;      // INBOX: [2][768] box of query cached_q
     int64_t cached_q = -1;
     Ctx next = load_ctx(item_first < item_end ? item_first : item_lo);
+    F_STAMP(0);
+    int n_done = 0;
+    (void)n_done;
 
     for (uint32_t item = item_first; item < item_end; item += item_step) {
         const Ctx cur = next;
@@ -688,6 +725,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch table is rewritten by the next item
         __builtin_amdgcn_wave_barrier();
         cached_q = q_idx;
+        F_STAMP(1 + 2 * n_done);
 
         // ---- the previous item's solve ends here (its last steps, score, store); this item's begins ---------------------
         if constexpr (SOLVE)
@@ -705,6 +743,8 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             if (q_len > 8 || c_len > 8 * cw) pend.valid |= 16u;
             slice = (pend.max_steps + kStages - 1) / kStages;
             have_pend = true;
+            F_STAMP(2 + 2 * n_done);
+            ++n_done;
         } else if constexpr (L2MAX) {
             float m = kNegBig;
 #pragma unroll
@@ -718,8 +758,10 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = diam2;
         }
     }
+    F_STAMP(6);
     if constexpr (SOLVE)
         if (have_pend && !a.skip_tail) solve_finish<CHUNK>(pend, a);   // the wave's last item: nothing left to hide it behind
+    F_STAMP(7);
 }
 
 }  // namespace
@@ -797,14 +839,25 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     return ASPIRE_OK;
 }
 
+}  // namespace aspire
+#ifdef ASPIRE_PHASE_CLOCK
+extern "C" void aspire_debug_fused_buffer(void* p) {
+    long long* q = (long long*)p;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aspire::g_fdbg), &q, sizeof(q));
+}
+#endif
+namespace aspire {
 // batched jobs with candidates of up to 32 rows against queries of <= 8 (the CHUNK form; items from chunk_prep_kernel)
 int launch_pair_fused_chunk(const ScoreArgs& a_in, int64_t items_bound, const float* qbox, hipStream_t stream) {
     ScoreArgs a = a_in;
-    a.skip_tail = 0;
+    a.skip_tail = tuning().fused_nosolve == 2;
     const int64_t cap = tuning().fused_waves > 0 ? tuning().fused_waves : 256 * 8;
     const int64_t waves = items_bound < cap ? items_bound : cap;
-    hipLaunchKernelGGL((pair_fused_kernel<true, true, false, false, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256),
-                       4 * kWaveLds * sizeof(float), stream, a, qbox);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (tuning().fused_nosolve == 1)      // timing experiments: the streaming phase alone
+        hipLaunchKernelGGL((pair_fused_kernel<true, false, false, false, false, true>), grid, dim3(256), 4 * kWaveLds * sizeof(float), stream, a, qbox);
+    else
+        hipLaunchKernelGGL((pair_fused_kernel<true, true, false, false, false, true>), grid, dim3(256), 4 * kWaveLds * sizeof(float), stream, a, qbox);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

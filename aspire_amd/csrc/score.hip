@@ -2761,7 +2761,7 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     // Short queries (facet-selected rows, models.py:127-163) against abstracts of up to 32 rows -- config 4's shape: the fused
     // kernel's CHUNK form, costs and solves of every pair in one launch behind a launch that sorts the candidates into items.
     const bool chunked = q->max_len <= 8 && max_rows > 8 && max_rows_all <= 8 * kMaxT && (form_t == 4 || (form_t == 0 && C >= kChunkMinCands)) &&
-                         stages == kStageAll && prm->scaling >= 0.25 && !tuning().fused_nosolve && !tuning().fused_valu;
+                         stages == kStageAll && prm->scaling >= 0.25 && !tuning().fused_valu;
     if (chunked) {
         ASPIRE_HIP_OK(hipMemsetAsync(grp_off, 0, sizeof(int32_t), s0));
         hipLaunchKernelGGL(chunk_prep_kernel, dim3((unsigned)J, (unsigned)chunk_parts(max_job) + 1), dim3(192), 0, s0, a.q, a.c, job_off, qbox,

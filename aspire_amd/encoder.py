@@ -62,12 +62,13 @@ class HipBertEncoder:
     def eval(self):
         return self
 
-    def forward_hidden(self, tokid_tt, token_type_ids=None, attention_mask=None):
-        """int64 [B, L] tensors (any device) -> last_hidden_state [B, L, 768] on the GPU."""
+    def forward_hidden(self, tokid_tt, token_type_ids=None, attention_mask=None, check_ids=True):
+        """int64 [B, L] tensors (any device) -> last_hidden_state [B, L, 768] on the GPU.  check_ids=False: the caller has
+        validated the token ids already (encode_to_pool checks all its batches with one device round trip)."""
         dev = self.device
         tok = tokid_tt.to(device=dev, dtype=torch.int64).contiguous()
         b, l = tok.shape
-        if int(tok.max()) >= self.config.vocab_size or int(tok.min()) < 0:
+        if check_ids and (int(tok.max()) >= self.config.vocab_size or int(tok.min()) < 0):
             raise IndexError('token id out of range')   # nn.Embedding raises IndexError on the reference path
         typ = token_type_ids.to(device=dev, dtype=torch.int64).contiguous() if token_type_ids is not None else None
         msk = attention_mask.to(device=dev, dtype=torch.int64).contiguous() if attention_mask is not None \

@@ -101,6 +101,48 @@ def cpu_baseline(query, cands, budget_s=18.0):
     }
 
 
+def config4_probe(device, J=50, NCAND=125, smax=20, reps=40):
+    """BASELINE config 4's shape on one GPU (outside the timed headline): the CSFCube re-rank -- 50 (query, facet) jobs, each query
+    (facet-selected rows, 1 .. 8) against its own pool of 125 abstracts of 3 .. 20 sentences (pp_settings.py:2-3, evaluate.py:58-76,
+    models.py:127-163), full ranking -- as ONE aspire_ot_rank_batch_f32 call, timed with HIP events on the launch stream; its own
+    roofline: algorithmic bytes = 4 D (sum of candidate rows + query rows) + 4 C over the call's duration."""
+    from aspire_amd import ops
+    g = torch.Generator().manual_seed(4)
+    c_lens = torch.randint(3, smax + 1, (J * NCAND,), generator=g)
+    q_lens = torch.randint(1, 9, (J,), generator=g)
+
+    def repset(lens):
+        start = torch.cumsum(lens, 0) - lens
+        rows = torch.randn(int(lens.sum()), D, generator=g).to(device)
+        return ops.DeviceRepSet(rows, start.to(torch.int32).to(device), lens.to(torch.int32).to(device), ext=0, max_len=int(lens.max()))
+
+    c, q = repset(c_lens), repset(q_lens)
+    job_off = (torch.arange(J + 1, dtype=torch.int32) * NCAND).to(device)
+    res = {}
+    for name, fn in (('otAspire', ops.ot_rank_batch), ('tsAspire', ops.l2max_rank_batch)):
+        out = fn(q, c, job_off, NCAND, NCAND)
+        for _ in range(5):
+            fn(q, c, job_off, NCAND, NCAND, out=out)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn(q, c, job_off, NCAND, NCAND, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / reps * 1e3
+        nbytes = 4 * D * (int(c_lens.sum()) + int(q_lens.sum())) + 4 * J * NCAND
+        gbs = nbytes / (us * 1e-6) / 1e9
+        res[name] = {'us_per_call': us, 'pairs_per_s': J * NCAND / (us * 1e-6),
+                     'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                                  'algorithmic_bytes_per_call': nbytes,
+                                  'what': 'the whole call (item sort + scoring launch + overflow scan + rank), back to back on one stream'}}
+    res['workload'] = (f'{J} jobs x {NCAND} candidates of 3 .. {smax} sentence rows, facet-selected queries of 1 .. 8 rows, k = {NCAND} '
+                       f'(full ranking), reps resident; data {sum(r["roofline"]["algorithmic_bytes_per_call"] for r in res.values()) // 2 / 2**20:.0f} MiB'
+                       f' < L3: warm')
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -141,8 +183,19 @@ def main():
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
+    # ---- N > 1: what the collective backend saw, gathered from every rank (self-verifying first RCCL contact: no 8-GPU node
+    # has run this code yet -- DESIGN.md section 5) ---------------------------------------------------------------------------
+    rccl = None
     if world > 1:
         dist.barrier()
+        props = torch.cuda.get_device_properties(device)
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.get_device_name(device), 'uuid': str(getattr(props, 'uuid', '')),
+                'gcn_arch': getattr(props, 'gcnArchName', ''), 'cus': props.multi_processor_count, 'xcds': props.multi_processor_count // 32,
+                'hbm_gib': round(props.total_memory / 2**30, 1), 'pid': os.getpid()}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        rccl = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_seen': sorted(d['rank'] for d in seen),
+                'distinct_devices': len({d['uuid'] or (d['pid'], d['local_rank']) for d in seen}), 'devices': seen}
     from aspire_amd import _lib, ops
     from aspire_amd.parallel import all_gather_flat
     lib = _lib.lib
@@ -298,9 +351,28 @@ def main():
             mine = ln.top_i.clone()
             everyone = torch.empty(world, K, TOPK, device=device, dtype=torch.int64)
             all_gather_flat(everyone.view(-1), mine.view(-1))
-            assert all(torch.equal(everyone[0], everyone[r]) for r in range(world)), 'ranks disagree on the merged ranking'
+            agree = all(torch.equal(everyone[0], everyone[r]) for r in range(world))
+            if rccl is not None:
+                rccl['merged_ranking_agrees_on_all_ranks'] = bool(agree and rccl.get('merged_ranking_agrees_on_all_ranks', True))
+                rccl['shards_in_merged_top_k'] = int(len(torch.unique(mine // NC)))
+            assert agree, 'ranks disagree on the merged ranking'
             assert len(torch.unique(mine // NC)) > 1, 'merged ranking holds candidates of one shard only'
 
+    if world > 1:
+        # the exchange on its own: HIP events on the lane's stream around the all-gather of one call's K x k keys (every rank takes
+        # part; rank 0 reports its own view)
+        ln = lanes[0]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        dist.barrier()
+        with torch.cuda.stream(ln.stream):
+            for a_ev, b_ev in evs:
+                a_ev.record(ln.stream)
+                all_gather_flat(ln.gathered.view(-1), ln.keys.view(-1))
+                b_ev.record(ln.stream)
+        torch.cuda.synchronize()
+        t = sorted(a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs)
+        rccl['all_gather_us'] = {'median': t[len(t) // 2] * 1e3, 'min': t[0] * 1e3, 'bytes_per_rank': K * TOPK * 8,
+                                 'what': f'all_gather_into_tensor of {K} x {TOPK} int64 keys per rank on the lane stream, 20 in a row'}
     out = None
     if rank == 0:
         # ---- per-stage kernel durations, live: HIP events on the launch stream around launches of ONE stage alone, on the
@@ -413,6 +485,17 @@ def main():
                                                                   'achieved_frac', 'issue_floor_us', 'kernel_us_per_call')}
                                            for k, v in sj.items() if isinstance(v, dict)}
             out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r2.sh)'
+        if rccl is not None:
+            out['rccl'] = rccl
+        out['cross_check'] = ('per-kernel durations (roofline.kernel_ms, profiles/*_kernel_stats.csv) add up to one_stream.ms_per_call; '
+                              '`value` has calls in flight on several streams, where per-kernel durations of overlapping launches mean '
+                              'nothing -- verify `one_stream`, treat `value` as the whole-job rate the driver can time from outside')
+        if world == 1 and not args.no_probes:
+            out['config4'] = config4_probe(device)
+            if not os.environ.get('ASPIRE_BENCH_NO_E2E'):
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import e2ebench
+                out['e2e'] = e2ebench.run(check=False)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(queries[:S], cands[:NC * S])
         print(json.dumps(out), flush=True)

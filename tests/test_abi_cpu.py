@@ -253,7 +253,7 @@ def test_kernel_register_budgets():
     # the fused otAspire kernel (table-driven and with in-wave tables): two 4-wave workgroups per CU (256 registers,
     # 43.5 KB of LDS each)
     fused = [v for k, v in res.items() if re.search(r'pair_fused_kernelILb1ELb1E', k)]
-    assert len(fused) == 3          # table-driven, in-wave tables (batches), in-wave query box (one query x a pool)
+    assert len(fused) == 4          # table-driven, in-wave tables (batches), in-wave query box (one query x a pool), CHUNK items
     for r in fused:
         assert r['vgpr'] + r['agpr'] <= 256
     for bn in (32, 64):

@@ -68,3 +68,11 @@ for form in ('small', 'tile'):
         print(f'otAspire batched, OT_FORM={form}: {t:8.1f} us')
     except Exception as e:          # a form that does not take this shape
         print(f'OT_FORM={form}: {type(e).__name__}: {e}')
+# the CHUNK form's phases (timing experiments, invalid scores): streaming phase alone / everything but each wave's last solve
+for pin in (dict(FUSED_NOSOLVE=1), dict(FUSED_NOSOLVE=2), dict(FUSED_WAVES=1024), dict(FUSED_WAVES=1536)):
+    try:
+        with _lib.pinned(**pin):
+            t = timed(lambda: ops.ot_rank_batch(q, c, job_off, NC, NC, out=out))
+        print(f'otAspire batched, {pin}: {t:8.1f} us')
+    except Exception as e:
+        print(f'{pin}: {type(e).__name__}: {e}')
