@@ -50,7 +50,7 @@ class BertWeights(ctypes.Structure):
     _fields_ = [('word_emb', c_void_p), ('pos_emb', c_void_p), ('type_emb', c_void_p), ('emb_ln_g', c_void_p),
                 ('emb_ln_b', c_void_p), ('layers', ctypes.POINTER(BertLayer)), ('n_layers', c_int32),
                 ('n_heads', c_int32), ('hidden', c_int32), ('ffn_dim', c_int32), ('vocab', c_int32),
-                ('max_pos', c_int32), ('n_types', c_int32), ('ln_eps', ctypes.c_float)]
+                ('max_pos', c_int32), ('n_types', c_int32), ('ln_eps', ctypes.c_float), ('planes', c_void_p)]
 
 
 class AspireHipError(RuntimeError):
@@ -67,6 +67,8 @@ SIGNATURES = {
     'aspire_span_mean_pool_rows_f32': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
     'aspire_cls_l2_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p, c_void_p]),
+    'aspire_bert_planes_bytes': (c_size_t, [ctypes.POINTER(BertWeights)]),
+    'aspire_bert_prepare_planes': (c_int, [ctypes.POINTER(BertWeights), c_void_p, c_size_t, c_void_p]),
     'aspire_bert_workspace_bytes': (c_size_t, [ctypes.POINTER(BertWeights), c_int64, c_int64]),
     'aspire_bert_forward_f32': (c_int, [ctypes.POINTER(BertWeights), c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -359,9 +359,223 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pre-split operands ("P layout") and the GEMM that streams them.  Round 2's bf16x3 kernel split BOTH fp32 operands into
+// their three bf16 planes on the fly, in every workgroup, for every tile (28 M VALU wave-instructions per 8192 x 2304 x 768
+// launch, 12 ds_write_b64 per thread and tile) although the weights never change and every activation is read by 6 - 24
+// column tiles: the matrix pipe was busy 0.37 - 0.41 of the launch.  Here the planes are formed ONCE -- the weights when the
+// model is loaded (aspire_bert_prepare_planes), an activation by the epilogue of the kernel that produces it (LayerNorm,
+// attention, the GELU GEMM) -- and the GEMM's main loop is LDS-DMA + fragment reads + MFMAs, no VALU work at all.
+//
+// P layout of a matrix X [R, K] (K % 16 == 0), 6 bytes per element: for every 16-wide k block kb and row r six 16-byte
+// pieces (plane pl, k half kh) = the 8 bf16 of plane pl at k = 16 kb + 8 kh .. + 7, stored at
+//     piece index ((kb * R + r) * 6 + 2 * pl + (kh ^ ((r >> 3) & 1)))
+// so that (a) the 128 rows of a tile at one k block are ONE contiguous 12 KB run: twelve global_load_lds_dwordx4 move it
+// into LDS exactly as it lies in HBM (the LDS image of an LDS-DMA is lane-linear), and (b) a fragment read -- lane = (row,
+// k half) reads its 16 bytes at 96 row + 32 pl + 16 (kh ^ row bit 3) -- is conflict free: 96-byte rows put rows r and r + 8
+// on the same banks, the k halves swapped in rows with bit 3 set move them apart (ds_read_b128 lane groups cover 16 rows whose
+// indices are distinct modulo 16).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPRowBytes = 96;                       // one row of one k block: 3 planes x 2 halves x 16 bytes
+constexpr int kPTile = 128 * kPRowBytes;             // one operand tile of one k step (12 KB)
+constexpr int kPPadRows = 128;                       // rows of slack behind a P matrix: the last row tile may read past R
+
+__host__ __device__ inline size_t p_bytes(int64_t R, int64_t K) { return (size_t)(R + kPPadRows) * K * 6; }
+
+// four consecutive k (k % 4 == 0) of row r -> the three planes' 8-byte halves
+__device__ __forceinline__ void p_store4(void* P, int64_t R, int64_t r, int k, float x, float y, float z, float w) {
+    uint32_t a1, a2, a3, b1, b2, b3;
+    split3_bf16(x, y, a1, a2, a3);
+    split3_bf16(z, w, b1, b2, b3);
+    const int kb = k >> 4, kh = (k >> 3) & 1, half = (k >> 2) & 1;
+    char* base = (char*)P + (((size_t)kb * R + r) * 6 + (kh ^ (int)((r >> 3) & 1))) * 16 + half * 8;
+    *reinterpret_cast<uint2*>(base) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(base + 32) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(base + 64) = make_uint2(a3, b3);
+}
+
+// X [R, K] fp32 row-major (row stride ld) -> P layout: the weights at model load, and the tools' operands
+__global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ X, int64_t R, int K, int ld, void* __restrict__ P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k4 = K / 4;
+    if (idx >= R * k4) return;
+    const int64_t r = idx / k4;
+    const int k = (int)(idx % k4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(X + r * ld + k);
+    p_store4(P, R, r, k, v.x, v.y, v.z, v.w);
+}
+
+struct PGemmArgs {
+    const void* Ap;      // P layout [M, K]
+    const void* Bp;      // P layout [N, K] (nn.Linear weight)
+    float* C;            // fp32 [M, ldc] out (F32 epilogue)
+    void* Cp;            // P layout [M, N] out (GELU_P epilogue: the next GEMM's A operand, its k dimension = N)
+    const float* bias;   // [N] or null
+    const float* res;    // [M, ldr] residual or null
+    int M, N, K, ldc, ldr;
+    int n_off;           // first column of this launch (a GEMM may run as a launch of 128-wide and one of 64-wide column tiles)
+};
+
+// One 16-byte-per-lane LDS-DMA: 64 lanes x 16 B from the lanes' global addresses to LDS bytes [lds_dst, lds_dst + 1024).  M0 is
+// compiler-reserved: saved and restored inside the statement.  hipcc does not count this load: the caller waits with
+// s_waitcnt vmcnt(N) itself.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// C = A . B^T on 128 x 128 tiles, BK = 16, four waves of 64 x 64, the six bf16 products per term of gemm_bf16x3_kernel.
+// NS-stage LDS ring filled by LDS-DMA NS - 1 tiles ahead; per k step and wave: 6 DMA pieces, 12 fragment reads, 24 MFMAs, one
+// barrier.  Order of a step: wait for the own pieces of tile t (s_waitcnt vmcnt(6 (NS - 2)): the younger tiles stay in
+// flight), barrier (everybody's pieces of tile t have landed AND everybody has read tile t - 1, whose slot is free now), issue
+// tile t + NS - 1 into that slot, read fragments, multiply.
+// SWAP: the MFMA's operands exchanged -- accumulator registers run along n, the lane is a row m -- for the epilogue that writes
+// GELU(.) straight into the P layout of the next GEMM's A operand (a lane then holds 4 consecutive k of its row: one 8-byte
+// store per plane); otherwise registers run along m, lanes along n: 128-byte coalesced fp32 stores, bias / residual fused.
+// BN = 64: 128 x 64 tiles (wave tile 64 x 32) for the columns that would otherwise leave a last round of workgroups half empty.
+template <int NS, int BN, bool SWAP>
+__global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
+    constexpr int TN = BN / 64;                             // 32-column blocks per wave
+    constexpr int kBTile = BN * kPRowBytes, kStage = kPTile + kBTile;
+    constexpr int kBPieces = kBTile / 1024;                 // 12 (BN = 128) or 6
+    constexpr int kBPerWave = (kBPieces + 3) / 4;           // 3 or 2 (BN = 64: waves 2, 3 repeat pieces 0, 1 -- equal counts per wave)
+    constexpr int kPerWave = 3 + kBPerWave;                 // LDS-DMA instructions per wave and stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lk = lane >> 5;
+    uint32_t bx, by;       // XCD-aware tile order, as gemm_f32_kernel
+    {
+        const uint32_t gx = gridDim.x, nb = gx * gridDim.y;
+        const uint32_t b = blockIdx.x + gx * blockIdx.y;
+        const uint32_t x = b & 7, q8 = nb >> 3, r8 = nb & 7;
+        const uint32_t L = x * q8 + (x < r8 ? x : r8) + (b >> 3);
+        bx = L % gx;
+        by = L / gx;
+    }
+    const int m0 = by * 128, n0 = g.n_off + bx * BN;
+    const int nk = g.K >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)p_smem;
+    // wave w moves pieces 3 w .. 3 w + 2 (1 KB each) of the A tile and pieces w, w + 4 (, w + 8) of the B tile
+    const char* a_src = (const char*)g.Ap + (size_t)m0 * kPRowBytes + (3 * wave) * 1024 + lane * 16;
+    const char* b_src = (const char*)g.Bp + (size_t)n0 * kPRowBytes + lane * 16;
+    const size_t a_step = (size_t)g.M * kPRowBytes, b_step = (size_t)g.N * kPRowBytes;
+    auto issue = [&](int slot, int kb) {
+        const uint32_t dst = lds0 + slot * kStage;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) glds16(a_src + kb * a_step + u * 1024, dst + (3 * wave + u) * 1024);
+#pragma unroll
+        for (int u = 0; u < kBPerWave; ++u) {
+            const int piece = (wave + 4 * u) % kBPieces;
+            glds16(b_src + kb * b_step + piece * 1024, dst + kPTile + piece * 1024);
+        }
+    };
+    const uint32_t frag = 16 * (lk ^ ((lr >> 3) & 1));
+    const unsigned char* a_rd = p_smem + (wr * 64 + lr) * kPRowBytes + frag;
+    const unsigned char* b_rd = p_smem + kPTile + (wc * 32 * TN + lr) * kPRowBytes + frag;
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s);
+    struct Frags {
+        bf16x8_t a[2][3], b[TN][3];
+    };
+    auto read_frags = [&](Frags& f, int slot) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                f.a[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_rd + slot * kStage + i * 32 * kPRowBytes + 32 * pl));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                f.b[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b_rd + slot * kStage + j * 32 * kPRowBytes + 32 * pl));
+        }
+    };
+    auto mma = [&](const Frags& f) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (SWAP)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j][PB[term]], f.a[i][PA[term]], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[term]], f.b[j][PB[term]], acc[i][j], 0, 0, 0);
+                }
+    };
+    static_assert(NS == 2 || NS == 3, "ring depth");
+    // (A second fragment register set -- tile t + 1's fragments read while tile t is multiplied, two LDS slots -- was built and
+    // measured: 8192 x 2304 x 768 177 us against 164; the MFMAs do not wait for LDS reads here.)
+    auto step = [&](int t, int slot) {
+        // the own pieces of tile t: everything but the NS - 2 younger tiles' pieces (none at the end of the loop)
+        if (NS == 3 && nk - 1 - t >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NS - 1 < nk) issue((slot + NS - 1) % NS, t + NS - 1);
+        Frags f;
+        read_frags(f, slot);
+        mma(f);
+    };
+    for (int t = 0; t < nk; t += NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (t + s < nk) step(t + s, s);
+    }
+
+    if constexpr (!SWAP) {
+        // C/D layout of the 32 x 32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * 32 * TN + 32 * j + lr;
+                const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (m >= g.M) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (g.res) v += g.res[(size_t)m * g.ldr + n];
+                    g.C[(size_t)m * g.ldc + n] = v;
+                }
+            }
+    } else {
+        // swapped: col = lane & 31 is the row m, the registers run along n in groups of 4 consecutive: GELU(acc + bias) goes
+        // straight into the P layout [M, N] (k dimension = n) of the next GEMM's A operand
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wr * 64 + 32 * i + lr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n = n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk;
+                    const float4 bv = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    p_store4(g.Cp, g.M, m, n, gelu_erf(acc[i][j][4 * q4 + 0] + bv.x), gelu_erf(acc[i][j][4 * q4 + 1] + bv.y),
+                             gelu_erf(acc[i][j][4 * q4 + 2] + bv.z), gelu_erf(acc[i][j][4 * q4 + 3] + bv.w));
+                }
+        }
+    }
+}
+
 // One wave per row of 768: lane holds 3 float4 (d = 4*lane + 256*c).
+// yp (optional): the row also goes out in the P layout (rows = `rows`), the A operand of the GEMM that reads it
 __device__ __forceinline__ void layernorm_row(float4 (&v)[3], const float* gamma, const float* beta, float eps,
-                                              float* out, int lane) {
+                                              float* out, int lane, void* yp = nullptr, int64_t rows = 0, int64_t row = 0) {
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
@@ -383,26 +597,27 @@ __device__ __forceinline__ void layernorm_row(float4 (&v)[3], const float* gamma
         o.z = (v[c].z - mean) * rstd * gm.z + bt.z;
         o.w = (v[c].w - mean) * rstd * gm.w + bt.w;
         *reinterpret_cast<float4*>(out + d) = o;
+        if (yp) p_store4(yp, rows, row, d, o.x, o.y, o.z, o.w);
     }
 }
 
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, float* __restrict__ y,
-                                                        int64_t rows) {
+                                                        int64_t rows, void* __restrict__ yp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float4 v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const float4*>(x + row * kD + 4 * lane + 256 * c);
-    layernorm_row(v, gamma, beta, eps, y + row * kD, lane);
+    layernorm_row(v, gamma, beta, eps, y + row * kD, lane, yp, rows, row);
 }
 
 __global__ void __launch_bounds__(256) embed_layernorm_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ typ,
                                                               const float* __restrict__ word, const float* __restrict__ pos,
                                                               const float* __restrict__ type_emb, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, float* __restrict__ y,
-                                                              int64_t rows, int64_t L) {
+                                                              int64_t rows, int64_t L, void* __restrict__ yp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -417,7 +632,7 @@ __global__ void __launch_bounds__(256) embed_layernorm_kernel(const int64_t* __r
         // BertEmbeddings: inputs_embeds + token_type_embeddings, then + position_embeddings
         v[c] = make_float4((a.x + b.x) + e.x, (a.y + b.y) + e.y, (a.z + b.z) + e.z, (a.w + b.w) + e.w);
     }
-    layernorm_row(v, gamma, beta, eps, y + row * kD, lane);
+    layernorm_row(v, gamma, beta, eps, y + row * kD, lane, yp, rows, row);
 }
 
 // scores [rows = B*H*L][ld] in place: softmax_j(x_j * scale + (mask[b][j] ? 0 : -FLT_MAX)); columns in [L, ld)
@@ -477,8 +692,10 @@ __global__ void __launch_bounds__(256) softmax_mask_kernel(float* __restrict__ s
 // HF semantics kept: scores / sqrt(64) + (1 - mask) * finfo.min, soft-max over keys (modeling_bert.py).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kFaLdK = 132, kFaLdV = 72;
+// ctxp (optional, instead of ctx): the context rows go out in the P layout [rows, 768] -- the A operand of the output projection
 __global__ void __launch_bounds__(256, 2) flash_attn_f32_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                                float* __restrict__ ctx, int L, int H) {
+                                                                float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp,
+                                                                int64_t rows) {
     __shared__ __attribute__((aligned(16))) float Ks[64][kFaLdK];     // [dim][key]
     __shared__ __attribute__((aligned(16))) float Vs[128][kFaLdV];    // [key][dim]
     __shared__ float kbias[128];
@@ -591,7 +808,14 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f32_kernel(const float* __r
     // ---- normalise and store: lane = query, registers = head dims (4 consecutive per group) --------------------
     const float l_tot = l_run + lane_xor<32>(l_run);
     const float inv = 1.0f / l_tot;
-    if (q_ok) {
+    if (q_ok && ctxp) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                p_store4(ctxp, rows, (int64_t)b * L + q_row, h * 64 + 32 * mb + 8 * g4 + 4 * lk, o[mb][4 * g4 + 0] * inv,
+                         o[mb][4 * g4 + 1] * inv, o[mb][4 * g4 + 2] * inv, o[mb][4 * g4 + 3] * inv);
+    } else if (q_ok) {
         float* op = ctx + ((size_t)b * L + q_row) * kD + h * 64;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -662,6 +886,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
     float *x, *qkv, *scores, *ctx, *tmp, *ffn;
+    void *actp, *ctxp, *ffnp;       // P-layout activations (pre-split GEMM operands): LayerNorm outputs, attention context, GELU(FFN1)
     size_t total;
 };
 
@@ -681,8 +906,64 @@ Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim) {
     w.ctx = take(M * kD);
     w.tmp = take(M * kD);
     w.ffn = take(M * ffn_dim);
+    auto take_p = [&](int64_t K) {
+        void* r = p + off;
+        off += align_up(p_bytes((int64_t)M, K));
+        return r;
+    };
+    w.actp = take_p(kD);
+    w.ctxp = take_p(kD);
+    w.ffnp = take_p(ffn_dim);
     w.total = off;
     return w;
+}
+
+// Launch of the P-layout GEMM (N % 128 == 0, K % 16 == 0): 128 x 128 tiles (wider wave tile: less LDS traffic per MFMA), or
+// 128 x 64 for a short-k GEMM whose 128-wide tiles could not give every resident workgroup slot a tile.  (Splitting the columns
+// of a GEMM into a launch of 128-wide tiles filling whole rounds and a launch of 64-wide ones for the rest -- 8192 x 2304: 768 +
+// 768 tiles instead of 1152 = 1.5 rounds -- was built and measured: 164 us either way.  A half-empty last round is not the
+// loss it looks like: its workgroups run faster for having the CU's matrix pipes to themselves.)
+template <int NS, int BN, bool SWAP>
+int launch_gemm_p_ns(PGemmArgs g, int n_off, int col_tiles, hipStream_t st) {
+    constexpr int lds = NS * (kPTile + BN * kPRowBytes);
+    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<NS, BN, SWAP>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    ASPIRE_HIP_OK(raised);
+    g.n_off = n_off;
+    hipLaunchKernelGGL((gemm_p_kernel<NS, BN, SWAP>), dim3(col_tiles, (g.M + 127) / 128), dim3(256), lds, st, g);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+template <bool SWAP>
+int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
+    ASPIRE_REQUIRE(g.N % 128 == 0 && g.K % 16 == 0, ASPIRE_ERR_UNSUPPORTED, "P-layout GEMM needs N %% 128 == 0 and K %% 16 == 0");
+    const int ring = tuning().gemm_ring == 3 ? 3 : 2;
+    const long long slots = ring == 2 ? 768 : 512, rows = (g.M + 127) / 128, n128 = g.N / 128;
+    // 128 x 64 tiles (twice the workgroups) where 128 x 128 ones cannot give every workgroup slot a tile and the k loop is short
+    // (measured at M = 8192: N = 768, K = 768 61 -> 58 us; K = 3072 211 -> 221 us: not there)
+    int c1 = (int)n128;
+    if (tuning().gemm_tile == 64 || (tuning().gemm_tile == 0 && rows * n128 < slots && g.K <= 1024)) c1 = 0;
+    if (c1 > 0)
+        if (int rc = ring == 2 ? launch_gemm_p_ns<2, 128, SWAP>(g, 0, c1, st) : launch_gemm_p_ns<3, 128, SWAP>(g, 0, c1, st)) return rc;
+    if (c1 < n128)
+        if (int rc = ring == 2 ? launch_gemm_p_ns<2, 64, SWAP>(g, c1 * 128, (int)(n128 - c1) * 2, st)
+                               : launch_gemm_p_ns<3, 64, SWAP>(g, c1 * 128, (int)(n128 - c1) * 2, st))
+            return rc;
+    return ASPIRE_OK;
+}
+// where a layer's four weight matrices sit in the prepared planes buffer
+struct PlaneOffsets {
+    size_t qkv, o, ffn1, ffn2, per_layer;
+};
+PlaneOffsets plane_offsets(int ffn_dim) {
+    PlaneOffsets o{};
+    size_t off = 0;
+    o.qkv = off; off += align_up(p_bytes(3 * kD, kD));
+    o.o = off; off += align_up(p_bytes(kD, kD));
+    o.ffn1 = off; off += align_up(p_bytes(ffn_dim, kD));
+    o.ffn2 = off; off += align_up(p_bytes(kD, ffn_dim));
+    o.per_layer = off;
+    return o;
 }
 
 }  // namespace
@@ -713,26 +994,38 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
     const int Lp = (int)((L + 3) / 4 * 4), H = w->n_heads, dh = kD / H;
     const unsigned row_blocks = (unsigned)((M + 3) / 4);
 
+    // P path: the weights' planes are prepared (aspire_bert_prepare_planes), BERT-base shapes tile by 128 -- every nn.Linear GEMM
+    // streams pre-split operands (gemm_p_kernel); otherwise (ASPIRE_HIP_GEMM=f32 | bf16x3, no planes) the round-2 kernels
+    const bool pp = w->planes != nullptr && tuning().gemm_form == 0 && dh == 64 && !tuning().attn_gemm && w->ffn_dim % 128 == 0;
+    const PlaneOffsets po = plane_offsets(w->ffn_dim);
     float* x = w->n_layers == 0 ? hidden_out : ws.x;
     hipLaunchKernelGGL(embed_layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, tok_ids, type_ids, w->word_emb, w->pos_emb,
-                       w->type_emb, w->emb_ln_g, w->emb_ln_b, w->ln_eps, x, M, L);
+                       w->type_emb, w->emb_ln_g, w->emb_ln_b, w->ln_eps, x, M, L, pp && w->n_layers > 0 ? ws.actp : nullptr);
     ASPIRE_LAUNCH_OK();
 
     for (int l = 0; l < w->n_layers; ++l) {
         const aspire_bert_layer& ly = w->layers[l];
-        float* out = (l == w->n_layers - 1) ? hidden_out : ws.x;  // LN2 writes the layer output (x is dead by then)
+        const bool last = l == w->n_layers - 1;
+        float* out = last ? hidden_out : ws.x;  // LN2 writes the layer output (x is dead by then)
+        const char* lp = (const char*)w->planes + (size_t)l * po.per_layer;
         GemmArgs g{};
+        PGemmArgs pg{};
         // 1. fused QKV projection: qkv [M, 2304] = x . Wqkv^T + bqkv
-        g = GemmArgs{};
-        g.A = x; g.B = ly.w_qkv; g.C = ws.qkv; g.bias = ly.b_qkv;
-        g.M = (int)M; g.N = 3 * kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = 3 * kD; g.nz2 = 1; g.alpha = 1.f;
-        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        if (pp) {
+            pg = PGemmArgs{ws.actp, lp + po.qkv, ws.qkv, nullptr, ly.b_qkv, nullptr, (int)M, 3 * kD, kD, 3 * kD, 0, 0};
+            if (int rc = launch_gemm_p<false>(pg, st)) return rc;
+        } else {
+            g = GemmArgs{};
+            g.A = x; g.B = ly.w_qkv; g.C = ws.qkv; g.bias = ly.b_qkv;
+            g.M = (int)M; g.N = 3 * kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = 3 * kD; g.nz2 = 1; g.alpha = 1.f;
+            if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        }
         // 2-4. attention.  Fused kernel (scores never leave the chip) unless ASPIRE_HIP_ATTN=gemm pins the
         // three-kernel form (QK^T GEMM, masked soft-max, PV GEMM) that the fused one is tested against.
         if (dh == 64 && !tuning().attn_gemm) {
             const unsigned qblocks = (unsigned)((L + 127) / 128);
             hipLaunchKernelGGL(flash_attn_f32_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkv, attn_mask, ws.ctx,
-                               (int)L, H);
+                               (int)L, H, pp ? ws.ctxp : nullptr, M);
             ASPIRE_LAUNCH_OK();
         } else {
             // 2. scores[b,h] = Q_bh . K_bh^T   (scale and mask are applied by the softmax kernel)
@@ -756,26 +1049,85 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
             if (int rc = launch_gemm<true>(g, (int)(B * H), st)) return rc;
         }
         // 5. attention output projection + residual, LayerNorm
-        g = GemmArgs{};
-        g.A = ws.ctx; g.B = ly.w_o; g.C = ws.tmp; g.bias = ly.b_o; g.res = x; g.ldr = kD;
-        g.M = (int)M; g.N = kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
-        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln1_g, ly.ln1_b, w->ln_eps, ws.ctx, M);
+        if (pp) {
+            pg = PGemmArgs{ws.ctxp, lp + po.o, ws.tmp, nullptr, ly.b_o, x, (int)M, kD, kD, kD, kD, 0};
+            if (int rc = launch_gemm_p<false>(pg, st)) return rc;
+        } else {
+            g = GemmArgs{};
+            g.A = ws.ctx; g.B = ly.w_o; g.C = ws.tmp; g.bias = ly.b_o; g.res = x; g.ldr = kD;
+            g.M = (int)M; g.N = kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
+            if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        }
+        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln1_g, ly.ln1_b, w->ln_eps, ws.ctx, M,
+                           pp ? ws.actp : nullptr);
         ASPIRE_LAUNCH_OK();
         // 6. FFN: GELU(h . W1^T + b1) . W2^T + b2 + h, LayerNorm          (h = ws.ctx)
-        g = GemmArgs{};
-        g.A = ws.ctx; g.B = ly.w_ffn1; g.C = ws.ffn; g.bias = ly.b_ffn1; g.gelu = 1;
-        g.M = (int)M; g.N = w->ffn_dim; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = w->ffn_dim; g.nz2 = 1; g.alpha = 1.f;
-        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
-        g = GemmArgs{};
-        g.A = ws.ffn; g.B = ly.w_ffn2; g.C = ws.tmp; g.bias = ly.b_ffn2; g.res = ws.ctx; g.ldr = kD;
-        g.M = (int)M; g.N = kD; g.K = w->ffn_dim; g.lda = w->ffn_dim; g.ldb = w->ffn_dim; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
-        if (int rc = launch_gemm<false>(g, 1, st)) return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln2_g, ly.ln2_b, w->ln_eps, out, M);
+        if (pp) {
+            pg = PGemmArgs{ws.actp, lp + po.ffn1, nullptr, ws.ffnp, ly.b_ffn1, nullptr, (int)M, w->ffn_dim, kD, 0, 0, 0};
+            if (int rc = launch_gemm_p<true>(pg, st)) return rc;
+            pg = PGemmArgs{ws.ffnp, lp + po.ffn2, ws.tmp, nullptr, ly.b_ffn2, ws.ctx, (int)M, kD, w->ffn_dim, kD, kD, 0};
+            if (int rc = launch_gemm_p<false>(pg, st)) return rc;
+        } else {
+            g = GemmArgs{};
+            g.A = ws.ctx; g.B = ly.w_ffn1; g.C = ws.ffn; g.bias = ly.b_ffn1; g.gelu = 1;
+            g.M = (int)M; g.N = w->ffn_dim; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = w->ffn_dim; g.nz2 = 1; g.alpha = 1.f;
+            if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+            g = GemmArgs{};
+            g.A = ws.ffn; g.B = ly.w_ffn2; g.C = ws.tmp; g.bias = ly.b_ffn2; g.res = ws.ctx; g.ldr = kD;
+            g.M = (int)M; g.N = kD; g.K = w->ffn_dim; g.lda = w->ffn_dim; g.ldb = w->ffn_dim; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
+            if (int rc = launch_gemm<false>(g, 1, st)) return rc;
+        }
+        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln2_g, ly.ln2_b, w->ln_eps, out, M,
+                           pp && !last ? ws.actp : nullptr);
         ASPIRE_LAUNCH_OK();
         x = out;
     }
     return ASPIRE_OK;
+}
+
+// The weights' bf16 planes, formed ONCE when the model is loaded: a device buffer of aspire_bert_planes_bytes(w) bytes that the
+// caller keeps next to the weights and hands over as aspire_bert_weights::planes.
+extern "C" size_t aspire_bert_planes_bytes(const aspire_bert_weights* w) {
+    if (!w || w->n_layers <= 0 || w->hidden != kD || w->ffn_dim <= 0) return 0;
+    return plane_offsets(w->ffn_dim).per_layer * (size_t)w->n_layers;
+}
+
+extern "C" int aspire_bert_prepare_planes(const aspire_bert_weights* w, void* planes, size_t planes_bytes, void* stream) {
+    ASPIRE_REQUIRE(w && planes, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    ASPIRE_REQUIRE(w->hidden == kD && w->ffn_dim % 128 == 0 && w->ffn_dim > 0, ASPIRE_ERR_UNSUPPORTED,
+                   "pre-split weights are built for hidden 768 and an ffn width that is a multiple of 128");
+    ASPIRE_REQUIRE(planes_bytes >= aspire_bert_planes_bytes(w), ASPIRE_ERR_INVALID_ARG, "planes buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    const PlaneOffsets po = plane_offsets(w->ffn_dim);
+    auto split = [&](const float* X, int64_t R, int K, void* P) {
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((R * (K / 4) + 255) / 256)), dim3(256), 0, st, X, R, K, K, P);
+    };
+    ASPIRE_HIP_OK(hipMemsetAsync(planes, 0, aspire_bert_planes_bytes(w), st));      // the slack rows behind every matrix
+    for (int l = 0; l < w->n_layers; ++l) {
+        const aspire_bert_layer& ly = w->layers[l];
+        char* lp = (char*)planes + (size_t)l * po.per_layer;
+        split(ly.w_qkv, 3 * kD, kD, lp + po.qkv);
+        split(ly.w_o, kD, kD, lp + po.o);
+        split(ly.w_ffn1, w->ffn_dim, kD, lp + po.ffn1);
+        split(ly.w_ffn2, kD, w->ffn_dim, lp + po.ffn2);
+        ASPIRE_LAUNCH_OK();
+    }
+    return ASPIRE_OK;
+}
+
+// Tuning hooks (not part of include/aspire_hip.h): an operand into the P layout, and one C = A . B^T (+bias) GEMM on P operands
+// (tools/gemmbench.py); swap != 0: the GELU -> P-layout epilogue (Cp [M, N]).
+extern "C" size_t aspire_debug_planes_bytes(int64_t R, int64_t K) { return p_bytes(R, K); }
+extern "C" int aspire_debug_split_planes(const float* X, int64_t R, int K, void* P, void* stream) {
+    ASPIRE_REQUIRE(K % 16 == 0, ASPIRE_ERR_UNSUPPORTED, "K %% 16");
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((R * (K / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, R, K, K, P);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+extern "C" int aspire_debug_gemm_planes(const void* Ap, const void* Bp, float* C, void* Cp, const float* bias, int M, int N, int K, int swap,
+                                        void* stream) {
+    PGemmArgs pg{Ap, Bp, C, Cp, bias, nullptr, M, N, K, N, 0, 0};
+    return swap ? launch_gemm_p<true>(pg, (hipStream_t)stream) : launch_gemm_p<false>(pg, (hipStream_t)stream);
 }
 
 // Tuning hook (not part of include/aspire_hip.h): one plain C = A . B^T (+bias) GEMM through the encoder's tile

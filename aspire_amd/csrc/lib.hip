@@ -40,6 +40,10 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         if (f != 0 && f != 96 && f != 128 && f != 64) return false;
         t.gemm_tile96 = f == 96;
         t.gemm_tile = f;
+    } else if (!strcmp(key, "GEMM_RING")) {
+        const int f = unset ? 0 : atoi(v);
+        if (f != 0 && f != 2 && f != 3) return false;
+        t.gemm_ring = f;
     } else if (!strcmp(key, "FUSED_VALU")) {
         t.fused_valu = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {
@@ -74,6 +78,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "ATTN")) v = t.attn_gemm ? "gemm" : "";
     else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : "";
     else if (!strcmp(key, "GEMM_TILE")) v = number(t.gemm_tile);
+    else if (!strcmp(key, "GEMM_RING")) v = number(t.gemm_ring);
     else if (!strcmp(key, "FUSED_VALU")) v = number(t.fused_valu);
     else if (!strcmp(key, "FUSED_NOSOLVE")) v = number(t.fused_nosolve);
     else if (!strcmp(key, "FUSED_NOSELF")) v = number(t.fused_noself);
@@ -85,7 +90,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

@@ -12,6 +12,7 @@ struct Tuning {
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
     int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default (bf16x3 for nn.Linear shapes), 1 f32 = fp32-input MFMA everywhere, 2 bf16x3 = three-way bf16 split on the bf16 matrix pipe
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
+    int gemm_ring = 0;       // ASPIRE_HIP_GEMM_RING=2 | 3: LDS ring depth of the P-layout GEMM (2: 48 KB, three workgroups per CU; default 3: 72 KB, two)
     int gemm_tile = 0;       // ASPIRE_HIP_GEMM_TILE=128 | 64: force 128 x 128 / 128 x 64 tiles in the bf16x3 form (tuning)
     int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
                              // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch

@@ -93,8 +93,15 @@ typedef struct {
     const aspire_bert_layer* layers;            /* HOST array of n_layers entries (device pointers inside) */
     int32_t n_layers, n_heads, hidden, ffn_dim, vocab, max_pos, n_types;
     float ln_eps;                               /* layer_norm_eps (1e-12) */
+    /* NULL, or the nn.Linear weights' pre-split bf16 planes: a DEVICE buffer of aspire_bert_planes_bytes(w) bytes filled once
+     * by aspire_bert_prepare_planes when the model is loaded (the weights never change).  With it the forward's GEMMs stream
+     * pre-split operands -- same fp32 accuracy (three bf16 planes per operand, six products per term), no conversion work in
+     * the main loop; without it every workgroup splits its fp32 tiles on the fly. */
+    const void* planes;
 } aspire_bert_weights;
 
+size_t aspire_bert_planes_bytes(const aspire_bert_weights* w);
+int aspire_bert_prepare_planes(const aspire_bert_weights* w, void* planes, size_t planes_bytes, void* stream);
 size_t aspire_bert_workspace_bytes(const aspire_bert_weights* w, int64_t B, int64_t L);
 int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64_t* tok_ids, const int64_t* type_ids,
                             const int64_t* attn_mask, int64_t B, int64_t L, float* hidden_out,
@@ -327,7 +334,7 @@ int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (tests, bench.py, tuning) -- not part of the surface that replaces reference code.
  *   aspire_debug_set   pin a kernel form / grid: key = "SINKHORN" (wave | block | block-norepair | block16 | block-dense | block-wide), "COST_PATH"
- *                      (mfma | valu), "OT_FORM" (small | tile | fused), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM" (f32 | bf16x3), "GEMM_TILE" (96 | 128 | 64),
+ *                      (mfma | valu), "OT_FORM" (small | tile | fused), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM" (f32 | bf16x3), "GEMM_TILE" (96 | 128 | 64), "GEMM_RING" (2 | 3),
  *                      "FUSED_VALU" (1),
  *                      "FUSED_NOSELF" (1), "FUSED_WAVES" (n), "FUSED_NOSOLVE" (1 | 2: timing only, invalid scores);
  *                      value NULL or "" restores the default.  The same switches are read

@@ -152,3 +152,60 @@ def test_gemm_bf16x3_form_is_fp32_accurate():
         scale = ref.abs().max().item()
         assert e3 <= max(2.0 * e32, 3e-7 * scale), (M, N, K, e32, e3, scale)
         assert (out['f32'] - out['bf16x3']).abs().max().item() <= 4e-6 * scale
+
+
+def test_gemm_on_presplit_operands_is_fp32_accurate():
+    """The P-layout GEMM (operands pre-split into three bf16 planes: the weights at model load, an activation by the kernel that
+    produces it; LDS-DMA tiles) against float64 and against the on-the-fly split: the same six products, the same error; M edges
+    (rows past the matrix feed unstored outputs only), both ring depths, 128 x 64 column tiles, and the GELU -> P-layout epilogue
+    of the first FFN GEMM (its output read back through a second P-layout GEMM against the identity)."""
+    import ctypes
+    from aspire_amd import _lib
+    L = _lib.lib
+    L.aspire_debug_gemm_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    L.aspire_debug_planes_bytes.restype = ctypes.c_size_t
+    L.aspire_debug_planes_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    L.aspire_debug_split_planes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.aspire_debug_gemm_planes.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(7)
+
+    def planes(X):
+        r, k = X.shape
+        P = torch.empty(L.aspire_debug_planes_bytes(r, k), dtype=torch.uint8, device='cuda')     # slack rows left uninitialised
+        assert L.aspire_debug_split_planes(X.data_ptr(), r, k, P.data_ptr(), st) == 0
+        return P
+
+    for M, N, K in ((8192, 2304, 768), (1000, 768, 3072), (130, 768, 768), (4100, 3072, 768)):
+        A = (torch.randn(M, K, generator=g) * torch.linspace(0.1, 3.0, K)).cuda()
+        B = (torch.randn(N, K, generator=g) + 0.5).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        ref = A.double() @ B.double().T + bias.double()
+        scale = ref.abs().max().item()
+        C0 = torch.empty(M, N, device='cuda')
+        with _lib.pinned(GEMM='bf16x3'):
+            assert L.aspire_debug_gemm_f32(A.data_ptr(), B.data_ptr(), C0.data_ptr(), bias.data_ptr(), M, N, K, st) == 0
+        Ap, Bp = planes(A), planes(B)
+        for pin in ({}, {'GEMM_RING': '3'}, {'GEMM_TILE': '64'}):
+            C = torch.full((M, N), float('nan'), device='cuda')
+            with _lib.pinned(**pin):
+                assert L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, bias.data_ptr(), M, N, K, 0, st) == 0
+            torch.cuda.synchronize()
+            assert torch.isfinite(C).all(), (M, N, K, pin)
+            err = (C.double() - ref).abs().max().item()
+            err0 = (C0.double() - ref).abs().max().item()
+            assert err <= max(1.5 * err0, 3e-7 * scale), (M, N, K, pin, err, err0)
+            assert (C - C0).abs().max().item() <= 2e-6 * scale, (M, N, K, pin)
+    # GELU epilogue into the P layout: H = GELU(A . B^T + bias) as planes, read back as H . I^T
+    M, N, K = 300, 256, 768
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (0.05 * torch.randn(N, K, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Hp = torch.empty(L.aspire_debug_planes_bytes(M, N), dtype=torch.uint8, device='cuda')
+    assert L.aspire_debug_gemm_planes(planes(A).data_ptr(), planes(B).data_ptr(), None, Hp.data_ptr(), bias.data_ptr(), M, N, K, 1, st) == 0
+    eye = torch.eye(N, device='cuda')
+    H = torch.empty(M, N, device='cuda')
+    assert L.aspire_debug_gemm_planes(Hp.data_ptr(), planes(eye).data_ptr(), H.data_ptr(), None, None, M, N, N, 0, st) == 0
+    torch.cuda.synchronize()
+    want = torch.nn.functional.gelu(A.double() @ B.double().T + bias.double())
+    assert (H.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
