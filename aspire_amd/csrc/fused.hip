@@ -84,21 +84,39 @@ __device__ __forceinline__ float max_li(float v) {
     return fmaxf(v, dpp_mov<0x128>(v, v));
 }
 __device__ __forceinline__ float sum16(float v) { return sum_li(sum_lj(v)); }
-// CHUNK: a candidate of up to 32 rows occupies w = 1, 2 or 4 of the wave's 16-lane groups (one per 8 of its rows: DPP rows
-// 2 k, 2 k + 1 or all four).  All-reduce across those groups: one v_permlane{16,32}_swap + add per level (common.h: swap_add).
+// CHUNK: a candidate of up to 32 rows occupies 1 .. 4 of the wave's 16-lane groups (one per 8 of its rows); an item's four groups
+// hold candidates of [4], [3, 1], [2, 2], [2, 1, 1] or [1, 1, 1, 1] chunks (a 2-chunk candidate on groups 0, 1 or 2, 3; a 3-chunk
+// one on 0 .. 2).  w (wave-uniform) = 4 for [4] and [3, 1], 2 for [2, 2] and [2, 1, 1], 1 otherwise; `wide` (per lane) = this
+// lane's candidate spans the exchange (w == 2: two groups; w == 4: three or four).  All-reduce across a candidate's groups: one
+// v_permlane{16,32}_swap + add per level (common.h: swap_add); a lane of a narrower candidate contributes the neutral element
+// and keeps its own value.
 template <bool XG>
-__device__ __forceinline__ float xg_sum(float v, int w) {
+__device__ __forceinline__ float xg_sum(float v, int w, bool wide) {
     if constexpr (XG) {
-        if (w >= 2) v = swap_add<16>(v, v);
-        if (w == 4) v = swap_add<32>(v, v);
+        if (w == 2) {
+            const float s = swap_add<16>(v, v);
+            v = wide ? s : v;
+        } else if (w == 4) {
+            float z = wide ? v : 0.f;
+            z = swap_add<16>(z, z);
+            z = swap_add<32>(z, z);
+            v = wide ? z : v;
+        }
     }
     return v;
 }
 template <bool XG>
-__device__ __forceinline__ float xg_max(float v, int w) {
+__device__ __forceinline__ float xg_max(float v, int w, bool wide) {
     if constexpr (XG) {
-        if (w >= 2) v = fmaxf(v, lane_xor<16>(v));
-        if (w == 4) v = fmaxf(v, lane_xor<32>(v));
+        if (w == 2) {
+            const float s = fmaxf(v, lane_xor<16>(v));
+            v = wide ? s : v;
+        } else if (w == 4) {
+            float z = wide ? v : -__builtin_inff();
+            z = fmaxf(z, lane_xor<16>(z));
+            z = fmaxf(z, lane_xor<32>(z));
+            v = wide ? z : v;
+        }
     }
     return v;
 }
@@ -122,29 +140,33 @@ struct Solve {
     int k, max_steps;      // wave-uniform: next step, steps of the longest of the wave's four schedules
     int n_mid_lo;          // wave-uniform: the shortest of the four schedules -- steps 2 .. n_mid_lo anneal in all four pairs
     unsigned valid;        // bit x: row x valid, bit 2 + y: column y valid, bit 4: a document longer than the tile (poison)
-    int w;                 // wave-uniform (CHUNK): lane groups per candidate, 1 otherwise
+    int w;                 // wave-uniform (CHUNK): widest exchange across lane groups the item needs (1, 2, 4), 1 otherwise
+    bool wide, first;      // per lane (CHUNK): this lane's candidate takes part in the exchange; its group holds the candidate's first chunk
     int64_t out;           // index into scores, < 0 = nothing to store (clamped tail candidate; CHUNK: not the candidate's first group)
 };
 
 template <bool XG = false>
 __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const float (&cost)[2][2], const float (&neg)[2][2],
-                                            const bool (&rv)[2], const bool (&cv)[2], float diam, int w = 1) {
+                                            const bool (&rv)[2], const bool (&cv)[2], float diam, int w = 1, bool wide = false,
+                                            bool first = true) {
     s.w = w;
+    s.wide = wide;
+    s.first = first;
     // ---- marginals: soft-max over sentences of the best match / temp --------------------------------------------------
     const float temp = (float)a.temp;
     {
         float qm[2], cm[2];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
-            qm[x] = xg_max<XG>(max_lj(fmaxf((rv[x] && cv[0]) ? neg[x][0] : kNegBig, (rv[x] && cv[1]) ? neg[x][1] : kNegBig)), w) / temp;
+            qm[x] = xg_max<XG>(max_lj(fmaxf((rv[x] && cv[0]) ? neg[x][0] : kNegBig, (rv[x] && cv[1]) ? neg[x][1] : kNegBig)), w, wide) / temp;
 #pragma unroll
         for (int y = 0; y < 2; ++y)
             cm[y] = max_li(fmaxf((rv[0] && cv[y]) ? neg[0][y] : kNegBig, (rv[1] && cv[y]) ? neg[1][y] : kNegBig)) / temp;
         const float mq = max_li(fmaxf(rv[0] ? qm[0] : kNegBig, rv[1] ? qm[1] : kNegBig));
-        const float mc = xg_max<XG>(max_lj(fmaxf(cv[0] ? cm[0] : kNegBig, cv[1] ? cm[1] : kNegBig)), w);
+        const float mc = xg_max<XG>(max_lj(fmaxf(cv[0] ? cm[0] : kNegBig, cv[1] ? cm[1] : kNegBig)), w, wide);
         const float sq = (rv[0] ? fast_exp(qm[0] - mq) : 0.f) + (rv[1] ? fast_exp(qm[1] - mq) : 0.f);
         const float sc = (cv[0] ? fast_exp(cm[0] - mc) : 0.f) + (cv[1] ? fast_exp(cm[1] - mc) : 0.f);
-        const float lsq = fast_log(sum_li(sq)), lsc = fast_log(xg_sum<XG>(sum_lj(sc), w));
+        const float lsq = fast_log(sum_li(sq)), lsc = fast_log(xg_sum<XG>(sum_lj(sc), w, wide));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             s.wa[t] = rv[t] ? fast_exp(qm[t] - mq - lsq) : 0.f;      // log_softmax(...).exp(); a zero weight is geomloss's
@@ -184,7 +206,7 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
         }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        s.f[t] = -2.f * h_first * __builtin_amdgcn_logf(xg_sum<XG>(sum_lj(rs[t]), w));
+        s.f[t] = -2.f * h_first * __builtin_amdgcn_logf(xg_sum<XG>(sum_lj(rs[t]), w, wide));
         s.g[t] = -2.f * h_first * __builtin_amdgcn_logf(sum_li(cs[t]));
     }
 }
@@ -197,9 +219,16 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
 // cut the step into basic blocks and the two row chains and the column chain, which otherwise interleave level by level, run
 // one after the other (measured on the config-4 shape: every wave's last solve 26 us).
 template <int W>
-__device__ __forceinline__ float xg_sum_w(float v) {
-    if constexpr (W >= 2) v = swap_add<16>(v, v);
-    if constexpr (W == 4) v = swap_add<32>(v, v);
+__device__ __forceinline__ float xg_sum_w(float v, bool wide) {
+    if constexpr (W == 2) {
+        const float s = swap_add<16>(v, v);
+        v = wide ? s : v;
+    } else if constexpr (W == 4) {
+        float z = wide ? v : 0.f;
+        z = swap_add<16>(z, z);
+        z = swap_add<32>(z, z);
+        v = wide ? z : v;
+    }
     return v;
 }
 template <int W = 1>
@@ -211,7 +240,7 @@ __device__ __forceinline__ void solve_step(Solve& s, float r2, float h) {
     const f2_t k1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
     const f2_t t0 = k0 * s.wb, t1 = k1 * s.wb;
     const f2_t cs = __builtin_elementwise_fma(k1, f2_t{s.wa.y, s.wa.y}, k0 * f2_t{s.wa.x, s.wa.x});
-    const f2_t lr = {__builtin_amdgcn_logf(xg_sum_w<W>(sum_lj(t0.x + t0.y))), __builtin_amdgcn_logf(xg_sum_w<W>(sum_lj(t1.x + t1.y)))};
+    const f2_t lr = {__builtin_amdgcn_logf(xg_sum_w<W>(sum_lj(t0.x + t0.y), s.wide)), __builtin_amdgcn_logf(xg_sum_w<W>(sum_lj(t1.x + t1.y), s.wide))};
     const f2_t lc = {__builtin_amdgcn_logf(sum_li(cs.x)), __builtin_amdgcn_logf(sum_li(cs.y))};
     s.f = __builtin_elementwise_fma(f2_t{-h, -h}, lr, s.f);
     s.g = __builtin_elementwise_fma(f2_t{-h, -h}, lc, s.g);
@@ -266,7 +295,7 @@ template <bool XG = false>
 __device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a, const f2_t f, const f2_t g) {
     const int lp = threadIdx.x & 15, li = lp >> 2, lj = lp & 3;
     // CHUNK: the <a, f> terms are counted once per candidate, by the group of its first chunk
-    const bool first_grp = !XG || ((threadIdx.x >> 4) & (s.w - 1)) == 0;
+    const bool first_grp = !XG || s.first;
     const bool rv[2] = {(s.valid & 1u) != 0, (s.valid & 2u) != 0}, cv[2] = {(s.valid & 4u) != 0, (s.valid & 8u) != 0};
     float score;
     if (a.want != ASPIRE_OT_PLAN_SIM) {
@@ -276,7 +305,7 @@ __device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a
             acc += (lj == 0 && rv[t] && first_grp) ? s.wa[t] * f[t] : 0.f;
             acc += (li == 0 && cv[t]) ? s.wb[t] * g[t] : 0.f;
         }
-        score = xg_sum<XG>(sum16(acc), s.w);
+        score = xg_sum<XG>(sum16(acc), s.w, s.wide);
         if (a.want == ASPIRE_OT_SIMILARITY) score = -score;
     } else {
         const float eb = (float)a.blur, rb = rcp_refined(eb);
@@ -289,7 +318,7 @@ __device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a
                 const float outer = valid ? f[x] + g[y] : 0.f;
                 acc += fast_exp(div_r(outer + s.neg[x][y], eb, rb)) * (s.wa[x] * s.wb[y]) * s.neg[x][y];
             }
-        score = xg_sum<XG>(sum16(acc), s.w);
+        score = xg_sum<XG>(sum16(acc), s.w, s.wide);
     }
     return score;
 }
@@ -376,13 +405,15 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
     struct Ctx {
         int64_t c_idx, q_idx;
         int c_len, q_len, c_start, q_start;
-        int row0, w;           // CHUNK: first row of this group's chunk; groups per candidate (wave-uniform)
+        int row0, w;           // CHUNK: first row of this group's chunk; widest exchange the item needs (wave-uniform: 1, 2, 4)
+        int gsz;               // CHUNK: lane groups of this group's candidate
         bool my_c_real;
     };
     auto load_ctx = [&](uint32_t item) {
         Ctx x;
         x.row0 = 0;
         x.w = 1;
+        x.gsz = 1;
         if constexpr (SELF) {
             const int job = __popcll(__ballot(gend <= (int)item));          // jobs that end at or before this item (empty ones included)
             const int g0 = job > 0 ? __builtin_amdgcn_readlane(gend, job - 1) : 0;
@@ -403,16 +434,19 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             x.q_idx = hd.x;
             x.q_len = hd.y;
             x.q_start = hd.z;
-            if constexpr (CHUNK) {
-                x.w = __builtin_amdgcn_readfirstlane(hd.w >> 8);
-                x.row0 = 8 * (p & (x.w - 1));
-                x.my_c_real = p < (hd.w & 0xff);
-            } else {
-                x.my_c_real = p < hd.w;
-            }
             x.c_idx = rec[4 + p];
             x.c_len = rec[8 + p];
             x.c_start = rec[12 + p];
+            if constexpr (CHUNK) {
+                // slot word (chunk_prep_kernel): length | first group of the candidate << 8 | its groups << 12 | real << 16
+                x.w = __builtin_amdgcn_readfirstlane(hd.w);
+                x.row0 = 8 * (p - ((x.c_len >> 8) & 3));
+                x.gsz = (x.c_len >> 12) & 7;
+                x.my_c_real = ((x.c_len >> 16) & 1) != 0;
+                x.c_len &= 0xff;
+            } else {
+                x.my_c_real = p < hd.w;
+            }
         } else {
             const uint32_t cg = nq == 1 ? item : item / nq;
             const uint32_t q_loc = nq == 1 ? 0 : item - cg * nq;
@@ -451,6 +485,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
         const int c_len = cur.c_len, q_len = cur.q_len, c_start = cur.c_start, q_start = cur.q_start;
         const bool my_c_real = cur.my_c_real;
         const int row0 = cur.row0, cw = cur.w;
+        const bool cwide = CHUNK && (cw == 2 ? cur.gsz == 2 : cur.gsz >= 3);       // this lane's candidate crosses lane groups
         const float* qdoc = a.q.rows + (size_t)q_start * kD;
         const float* sy_doc = a.c.rows + (size_t)c_start * kD;                 // staging group == compute group
         // the query's per-coordinate box; with caller-supplied diameters any readable row stands in (the box term is then
@@ -508,16 +543,26 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                     // the candidate's other chunks sit in the neighbouring lane groups (a chunk past the document's end repeats
                     // its last row: box neutral)
                     if (cw >= 2) {
-                        mn.x = fminf(mn.x, lane_xor<16>(mn.x)); mn.y = fminf(mn.y, lane_xor<16>(mn.y));
-                        mn.z = fminf(mn.z, lane_xor<16>(mn.z)); mn.w = fminf(mn.w, lane_xor<16>(mn.w));
-                        mx.x = fmaxf(mx.x, lane_xor<16>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<16>(mx.y));
-                        mx.z = fmaxf(mx.z, lane_xor<16>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<16>(mx.w));
-                    }
-                    if (cw == 4) {
-                        mn.x = fminf(mn.x, lane_xor<32>(mn.x)); mn.y = fminf(mn.y, lane_xor<32>(mn.y));
-                        mn.z = fminf(mn.z, lane_xor<32>(mn.z)); mn.w = fminf(mn.w, lane_xor<32>(mn.w));
-                        mx.x = fmaxf(mx.x, lane_xor<32>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<32>(mx.y));
-                        mx.z = fmaxf(mx.z, lane_xor<32>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<32>(mx.w));
+                        const float inf = __builtin_inff();
+                        float4 zn = mn, zx = mx;
+                        if (!cwide) {           // a narrower candidate in the item: neutral towards its neighbours, keeps its own box
+                            zn = make_float4(inf, inf, inf, inf);
+                            zx = make_float4(-inf, -inf, -inf, -inf);
+                        }
+                        zn.x = fminf(zn.x, lane_xor<16>(zn.x)); zn.y = fminf(zn.y, lane_xor<16>(zn.y));
+                        zn.z = fminf(zn.z, lane_xor<16>(zn.z)); zn.w = fminf(zn.w, lane_xor<16>(zn.w));
+                        zx.x = fmaxf(zx.x, lane_xor<16>(zx.x)); zx.y = fmaxf(zx.y, lane_xor<16>(zx.y));
+                        zx.z = fmaxf(zx.z, lane_xor<16>(zx.z)); zx.w = fmaxf(zx.w, lane_xor<16>(zx.w));
+                        if (cw == 4) {
+                            zn.x = fminf(zn.x, lane_xor<32>(zn.x)); zn.y = fminf(zn.y, lane_xor<32>(zn.y));
+                            zn.z = fminf(zn.z, lane_xor<32>(zn.z)); zn.w = fminf(zn.w, lane_xor<32>(zn.w));
+                            zx.x = fmaxf(zx.x, lane_xor<32>(zx.x)); zx.y = fmaxf(zx.y, lane_xor<32>(zx.y));
+                            zx.z = fmaxf(zx.z, lane_xor<32>(zx.z)); zx.w = fmaxf(zx.w, lane_xor<32>(zx.w));
+                        }
+                        if (cwide) {
+                            mn = zn;
+                            mx = zx;
+                        }
                     }
                 }
                 if constexpr (!INBOX && !L2MAX) {
@@ -738,9 +783,9 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
                 cv[t] = row0 + 2 * lj + t < c_len;
             }
             const float diam = own_diam ? fmaxf(sqrtf(diam2), kMinDiameter) : a.diameter[q_idx * a.n_groups + c_idx / a.diam_group];      // CROSS only
-            solve_begin<CHUNK>(pend, a, cost, neg, rv, cv, diam, cw);
+            solve_begin<CHUNK>(pend, a, cost, neg, rv, cv, diam, cw, cwide, row0 == 0);
             pend.out = (my_c_real && row0 == 0) ? (mapped ? c_idx : q_idx * a.c.n + c_idx) : (int64_t)-1;
-            if (q_len > 8 || c_len > 8 * cw) pend.valid |= 16u;
+            if (q_len > 8 || c_len > 8 * cur.gsz) pend.valid |= 16u;
             slice = (pend.max_steps + kStages - 1) / kStages;
             have_pend = true;
             F_STAMP(2 + 2 * n_done);
@@ -751,14 +796,17 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 2; ++y) m = fmaxf(m, (2 * li + x < q_len && row0 + 2 * lj + y < c_len) ? neg[x][y] : kNegBig);
-            m = xg_max<CHUNK>(max_li(max_lj(m)), cw);
-            if (q_len > 8 || c_len > 8 * cw) m = __builtin_nanf("");          // longer than the tile: never truncated silently
+            m = xg_max<CHUNK>(max_li(max_lj(m)), cw, cwide);
+            if (q_len > 8 || c_len > 8 * cur.gsz) m = __builtin_nanf("");          // longer than the tile: never truncated silently
             if (my_c_real && lp == 0 && row0 == 0) a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = m;
         } else if (my_c_real && lp == 0) {
             a.scores[mapped ? c_idx : q_idx * a.c.n + c_idx] = diam2;
         }
     }
     F_STAMP(6);
+    // (CHUNK batches are a round and a half of items: a wave in its last solve shares its SIMD with a wave that still streams an
+    // item and paces the launch.  Lowering the solving wave's priority -- s_setprio 2 for the item loop, 0 here -- measured
+    // nothing: 97.6 against 96.7 us on the config-4 shape.)
     if constexpr (SOLVE)
         if (have_pend && !a.skip_tail) solve_finish<CHUNK>(pend, a);   // the wave's last item: nothing left to hide it behind
     F_STAMP(7);
@@ -847,6 +895,16 @@ extern "C" void aspire_debug_fused_buffer(void* p) {
 }
 #endif
 namespace aspire {
+// tsAspire on the same items: the streaming phase with the max epilogue
+int launch_pair_fused_chunk_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream) {
+    const int64_t cap = tuning().fused_waves > 0 ? tuning().fused_waves : 256 * 8;
+    const int64_t waves = items_bound < cap ? items_bound : cap;
+    hipLaunchKernelGGL((pair_fused_kernel<true, false, false, true, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256),
+                       4 * kWaveLds * sizeof(float), stream, a, (const float*)nullptr);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
 // batched jobs with candidates of up to 32 rows against queries of <= 8 (the CHUNK form; items from chunk_prep_kernel)
 int launch_pair_fused_chunk(const ScoreArgs& a_in, int64_t items_bound, const float* qbox, hipStream_t stream) {
     ScoreArgs a = a_in;

@@ -2568,17 +2568,20 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
 }
 
 // Items of the fused kernel's CHUNK form (fused.hip) for batched jobs whose candidates reach 9 .. 32 rows: an item = four 8-row
-// chunks of candidates of ONE job -- four candidates of <= 8 rows, two of 9 .. 16 or one of 17 .. 32.  Block (j, part) sorts its
-// slice of job j's candidates into those three classes (LDS counters), reserves its items with ONE atomicAdd on the launch's
-// item counter (items need not be contiguous per job: a score is stored by candidate index) and writes the 64-byte item
-// records: [0] query, [1] its len, [2] its first row, [3] real chunk slots | lane groups per candidate << 8, [4..7] the
-// slots' candidates, [8..11] their lens, [12..15] their first rows (a partial item's empty slots repeat its first candidate:
-// scored again, stored once).  Block (j, last) forms the query's box, as in batch_prep_kernel.
+// chunk slots holding candidates of ONE job with [4], [3, 1], [2, 2], [2, 1, 1] or [1, 1, 1, 1] chunks (a 2-chunk candidate on
+// slots 0, 1 or 2, 3; a 3-chunk one on 0 .. 2 with a 1-chunk candidate beside it: on the config-4 shape 3300 -> 2950 items, so
+// that no SIMD of the scoring launch holds two waves of two items each).  Block (j, part) counts its slice of job j's candidates
+// by chunk count (LDS counters), reserves its items with ONE atomicAdd on the launch's item counter (items need not be
+// contiguous per job: a score is stored by candidate index), gives every candidate its place by its rank within its class, and
+// writes the 64-byte item records: [0] query, [1] its len, [2] its first row, [3] widest exchange across lane groups the item
+// needs (1, 2, 4), [4..7] the slots' candidates, [8..11] per slot: len | first slot of the candidate << 8 | its slots << 12 |
+// real << 16, [12..15] the slots' first rows.  Slots that stay empty repeat the item's first candidate as a one-chunk
+// candidate (scored, never stored).  Block (j, last) forms the query's box, as in batch_prep_kernel.
 constexpr int kChunkPrepPart = 384;      // candidates per classification block
 __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, float* __restrict__ qbox,
                                                          int32_t* __restrict__ cand_job, int32_t* __restrict__ counter,
                                                          int32_t* __restrict__ grp_rec) {
-    __shared__ int cnt[3], base[3], pos[3];
+    __shared__ int cnt[4], pos[4], base_s;
     const int j = blockIdx.x, tid = threadIdx.x;
     if (blockIdx.y == gridDim.y - 1) {
         const int n = q.len[j];
@@ -2591,53 +2594,74 @@ __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, con
     }
     const int c0 = job_off[j] + blockIdx.y * kChunkPrepPart, c1 = min(job_off[j + 1], c0 + kChunkPrepPart);
     if (c0 >= c1) return;
-    if (tid < 3) cnt[tid] = pos[tid] = 0;
+    if (tid < 4) cnt[tid] = pos[tid] = 0;
     __syncthreads();
-    int len[2], start[2];
+    int len[2], start[2], nch[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int cc = c0 + tid + 192 * r;
         len[r] = cc < c1 ? c.len[cc] : 0;
         start[r] = cc < c1 ? c.start[cc] : 0;
+        nch[r] = min(4, max(1, (len[r] + 7) >> 3));          // chunks (a longer document is poisoned by the kernel)
         if (cc < c1) {
-            atomicAdd(&cnt[len[r] <= 8 ? 0 : len[r] <= 16 ? 1 : 2], 1);
+            atomicAdd(&cnt[nch[r] - 1], 1);
             cand_job[cc] = j;
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        const int i0 = (cnt[0] + 3) >> 2, i1 = (cnt[1] + 1) >> 1, i2 = cnt[2];
-        const int b = atomicAdd(counter, i0 + i1 + i2);
-        base[0] = b;
-        base[1] = b + i0;
-        base[2] = b + i0 + i1;
-    }
+    // the block's items, in this order: [4] x n4, [3, 1] x n3, [2, 2] x n2 / 2, one [2, 1, 1] if n2 is odd, [1, 1, 1, 1] for the
+    // singles the [3, 1] and [2, 1, 1] items have left
+    const int n1 = cnt[0], n2 = cnt[1], n3 = cnt[2], n4 = cnt[3];
+    const int s3 = min(n1, n3);                               // singles beside 3-chunk candidates
+    const int odd2 = n2 & 1, s2 = odd2 ? min(n1 - s3, 2) : 0; // singles beside the odd 2-chunk candidate
+    const int n1r = n1 - s3 - s2, items1 = (n1r + 3) >> 2;
+    if (tid == 0) base_s = atomicAdd(counter, n4 + n3 + (n2 >> 1) + odd2 + items1);
     __syncthreads();
+    const int b4 = base_s, b3 = b4 + n4, b2 = b3 + n3, bo = b2 + (n2 >> 1), b1 = bo + odd2;
     const int q_len = q.len[j], q_start = q.start[j];
+    auto put = [&](int item, int slot, int cc, int ln, int st, int g0, int gsz, int real) {
+        int32_t* rec = grp_rec + (size_t)item * 16;
+        rec[4 + slot] = cc;
+        rec[8 + slot] = ln | (g0 << 8) | (gsz << 12) | (real << 16);
+        rec[12 + slot] = st;
+    };
+    auto head = [&](int item, int w) {
+        int32_t* rec = grp_rec + (size_t)item * 16;
+        rec[0] = j;
+        rec[1] = q_len;
+        rec[2] = q_start;
+        rec[3] = w;
+    };
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int cc = c0 + tid + 192 * r;
         if (cc >= c1) continue;
-        const int cls = len[r] <= 8 ? 0 : len[r] <= 16 ? 1 : 2;
-        const int w = 1 << cls, per = 4 >> cls;            // lane groups per candidate, candidates per item
-        const int ps = atomicAdd(&pos[cls], 1);
-        const int it = ps >> (2 - cls), sub = ps & (per - 1);
-        int32_t* rec = grp_rec + (size_t)(base[cls] + it) * 16;
-        const int in_item = min(per, cnt[cls] - it * per);   // real candidates of this item
-        for (int t = 0; t < w; ++t) {
-            rec[4 + sub * w + t] = cc;
-            rec[8 + sub * w + t] = len[r];
-            rec[12 + sub * w + t] = start[r];
-        }
-        if (sub == 0) {
-            rec[0] = j;
-            rec[1] = q_len;
-            rec[2] = q_start;
-            rec[3] = (in_item * w) | (w << 8);
-            for (int t = in_item * w; t < 4; ++t) {
-                rec[4 + t] = cc;
-                rec[8 + t] = len[r];
-                rec[12 + t] = start[r];
+        const int k = nch[r], ps = atomicAdd(&pos[k - 1], 1), ln = len[r], st = start[r];
+        if (k == 4) {
+            for (int t = 0; t < 4; ++t) put(b4 + ps, t, cc, ln, st, 0, 4, 1);
+            head(b4 + ps, 4);
+        } else if (k == 3) {
+            for (int t = 0; t < 3; ++t) put(b3 + ps, t, cc, ln, st, 0, 3, 1);
+            if (ps >= s3) put(b3 + ps, 3, cc, ln, st, 3, 1, 0);             // no single left for this item
+            head(b3 + ps, 4);
+        } else if (k == 2) {
+            const bool last_odd = odd2 && ps == n2 - 1;
+            const int item = last_odd ? bo : b2 + (ps >> 1), s0 = last_odd ? 0 : 2 * (ps & 1);
+            put(item, s0, cc, ln, st, s0, 2, 1);
+            put(item, s0 + 1, cc, ln, st, s0, 2, 1);
+            if (s0 == 0) head(item, 2);
+            if (last_odd)
+                for (int t = 2 + s2; t < 4; ++t) put(item, t, cc, ln, st, t, 1, 0);
+        } else if (ps < s3) {
+            put(b3 + ps, 3, cc, ln, st, 3, 1, 1);
+        } else if (ps < s3 + s2) {
+            put(bo, 2 + (ps - s3), cc, ln, st, 2 + (ps - s3), 1, 1);
+        } else {
+            const int rr = ps - s3 - s2, item = b1 + (rr >> 2), slot = rr & 3;
+            put(item, slot, cc, ln, st, slot, 1, 1);
+            if (slot == 0) {
+                head(item, 1);
+                for (int t = min(4, n1r - (rr & ~3)); t < 4; ++t) put(item, t, cc, ln, st, t, 1, 0);
             }
         }
     }
@@ -2847,7 +2871,7 @@ L2BatchLayout l2_batch_layout(int64_t J, int64_t C, int64_t max_job, int64_t k) 
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
     L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
-    L.grp_rec = o; o = align16(o + (size_t)(C / 4 + J + 1) * 16 * sizeof(int32_t));
+    L.grp_rec = o; o = align16(o + ((size_t)chunk_items_bound(J, C, max_job) + 1) * 16 * sizeof(int32_t));     // (room for the CHUNK form's items)
     L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));      // (written by the tables kernel, unused by max-sim)
     L.gate = o; o = align16(o + 16);
     L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
@@ -2914,6 +2938,19 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     // (small batches too: a wave walks an item's twelve stages in ~15 us, what a one-workgroup-per-pair launch takes anyway)
     // batches of <= 64 jobs of short documents: the streaming kernel's waves derive the tables themselves (fused.hip, SELF) --
     // one launch in front of the rank, at any size (2 x 20: 19 us either way)
+    // short queries against abstracts of up to 32 rows (config 4's shape): the CHUNK items of ot_rank_batch, max epilogue
+    if (q->max_len <= 8 && max_rows > 8 && max_rows <= 8 * kMaxT && (form_t == 4 || (form_t == 0 && C >= kChunkMinCands)) && !one_form) {
+        ASPIRE_HIP_OK(hipMemsetAsync((int32_t*)(wsb + L.grp_off), 0, sizeof(int32_t), s0));
+        hipLaunchKernelGGL(chunk_prep_kernel, dim3((unsigned)J, (unsigned)chunk_parts(max_job) + 1), dim3(192), 0, s0, a.q, a.c, job_off,
+                           (float*)(wsb + L.qbox), (int32_t*)(wsb + L.cand_job), (int32_t*)(wsb + L.grp_off), (int32_t*)(wsb + L.grp_rec));
+        ASPIRE_LAUNCH_OK();
+        if (int rc = launch_pair_fused_chunk_l2max(a, chunk_items_bound(J, C, max_job), s0)) return rc;
+        const size_t need = aspire_topk_workspace_bytes(J, max_job, k);
+        if (k > 0)
+            return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
+                            need ? wsb + L.topk : nullptr, need, stream, job_off, job_base);
+        return ASPIRE_OK;
+    }
     const bool self = form_t != 1 && max_rows <= 8 && J <= 64 && !tuning().fused_noself && !one_form;
     const bool streaming = form_t != 1 && (self || big || form_t >= 2 || groups_bound >= kL2StreamMinGroups) && !one_form;
     if (!self) {

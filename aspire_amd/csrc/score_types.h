@@ -128,6 +128,7 @@ int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbo
 int launch_fused_repair(const ScoreArgs& a, bool self, int max_rows, hipStream_t stream);
 // CHUNK form: items = four 8-row chunks (chunk_prep_kernel's records in a.grp_rec, their count in a.grp_off[0])
 int launch_pair_fused_chunk(const ScoreArgs& a, int64_t items_bound, const float* qbox, hipStream_t stream);
+int launch_pair_fused_chunk_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);
 int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_t stream, bool self = false);
 bool tile16_path_ok(const aspire_repset* q, const aspire_repset* c, int pairing);
 int launch_pair_tile16_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);

@@ -108,3 +108,29 @@ def test_chunk_form_shared_sentences_hparams_and_plan_similarity(amd):
     with amd.lib.pinned(OT_FORM='small'):
         sims_other, _, _ = _run(amd, queries, cands, off, want=amd.lib.OT_PLAN_SIM)
     np.testing.assert_allclose(sims, sims_other, atol=2e-2 * 2.0, rtol=0)     # plan-similarity noise floor (test_gpu_scoring) x the vectors' scale
+
+
+@pytest.mark.parametrize('seed,sizes,cmax', [(41, [125] * 50, 20), (42, [300, 0, 7, 90, 1], 32)])
+def test_chunk_form_max_sim(amd, seed, sizes, cmax):
+    """tsAspire on the same items (the streaming phase with the max epilogue, fused.hip L2MAX + CHUNK): against the oracle's
+    allpair_masked_dist_l2max and against the one-workgroup-per-candidate kernels on the same jobs."""
+    queries, cands, off = _batch(amd, seed, sizes, cmax=cmax)
+    q = amd.ops.DeviceRepSet.from_list(queries)
+    c = amd.ops.DeviceRepSet.from_list(cands)
+    job_off = torch.tensor(off, dtype=torch.int32).cuda()
+    max_job = int(np.diff(off).max())
+    got, _, top_i = amd.ops.l2max_rank_batch(q, c, job_off, max_job, max_job)
+    with amd.lib.pinned(OT_FORM='small'):
+        other, _, _ = amd.ops.l2max_rank_batch(q, c, job_off, max_job, max_job)
+    got, other, top_i = got.cpu().numpy(), other.cpu().numpy(), top_i.cpu().numpy()
+    np.testing.assert_allclose(got, other, atol=4e-5, rtol=0)
+    rng = np.random.default_rng(seed)
+    for j, n in enumerate(sizes):
+        if n == 0:
+            continue
+        pick = sorted(set([0, n - 1] + rng.integers(0, n, size=min(n, 6)).tolist()))
+        want = [-orc.allpair_masked_dist_l2max(orc.RepLen(queries[j][None].permute(0, 2, 1), [len(queries[j])]),
+                                               orc.RepLen(cands[off[j] + i][None].permute(0, 2, 1), [len(cands[off[j] + i])])).item()
+                for i in pick]
+        np.testing.assert_allclose(got[off[j] + np.array(pick)], want, atol=TOL, rtol=0)
+        assert top_i[j, :n].tolist() == orc.rank_descending(got[off[j]:off[j + 1]].tolist())
