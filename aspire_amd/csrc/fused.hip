@@ -134,6 +134,7 @@ struct Solve {
     f2_t neg[2];           // -cdist of the valid block (plan-weighted similarity output only)
     f2_t wa, wb;           // marginals (pair_distances.py:57-60)
     f2_t f, g;             // potentials
+    float diam;            // the pair's epsilon_0 (the safe re-solve starts the schedule over)
     float r2, h;           // this step's log2e / eps and eps ln2 / 2: through the annealed part of the schedule the next step's
                            // follow by one multiply each (eps *= scaling) -- no transcendental for the constants
     int n_mid;             // annealed values between diam and blur; step k: 0 = diam, 1 .. n_mid, n_mid + 1 = blur, n_mid + 2 = final
@@ -152,6 +153,7 @@ __device__ __forceinline__ void solve_begin(Solve& s, const ScoreArgs& a, const 
     s.w = w;
     s.wide = wide;
     s.first = first;
+    s.diam = diam;
     // ---- marginals: soft-max over sentences of the best match / temp --------------------------------------------------
     const float temp = (float)a.temp;
     {
@@ -323,18 +325,93 @@ __device__ __forceinline__ float solve_output(const Solve& s, const ScoreArgs& a
     return score;
 }
 
+// The fast solve shifts its log-sum-exps by the previous potential instead of a maximum: sums stay ~1 and six cross-lane steps leave
+// the chain, but a sum CAN leave fp32 range -- scaling below ~0.03, or, at any scaling, a candidate that shares a sentence with
+// the query on large vectors (a zero cost beside costs of ~80).  Such a pair used to be poisoned with NaN and re-solved by a
+// launch behind every scoring launch (4.7 us of a 108 us call, nearly always for nothing).  Now the wave that finds a poisoned
+// pair solves it again on the spot in geomloss's own form -- log-weights in the exponent (a weight of zero: -100000), every
+// log-sum-exp shifted by its maximum, the schedule from the top: epsilon = diam twice, then x scaling down to blur, averaged
+// updates, one simultaneous un-averaged update at blur (sinkhorn_loop of geomloss 0.2.4).  Rare and short.
+template <bool XG>
+__device__ __forceinline__ float solve_safe(Solve& s, const ScoreArgs& a) {
+    const bool rv[2] = {(s.valid & 1u) != 0, (s.valid & 2u) != 0}, cv[2] = {(s.valid & 4u) != 0, (s.valid & 8u) != 0};
+    float la[2], lb[2], f[2], g[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        la[t] = (rv[t] && s.wa[t] > 0.f) ? logf(s.wa[t]) : -100000.f;
+        lb[t] = (cv[t] && s.wb[t] > 0.f) ? logf(s.wb[t]) : -100000.f;
+        f[t] = g[t] = 0.f;
+    }
+    // one pair of softmins at eps from potentials (fi, gi): ft_x = -eps LSE_y(lb_y + (gi_y - C_xy) / eps), gt_y likewise
+    auto softmins = [&](float eps, const float (&fi)[2], const float (&gi)[2], float (&ft)[2], float (&gt)[2]) {
+        const float re = 1.0f / eps;
+        float ar[2][2], ac[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                ar[x][y] = lb[y] + (gi[y] - s.mc[x][y]) * re;
+                ac[x][y] = la[x] + (fi[x] - s.mc[x][y]) * re;
+            }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float m = xg_max<XG>(max_lj(fmaxf(ar[x][0], ar[x][1])), s.w, s.wide);
+            const float e = xg_sum<XG>(sum_lj(expf(ar[x][0] - m) + expf(ar[x][1] - m)), s.w, s.wide);
+            ft[x] = -eps * (m + logf(e));
+        }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const float m = max_li(fmaxf(ac[0][y], ac[1][y]));
+            const float e = sum_li(expf(ac[0][y] - m) + expf(ac[1][y] - m));
+            gt[y] = -eps * (m + logf(e));
+        }
+    };
+    // the wave's pairs run their own schedules; the loop goes to the longest (wave-uniform), a finished pair idles
+    int n_max = s.n_mid;
+    n_max = max(n_max, __shfl_xor(n_max, 16));
+    n_max = max(n_max, __shfl_xor(n_max, 32));
+    n_max = __builtin_amdgcn_readfirstlane(n_max);
+    const float eb = (float)a.blur, scal = (float)a.scaling;
+    float ft[2], gt[2];
+    softmins(s.diam, f, g, ft, gt);          // initialisation at eps_0 = diam
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f[t] = ft[t];
+        g[t] = gt[t];
+    }
+    float eps = s.diam;
+#pragma unroll 1
+    for (int k = 0; k <= n_max + 1; ++k) {   // k = 0: diam, 1 .. n_mid: diam scaling^(k-1) (the first of them diam again), n_mid + 1: blur
+        const bool mine = k <= s.n_mid + 1;
+        const float e = k > s.n_mid ? eb : eps;
+        softmins(e, f, g, ft, gt);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f[t] = mine ? 0.5f * (f[t] + ft[t]) : f[t];
+            g[t] = mine ? 0.5f * (g[t] + gt[t]) : g[t];
+        }
+        if (k >= 1) eps *= scal;
+    }
+    softmins(eb, f, g, ft, gt);              // the last extrapolation: both from the previous pair, not averaged
+    return solve_output<XG>(s, a, f2_t{ft[0], ft[1]}, f2_t{gt[0], gt[1]});
+}
+
 // finish a solve: remaining steps, the score, the store
 template <bool XG = false>
 __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
     solve_steps<XG>(s, a, -1);
     float score = solve_output<XG>(s, a, s.f, s.g);
-    // An overflowed / vanished sum (extreme scaling) has turned into inf / nan that sticks to the potentials and reaches
-    // the score: the pair is poisoned with NaN and solved again by the long-form kernel that follows (launch_pair_fused);
-    // so is a document longer than the tile -- never truncated silently.
-    if (!(fabsf(score) < 1e30f) || (s.valid & 16u)) score = __builtin_nanf("");
-    // ... and a clearly NEGATIVE transport cost (an entropic OT value is >= 0 up to rounding): sums that left fp32 range on the
-    // way and came back finite (seen with a sentence shared by query and candidate on large vectors)
-    if (a.want != ASPIRE_OT_PLAN_SIM && (a.want == ASPIRE_OT_SIMILARITY ? score : -score) > 1e-2f) score = __builtin_nanf("");
+    // an overflowed / vanished sum has turned into inf / nan that sticks to the potentials and reaches the score; so does a clearly
+    // NEGATIVE transport cost (an entropic OT value is >= 0 up to rounding): sums that left fp32 range on the way and came back
+    // finite (seen with a sentence shared by query and candidate on large vectors)
+    bool bad = !(fabsf(score) < 1e30f);
+    if (a.want != ASPIRE_OT_PLAN_SIM && (a.want == ASPIRE_OT_SIMILARITY ? score : -score) > 1e-2f) bad = true;
+    if (__any(bad && !(s.valid & 16u))) {
+        const float again = solve_safe<XG>(s, a);
+        if (bad) score = again;
+    }
+    // a document longer than the tile is never truncated silently: NaN, for the kernels queued behind this one (hybrid forms)
+    if (s.valid & 16u) score = __builtin_nanf("");
     if (s.out >= 0 && (threadIdx.x & 15) == 0) a.scores[s.out] = score;
 }
 
@@ -846,7 +923,7 @@ int launch_pair_fused_l2max(const ScoreArgs& a, int64_t groups_bound, hipStream_
 }
 
 // groups_bound: upper bound of the launch's items (groups of four candidates x queries)
-int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, hipStream_t stream, bool repair) {
+int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* qbox, hipStream_t stream) {
     // two 4-wave workgroups per CU are resident.  (Built for three -- 168 registers, the kernel-invariant values spilled,
     // the norm table already shares the stage buffer so the LDS fits -- the 20 x 1000 call went from 120 to 144 us.)
     ScoreArgs a = a_in;
@@ -883,7 +960,6 @@ int launch_pair_fused(const ScoreArgs& a_in, int64_t groups_bound, const float* 
     }
     else hipLaunchKernelGGL((pair_fused_kernel<true, true>), grid, dim3(256), lds, stream, a, qbox);
     ASPIRE_LAUNCH_OK();
-    if (repair) return launch_fused_repair(a, self, 8, stream);
     return ASPIRE_OK;
 }
 
@@ -918,18 +994,6 @@ int launch_pair_fused_chunk(const ScoreArgs& a_in, int64_t items_bound, const fl
         hipLaunchKernelGGL((pair_fused_kernel<true, true, false, false, false, true>), grid, dim3(256), 4 * kWaveLds * sizeof(float), stream, a, qbox);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
-}
-
-// The fused kernel's shifted sums can leave fp32 range -- scaling below ~0.03 (the exponent of K grows by 1 / scaling from one
-// step to the next), or, at ANY scaling, a candidate that shares a sentence with the query when the vectors are large (a zero
-// cost next to costs of ~80: found by the fuzz sweep at 2 x N(0,1)) -- and poison the pair's score with NaN: this launch
-// re-solves exactly those pairs with geomloss's own max-shifted formulation (one workgroup per pair, all but the NaN ones
-// return at once).  self: the launch had no candidate -> job table (the kernel searches job_off).
-int launch_fused_repair(const ScoreArgs& a_in, bool self, int max_rows, hipStream_t stream) {
-    ScoreArgs a = a_in;
-    if (self) a.qmap = nullptr;
-    a.gate = nullptr;
-    return launch_pair_generic(a, 2, 0, max_rows, max_rows, stream);
 }
 
 }  // namespace aspire

@@ -59,8 +59,6 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 }
 
 // mode 0: otAspire (a.want, extras);  mode 1: tsAspire max-sim (a.scores = max over valid entries of -cdist, pair_sims);
-// mode 2: otAspire for exactly the pairs whose score is NaN (the fused kernel's poisoned pairs: overflowed sums at extreme
-// scaling, documents longer than its tile)
 __device__ __forceinline__ void pair_generic_body(const ScoreArgs& a, int mode, int skip_up_to, int rows_q, int rows_c, int64_t p,
                                                   float* lds) {
     const int tid = threadIdx.x;
@@ -275,28 +273,6 @@ __global__ void __launch_bounds__(kGenThreads) pair_generic_kernel(ScoreArgs a, 
     pair_generic_body(a, mode, skip_up_to, rows_q, rows_c, p, lds);
 }
 
-// mode 2: otAspire for exactly the pairs whose score is NaN.  A workgroup scans 64 scores (every wave takes the same ballot)
-// and solves the poisoned ones one after the other -- a launch that usually finds nothing costs a few microseconds
-// (one workgroup per pair, 20 000 of them returning at once, was 13 us).
-__global__ void __launch_bounds__(kGenThreads) pair_generic_repair_kernel(ScoreArgs a, int rows_q, int rows_c) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63;
-    const int64_t base = ((int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x) * 64;
-    const int64_t P = a.pairing != ASPIRE_PAIR_CROSS ? a.c.n : a.q.n * a.c.n;
-    bool bad = false;
-    if (base + lane < P) {
-        const float s = a.scores[base + lane];
-        bad = s != s;
-    }
-    unsigned long long todo = __ballot(bad);
-    while (todo) {
-        const int k = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        pair_generic_body(a, 0, 0, rows_q, rows_c, base + k, lds);
-        __syncthreads();
-    }
-}
-
 }  // namespace
 
 int generic_max_rows(void) { return 128; }
@@ -312,15 +288,6 @@ int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q
     if (lds_bytes > 64 * 1024) {      // more than the default dynamic LDS limit: raise it (per function, sticky, harmless to repeat)
         ASPIRE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024));
-        ASPIRE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_generic_repair_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-    if (mode == 2) {
-        const int64_t wgs = (P + 63) / 64, gx = wgs < 1048576 ? wgs : 1048576, gy2 = (wgs + gx - 1) / gx;
-        ASPIRE_REQUIRE(gy2 <= 65535, ASPIRE_ERR_UNSUPPORTED, "too many pairs (%lld) for the long-document kernel", (long long)P);
-        hipLaunchKernelGGL(pair_generic_repair_kernel, dim3((unsigned)gx, (unsigned)gy2), dim3(kGenThreads), lds_bytes, stream, a, rows_q, rows_c);
-        ASPIRE_LAUNCH_OK();
-        return ASPIRE_OK;
     }
     // grid.x * grid.y >= P with grid.y <= 65535: pair = x + y * grid.x
     const int64_t gxx = P < 1048576 ? P : 1048576;

@@ -2419,7 +2419,6 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         }
         if (int rc = launch_pair_fused(a, groups4_all, inbox ? nullptr : qbox, (hipStream_t)stream)) return rc;
     }
-    bool hybrid1 = false;
     // ONE short query against a big pool whose documents reach 9 .. 16 rows: the hybrid of ot_rank_batch -- the fused kernel in
     // front of the 16-row kernels, a census of the long pairs on the device decides who scores what (ScoreArgs::gate).  The
     // counter lives in the 32 spare bytes in front of the query boxes.
@@ -2433,8 +2432,7 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         ASPIRE_LAUNCH_OK();
         a.gate = gate;
         a.gate_limit = (int32_t)(c->n / 24);
-        if (int rc = launch_pair_fused(a, groups4_all, nullptr, (hipStream_t)stream, false)) return rc;
-        hybrid1 = true;
+        if (int rc = launch_pair_fused(a, groups4_all, nullptr, (hipStream_t)stream)) return rc;
     }
     const int rc_run = fused ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
@@ -2454,11 +2452,6 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         return (int)ASPIRE_OK;
     });
     if (rc_run) return rc_run;
-    if (hybrid1) {      // the fused kernel's overflowed short pairs, behind the kernels that rewrote the long ones
-        a.cand0 = 0;
-        a.cand1 = c->n;
-        if (int rc = launch_fused_repair(a, false, 16, (hipStream_t)stream)) return rc;
-    }
     if (rank.k > 0) {
         // the rank kernels follow the scores on the same stream (their scratch sits behind the OT workspace proper,
         // which aspire_ot_workspace_bytes keeps a multiple of 16 bytes)
@@ -2792,7 +2785,6 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
                            cand_job, grp_off, grp_rec);
         ASPIRE_LAUNCH_OK();
         if (int rc = launch_pair_fused_chunk(a, chunk_items_bound(J, C, max_job), qbox, s0)) return rc;
-        if (int rc = launch_fused_repair(a, false, 8 * kMaxT, s0)) return rc;
         if (k > 0)
             return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
                             topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);
@@ -2817,11 +2809,11 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
         ASPIRE_LAUNCH_OK();
         a.gate = gate;
         a.gate_limit = (int32_t)(C / 24);     // up to ~4 % long pairs (measured crossover at 20 x 1000: 5 %): fused kernel + the 16-row kernels on the long pairs only
-        if (int rc = launch_pair_fused(a, groups_bound, qbox, s0, false)) return rc;
+        if (int rc = launch_pair_fused(a, groups_bound, qbox, s0)) return rc;
     }
     if (fused) {
         if (stages & (kStageCost | kStageSolve))
-            if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0, false)) return rc;
+            if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0)) return rc;
     } else {
         const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
             constexpr int T = decltype(tc)::value;
@@ -2839,10 +2831,6 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
         if (max_rows_all > max_rows && (stages & kStageSolve))
             if (int rc = launch_pair_generic(a, 0, max_rows, q->max_len, c->max_len, s0)) return rc;
     }
-    // the fused kernel's overflowed pairs (NaN) re-solved in the max-shifted form: behind the kernels that rewrite the long
-    // pairs (hybrid), in front of the rank; counted with the rank stage by the stage-timing entry
-    if ((fused || hybrid) && (stages & kStageRank))
-        if (int rc = launch_fused_repair(a, self, hybrid ? 16 : 8, s0)) return rc;
     if (k > 0 && (stages & kStageRank))
         return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
                         topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);

@@ -122,10 +122,8 @@ int launch_pair_generic(const ScoreArgs& a, int mode, int skip_up_to, int rows_q
 bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm);
 bool fused_inbox_ok(const aspire_repset* q, const float* diameter);
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
-// repair: follow up with launch_fused_repair (callers that time the kernel alone, or queue other kernels that rewrite poisoned
-// pairs first, pass false and launch it themselves)
-int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream, bool repair = true);
-int launch_fused_repair(const ScoreArgs& a, bool self, int max_rows, hipStream_t stream);
+// (a pair whose shifted sums leave fp32 range is solved again in the max-shifted form by the wave that finds it: fused.hip, solve_safe)
+int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
 // CHUNK form: items = four 8-row chunks (chunk_prep_kernel's records in a.grp_rec, their count in a.grp_off[0])
 int launch_pair_fused_chunk(const ScoreArgs& a, int64_t items_bound, const float* qbox, hipStream_t stream);
 int launch_pair_fused_chunk_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);

@@ -44,10 +44,12 @@ def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, metho
     from . import scorer
     results = {}
     query_ids = list(test_pool.keys())
+    all_resident = False
     if resident:
         wanted = [c for pool in test_pool.values() for c in pool['cands']]
         if wanted and not rep_store.resident(wanted):
             rep_store.to_device(wanted)
+        all_resident = bool(wanted)
 
     def query_reps(query_id):
         return rep_store.faceted(query_id, facet, pred_labels[query_id]) if facet is not None else rep_store.get(query_id)
@@ -55,8 +57,17 @@ def score(results_dir, test_pool, rep_store, facet=None, pred_labels=None, metho
     if schedule == 'pair' and method in ('ot', 'l2max') and queries_per_call > 1:
         for lo in range(0, len(query_ids), queries_per_call):
             ids = query_ids[lo:lo + queries_per_call]
-            pools = [rep_store.pool(list(test_pool[i]['cands'])) for i in ids]
-            ranked = scorer.rank_pools([query_reps(i) for i in ids], pools, method=method, hparams=hparams)
+            cand_lists = [test_pool[i]['cands'] for i in ids]
+            if resident and all_resident:
+                # the pools' device tables are built once and cached (RepStore.pool_batch): one upload of the queries, one call;
+                # evaluate.py:77 stores -similarity
+                ranked = scorer.rank_pool_batch([query_reps(i) for i in ids], rep_store.pool_batch(cand_lists), method=method,
+                                                hparams=hparams, sign=-1.0)
+                results.update(zip(ids, ranked))
+                continue
+            else:
+                pools = [rep_store.pool(list(cl)) for cl in cand_lists]
+                ranked = scorer.rank_pools([query_reps(i) for i in ids], pools, method=method, hparams=hparams)
             for query_id, r in zip(ids, ranked):
                 results[query_id] = [(cid, -1 * sim) for cid, sim in r]     # evaluate.py:77
     else:

@@ -92,6 +92,25 @@ class RepStore:
         idx = getattr(self, '_dev_index', None)
         return idx is not None and all(p in idx for p in pids)
 
+    def pool_batch(self, pid_lists):
+        """The pools of several queries (each a list of paper ids, pool order) as ONE scorer.PoolBatch over the resident matrix:
+        the jobs' index lists and offsets are built and uploaded once and cached by content -- the next score step over the same
+        pools (another facet, another aggregation) re-uses the device tables.  Needs `to_device` to hold every paper."""
+        from .scorer import PoolBatch
+        key = tuple(tuple(p) for p in pid_lists)
+        cache = self.__dict__.setdefault('_batch_cache', {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] is self._dev_rows:
+            return hit[1]
+        idx = self._dev_index
+        where = [[idx[p] for p in pids] for pids in key]
+        batch = PoolBatch(self._dev_rows, [np.fromiter((s for s, _ in w), dtype=np.int64, count=len(w)) for w in where],
+                          [np.fromiter((n for _, n in w), dtype=np.int64, count=len(w)) for w in where], key)
+        if len(cache) >= 64:
+            cache.clear()
+        cache[key] = (self._dev_rows, batch)
+        return batch
+
     def pool(self, pids):
         """The reps of `pids` (in this order = pool order) as a CandidatePool on the GPU: index lists into the resident matrix
         when `to_device` holds all of them, else uploaded now."""

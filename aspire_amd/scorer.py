@@ -10,6 +10,8 @@ Here a whole candidate pool is scored by ONE launch against sentence reps that s
 two reference loops differ only in how geomloss's epsilon schedule is grouped, which is the
 ``schedule`` argument.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -41,6 +43,79 @@ class CandidatePool:
 
 def _as_pool(x):
     return x if isinstance(x, CandidatePool) else CandidatePool(x)
+
+
+class PoolBatch:
+    """J candidate pools over ONE resident row matrix, laid back to back the way aspire_ot_rank_batch_f32 takes them: the jobs'
+    (start, len) index lists and job_off, uploaded ONCE as one int32 buffer and kept.  RepStore.pool_batch builds (and caches)
+    them, so that a score step over the same pools -- another facet, another aggregation, the next repetition -- re-uses the
+    device tables instead of rebuilding them per call (torch.cat + cumsum + small uploads were ~100 x the kernels' time on the
+    config-4 shape)."""
+
+    def __init__(self, rows, starts, lens, pids_list):
+        dev = rows.device
+        self.sizes = [len(x) for x in lens]
+        self.pids = [np.asarray(p, dtype=object) for p in pids_list]
+        c_total = int(sum(self.sizes))
+        flat_start = np.concatenate(starts).astype(np.int32) if c_total else np.zeros(0, np.int32)
+        flat_len = np.concatenate(lens).astype(np.int32) if c_total else np.zeros(0, np.int32)
+        if c_total and int(flat_len.min()) <= 0:
+            raise ValueError('a document without sentence rows cannot be scored (the reference raises on it: pair_distances.py:57)')
+        job_off = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int32)
+        meta = torch.from_numpy(np.concatenate([flat_start, flat_len, job_off])).to(dev)
+        self.max_job = max(self.sizes) if self.sizes else 0
+        self.job_off = meta[2 * c_total:]
+        self.c = ops.DeviceRepSet(rows, meta[:c_total], meta[c_total:2 * c_total], ext=0,
+                                  max_len=int(flat_len.max()) if c_total else 0) if c_total else None
+        self._out = {}          # (k, key_form) -> preallocated outputs + workspace of the last call with that k
+
+
+def rank_pool_batch(query_reps_list, batch, k=None, hparams=None, method='ot', deterministic=False, sign=1.0):
+    """rank_pools on a prepared PoolBatch (RepStore.pool_batch): ONE upload of the queries (rows + index list), one library call,
+    two small downloads.  Returns per query [(pid, sign * score), ...] as rank_pools does (evaluate.py:77 stores -similarity:
+    sign = -1 negates on the way out, one numpy multiply instead of a Python loop over the pairs)."""
+    hparams = hparams or {}
+    if method not in ('ot', 'l2max'):
+        raise ValueError(f'Unknown aggregation: {method}')
+    if hparams.get('geoml_reach', None) is not None:
+        raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
+    assert len(query_reps_list) == len(batch.sizes), 'one pool per query'
+    if batch.max_job == 0:
+        return [[] for _ in batch.sizes]
+    k = batch.max_job if k is None else min(k, batch.max_job)
+    dev = batch.c.rows.device
+    q_lens = [int(np.shape(r)[0]) for r in query_reps_list]
+    if min(q_lens) <= 0:
+        raise ValueError('a document without sentence rows cannot be scored (the reference raises on it: pair_distances.py:57)')
+    q_rows = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.float32) for r in query_reps_list], 0))).to(dev)
+    q_len_np = np.asarray(q_lens, dtype=np.int32)
+    q_meta = torch.from_numpy(np.concatenate([np.cumsum(q_len_np) - q_len_np, q_len_np]).astype(np.int32)).to(dev)
+    j = len(q_lens)
+    q = ops.DeviceRepSet(q_rows, q_meta[:j], q_meta[j:], ext=0, max_len=max(q_lens))
+    slot = batch._out.get((k, method))
+    if slot is None:
+        slot = batch._out[(k, method)] = {
+            'out': (torch.empty(batch.c.n, device=dev), torch.empty(j, k, device=dev), torch.empty(j, k, device=dev, dtype=torch.int64)),
+            'ws': None}
+    if method == 'l2max':
+        qs, cs = q.struct(), batch.c.struct()
+        if slot['ws'] is None:
+            slot['ws'] = torch.empty(max(_lib.lib.aspire_l2max_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), batch.max_job, k), 16), device=dev, dtype=torch.uint8)
+        _, top_s, top_i = ops.l2max_rank_batch(q, batch.c, batch.job_off, batch.max_job, k, out=slot['out'], workspace=slot['ws'],
+                                               one_form=deterministic)
+    else:
+        qs, cs = q.struct(), batch.c.struct()
+        if slot['ws'] is None:
+            slot['ws'] = torch.empty(max(_lib.lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), batch.max_job, k), 16), device=dev, dtype=torch.uint8)
+        _, top_s, top_i = ops.ot_rank_batch(q, batch.c, batch.job_off, batch.max_job, k, blur=hparams.get('geoml_blur', 0.05),
+                                            scaling=hparams.get('geoml_scaling', 0.9), sent_sm_temp=hparams.get('sent_sm_temp', 1.0),
+                                            want=_lib.OT_SIMILARITY, out=slot['out'], workspace=slot['ws'], one_form=deterministic)
+    top_s, top_i = top_s.cpu().numpy().astype(np.float64) * sign, top_i.cpu().numpy()
+    ranked = []
+    for pids, n, rs, ri in zip(batch.pids, batch.sizes, top_s, top_i):
+        kk = min(k, n)
+        ranked.append(list(zip(pids[ri[:kk]].tolist(), rs[:kk].tolist())))
+    return ranked
 
 
 def _cdist_runs(q, c, group):

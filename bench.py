@@ -11,7 +11,7 @@ per pair, AspireModel.get_similarity) of the 1000 pairs, then the stable descend
 are K independent (query, pool) jobs and go through ONE library call, aspire_ot_rank_batch_f32 -- a small launch that
 builds the job tables and query boxes (batches of more than 64 jobs only), ONE scoring launch over the K x 1000 pairs (costs and Sinkhorn solves fused: a
 wave streams four candidates' rows, then solves those four pairs from its registers while other waves stream), one
-K-workgroup rank launch.  No hipGraphs.  Consecutive calls are independent requests and go round-robin over --streams
+K-workgroup rank launch -- two launches per call.  No hipGraphs.  Consecutive calls are independent requests and go round-robin over --streams
 caller streams (default 3), each with its own outputs and workspace: the end of one call (the last Sinkhorn solves,
 the rank launch -- neither touches HBM) overlaps the next call's streaming.  `one_stream` in the JSON is the same schedule
 with one call at a time.
@@ -468,7 +468,7 @@ def main():
                          'l3_resident_frac': algorithmic_bytes(n_l3) / (cost_l3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cost_l3_ms else None,
                          'l3_resident': {'jobs': n_l3, 'kernel_ms': cost_l3_ms, 'bytes': algorithmic_bytes(n_l3)},
                          'stages_ms': {'tables+boxes': prep_ms, 'score': cost_ms, 'rank': rank_ms, 'call_elapsed': elapsed / R * 1e3,
-                                       'note': 'rank = the overflow-repair scan behind the scoring kernel (~5 us, usually finds nothing) + the rank launch'},
+                                       'note': 'score = ONE launch (costs + Sinkhorn solves; a pair whose shifted sums leave fp32 range is re-solved in the max-shifted form by the wave that finds it), rank = the rank launch'},
                          'two_kernel_form': {'cost_ms': cost_only_ms, 'sinkhorn_ms': solve_only_ms,
                                              'cost_frac': bytes_per_launch / (cost_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cost_only_ms else None},
                          'step': {'what': 'all kernels of a schedule (timed region, calls in flight as configured) against the same '

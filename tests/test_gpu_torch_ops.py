@@ -110,4 +110,10 @@ def test_bert_encoder_op_matches_the_encoder_class(amd):
               sd[p + 'output.LayerNorm.weight'], sd[p + 'output.LayerNorm.bias']]
     w = [t.detach().float().cuda().contiguous() for t in w]
     got = torch.ops.aspire.bert_encoder_forward(tok.cuda(), seg.cuda(), mask.cuda(), w, 12, 1e-12)
-    assert torch.equal(got, want)
+    # the op takes bare weight tensors (no prepared bf16 planes: its GEMMs split their operands on the fly), the class streams
+    # pre-split operands: the same six products per term in another launch geometry -- equal to fp32 rounding, and bit-equal once
+    # the class is pinned to the on-the-fly form
+    assert torch.allclose(got, want, atol=2e-5, rtol=0)
+    from aspire_amd._lib import pinned
+    with pinned(GEMM='bf16x3'):
+        assert torch.equal(got, enc.forward_hidden(tok, seg, mask))
