@@ -998,7 +998,7 @@ __device__ __forceinline__ float box_partial(const RowSet& r) {
 // streams): at 197 registers two of these waves leave room for two 52-register Sinkhorn waves; at 256 nothing fits beside
 // them and overlapped throughput fell from ~110 to ~70 M alignments/s with every kernel's own time unchanged.
 // tests/test_abi_cpu.py pins the budgets.  (Superseded forms -- one register set with buffer loads, a matrix-core
-// form, cost + solve fused per workgroup -- are described in DESIGN.md "Tried and dropped".)
+// form, cost + solve fused per workgroup -- are described in NOTES.md "Tried and dropped".)
 template <bool SUB>
 __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs<1>& ws, uint32_t T_rt, float* lds) {
     const uint32_t T = SUB ? T_rt : 1u;

@@ -262,7 +262,7 @@ int aspire_topk_desc_f32(const float* scores, int64_t Q, int64_t C, int64_t k, i
  * scores [Q, C] exactly as aspire_ot_sinkhorn_f32 (pairing = ASPIRE_PAIR_CROSS, no pair outputs) followed by the
  * per-query rank exactly as aspire_topk_desc_f32 (top_scores, top_idx) or aspire_topk_keys_f32 (keys != NULL).
  * One host call, the kernels queued back to back on `stream`.  (A variant with the rank fused into the Sinkhorn
- * kernel's last workgroup was measured slower than the separate rank kernel -- DESIGN.md -- and is not kept.)
+ * kernel's last workgroup was measured slower than the separate rank kernel -- NOTES.md -- and is not kept.)
  * Workspace: aspire_ot_rank_workspace_bytes(q, c, k).
  * ------------------------------------------------------------------------------------------- */
 size_t aspire_ot_rank_workspace_bytes(const aspire_repset* q, const aspire_repset* c, int64_t k);

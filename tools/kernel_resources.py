@@ -4,7 +4,7 @@
 
 The shared library carries one clang offload bundle per translation unit; each holds a gfx950 ELF whose
 NT_AMDGPU_METADATA note (msgpack) lists .vgpr_count / .sgpr_count / .group_segment_fixed_size per kernel.
-tests/test_abi_cpu.py uses this to pin the budgets that co-residency depends on ("register budgets").
+tests/test_abi_cpu.py uses this to pin the budgets that co-residency depends on (NOTES.md, section 3).
 """
 import re
 import struct
