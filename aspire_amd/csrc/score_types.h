@@ -132,5 +132,8 @@ bool tile16_path_ok(const aspire_repset* q, const aspire_repset* c, int pairing)
 int launch_pair_tile16_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);
 int launch_pair_tile16(const ScoreArgs& a, float* cost, float* neg, float* diam2, int64_t items_bound, const float* qbox,
                        hipStream_t stream);
+int launch_pair_tile16_rec(const ScoreArgs& a, int T, float* cost, float* neg, float* diam2, int64_t items_bound, const float* qbox,
+                           hipStream_t stream);
+int launch_pair_tile16_rec_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);
 
 }  // namespace aspire

@@ -39,8 +39,13 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 
 // L2MAX: tsAspire on the same streaming phase -- the score is the maximum of -cdist over the valid block
 // (allpair_masked_dist_l2max, pair_distances.py:167-176); no boxes, nothing goes to the workspace.
-template <bool L2MAX>
-__global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs<2> ws, const float* __restrict__ qbox) {
+// REC (batched jobs with documents of 17 .. 32 rows: whole abstracts on both sides, pp_settings.py:2-3): the items come from
+// chunk16_prep_kernel's records -- a 16-row half of the query against two candidates of <= 16 rows or against the two halves of
+// ONE candidate of 17 .. 32 (its box then joins across the wave's two candidate slots) -- and a pair's 16 x 16 blocks land in
+// workspace slots of TW x TW tiles of 8 (TW = 3, 4), which sinkhorn_block_kernel<TW, ..> solves.  (Before: the VALU tile loop.)
+template <bool L2MAX, int TW = 2, bool REC = false>
+__global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs<TW> ws, const float* __restrict__ qbox) {
+    constexpr int LDW = 8 * TW, EW = 64 * TW * TW;            // workspace slot: row stride, entries
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const bool selective = gate_few_long(a);                // hybrid: only the pairs that hold a document of more than 8 rows
     const int lane = threadIdx.x & 63;
@@ -51,8 +56,9 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
     const uint32_t nq = mapped ? 1u : (uint32_t)a.q.n;
     const uint32_t ncand = (uint32_t)(a.cand1 - a.cand0);
     // MAPPED: the job tables count groups of FOUR candidates (batch_prep_kernel); an item is half of one
-    const uint32_t g4_lo = mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
-    const uint32_t n_items = mapped ? 2u * ((uint32_t)a.grp_off[a.job1] - g4_lo) : ((ncand + 1) / 2) * nq;   // CROSS: (pair of candidates, query), group-major
+    const uint32_t g4_lo = (mapped && !REC) ? (uint32_t)a.grp_off[a.job0] : 0u;
+    const uint32_t n_items = REC ? (uint32_t)a.grp_off[0]        // the item counter chunk16_prep_kernel has left
+                                 : mapped ? 2u * ((uint32_t)a.grp_off[a.job1] - g4_lo) : ((ncand + 1) / 2) * nq;   // CROSS: (pair of candidates, query), group-major
     const uint32_t n_waves = gridDim.x * 4;
     const bool own_diam = a.diameter == nullptr && !L2MAX;
 
@@ -62,11 +68,30 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
     struct Ctx {
         int64_t c_idx, q_idx, slot;
         int c_len, q_len, c_start, q_start;
-        bool my_c_real;
+        int qrow0, crow0;      // REC: first row of the query half / of this slot's candidate half
+        bool my_c_real, wide;  // REC: wide = the wave's two slots are the halves of one candidate
     };
     auto load_ctx = [&](uint32_t item) {
         Ctx x;
+        x.qrow0 = x.crow0 = 0;
+        x.wide = false;
         uint32_t q_loc, c_loc0, c_end;
+        if constexpr (REC) {
+            const int32_t* rec = a.grp_rec + (size_t)item * 16;
+            const int4 hd = *reinterpret_cast<const int4*>(rec);
+            x.q_idx = hd.x;
+            x.q_len = hd.y;
+            x.q_start = hd.z;
+            x.qrow0 = 16 * (hd.w & 1);
+            x.wide = (hd.w >> 8) != 0;
+            x.c_idx = rec[4 + cs];
+            x.c_len = rec[6 + cs];
+            x.c_start = rec[8 + cs];
+            x.crow0 = rec[10 + cs];
+            x.my_c_real = rec[12 + cs] != 0;
+            x.slot = x.c_idx;
+            return x;
+        }
         if (mapped) {
             const uint32_t g4 = g4_lo + (item >> 1);
             q_loc = (uint32_t)a.grp_job[g4];
@@ -97,6 +122,8 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
         next = load_ctx(item + n_waves < n_items ? item + n_waves : item);      // one item ahead (fused.hip)
         const int64_t q_idx = cur.q_idx, slot = cur.slot;
         const int c_len = cur.c_len, q_len = cur.q_len, c_start = cur.c_start;
+        const int qrow0 = cur.qrow0, crow0 = cur.crow0;
+        const bool wide = cur.wide;
         if (selective && !__any(cur.my_c_real && (cur.q_len > 8 || cur.c_len > 8))) continue;      // the fused kernel scored this item
         const bool my_c_real = cur.my_c_real && (!selective || cur.q_len > 8 || cur.c_len > 8);
         const float* qdoc = a.q.rows + (size_t)cur.q_start * kD;
@@ -120,13 +147,13 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
         auto issue_loads = [&](int st) {
             const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vy[j] = ld4_stream(sy_doc + (size_t)min(8 * hp + j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
+            for (int j = 0; j < 8; ++j) vy[j] = ld4_stream(sy_doc + (size_t)min(crow0 + 8 * hp + j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
             if constexpr (!L2MAX) {
                 qmn = ld4(qb + dofs);
                 qmx = ld4(qb + qb_hi + dofs);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) vx[k] = ld4(qdoc + (size_t)min(4 * p + k, q_len - 1) * kD + dofs);
+            for (int k = 0; k < 4; ++k) vx[k] = ld4(qdoc + (size_t)min(qrow0 + 4 * p + k, q_len - 1) * kD + dofs);
         };
         auto sq_acc = [](f2_t acc, const float4& v) {
             acc = __builtin_elementwise_fma(f2_t{v.x, v.y}, f2_t{v.x, v.y}, acc);
@@ -154,6 +181,13 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
                     mn.z = fminf(mn.z, lane_xor<16>(mn.z)); mn.w = fminf(mn.w, lane_xor<16>(mn.w));
                     mx.x = fmaxf(mx.x, lane_xor<16>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<16>(mx.y));
                     mx.z = fmaxf(mx.z, lane_xor<16>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<16>(mx.w));
+                    if constexpr (REC)
+                        if (wide) {       // the candidate's other 16 rows sit in the wave's other slot
+                            mn.x = fminf(mn.x, lane_xor<32>(mn.x)); mn.y = fminf(mn.y, lane_xor<32>(mn.y));
+                            mn.z = fminf(mn.z, lane_xor<32>(mn.z)); mn.w = fminf(mn.w, lane_xor<32>(mn.w));
+                            mx.x = fmaxf(mx.x, lane_xor<32>(mx.x)); mx.y = fmaxf(mx.y, lane_xor<32>(mx.y));
+                            mx.z = fmaxf(mx.z, lane_xor<32>(mx.z)); mx.w = fmaxf(mx.w, lane_xor<32>(mx.w));
+                        }
                     const f2_t dlo = {fmaxf(mx.x, qmx.x) - fminf(mn.x, qmn.x), fmaxf(mx.y, qmx.y) - fminf(mn.y, qmn.y)};
                     const f2_t dhi = {fmaxf(mx.z, qmx.z) - fminf(mn.z, qmn.z), fmaxf(mx.w, qmx.w) - fminf(mn.w, qmn.w)};
                     dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
@@ -175,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
             {
                 const float* xm = lds + (4 * miq + mt) * kRowStride;
                 const float* ym = lds + (16 + p * 8 + 4 * mjq + mt) * kRowStride;
-                if (q_len > 8) {
+                if (q_len - qrow0 > 8) {
 #pragma unroll 4
                     for (int c = 0; c < kCh; ++c) {
                         const float4 x0 = *reinterpret_cast<const float4*>(xm + c * 4);
@@ -240,24 +274,24 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
 
         // ---- the pair's entries (i = 8 s + 4 iq + r, j = 8 hp + 4 jq + t) ---------------------------------------------
         const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
-        const int j = 8 * hp + 4 * mjq + mt;
+        const int j = crow0 + 8 * hp + 4 * mjq + mt;
         bool redo[2][4];
         float negv[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 8 * s + 4 * miq + r;
+                const int i = qrow0 + 8 * s + 4 * miq + r;
                 const float dot = macc[s][0][r] + macc[s][1][r];
                 const float sq = fmaf(-2.f, dot, xx[s][r]) + yy;
                 const float ns = xx[s][r] + yy;
                 redo[s][r] = my_c_real && !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
                 negv[s][r] = -sqrtf(fmaxf(sq, 0.f));
                 if constexpr (!L2MAX)
-                    if (my_c_real) ws.cost[slot * 256 + i * 16 + j] = sqrtf(fmaxf(sq, 1e-8f));
+                    if (my_c_real && (!REC || (i < LDW && j < LDW))) ws.cost[slot * EW + i * LDW + j] = sqrtf(fmaxf(sq, 1e-8f));
             }
         if constexpr (!L2MAX)
-            if (my_c_real && own_diam && lp == 0 && hp == 0) ws.diam2[slot] = diam2;
+            if (my_c_real && own_diam && lp == 0 && hp == 0 && qrow0 == 0 && crow0 == 0) ws.diam2[slot] = diam2;
         // direct-formula redo, the whole wave on one entry (12 coordinates per lane), four entries per memory round trip
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -275,7 +309,8 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {            // all 24 loads go out before the first is consumed
                         const int o = owner[e] >= 0 ? owner[e] : owner[0];
-                        const int ob = o >> 2, oi = 8 * s + 4 * ((ob >> 1) & 1) + r, oj = 8 * ((ob >> 2) & 1) + 4 * (ob & 1) + (o & 3);
+                        const int ob = o >> 2, oi = qrow0 + 8 * s + 4 * ((ob >> 1) & 1) + r;
+                        const int oj = (REC ? __builtin_amdgcn_readlane(crow0, o) : 0) + 8 * ((ob >> 2) & 1) + 4 * (ob & 1) + (o & 3);
                         const int cs_e = __builtin_amdgcn_readlane(c_start, o);
                         const float* qrow = qdoc + (size_t)oi * kD + 4 * lane;
                         const float* crow = a.c.rows + ((size_t)cs_e + oj) * kD + 4 * lane;
@@ -308,16 +343,21 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, (8 * s + 4 * miq + r < q_len && j < c_len) ? negv[s][r] : kNegBig);
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, (qrow0 + 8 * s + 4 * miq + r < q_len && j < c_len) ? negv[s][r] : kNegBig);
             m = fmaxf(m, lane_xor<1>(m)); m = fmaxf(m, lane_xor<2>(m)); m = fmaxf(m, lane_xor<4>(m)); m = fmaxf(m, lane_xor<8>(m));
             m = fmaxf(m, lane_xor<16>(m));                                    // the candidate's two halves
-            if (q_len > 16 || c_len > 16) m = __builtin_nanf("");          // longer than the tile: never truncated silently
-            if (my_c_real && lp == 0 && hp == 0) a.scores[mapped ? cur.c_idx : q_idx * a.c.n + cur.c_idx] = m;
+            if constexpr (REC)
+                if (wide) m = fmaxf(m, lane_xor<32>(m));                      // ... of each of its two slots
+            if (q_len > 16 || c_len > (REC && wide ? 32 : 16)) m = __builtin_nanf("");          // longer than the tile: never truncated silently
+            if (my_c_real && lp == 0 && hp == 0 && crow0 == 0) a.scores[mapped ? cur.c_idx : q_idx * a.c.n + cur.c_idx] = m;
         } else if (my_c_real) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ws.neg[slot * 256 + (8 * s + 4 * miq + r) * 16 + j] = negv[s][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int i = qrow0 + 8 * s + 4 * miq + r;
+                    if (!REC || (i < LDW && j < LDW)) ws.neg[slot * EW + i * LDW + j] = negv[s][r];
+                }
         }
     }
 }
@@ -336,7 +376,7 @@ int launch_pair_tile16(const ScoreArgs& a, float* cost, float* neg, float* diam2
                        hipStream_t stream) {
     PairWs<2> ws{cost, neg, diam2};
     const int64_t waves = items_bound < 256 * 8 ? items_bound : 256 * 8;
-    hipLaunchKernelGGL(pair_tile16_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws,
+    hipLaunchKernelGGL((pair_tile16_kernel<false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws,
                        qbox);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
@@ -346,8 +386,32 @@ int launch_pair_tile16(const ScoreArgs& a, float* cost, float* neg, float* diam2
 int launch_pair_tile16_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream) {
     PairWs<2> ws{nullptr, nullptr, nullptr};
     const int64_t waves = items_bound < 256 * 8 ? items_bound : 256 * 8;
-    hipLaunchKernelGGL(pair_tile16_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws,
+    hipLaunchKernelGGL((pair_tile16_kernel<true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws,
                        (const float*)nullptr);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+// REC items (chunk16_prep_kernel's records in a.grp_rec, their count in a.grp_off[0]); T = the workspace slots' tile width (3, 4)
+int launch_pair_tile16_rec(const ScoreArgs& a, int T, float* cost, float* neg, float* diam2, int64_t items_bound, const float* qbox,
+                           hipStream_t stream) {
+    const int64_t waves = items_bound < 256 * 8 ? items_bound : 256 * 8;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (T == 3) {
+        PairWs<3> ws{cost, neg, diam2};
+        hipLaunchKernelGGL((pair_tile16_kernel<false, 3, true>), grid, dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws, qbox);
+    } else {
+        PairWs<4> ws{cost, neg, diam2};
+        hipLaunchKernelGGL((pair_tile16_kernel<false, 4, true>), grid, dim3(256), 4 * kWaveLds * sizeof(float), stream, a, ws, qbox);
+    }
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+int launch_pair_tile16_rec_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream) {
+    PairWs<4> ws{nullptr, nullptr, nullptr};
+    const int64_t waves = items_bound < 256 * 8 ? items_bound : 256 * 8;
+    hipLaunchKernelGGL((pair_tile16_kernel<true, 4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * kWaveLds * sizeof(float), stream,
+                       a, ws, (const float*)nullptr);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

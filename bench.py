@@ -482,9 +482,9 @@ def main():
             # counter profile of the configs-3/5 shapes -- not measured in this run
             sj = json.load(open(spath))
             out['roofline']['sinkhorn'] = {k: {f: v[f] for f in ('what', 'kernel', 'ns_per_pair', 'valu_wave_instructions_per_pair', 'bound',
-                                                                  'achieved_frac', 'issue_floor_us', 'kernel_us_per_call')}
+                                                                  'achieved_frac', 'issue_floor_us', 'kernel_us_per_call', 'algorithmic_floor') if f in v}
                                            for k, v in sj.items() if isinstance(v, dict)}
-            out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r2.sh)'
+            out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r3.sh)'
         if rccl is not None:
             out['rccl'] = rccl
         out['cross_check'] = ('per-kernel durations (roofline.kernel_ms, profiles/*_kernel_stats.csv) add up to one_stream.ms_per_call; '

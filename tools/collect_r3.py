@@ -39,7 +39,8 @@ def kernel_rows(path, pattern):
     if path:
         for r in csv.DictReader(open(path)):
             if re.search(pattern, r['Name']):
-                rows.append(dict(name=re.sub(r'\(.*', '', r['Name'])[-70:], calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3,
+                m = re.search(r'(\w+_kernel)(<[^(]*>)?', r['Name'])
+                rows.append(dict(name=(m.group(0) if m else r['Name'])[:80], calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3,
                                  min_us=float(r['MinNs']) / 1e3))
     return rows
 
@@ -126,9 +127,12 @@ if g1 and gk:
     us = gk[0]['avg_us']
     busy = g1['SQ_VALU_MFMA_BUSY_CYCLES'] / SIMDS
     gui = g3.get('GRBM_GUI_ACTIVE')
+    gui = gui / 8 if gui else None          # rocprofv3 sums the counter over the chip's 8 XCDs (one GRBM each)
     summary['gemm'] = {'kernel': gk[0], 'mfma_busy_cycles_per_simd': busy, 'mfma_busy_frac_at_2.4GHz': busy / (us * 1e-6 * CLOCK_GHZ * 1e9),
-                       'GRBM_GUI_ACTIVE_per_launch': gui, 'effective_clock_GHz': gui / (us * 1e3) if gui else None,
+                       'GRBM_GUI_ACTIVE_per_launch_per_xcd': gui, 'effective_clock_GHz': gui / (us * 1e3) if gui else None,
                        'mfma_busy_frac_at_effective_clock': busy / gui if gui else None,
+                       'note': 'SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs against the launch duration at the nominal 2.4 GHz and against the cycles '
+                               'the chip actually ran (GRBM_GUI_ACTIVE / 8 XCDs, a separate counter pass of the same five launches)',
                        'wave_cycle_split': {k: g1.get(k) for k in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU')}}
 for name in ('gemmbench', 'poolbench'):
     p = os.path.join(SRC, name + '.log')
@@ -142,7 +146,9 @@ if os.path.exists(p):
     txt = open(p).read()
     i = txt.find('{')
     if i >= 0:
-        open(os.path.join(DST, 'r03_e2e.json'), 'w').write(txt[i:])
+        obj, _ = json.JSONDecoder().raw_decode(txt[i:])
+        json.dump(obj, open(os.path.join(DST, 'r03_e2e.json'), 'w'), indent=1)
+        summary['e2e'] = obj
 copy_stats('pool_stats', 'r03_pool_B256_L512_kernel_stats.csv')
 # ---- 4. the stand-alone Sinkhorn kernel: VALU busy AND an algorithmic floor ---------------------------------------------------------
 sink = {}
