@@ -2659,6 +2659,72 @@ __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, con
         }
     }
 }
+// Items of the 16-row streaming kernel's REC form (tile16.hip) for batched jobs whose queries AND candidates can have 9 .. 32 rows:
+// an item = a 16-row half of the query against two candidate slots of 16 rows -- two candidates of <= 16 rows, or the two halves
+// of one candidate of 17 .. 32.  Same scheme as chunk_prep_kernel (counts in LDS, one atomicAdd on the launch's item counter per
+// block, a candidate's place by its rank within its class); a query of more than 16 rows gets every item twice, once per half.
+// Record: [0] query, [1] its len, [2] its first row, [3] query half | wide << 8, [4,5] the slots' candidates, [6,7] their lens,
+// [8,9] their first rows, [10,11] first row of the slot's half (0 / 16), [12,13] real.
+__global__ void __launch_bounds__(192) chunk16_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, float* __restrict__ qbox,
+                                                           int32_t* __restrict__ cand_job, int32_t* __restrict__ counter,
+                                                           int32_t* __restrict__ grp_rec) {
+    __shared__ int cnt[2], pos[2], base_s;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (blockIdx.y == gridDim.y - 1) {
+        const int n = q.len[j];
+        const float* doc = q.rows + (size_t)q.start[j] * kD + tid * 4;
+        float4 mn, mx;
+        doc_box_chunk(doc, n, mn, mx);
+        *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + tid * 4) = mn;
+        *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + kD + tid * 4) = mx;
+        return;
+    }
+    const int c0 = job_off[j] + blockIdx.y * kChunkPrepPart, c1 = min(job_off[j + 1], c0 + kChunkPrepPart);
+    if (c0 >= c1) return;
+    if (tid < 2) cnt[tid] = pos[tid] = 0;
+    __syncthreads();
+    int len[2], start[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int cc = c0 + tid + 192 * r;
+        len[r] = cc < c1 ? c.len[cc] : 0;
+        start[r] = cc < c1 ? c.start[cc] : 0;
+        if (cc < c1) {
+            atomicAdd(&cnt[len[r] > 16 ? 1 : 0], 1);
+            cand_job[cc] = j;
+        }
+    }
+    __syncthreads();
+    const int q_len = q.len[j], q_start = q.start[j], nqh = q_len > 16 ? 2 : 1;
+    const int n_narrow = cnt[0], n_wide = cnt[1], per_half = ((n_narrow + 1) >> 1) + n_wide;
+    if (tid == 0) base_s = atomicAdd(counter, nqh * per_half);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int cc = c0 + tid + 192 * r;
+        if (cc >= c1) continue;
+        const bool wide = len[r] > 16;
+        const int ps = atomicAdd(&pos[wide ? 1 : 0], 1);
+        const int local = wide ? ((n_narrow + 1) >> 1) + ps : ps >> 1, slot = wide ? 0 : ps & 1;
+        const bool alone = !wide && slot == 0 && ps == n_narrow - 1;      // an odd narrow candidate: its item's second slot repeats it
+        for (int qh = 0; qh < nqh; ++qh) {
+            int32_t* rec = grp_rec + (size_t)(base_s + qh * per_half + local) * 16;
+            if (slot == 0) {
+                rec[0] = j;
+                rec[1] = q_len;
+                rec[2] = q_start;
+                rec[3] = qh | (wide ? 256 : 0);
+            }
+            for (int t = slot; t < (wide || alone ? 2 : slot + 1); ++t) {
+                rec[4 + t] = cc;
+                rec[6 + t] = len[r];
+                rec[8 + t] = start[r];
+                rec[10 + t] = wide ? 16 * t : 0;
+                rec[12 + t] = (wide || t == slot) ? 1 : 0;
+            }
+        }
+    }
+}
 // parts (classification blocks) per job, and the bound on the items the launch can make
 int64_t chunk_parts(int64_t max_job) { return max_job > 0 ? (max_job + kChunkPrepPart - 1) / kChunkPrepPart : 1; }
 int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job) { return C + 3 * J * chunk_parts(max_job); }
@@ -2677,7 +2743,8 @@ BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, in
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
     L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
     // (documents of more than 8 rows: room for the CHUNK form's items, up to one per candidate)
-    const size_t n_rec = max_rows > 8 ? (size_t)chunk_items_bound(J, C, max_job) + 1 : (size_t)(C / 4 + J + 1);
+    const size_t n_rec = max_rows > 16 ? 2 * (size_t)chunk_items_bound(J, C, max_job) + 1       // (16-row items, per query half)
+                         : max_rows > 8 ? (size_t)chunk_items_bound(J, C, max_job) + 1 : (size_t)(C / 4 + J + 1);
     L.grp_rec = o; o = align16(o + n_rec * 16 * sizeof(int32_t));
     L.gate = o; o = align16(o + 16);
     L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
@@ -2790,6 +2857,34 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
                             topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);
         return ASPIRE_OK;
     }
+    // Whole abstracts on both sides, documents of 17 .. 32 rows among them (un-faceted queries: pp_settings.py:2-3): the 16-row
+    // streaming kernel on record items (a query half against two candidate halves) + the block Sinkhorn kernel on 24- / 32-row
+    // workspace slots.  (Before: the VALU tile loop, one workgroup per candidate.)
+    const bool rec16 = !chunked && max_rows > 16 && max_rows_all <= 8 * kMaxT && (form_t == 4 || (form_t == 0 && C >= kChunkMinCands)) &&
+                       stages == kStageAll && tuning().cost_path != 2;
+    if (rec16) {
+        ASPIRE_HIP_OK(hipMemsetAsync(grp_off, 0, sizeof(int32_t), s0));
+        hipLaunchKernelGGL(chunk16_prep_kernel, dim3((unsigned)J, (unsigned)chunk_parts(max_job) + 1), dim3(192), 0, s0, a.q, a.c, job_off, qbox,
+                           cand_job, grp_off, grp_rec);
+        ASPIRE_LAUNCH_OK();
+        const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
+            constexpr int T = decltype(tc)::value;
+            if constexpr (T >= 3) {
+                PairWs<T> ws;
+                ws.cost = (float*)(wsb + L.slots);
+                ws.neg = ws.cost + C * PairWs<T>::kEntries;
+                ws.diam2 = ws.neg + C * PairWs<T>::kEntries;
+                if (int rc = launch_pair_tile16_rec(a, T, ws.cost, ws.neg, ws.diam2, 2 * chunk_items_bound(J, C, max_job), qbox, s0)) return rc;
+                return launch_sinkhorn_stage<T>(a, ws, C, max_rows, false, 3, s0);
+            }
+            return (int)ASPIRE_ERR_UNSUPPORTED;
+        });
+        if (rc_run) return rc_run;
+        if (k > 0)
+            return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
+                            topk_need ? wsb + L.topk : nullptr, topk_need, stream, job_off, job_base);
+        return ASPIRE_OK;
+    }
     // batches of <= 64 jobs on the fused kernel need no tables launch: the kernel's waves derive them (fused.hip, SELF)
     const bool self = fused && fused_self_ok(J, prm);
     if ((stages & kStagePrep) && !self) {
@@ -2859,7 +2954,7 @@ L2BatchLayout l2_batch_layout(int64_t J, int64_t C, int64_t max_job, int64_t k) 
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
     L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
-    L.grp_rec = o; o = align16(o + ((size_t)chunk_items_bound(J, C, max_job) + 1) * 16 * sizeof(int32_t));     // (room for the CHUNK form's items)
+    L.grp_rec = o; o = align16(o + (2 * (size_t)chunk_items_bound(J, C, max_job) + 1) * 16 * sizeof(int32_t));     // (room for the CHUNK / REC forms' items)
     L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));      // (written by the tables kernel, unused by max-sim)
     L.gate = o; o = align16(o + 16);
     L.topk = o; o = align16(o + aspire_topk_workspace_bytes(J, max_job, k));
@@ -2933,6 +3028,20 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
                            (float*)(wsb + L.qbox), (int32_t*)(wsb + L.cand_job), (int32_t*)(wsb + L.grp_off), (int32_t*)(wsb + L.grp_rec));
         ASPIRE_LAUNCH_OK();
         if (int rc = launch_pair_fused_chunk_l2max(a, chunk_items_bound(J, C, max_job), s0)) return rc;
+        const size_t need = aspire_topk_workspace_bytes(J, max_job, k);
+        if (k > 0)
+            return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,
+                            need ? wsb + L.topk : nullptr, need, stream, job_off, job_base);
+        return ASPIRE_OK;
+    }
+    // whole abstracts of up to 32 rows against queries of 9 .. 16: the 16-row streaming kernel on record items, max epilogue (a
+    // query of more than 16 rows would need its two halves' maxima joined across items: the per-candidate kernel keeps those)
+    if (q->max_len <= 16 && max_rows > 16 && max_rows <= 8 * kMaxT && (form_t == 4 || (form_t == 0 && C >= kChunkMinCands)) && !one_form) {
+        ASPIRE_HIP_OK(hipMemsetAsync((int32_t*)(wsb + L.grp_off), 0, sizeof(int32_t), s0));
+        hipLaunchKernelGGL(chunk16_prep_kernel, dim3((unsigned)J, (unsigned)chunk_parts(max_job) + 1), dim3(192), 0, s0, a.q, a.c, job_off,
+                           (float*)(wsb + L.qbox), (int32_t*)(wsb + L.cand_job), (int32_t*)(wsb + L.grp_off), (int32_t*)(wsb + L.grp_rec));
+        ASPIRE_LAUNCH_OK();
+        if (int rc = launch_pair_tile16_rec_l2max(a, 2 * chunk_items_bound(J, C, max_job), s0)) return rc;
         const size_t need = aspire_topk_workspace_bytes(J, max_job, k);
         if (k > 0)
             return topk_run(scores, J, max_job, k, 0, keys ? nullptr : top_scores, keys ? nullptr : top_idx, keys,

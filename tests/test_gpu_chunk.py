@@ -134,3 +134,37 @@ def test_chunk_form_max_sim(amd, seed, sizes, cmax):
                 for i in pick]
         np.testing.assert_allclose(got[off[j] + np.array(pick)], want, atol=TOL, rtol=0)
         assert top_i[j, :n].tolist() == orc.rank_descending(got[off[j]:off[j + 1]].tolist())
+
+
+@pytest.mark.parametrize('seed,sizes,cmax,qmax', [(51, [90] * 8, 20, 20), (52, [300, 0, 1, 45, 130], 32, 32), (53, [400], 24, 12)])
+def test_record_items_for_whole_abstracts_on_both_sides(amd, seed, sizes, cmax, qmax):
+    """Un-faceted queries: whole abstracts of up to 32 sentences on BOTH sides (pp_settings.py:2-3).  The 16-row streaming kernel on
+    record items (tile16.hip REC: a 16-row half of the query against two candidate halves) + the block Sinkhorn kernel on 24- /
+    32-row workspace slots, against the oracle and against the per-candidate tile-loop kernels; tsAspire for queries of <= 16."""
+    queries, cands, off = _batch(amd, seed, sizes, cmax=cmax, qmax=qmax)
+    cands[0] = torch.randn(cmax, 768, generator=torch.Generator().manual_seed(seed))       # the longest document is present
+    got, _, top_i = _run(amd, queries, cands, off)
+    with amd.lib.pinned(OT_FORM='small'):
+        other, _, _ = _run(amd, queries, cands, off)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, other, atol=5e-5, rtol=0)
+    rng = np.random.default_rng(seed)
+    for j, n in enumerate(sizes):
+        if n == 0:
+            continue
+        pick = sorted(set([0, n - 1] + rng.integers(0, n, size=min(n, 5)).tolist()))
+        want = np.array([orc.get_similarity(queries[j], cands[off[j] + i]) for i in pick], dtype=np.float32)
+        np.testing.assert_allclose(got[off[j] + np.array(pick)], want, atol=TOL, rtol=0)
+        assert top_i[j, :n].tolist() == orc.rank_descending(got[off[j]:off[j + 1]].tolist())
+    if qmax <= 16:
+        q = amd.ops.DeviceRepSet.from_list(queries)
+        c = amd.ops.DeviceRepSet.from_list(cands)
+        job_off = torch.tensor(off, dtype=torch.int32).cuda()
+        max_job = int(np.diff(off).max())
+        l2, _, _ = amd.ops.l2max_rank_batch(q, c, job_off, max_job, max_job)
+        with amd.lib.pinned(OT_FORM='small'):
+            l2o, _, _ = amd.ops.l2max_rank_batch(q, c, job_off, max_job, max_job)
+        np.testing.assert_allclose(l2.cpu().numpy(), l2o.cpu().numpy(), atol=4e-5, rtol=0)
+        want = -orc.allpair_masked_dist_l2max(orc.RepLen(queries[0][None].permute(0, 2, 1), [len(queries[0])]),
+                                              orc.RepLen(cands[0][None].permute(0, 2, 1), [len(cands[0])])).item()
+        assert abs(float(l2[0]) - want) < TOL

@@ -8,6 +8,7 @@ import torch
 from aspire_amd import _lib, ops
 
 J, NC, SMAX = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (50, 125, 20)
+QMAX = int(sys.argv[4]) if len(sys.argv) > 4 else 8          # query rows 1 .. QMAX (8: facet-selected; 20: whole abstracts)
 dev = torch.device('cuda')
 g = torch.Generator().manual_seed(4)
 
@@ -30,7 +31,7 @@ def timed(fn, n=50):
 
 
 c_lens = torch.randint(3, SMAX + 1, (J * NC,), generator=g)
-q_lens = torch.randint(1, min(SMAX, 8) + 1, (J,), generator=g)
+q_lens = torch.randint(1, min(SMAX, QMAX) + 1, (J,), generator=g)
 c, q = repset(c_lens), repset(q_lens)
 job_off = (torch.arange(J + 1, dtype=torch.int32) * NC).to(dev)
 pairs = J * NC
