@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const f
             x.c_idx = cand;
             x.c_len = a.c.len[cand];
             x.c_start = a.c.start[cand];
-        } else if (mapped) {
+        } else if (mapped || CHUNK) {
             // the group's record (batch_prep_kernel): ONE memory round trip where the job tables + document tables take four
             const int32_t* rec = a.grp_rec + (size_t)item * 16;
             const int4 hd = *reinterpret_cast<const int4*>(rec);

@@ -2320,6 +2320,19 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
                  const float* diameter, int64_t diam_group, int want, float* scores, float* out_qdistr, float* out_cdistr,
                  float* out_pairsims, float* out_plan, void* workspace, size_t workspace_bytes, void* stream, const RankReq& rank,
                  bool cost_only);
+}  // namespace
+namespace aspire {
+namespace {
+// (defined with the batched entry points below)
+__global__ void chunk_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, float* __restrict__ qbox, int32_t* __restrict__ cand_job,
+                                  int32_t* __restrict__ counter, int32_t* __restrict__ grp_rec);
+int64_t chunk_parts(int64_t max_job);
+int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job);
+// smallest pool / batch (candidates) that takes the CHUNK / REC forms (below: the small-batch kernels; tools/csfbench.py sweeps)
+constexpr int64_t kChunkMinCands = 256;
+}  // namespace
+}  // namespace aspire
+namespace {
 
 // Documents beyond the tile kernels' 32 rows: padded tensors that wide go through the one-workgroup-per-pair kernel
 // (generic.hip) for every pair; CSR pools run the tile kernels with their documents' bound clamped to 32 rows (every pair
@@ -2387,7 +2400,16 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     // queries they tie, from three the Gram tiles win: 623 vs 565 us)
     const bool stream16 = q->n == 1 && c->n >= 4096 && tile16_path_ok(q, c, pairing) && tuning().cost_path != 1 &&
                           tuning().ot_form != 1;
-    const bool gram = gram_path_wanted(q, c, pairing) && !stream16;
+    const int form_t = tuning().ot_form;
+    // ONE short query (facet-selected rows) against a pool of abstracts of up to 32 rows: the fused kernel's CHUNK form, as in
+    // ot_rank_batch (1 x 20 000 x (3..20): 674 us on the Gram tiles + block Sinkhorn before) -- the item records and their counter
+    // take the (unused) front of the pair-slot workspace.
+    const bool chunk1 = pairing == ASPIRE_PAIR_CROSS && q->n == 1 && q->ext == 0 && c->ext == 0 && q->max_len <= 8 && c->max_len > 8 &&
+                        c->max_len <= 8 * kMaxT && c->n >= kChunkMinCands && c->n < ((int64_t)1 << 30) && !extra && !cost_only && !diameter &&
+                        (form_t == 0 || form_t == 4) && prm->scaling >= 0.25 && !tuning().fused_nosolve && !tuning().fused_valu &&
+                        tuning().cost_path == 0 && workspace &&
+                        (size_t)(chunk_items_bound(1, c->n, c->n) + 2) * 64 + 64 + qbox_bytes(q) + 64 <= workspace_bytes;
+    const bool gram = gram_path_wanted(q, c, pairing) && !stream16 && !chunk1;
     ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + kWsSlack, ASPIRE_ERR_INVALID_ARG,
                    "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
                    workspace_bytes, per_cand, aspire_ot_workspace_bytes(q, c, pairing));
@@ -2405,7 +2427,6 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     float* qbox = (float*)((char*)workspace + ((workspace_bytes - qbox_bytes(q)) & ~(size_t)15));
     // Few queries against a big pool of short documents: costs and solves in ONE launch, no workspace slots, no candidate
     // chunks (fused.hip).
-    const int form_t = tuning().ot_form;
     const int64_t groups4_all = (c->n + 3) / 4 * q->n;
     const bool fused = pairing == ASPIRE_PAIR_CROSS && !extra && !gram && !cost_only && fused_path_ok(q, c) &&
                        (form_t == 3 || (form_t == 0 && groups4_all >= (q->n == 1 ? kStreamMinGroups1 : 2048)));
@@ -2419,22 +2440,20 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         }
         if (int rc = launch_pair_fused(a, groups4_all, inbox ? nullptr : qbox, (hipStream_t)stream)) return rc;
     }
-    // ONE short query against a big pool whose documents reach 9 .. 16 rows: the hybrid of ot_rank_batch -- the fused kernel in
-    // front of the 16-row kernels, a census of the long pairs on the device decides who scores what (ScoreArgs::gate).  The
-    // counter lives in the 32 spare bytes in front of the query boxes.
-    if (stream16 && !gram && !fused && !extra && !cost_only && !diameter && q->max_len <= 8 && form_t == 0 && prm->scaling >= 0.25 &&
-        want != ASPIRE_OT_PLAN_SIM && !tuning().fused_nosolve && !tuning().fused_valu && sinkhorn_form_honours_gate()) {
-        int32_t* gate = (int32_t*)((char*)qbox - 16);
+    if (chunk1) {
         a.cand0 = 0;
         a.cand1 = c->n;
-        ASPIRE_HIP_OK(hipMemsetAsync(gate, 0, sizeof(int32_t), (hipStream_t)stream));
-        hipLaunchKernelGGL(long_pair_census_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, gate);
+        int32_t* counter = (int32_t*)workspace;
+        int32_t* recs = (int32_t*)((char*)workspace + 64);
+        a.grp_off = counter;
+        a.grp_rec = recs;
+        ASPIRE_HIP_OK(hipMemsetAsync(counter, 0, sizeof(int32_t), (hipStream_t)stream));
+        hipLaunchKernelGGL(chunk_prep_kernel, dim3(1, (unsigned)chunk_parts(c->n) + 1), dim3(192), 0, (hipStream_t)stream, a.q, a.c,
+                           (const int32_t*)nullptr, qbox, (int32_t*)nullptr, counter, recs);
         ASPIRE_LAUNCH_OK();
-        a.gate = gate;
-        a.gate_limit = (int32_t)(c->n / 24);
-        if (int rc = launch_pair_fused(a, groups4_all, nullptr, (hipStream_t)stream)) return rc;
+        if (int rc = launch_pair_fused_chunk(a, chunk_items_bound(1, c->n, c->n), qbox, (hipStream_t)stream)) return rc;
     }
-    const int rc_run = fused ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
+    const int rc_run = (fused || chunk1) ? (int)ASPIRE_OK : dispatch_T(max_rows, [&](auto tc) -> int {
         constexpr int T = decltype(tc)::value;
         for (int64_t c0 = 0; c0 < c->n; c0 += cand_per_chunk) {
             a.cand0 = c0;
@@ -2571,6 +2590,7 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
 // real << 16, [12..15] the slots' first rows.  Slots that stay empty repeat the item's first candidate as a one-chunk
 // candidate (scored, never stored).  Block (j, last) forms the query's box, as in batch_prep_kernel.
 constexpr int kChunkPrepPart = 384;      // candidates per classification block
+// job_off == nullptr: ONE query against the pool [0, c.n) (the single-pool entry points); cand_job may be null then.
 __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, float* __restrict__ qbox,
                                                          int32_t* __restrict__ cand_job, int32_t* __restrict__ counter,
                                                          int32_t* __restrict__ grp_rec) {
@@ -2585,7 +2605,7 @@ __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, con
         *reinterpret_cast<float4*>(qbox + (size_t)j * 2 * kD + kD + tid * 4) = mx;
         return;
     }
-    const int c0 = job_off[j] + blockIdx.y * kChunkPrepPart, c1 = min(job_off[j + 1], c0 + kChunkPrepPart);
+    const int c0 = (job_off ? job_off[j] : 0) + blockIdx.y * kChunkPrepPart, c1 = min(job_off ? job_off[j + 1] : (int)c.n, c0 + kChunkPrepPart);
     if (c0 >= c1) return;
     if (tid < 4) cnt[tid] = pos[tid] = 0;
     __syncthreads();
@@ -2598,7 +2618,7 @@ __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, con
         nch[r] = min(4, max(1, (len[r] + 7) >> 3));          // chunks (a longer document is poisoned by the kernel)
         if (cc < c1) {
             atomicAdd(&cnt[nch[r] - 1], 1);
-            cand_job[cc] = j;
+            if (cand_job) cand_job[cc] = j;
         }
     }
     __syncthreads();
@@ -2728,8 +2748,6 @@ __global__ void __launch_bounds__(192) chunk16_prep_kernel(RepSet q, RepSet c, c
 // parts (classification blocks) per job, and the bound on the items the launch can make
 int64_t chunk_parts(int64_t max_job) { return max_job > 0 ? (max_job + kChunkPrepPart - 1) / kChunkPrepPart : 1; }
 int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job) { return C + 3 * J * chunk_parts(max_job); }
-// smallest batch (candidates) that takes the CHUNK form (below: the small-batch kernels; tools/csfbench.py sweeps)
-constexpr int64_t kChunkMinCands = 256;
 
 struct BatchLayout {
     size_t slots, qbox, cand_job, grp_job, grp_off, grp_rec, gate, topk, total;

@@ -217,7 +217,8 @@ def test_batch_hybrid_short_pools_with_a_few_long_documents(amd, p_long):
 @pytest.mark.parametrize('p_long', [0.003, 0.5])
 def test_single_pool_hybrid(amd, p_long):
     """one short query against a big pool with a share of 9 .. 16-row documents (aspire_ot_sinkhorn_f32 / aspire_ot_rank_f32):
-    the same device-side hybrid as the batch entry, against the 16-row streaming path pinned and the oracle"""
+    the fused kernel's CHUNK form (round 3; before: a device-side hybrid of the 8-row fused kernel and the 16-row kernels),
+    against the 16-row streaming path pinned and the oracle"""
     g = torch.Generator().manual_seed(77)
     nc = 9100
     lens = torch.where(torch.rand(nc, generator=g) < p_long, torch.randint(9, 17, (nc,), generator=g), torch.randint(1, 9, (nc,), generator=g))
@@ -229,10 +230,7 @@ def test_single_pool_hybrid(amd, p_long):
     with amd.pinned(OT_FORM='tile'):
         ref = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
     assert np.isfinite(hyb).all()
-    if p_long > 0.4:
-        assert np.array_equal(hyb, ref)
-    else:
-        np.testing.assert_allclose(hyb, ref, atol=5e-5, rtol=0)
+    np.testing.assert_allclose(hyb, ref, atol=5e-5, rtol=0)
     idx = [0, 11, 12, nc - 1] + [int(i) for i in np.nonzero(lens.numpy() > 8)[0][:3]]
     want = np.array([-orc.get_similarity(query, cands[i]) for i in idx], dtype=np.float32)
     np.testing.assert_allclose(hyb[idx], want, atol=TOL, rtol=0)
