@@ -433,8 +433,15 @@ __device__ __forceinline__ void solve_finish(Solve& s, const ScoreArgs& a) {
 // (score.hip) sorts a job's candidates into such items.  The streaming phase is the same (a group stages rows row0 .. row0 + 7
 // of its document; the candidate's per-coordinate box is joined across its groups), the solve's row sums and the marginals'
 // normalisations cross the candidate's groups (xg_sum / xg_max).
+// (-DASPIRE_FUSED_WAVES3: the experiment of NOTES.md -- the same kernel built for three workgroups per CU, 168 registers: the
+// compiler spills the kernel-invariant values and the launch gets slower; profiles/r03_fused_3waves_* hold its counters)
+#ifdef ASPIRE_FUSED_WAVES3
+#define ASPIRE_FUSED_MIN_WAVES 3
+#else
+#define ASPIRE_FUSED_MIN_WAVES 2
+#endif
 template <bool MFMA, bool SOLVE = true, bool SELF = false, bool L2MAX = false, bool QBOX = false, bool CHUNK = false>
-__global__ void __launch_bounds__(256, 2) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
+__global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel(ScoreArgs a, const float* __restrict__ qbox) {
     static_assert(!CHUNK || (MFMA && !SELF && !QBOX), "CHUNK: table-driven items only");
     constexpr bool INBOX = (SELF || QBOX) && !L2MAX;        // the query's box comes from the staged query rows (max-sim needs none)
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
