@@ -194,6 +194,15 @@ def _score_run(q, c, method, schedule, hparams, score_batch_size, cdist_mode, de
     if hparams.get('geoml_reach', None) is not None:
         raise NotImplementedError('unbalanced OT (geoml_reach) is not built')
     if schedule == 'pair':
+        if 1 < q.n <= 32 and q.max_len <= 8 and 8 < c.max_len <= 32 and c.ext == 0 and c.n >= 256 and not deterministic:
+            # a few short queries (the facets of one paper, models.py:127-163) against ONE pool of whole abstracts: as batched jobs
+            # over the same index list -- the fused kernel's CHUNK form scores each of them in the one launch (the cross-product
+            # entry would take the Gram tiles + a Sinkhorn launch, built for many queries)
+            dev = c.rows.device
+            cc = ops.DeviceRepSet(c.rows, c.start.repeat(q.n), c.len.repeat(q.n), ext=0, max_len=c.max_len)
+            job_off = (torch.arange(q.n + 1, dtype=torch.int64) * c.n).to(torch.int32).to(dev)
+            sims, _, _ = ops.ot_rank_batch(q, cc, job_off, c.n, 0, want=_lib.OT_SIMILARITY, **kw)
+            return sims.view(q.n, c.n)
         dist = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_DISTANCE, one_form=deterministic, **kw)
         return (-dist).view(q.n, c.n)
     diam = ops.group_diameter(q, c, _lib.PAIR_CROSS, group=score_batch_size)

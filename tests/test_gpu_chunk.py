@@ -168,3 +168,20 @@ def test_record_items_for_whole_abstracts_on_both_sides(amd, seed, sizes, cmax, 
         want = -orc.allpair_masked_dist_l2max(orc.RepLen(queries[0][None].permute(0, 2, 1), [len(queries[0])]),
                                               orc.RepLen(cands[0][None].permute(0, 2, 1), [len(cands[0])])).item()
         assert abs(float(l2[0]) - want) < TOL
+
+
+def test_a_few_facet_queries_against_one_pool(amd):
+    """score_pool with the facets of one paper (three short queries) against one pool of whole abstracts: scored as batched jobs
+    over the same index list (CHUNK form) -- the same numbers as one query per call and as the oracle."""
+    g = torch.Generator().manual_seed(61)
+    lens = torch.randint(3, 21, (700,), generator=g).tolist()
+    cands = [torch.randn(n, 768, generator=g) for n in lens]
+    queries = [torch.randn(n, 768, generator=g) for n in (2, 5, 8)]
+    got = amd.scorer.score_pool(queries, cands, method='ot', schedule='pair').cpu().numpy()
+    assert got.shape == (3, 700) and np.isfinite(got).all()
+    for i in range(3):
+        one = amd.scorer.score_pool([queries[i]], cands, method='ot', schedule='pair').cpu().numpy()[0]
+        np.testing.assert_allclose(got[i], one, atol=5e-5, rtol=0)
+    idx = [(0, 0), (1, 350), (2, 699)]
+    want = np.array([orc.get_similarity(queries[i], cands[j]) for i, j in idx], dtype=np.float32)
+    np.testing.assert_allclose([got[i, j] for i, j in idx], want, atol=TOL, rtol=0)
