@@ -467,9 +467,22 @@ __global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel
             if (lane >= m) gend += t;
         }
     }
+    // CHUNK with regions: lane l holds the items of slices 0 .. l (the slices' counts, prefix-summed)
+    int cend = 0;
+    if constexpr (CHUNK) {
+        if (a.chunk_regions > 0) {
+            cend = lane < a.chunk_regions ? a.grp_off[lane] : 0;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const int t = __shfl_up(cend, m);
+                if (lane >= m) cend += t;
+            }
+        }
+    }
     const uint32_t item_lo = (SELF || CHUNK) ? 0u : mapped ? (uint32_t)a.grp_off[a.job0] : 0u;
     const uint32_t n_items = SELF ? (uint32_t)__builtin_amdgcn_readlane(gend, 63)
-                                  : CHUNK ? (uint32_t)a.grp_off[0]          // the item counter chunk_prep_kernel has left
+                                  : CHUNK ? (a.chunk_regions > 0 ? (uint32_t)__builtin_amdgcn_readlane(cend, 63)
+                                                                 : (uint32_t)a.grp_off[0])          // the item counter chunk_prep_kernel has left
                                   : mapped ? (uint32_t)a.grp_off[a.job1] : ((ncand + 3) / 4) * nq;   // item = (candidate group, query), group-major
     const uint32_t n_waves = gridDim.x * 4;
     const bool own_diam = a.diameter == nullptr;            // else: the caller's per-group diameters (caching_score's batches)
@@ -513,7 +526,15 @@ __global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel
             x.c_start = a.c.start[cand];
         } else if (mapped || CHUNK) {
             // the group's record (batch_prep_kernel): ONE memory round trip where the job tables + document tables take four
-            const int32_t* rec = a.grp_rec + (size_t)item * 16;
+            size_t rec_i = item;
+            if constexpr (CHUNK) {
+                if (a.chunk_regions > 0) {      // item -> (slice, place in the slice's region)
+                    const int sl = __popcll(__ballot(cend <= (int)item));
+                    const int g0 = sl > 0 ? __builtin_amdgcn_readlane(cend, sl - 1) : 0;
+                    rec_i = (size_t)sl * a.chunk_region_cap + (item - g0);
+                }
+            }
+            const int32_t* rec = a.grp_rec + rec_i * 16;
             const int4 hd = *reinterpret_cast<const int4*>(rec);
             x.q_idx = hd.x;
             x.q_len = hd.y;

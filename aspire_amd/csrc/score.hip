@@ -2325,7 +2325,10 @@ namespace aspire {
 namespace {
 // (defined with the batched entry points below)
 __global__ void chunk_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, float* __restrict__ qbox, int32_t* __restrict__ cand_job,
-                                  int32_t* __restrict__ counter, int32_t* __restrict__ grp_rec);
+                                  int32_t* __restrict__ counter, int32_t* __restrict__ grp_rec, int region_cap);
+// CHUNK items without a counter (ScoreArgs::chunk_regions): slices = J * parts <= 64; a slice's region holds min(384, max_job) records
+inline int chunk_regions_of(int64_t J, int64_t max_job);
+inline int chunk_region_cap_of(int64_t max_job) { return (int)(max_job < 384 ? (max_job > 0 ? max_job : 1) : 384); }
 int64_t chunk_parts(int64_t max_job);
 int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job);
 // smallest pool / batch (candidates) that takes the CHUNK / REC forms (below: the small-batch kernels; tools/csfbench.py sweeps)
@@ -2408,7 +2411,7 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
                         c->max_len <= 8 * kMaxT && c->n >= kChunkMinCands && c->n < ((int64_t)1 << 30) && !extra && !cost_only && !diameter &&
                         (form_t == 0 || form_t == 4) && prm->scaling >= 0.25 && !tuning().fused_nosolve && !tuning().fused_valu &&
                         tuning().cost_path == 0 && workspace &&
-                        (size_t)(chunk_items_bound(1, c->n, c->n) + 2) * 64 + 64 + qbox_bytes(q) + 64 <= workspace_bytes;
+                        (size_t)(chunk_items_bound(1, c->n, c->n) + 2) * 64 + 256 + qbox_bytes(q) + 64 <= workspace_bytes;
     const bool gram = gram_path_wanted(q, c, pairing) && !stream16 && !chunk1;
     ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + kWsSlack, ASPIRE_ERR_INVALID_ARG,
                    "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
@@ -2444,12 +2447,14 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
         a.cand0 = 0;
         a.cand1 = c->n;
         int32_t* counter = (int32_t*)workspace;
-        int32_t* recs = (int32_t*)((char*)workspace + 64);
+        int32_t* recs = (int32_t*)((char*)workspace + 256);
         a.grp_off = counter;
         a.grp_rec = recs;
-        ASPIRE_HIP_OK(hipMemsetAsync(counter, 0, sizeof(int32_t), (hipStream_t)stream));
+        a.chunk_regions = chunk_regions_of(1, c->n);
+        a.chunk_region_cap = chunk_region_cap_of(c->n);
+        if (a.chunk_regions == 0) ASPIRE_HIP_OK(hipMemsetAsync(counter, 0, sizeof(int32_t), (hipStream_t)stream));
         hipLaunchKernelGGL(chunk_prep_kernel, dim3(1, (unsigned)chunk_parts(c->n) + 1), dim3(192), 0, (hipStream_t)stream, a.q, a.c,
-                           (const int32_t*)nullptr, qbox, (int32_t*)nullptr, counter, recs);
+                           (const int32_t*)nullptr, qbox, (int32_t*)nullptr, counter, recs, a.chunk_regions > 0 ? a.chunk_region_cap : 0);
         ASPIRE_LAUNCH_OK();
         if (int rc = launch_pair_fused_chunk(a, chunk_items_bound(1, c->n, c->n), qbox, (hipStream_t)stream)) return rc;
     }
@@ -2591,10 +2596,13 @@ __global__ void __launch_bounds__(192) batch_prep_kernel(RepSet q, RepSet c, con
 // candidate (scored, never stored).  Block (j, last) forms the query's box, as in batch_prep_kernel.
 constexpr int kChunkPrepPart = 384;      // candidates per classification block
 // job_off == nullptr: ONE query against the pool [0, c.n) (the single-pool entry points); cand_job may be null then.
+// region_cap > 0 (at most 64 slices): no counter -- slice s = j * parts + part leaves its item count in counter[s] and its records in
+// records [s * region_cap, ..) (ScoreArgs::chunk_regions).
 __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, const int32_t* __restrict__ job_off, float* __restrict__ qbox,
                                                          int32_t* __restrict__ cand_job, int32_t* __restrict__ counter,
-                                                         int32_t* __restrict__ grp_rec) {
+                                                         int32_t* __restrict__ grp_rec, int region_cap) {
     __shared__ int cnt[4], pos[4], base_s;
+    const int slice = blockIdx.x * (gridDim.y - 1) + blockIdx.y;
     const int j = blockIdx.x, tid = threadIdx.x;
     if (blockIdx.y == gridDim.y - 1) {
         const int n = q.len[j];
@@ -2606,7 +2614,10 @@ __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, con
         return;
     }
     const int c0 = (job_off ? job_off[j] : 0) + blockIdx.y * kChunkPrepPart, c1 = min(job_off ? job_off[j + 1] : (int)c.n, c0 + kChunkPrepPart);
-    if (c0 >= c1) return;
+    if (c0 >= c1) {
+        if (region_cap > 0 && tid == 0) counter[slice] = 0;
+        return;
+    }
     if (tid < 4) cnt[tid] = pos[tid] = 0;
     __syncthreads();
     int len[2], start[2], nch[2];
@@ -2628,7 +2639,15 @@ __global__ void __launch_bounds__(192) chunk_prep_kernel(RepSet q, RepSet c, con
     const int s3 = min(n1, n3);                               // singles beside 3-chunk candidates
     const int odd2 = n2 & 1, s2 = odd2 ? min(n1 - s3, 2) : 0; // singles beside the odd 2-chunk candidate
     const int n1r = n1 - s3 - s2, items1 = (n1r + 3) >> 2;
-    if (tid == 0) base_s = atomicAdd(counter, n4 + n3 + (n2 >> 1) + odd2 + items1);
+    if (tid == 0) {
+        const int items = n4 + n3 + (n2 >> 1) + odd2 + items1;
+        if (region_cap > 0) {
+            counter[slice] = items;
+            base_s = slice * region_cap;
+        } else {
+            base_s = atomicAdd(counter, items);
+        }
+    }
     __syncthreads();
     const int b4 = base_s, b3 = b4 + n4, b2 = b3 + n3, bo = b2 + (n2 >> 1), b1 = bo + odd2;
     const int q_len = q.len[j], q_start = q.start[j];
@@ -2747,7 +2766,15 @@ __global__ void __launch_bounds__(192) chunk16_prep_kernel(RepSet q, RepSet c, c
 }
 // parts (classification blocks) per job, and the bound on the items the launch can make
 int64_t chunk_parts(int64_t max_job) { return max_job > 0 ? (max_job + kChunkPrepPart - 1) / kChunkPrepPart : 1; }
-int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job) { return C + 3 * J * chunk_parts(max_job); }
+inline int chunk_regions_of(int64_t J, int64_t max_job) {
+    const int64_t n = J * chunk_parts(max_job);
+    return n <= 64 ? (int)n : 0;
+}
+int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job) {
+    const int64_t by_count = C + 3 * J * chunk_parts(max_job);
+    const int64_t by_region = (int64_t)chunk_regions_of(J, max_job) * chunk_region_cap_of(max_job);      // (regions mode: every slice its own region)
+    return by_count > by_region ? by_count : by_region;
+}
 
 struct BatchLayout {
     size_t slots, qbox, cand_job, grp_job, grp_off, grp_rec, gate, topk, total;
@@ -2759,7 +2786,7 @@ BatchLayout batch_layout(int64_t J, int64_t C, int max_rows, int64_t max_job, in
     L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
-    L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
+    L.grp_off = o; o = align16(o + (size_t)(J + 1 > 64 ? J + 1 : 64) * sizeof(int32_t));
     // (documents of more than 8 rows: room for the CHUNK form's items, up to one per candidate)
     const size_t n_rec = max_rows > 16 ? 2 * (size_t)chunk_items_bound(J, C, max_job) + 1       // (16-row items, per query half)
                          : max_rows > 8 ? (size_t)chunk_items_bound(J, C, max_job) + 1 : (size_t)(C / 4 + J + 1);
@@ -2865,9 +2892,11 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     const bool chunked = q->max_len <= 8 && max_rows > 8 && max_rows_all <= 8 * kMaxT && (form_t == 4 || (form_t == 0 && C >= kChunkMinCands)) &&
                          stages == kStageAll && prm->scaling >= 0.25 && !tuning().fused_valu;
     if (chunked) {
-        ASPIRE_HIP_OK(hipMemsetAsync(grp_off, 0, sizeof(int32_t), s0));
+        a.chunk_regions = chunk_regions_of(J, max_job);
+        a.chunk_region_cap = chunk_region_cap_of(max_job);
+        if (a.chunk_regions == 0) ASPIRE_HIP_OK(hipMemsetAsync(grp_off, 0, sizeof(int32_t), s0));
         hipLaunchKernelGGL(chunk_prep_kernel, dim3((unsigned)J, (unsigned)chunk_parts(max_job) + 1), dim3(192), 0, s0, a.q, a.c, job_off, qbox,
-                           cand_job, grp_off, grp_rec);
+                           cand_job, grp_off, grp_rec, a.chunk_regions > 0 ? a.chunk_region_cap : 0);
         ASPIRE_LAUNCH_OK();
         if (int rc = launch_pair_fused_chunk(a, chunk_items_bound(J, C, max_job), qbox, s0)) return rc;
         if (k > 0)
@@ -2971,7 +3000,7 @@ L2BatchLayout l2_batch_layout(int64_t J, int64_t C, int64_t max_job, int64_t k) 
     size_t o = 0;
     L.cand_job = o; o = align16(o + (size_t)C * sizeof(int32_t));
     L.grp_job = o; o = align16(o + (size_t)(C / 4 + J + 1) * sizeof(int32_t));
-    L.grp_off = o; o = align16(o + (size_t)(J + 1) * sizeof(int32_t));
+    L.grp_off = o; o = align16(o + (size_t)(J + 1 > 64 ? J + 1 : 64) * sizeof(int32_t));
     L.grp_rec = o; o = align16(o + (2 * (size_t)chunk_items_bound(J, C, max_job) + 1) * 16 * sizeof(int32_t));     // (room for the CHUNK / REC forms' items)
     L.qbox = o; o = align16(o + (size_t)J * 2 * kD * sizeof(float));      // (written by the tables kernel, unused by max-sim)
     L.gate = o; o = align16(o + 16);
@@ -3041,9 +3070,12 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     // one launch in front of the rank, at any size (2 x 20: 19 us either way)
     // short queries against abstracts of up to 32 rows (config 4's shape): the CHUNK items of ot_rank_batch, max epilogue
     if (q->max_len <= 8 && max_rows > 8 && max_rows <= 8 * kMaxT && (form_t == 4 || (form_t == 0 && C >= kChunkMinCands)) && !one_form) {
-        ASPIRE_HIP_OK(hipMemsetAsync((int32_t*)(wsb + L.grp_off), 0, sizeof(int32_t), s0));
+        a.chunk_regions = chunk_regions_of(J, max_job);
+        a.chunk_region_cap = chunk_region_cap_of(max_job);
+        if (a.chunk_regions == 0) ASPIRE_HIP_OK(hipMemsetAsync((int32_t*)(wsb + L.grp_off), 0, sizeof(int32_t), s0));
         hipLaunchKernelGGL(chunk_prep_kernel, dim3((unsigned)J, (unsigned)chunk_parts(max_job) + 1), dim3(192), 0, s0, a.q, a.c, job_off,
-                           (float*)(wsb + L.qbox), (int32_t*)(wsb + L.cand_job), (int32_t*)(wsb + L.grp_off), (int32_t*)(wsb + L.grp_rec));
+                           (float*)(wsb + L.qbox), (int32_t*)(wsb + L.cand_job), (int32_t*)(wsb + L.grp_off), (int32_t*)(wsb + L.grp_rec),
+                           a.chunk_regions > 0 ? a.chunk_region_cap : 0);
         ASPIRE_LAUNCH_OK();
         if (int rc = launch_pair_fused_chunk_l2max(a, chunk_items_bound(J, C, max_job), s0)) return rc;
         const size_t need = aspire_topk_workspace_bytes(J, max_job, k);

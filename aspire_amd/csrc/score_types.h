@@ -47,6 +47,10 @@ struct ScoreArgs {
     int32_t max_job_groups;   // host-side launch geometry: upper bound of a job's groups of four
     int32_t tile_form;        // host-side: the batch runs on the throughput kernels
     int32_t skip_tail;        // diagnostics (FUSED_NOSOLVE=2): the fused kernel drops every wave's LAST solve (timing of the exposed tail)
+    // CHUNK items without a counter: with <= 64 classification blocks ("slices") every block writes its item count to grp_off[slice]
+    // and its records into its own region of chunk_region_cap records; a wave of the scoring kernel prefix-scans the 64 counts
+    // itself (as the SELF form does with job_off) -- no atomics, no memset in front of the call.  0: grp_off[0] = the item counter.
+    int32_t chunk_regions, chunk_region_cap;
     // Hybrid for pools of mostly short documents with a few of 9 .. 16 rows: a census of the long pairs (gate[0], written by
     // long_pair_census_kernel earlier on the stream) decides ON THE DEVICE how the queued kernels work.  Few long pairs
     // (gate[0] <= gate_limit): the fused kernel scores the short pairs and poisons the long ones, the 16-row streaming kernel
