@@ -919,8 +919,8 @@ __global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel
 
 }  // namespace
 
-// batched jobs: few enough jobs for the in-wave tables (one lane per job), and hyper-parameters that never need the repair
-// pass (which indexes the candidate -> job table)
+// batched jobs: few enough jobs for the in-wave tables (one lane per job), and hyper-parameters at which overflowed sums (each
+// re-solved by the wave that finds it) stay the exception
 bool fused_self_ok(int64_t jobs, const aspire_ot_params* prm) {
     return jobs <= 64 && prm->scaling >= 0.25 && tuning().fused_nosolve != 1 && !tuning().fused_valu && !tuning().fused_noself;
 }

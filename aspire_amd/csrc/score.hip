@@ -1888,7 +1888,7 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
             }
         score = blk_sum_i<LD>(blk_sum_j<LD>(acc));
     }
-    // an overflowed / vanished sum sticks to the potentials as inf / nan: poison the pair (repaired afterwards)
+    // an overflowed / vanished sum sticks to the potentials as inf / nan: poison the pair (sinkhorn_repair_kernel re-solves it)
     if (!(fabsf(score) < 1e30f) || q_len > LD * R || c_len > LD * R) score = __builtin_nanf("");
     if (real && lp == 0) a.scores[p] = score;
 }
@@ -1909,8 +1909,7 @@ __global__ void __launch_bounds__(256) sinkhorn_repair_kernel(ScoreArgs a, PairW
         const PairIdx ix = pair_of_slot(a, base + lane);
         const float s = a.scores[ix.p];
         bad = !(fabsf(s) < 1e30f);
-        // hybrid, few long pairs: only those have slots in the workspace -- a short pair the fused kernel poisoned (overflow)
-        // waits for the long-form repair behind this launch (launch_fused_repair)
+        // hybrid, few long pairs: only those have slots in the workspace (the fused kernel re-solves its own overflowed pairs)
         if (gate_few_long(a) && a.q.len[ix.q_idx] <= 8 && a.c.len[ix.c_idx] <= 8) bad = false;
     }
     unsigned long long todo = __ballot(bad);

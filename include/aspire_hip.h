@@ -277,9 +277,10 @@ int aspire_ot_rank_f32(const aspire_repset* q, const aspire_repset* c, int64_t D
  * laid back to back in one CSR rep set -- against query j of `q`, one epsilon schedule per pair
  * (AspireModel.get_similarity, src/evaluation/utils/models.py:190-197), and ranks each pool on its own (stable
  * descending, evaluate.py:76).  Launches on `stream`: ONE scoring launch over all pairs (costs and Sinkhorn solves fused
- * once the batch fills the chip), a short launch that scans the scores for pairs whose sums left fp32 range and re-solves them
- * (usually none), and one rank launch with a workgroup per job; batches of more than 64 jobs, and the small-batch kernel
- * forms, put a launch in front that builds the job tables and the query boxes.  Everything runs on the
+ * once the batch fills the chip; a pair whose sums leave fp32 range is re-solved in the max-shifted form by the wave that finds
+ * it) and one rank launch with a workgroup per job; batches of more than 64 jobs, batches whose documents exceed 8 rows (a launch
+ * that sorts the candidates into chunk items) and the small-batch kernel forms put a launch in front that builds the job tables
+ * and the query boxes.  Documents of up to 128 rows are accepted (33 .. 128: one workgroup per pair).  Everything runs on the
  * caller's stream: independent calls on different streams (each with its own outputs and workspace) overlap.
  *   q          J query documents (q->n == J), CSR (ext == 0)
  *   c          every job's candidates (c->n == C == job_off[J]), CSR (ext == 0)
