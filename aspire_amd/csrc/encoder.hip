@@ -850,7 +850,7 @@ int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     // TFLOP/s-equivalent against 136-151 with 128 x 64 tiles, N = 2304 166 against 148 with 128 x 96 -- the wider wave tile
     // reads less LDS per MFMA, and LDS bandwidth is what the six-product form runs into next).
     if constexpr (!B_KN) {
-        if (tuning().gemm_form != 1 && g.K % 16 == 0) {
+        if (tuning().gemm_form != 1 && g.K % 16 == 0) {       // (gemm_form 3 = planes pins the P layout in the forward; a bare GEMM has none)
             const int ft = tuning().gemm_tile;
             if (ft == 96 && g.N % 96 == 0) {
                 hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 96, 1>), dim3(g.N / 96, (g.M + 127) / 128, batch), dim3(256), 0, st, g);
@@ -996,7 +996,11 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
 
     // P path: the weights' planes are prepared (aspire_bert_prepare_planes), BERT-base shapes tile by 128 -- every nn.Linear GEMM
     // streams pre-split operands (gemm_p_kernel); otherwise (ASPIRE_HIP_GEMM=f32 | bf16x3, no planes) the round-2 kernels
-    const bool pp = w->planes != nullptr && tuning().gemm_form == 0 && dh == 64 && !tuning().attn_gemm && w->ffn_dim % 128 == 0;
+    // -- from ~3000 token rows on: below, the 128 x 128 tiles of the P-layout GEMM are too few to fill the chip and its 192-step k loop
+    // (K = 3072) sets the time (measured M = 1024: FFN2 110 vs 71 us; M = 4096: 112 vs 147), while the on-the-fly kernels pick
+    // smaller tiles there
+    const bool pp = w->planes != nullptr && (tuning().gemm_form == 0 ? M >= 3072 : tuning().gemm_form == 3) && dh == 64 && !tuning().attn_gemm &&
+                    w->ffn_dim % 128 == 0;
     const PlaneOffsets po = plane_offsets(w->ffn_dim);
     float* x = w->n_layers == 0 ? hidden_out : ws.x;
     hipLaunchKernelGGL(embed_layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, tok_ids, type_ids, w->word_emb, w->pos_emb,

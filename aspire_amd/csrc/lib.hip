@@ -32,7 +32,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         if (!unset && strcmp(v, "gemm")) return false;
         t.attn_gemm = unset ? 0 : 1;
     } else if (!strcmp(key, "GEMM")) {
-        const int f = unset ? 0 : !strcmp(v, "f32") ? 1 : !strcmp(v, "bf16x3") ? 2 : -1;
+        const int f = unset ? 0 : !strcmp(v, "f32") ? 1 : !strcmp(v, "bf16x3") ? 2 : !strcmp(v, "planes") ? 3 : -1;
         if (f < 0) return false;
         t.gemm_form = f;
     } else if (!strcmp(key, "GEMM_TILE")) {
@@ -76,7 +76,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     } else if (!strcmp(key, "COST_PATH")) v = t.cost_path == 1 ? "mfma" : t.cost_path == 2 ? "valu" : "";
     else if (!strcmp(key, "COST1_BLOCKS")) v = number(t.cost1_blocks);
     else if (!strcmp(key, "ATTN")) v = t.attn_gemm ? "gemm" : "";
-    else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : "";
+    else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : t.gemm_form == 3 ? "planes" : "";
     else if (!strcmp(key, "GEMM_TILE")) v = number(t.gemm_tile);
     else if (!strcmp(key, "GEMM_RING")) v = number(t.gemm_ring);
     else if (!strcmp(key, "FUSED_VALU")) v = number(t.fused_valu);

@@ -10,7 +10,7 @@ struct Tuning {
     int cost_path = 0;       // ASPIRE_HIP_COST_PATH: 0 by shape, 1 mfma (Gram kernel), 2 valu
     int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
-    int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default (bf16x3 for nn.Linear shapes), 1 f32 = fp32-input MFMA everywhere, 2 bf16x3 = three-way bf16 split on the bf16 matrix pipe
+    int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default (pre-split operands from ~3000 token rows on, else bf16x3), 1 f32 = fp32-input MFMA everywhere, 2 bf16x3 = operands split on the fly, 3 planes = pre-split operands at any size
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
     int gemm_ring = 0;       // ASPIRE_HIP_GEMM_RING=2 | 3: LDS ring depth of the P-layout GEMM (2: 48 KB, three workgroups per CU; default 3: 72 KB, two)
     int gemm_tile = 0;       // ASPIRE_HIP_GEMM_TILE=128 | 64: force 128 x 128 / 128 x 64 tiles in the bf16x3 form (tuning)

@@ -209,3 +209,24 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
     torch.cuda.synchronize()
     want = torch.nn.functional.gelu(A.double() @ B.double().T + bias.double())
     assert (H.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize('n_layers,b,l', [(2, 4, 128), (12, 2, 64), (1, 2, 300), (2, 2, 502), (1, 3, 37)])
+def test_bert_forward_on_presplit_operands_small_shapes(n_layers, b, l):
+    """The forward on pre-split operands (P layout, LDS-DMA GEMM, planes written by the LayerNorm / attention / GELU epilogues) is the
+    default from ~3000 token rows on (the 12-layer B = 32, L = 256 test of test_gpu_pipeline.py runs it); pinned here at small
+    shapes -- row counts that are no multiple of the 128-row tile, L = 502 -- against HuggingFace BertModel at 1e-4 and against the
+    on-the-fly-split form."""
+    from aspire_amd._lib import pinned
+    from aspire_amd.encoder import HipBertEncoder
+    m = _bert(n_layers, seed=7)
+    tok, seg, mask, _ = _batch(b, l, 3000, seed=200 + l)
+    with torch.no_grad():
+        want = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
+    enc = HipBertEncoder(m)
+    with pinned(GEMM='planes'):
+        got = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+    with pinned(GEMM='bf16x3'):
+        other = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+    assert (got - want).abs().max().item() < TOL
+    assert (got - other).abs().max().item() < 2e-5
