@@ -83,6 +83,20 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
     scores, top_s, top_i = ops.ot_rank(q, pool.repset, kk, want=_lib.OT_SIMILARITY)
     torch.cuda.synchronize()
     t_score = time.perf_counter() - t0
+    # the same score + rank stage on i.i.d. N(0, 1) reps of the same shapes: random-init BERT puts every sentence rep almost on
+    # one line (cosine ~0.99), where the matrix-pipe cost kernel's |x|^2 - 2 x.y + |y|^2 cancels and nearly every entry is redone
+    # with the direct formula (NOTES.md section 3: pair_gram_kernel) -- trained reps are not like that
+    g = torch.Generator().manual_seed(seed + 7)
+    iid_c = ops.DeviceRepSet(torch.randn(n_docs * S, 768, generator=g).to(dev), pool.repset.start, pool.repset.len, ext=0, max_len=S)
+    iid_q = ops.DeviceRepSet(torch.randn(n_queries * S, 768, generator=g).to(dev), q.start, q.len, ext=0, max_len=S)
+    ops.ot_rank(iid_q, iid_c, kk, want=_lib.OT_SIMILARITY)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.ot_rank(iid_q, iid_c, kk, want=_lib.OT_SIMILARITY)
+    torch.cuda.synchronize()
+    t_score_iid = time.perf_counter() - t0
+    cosq = torch.nn.functional.normalize(pool.repset.rows[:2048], dim=1)
+    mean_cos = float((cosq @ cosq.T).mean())
     out = {
         'what': f'config 5, one GPU slice: {n_docs} docs x {L} tokens ({S} sentences) encoded in batches of {BATCH} straight into the resident '
                 f'rep store, then {n_queries} queries x otAspire + top-{kk} on it (pp_gen_nearest.py:141-202); synthetic tokens, '
@@ -90,6 +104,8 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
         'docs': n_docs, 'tokens': L, 'sents': S, 'queries': n_queries,
         'encode_s': t_encode, 'docs_per_s': n_docs / t_encode,
         'score_rank_s': t_score, 'pairs_per_s': n_queries * n_docs / t_score,
+        'score_rank_on_iid_reps_s': t_score_iid, 'pairs_per_s_on_iid_reps': n_queries * n_docs / t_score_iid,
+        'mean_cosine_of_encoded_reps': mean_cos,
         'split_ms': {'encoder_kernels': enc_ms * n_batches, 'pooling_kernels': pool_ms * n_batches,
                      'encode_host_and_gaps': t_encode * 1e3 - (enc_ms + pool_ms) * n_batches, 'ot_and_rank': t_score * 1e3},
         'encoder_share_of_total': enc_ms * n_batches / (t_encode * 1e3 + t_score * 1e3),
