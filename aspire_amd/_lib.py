@@ -22,6 +22,8 @@ ASPIRE_OK, ASPIRE_ERR_INVALID_ARG, ASPIRE_ERR_UNSUPPORTED, ASPIRE_ERR_HIP = 0, 1
 CDIST_AUTO, CDIST_DIRECT, CDIST_MM = 0, 1, 2
 CDIST_ONE_FORM = 0x100       # or'ed into cdist_mode of the max-sim entry points: one kernel form whatever the call's size
 OT_FLAG_ONE_FORM = 1         # aspire_ot_params.flags: the same for otAspire
+CDIST_CENTER = 0x200         # rows with a large common component: subtract the query's mean row before the expansion (max-sim entries)
+OT_FLAG_CENTER = 2           # the same for otAspire
 PAIR_CROSS, PAIR_PAIRED = 0, 1
 OT_DISTANCE, OT_PLAN_SIM, OT_SIMILARITY = 0, 1, 2
 AGG_MAX, AGG_TOP2, AGG_ATTENTION = 0, 1, 2

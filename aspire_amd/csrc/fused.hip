@@ -633,6 +633,26 @@ __global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel
             // ---- stage: registers -> LDS, with box / norm side products; only THEN the next stage's loads go out, into
             // the registers just consumed (hoisted above the side products they need a second set of 48 registers and a
             // copy of all of them per stage); they fly under this stage's arithmetic ----
+            if (a.center) {
+                // centre of the rows at this lane's chunk: the mean of the eight staged query rows (rows past the query's end repeat
+                // its last one: any vector near the data will do) -- two rows per lane group, summed across the four groups
+                float4 mu = make_float4(vx[0].x + vx[1].x, vx[0].y + vx[1].y, vx[0].z + vx[1].z, vx[0].w + vx[1].w);
+                mu.x += lane_xor<16>(mu.x); mu.y += lane_xor<16>(mu.y); mu.z += lane_xor<16>(mu.z); mu.w += lane_xor<16>(mu.w);
+                mu.x += lane_xor<32>(mu.x); mu.y += lane_xor<32>(mu.y); mu.z += lane_xor<32>(mu.z); mu.w += lane_xor<32>(mu.w);
+                mu.x *= 0.125f; mu.y *= 0.125f; mu.z *= 0.125f; mu.w *= 0.125f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    vy[j].x -= mu.x; vy[j].y -= mu.y; vy[j].z -= mu.z; vy[j].w -= mu.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    vx[k].x -= mu.x; vx[k].y -= mu.y; vx[k].z -= mu.z; vx[k].w -= mu.w;
+                }
+                if constexpr (!INBOX && !L2MAX) {       // the query's box (from the tables launch) moves with its rows
+                    qmn.x -= mu.x; qmn.y -= mu.y; qmn.z -= mu.z; qmn.w -= mu.w;
+                    qmx.x -= mu.x; qmx.y -= mu.y; qmx.z -= mu.z; qmx.w -= mu.w;
+                }
+            }
             float4 mn = vy[0], mx = vy[0];
             {
 #pragma unroll

@@ -2057,8 +2057,8 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     ASPIRE_REQUIRE(scores, ASPIRE_ERR_INVALID_ARG, "scores is null");
     ASPIRE_REQUIRE((!pair_sims && !pair_softmax) || (q->ext > 0 && c->ext > 0), ASPIRE_ERR_INVALID_ARG,
                    "pair outputs need padded extents (ext > 0)");
-    const bool one_form = (cdist_mode & ASPIRE_CDIST_ONE_FORM) != 0;
-    cdist_mode &= ~ASPIRE_CDIST_ONE_FORM;
+    const bool one_form = (cdist_mode & ASPIRE_CDIST_ONE_FORM) != 0, center = (cdist_mode & ASPIRE_CDIST_CENTER) != 0;
+    cdist_mode &= ~(ASPIRE_CDIST_ONE_FORM | ASPIRE_CDIST_CENTER);
     ASPIRE_REQUIRE(!one_form || agg == ASPIRE_AGG_MAX, ASPIRE_ERR_UNSUPPORTED, "ASPIRE_CDIST_ONE_FORM is built for the max-sim score only");
     ScoreArgs a{};
     a.q = to_dev(q);
@@ -2070,6 +2070,7 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     a.scores = scores;
     a.out_pairsims = pair_sims;
     a.out_plan = pair_softmax;
+    a.center = center;
     if (one_form)      // every pair through the long-form kernel, whatever the size of the call (include/aspire_hip.h)
         return launch_pair_generic(a, 1, 0, q->ext > 0 ? q->ext : q->max_len, c->ext > 0 ? c->ext : c->max_len, (hipStream_t)stream);
     // ONE query against a big pool of 9 .. 16-row documents: the streaming kernel's max-sim form (tile16.hip)
@@ -2183,6 +2184,7 @@ void fill_ot_args(ScoreArgs& a, const aspire_repset* q, const aspire_repset* c, 
     a.n_groups = diameter ? (c->n + diam_group - 1) / diam_group : 0;
     a.want = want;
     a.scores = scores;
+    a.center = (prm->flags & ASPIRE_OT_FLAG_CENTER) != 0;
 }
 
 // The hybrid forms (fused kernel in front of the 16-row kernels, ScoreArgs::gate) need a solve stage that leaves the short pairs'
@@ -3041,13 +3043,14 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
                    "workspace too small: %zu bytes given, aspire_l2max_rank_batch_workspace_bytes says %zu", workspace_bytes, L.total);
     ASPIRE_REQUIRE(((uintptr_t)workspace & 15) == 0, ASPIRE_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
     char* wsb = (char*)workspace;
-    const bool one_form = (cdist_mode & ASPIRE_CDIST_ONE_FORM) != 0;
-    cdist_mode &= ~ASPIRE_CDIST_ONE_FORM;
+    const bool one_form = (cdist_mode & ASPIRE_CDIST_ONE_FORM) != 0, center = (cdist_mode & ASPIRE_CDIST_CENTER) != 0;
+    cdist_mode &= ~(ASPIRE_CDIST_ONE_FORM | ASPIRE_CDIST_CENTER);
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
     a.pairing = kPairMapped;
     a.cdist_mode = cdist_mode;
+    a.center = center;
     a.agg = ASPIRE_AGG_MAX;
     a.temp = 1.0;
     a.scores = scores;

@@ -163,6 +163,27 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
 #pragma unroll 1
         for (int st = 0; st < kStages; ++st) {
             // ---- stage: registers -> LDS with norm / box side products, THEN the next stage's loads into the same registers ----
+            if (a.center) {
+                // rows sharing a large common component (ASPIRE_OT_FLAG_CENTER, fused.hip): the mean of the sixteen staged query
+                // rows comes off every row and off the query's box before anything is squared
+                float4 mu = make_float4(vx[0].x + vx[1].x + vx[2].x + vx[3].x, vx[0].y + vx[1].y + vx[2].y + vx[3].y,
+                                        vx[0].z + vx[1].z + vx[2].z + vx[3].z, vx[0].w + vx[1].w + vx[2].w + vx[3].w);
+                mu.x += lane_xor<16>(mu.x); mu.y += lane_xor<16>(mu.y); mu.z += lane_xor<16>(mu.z); mu.w += lane_xor<16>(mu.w);
+                mu.x += lane_xor<32>(mu.x); mu.y += lane_xor<32>(mu.y); mu.z += lane_xor<32>(mu.z); mu.w += lane_xor<32>(mu.w);
+                mu.x *= 0.0625f; mu.y *= 0.0625f; mu.z *= 0.0625f; mu.w *= 0.0625f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    vy[j].x -= mu.x; vy[j].y -= mu.y; vy[j].z -= mu.z; vy[j].w -= mu.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    vx[k].x -= mu.x; vx[k].y -= mu.y; vx[k].z -= mu.z; vx[k].w -= mu.w;
+                }
+                if constexpr (!L2MAX) {
+                    qmn.x -= mu.x; qmn.y -= mu.y; qmn.z -= mu.z; qmn.w -= mu.w;
+                    qmx.x -= mu.x; qmx.y -= mu.y; qmx.z -= mu.z; qmx.w -= mu.w;
+                }
+            }
             {
                 float4 mn = vy[0], mx = vy[0];
 #pragma unroll

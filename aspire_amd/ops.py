@@ -86,6 +86,24 @@ class DeviceRepSet:
         return DeviceRepSet(self.rows, self.start[lo:hi].contiguous(), self.len[lo:hi].contiguous(), self.ext,
                             self.max_len, lens_host=self.lens_host[lo:hi] if self.lens_host is not None else None)
 
+    def center_hint(self):
+        """True when the rows share a large common component (|mean row|^2 > 0.25 x the mean squared norm, i.e. a mean cosine of
+        roughly 0.25 between unrelated rows -- sentence-embedding spaces are usually far above that): the scoring calls then set
+        ASPIRE_OT_FLAG_CENTER / ASPIRE_CDIST_CENTER (include/aspire_hip.h).  From a sample of up to 512 rows, once per rep set."""
+        if getattr(self, '_center_hint', None) is None:
+            hint = getattr(self.rows, '_aspire_center_hint', None)     # kept on the matrix: index lists into it share the answer
+            if hint is None:
+                n = int(self.rows.shape[0])
+                if n == 0:
+                    hint = False
+                else:
+                    sample = self.rows[::max(1, n // 512)][:512]
+                    m = sample.mean(0)
+                    hint = bool((m @ m) > 0.25 * (sample * sample).sum(1).mean())
+                self.rows._aspire_center_hint = hint
+            self._center_hint = hint
+        return self._center_hint
+
     def host_lens(self):
         if self.lens_host is None:
             self.lens_host = self.len.cpu().tolist()
@@ -134,6 +152,8 @@ def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want
     include/aspire_hip.h, ASPIRE_CDIST_ONE_FORM."""
     if one_form:
         cdist_mode |= _lib.CDIST_ONE_FORM
+    if c.center_hint():
+        cdist_mode |= _lib.CDIST_CENTER
     p = _npairs(q, c, pairing)
     dev = q.rows.device
     scores = torch.empty(p, device=dev, dtype=torch.float32)
@@ -183,7 +203,7 @@ def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_t
     if want_extras:
         extras = [torch.empty(p, q.ext, device=dev), torch.empty(p, c.ext, device=dev),
                   torch.empty(p, q.ext, c.ext, device=dev), torch.empty(p, q.ext, c.ext, device=dev)]
-    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, _lib.OT_FLAG_ONE_FORM if one_form else 0)
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, (_lib.OT_FLAG_ONE_FORM if one_form else 0) | (_lib.OT_FLAG_CENTER if c.center_hint() else 0))
     qs, cs = q.struct(), c.struct()
     nbytes = lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), pairing)
     ws = workspace if workspace is not None else torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
@@ -201,7 +221,7 @@ def ot_rank(q, c, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.C
     is of the OUTPUT; pass want=OT_PLAN_SIM for similarities) -- or (scores, keys [Q, k]) with key_form."""
     dev = q.rows.device
     scores = torch.empty(q.n, c.n, device=dev, dtype=torch.float32)
-    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, _lib.OT_FLAG_ONE_FORM if one_form else 0)
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, (_lib.OT_FLAG_ONE_FORM if one_form else 0) | (_lib.OT_FLAG_CENTER if c.center_hint() else 0))
     qs, cs = q.struct(), c.struct()
     nbytes = lib.aspire_ot_rank_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), k)
     ws = torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
@@ -238,7 +258,7 @@ def ot_rank_batch(q, c, job_off, max_job, k, blur=0.05, scaling=0.9, sent_sm_tem
         top_s = torch.empty(q.n, k, device=dev, dtype=torch.float32) if k > 0 and not key_form else None
         top_i = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and not key_form else None
         keys = torch.empty(q.n, k, device=dev, dtype=torch.int64) if k > 0 and key_form else None
-    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, _lib.OT_FLAG_ONE_FORM if one_form else 0)
+    prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, (_lib.OT_FLAG_ONE_FORM if one_form else 0) | (_lib.OT_FLAG_CENTER if c.center_hint() else 0))
     qs, cs = q.struct(), c.struct()
     if workspace is None:
         nbytes = lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), max_job, k)
@@ -256,6 +276,8 @@ def l2max_rank_batch(q, c, job_off, max_job, k, cdist_mode=_lib.CDIST_AUTO, out=
     dev = q.rows.device
     if one_form:
         cdist_mode |= _lib.CDIST_ONE_FORM
+    if c.center_hint():
+        cdist_mode |= _lib.CDIST_CENTER
     _i32(job_off, 'job_off')
     assert job_off.numel() == q.n + 1, 'job_off must have one entry per job plus one'
     keys = None

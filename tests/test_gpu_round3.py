@@ -129,3 +129,42 @@ def test_hybrid_forms_leave_short_pairs_alone_under_a_pinned_wave_solver(amd):
         for i, s in enumerate(w):
             if i in top:
                 assert abs(top[i] - s) < TOL
+
+
+def test_rows_with_a_common_component_are_centred(amd):
+    """Anisotropic embeddings (every row = a common vector + its own part, mean cosine ~0.8): the expansion |x|^2 - 2 x.y + |y|^2
+    cancels for nearly every entry; with ASPIRE_OT_FLAG_CENTER (set by aspire_amd.ops from a sample of the pool) the fused kernels
+    subtract the query's mean row first.  Same numbers as the oracle -- one pool, batched jobs (8-row and chunked), max-sim."""
+    g = torch.Generator().manual_seed(111)
+    base = 2.0 * torch.randn(768, generator=g)
+    mk = lambda n: torch.randn(int(n), 768, generator=g) + base
+    lens = torch.randint(1, 9, (4200,), generator=g).tolist()
+    cands = [mk(n) for n in lens]
+    queries = [mk(7), mk(3)]
+    c = amd.ops.DeviceRepSet.from_list(cands)
+    assert c.center_hint() and not amd.ops.DeviceRepSet.from_list(_docs(3, [8] * 64)).center_hint()
+    got = amd.scorer.score_pool(queries[:1], cands, method='ot').cpu().numpy()[0]
+    idx = [0, 1, 2099, 4199]
+    want = np.array([orc.get_similarity(queries[0], cands[i]) for i in idx], dtype=np.float32)
+    np.testing.assert_allclose(got[idx], want, atol=TOL, rtol=0)
+    l2 = amd.scorer.score_pool(queries[:1], cands, method='l2max').cpu().numpy()[0]
+    want_l2 = [-orc.allpair_masked_dist_l2max(orc.RepLen(queries[0][None].permute(0, 2, 1), [7]),
+                                              orc.RepLen(cands[i][None].permute(0, 2, 1), [len(cands[i])])).item() for i in idx]
+    np.testing.assert_allclose(l2[idx], want_l2, atol=TOL, rtol=0)
+    # one pool of 9 .. 32-row documents against a 14-row query: the 16-row tile kernels
+    long_c = [mk(n) for n in torch.randint(9, 33, (600,), generator=g).tolist()]
+    long_q = mk(14)
+    for method, ref in (('ot', lambda c_: orc.get_similarity(long_q, c_)),
+                        ('l2max', lambda c_: -orc.allpair_masked_dist_l2max(orc.RepLen(long_q[None].permute(0, 2, 1), [14]),
+                                                                            orc.RepLen(c_[None].permute(0, 2, 1), [len(c_)])).item())):
+        got = amd.scorer.score_pool([long_q], long_c, method=method).cpu().numpy()[0]
+        np.testing.assert_allclose(got[[0, 299, 599]], [ref(long_c[i]) for i in (0, 299, 599)], atol=TOL, rtol=0)
+    # batched jobs: 8-row documents (fused kernel) and abstracts of up to 20 rows (CHUNK items)
+    for cmax in (8, 20, 32):                               # 32: the 16-row tile kernels' record items
+        lens2 = torch.randint(1, cmax + 1, (1600,), generator=g).tolist()
+        docs = [mk(n) for n in lens2]
+        pools = [docs[:800], docs[800:]]
+        ranked = amd.scorer.rank_pools(queries, pools, k=5)
+        for j in range(2):
+            for pid, s in ranked[j][:3]:
+                assert abs(s - orc.get_similarity(queries[j], pools[j][pid])) < TOL, (cmax, j, pid)
