@@ -362,53 +362,74 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Pre-split operands ("P layout") and the GEMM that streams them.  Round 2's bf16x3 kernel split BOTH fp32 operands into
-// their three bf16 planes on the fly, in every workgroup, for every tile (28 M VALU wave-instructions per 8192 x 2304 x 768
-// launch, 12 ds_write_b64 per thread and tile) although the weights never change and every activation is read by 6 - 24
-// column tiles: the matrix pipe was busy 0.37 - 0.41 of the launch.  Here the planes are formed ONCE -- the weights when the
-// model is loaded (aspire_bert_prepare_planes), an activation by the epilogue of the kernel that produces it (LayerNorm,
-// attention, the GELU GEMM) -- and the GEMM's main loop is LDS-DMA + fragment reads + MFMAs, no VALU work at all.
+// three bf16 planes on the fly, in every workgroup, for every tile (28 M VALU wave-instructions per 8192 x 2304 x 768
+// launch) and paid SIX matrix instructions per term; the matrix pipe was busy 0.37 - 0.41 of the launch and throttled the
+// clock.  Here the planes are formed ONCE -- the weights when the model is loaded (aspire_bert_prepare_planes), an activation
+// by the epilogue of the kernel that produces it (LayerNorm, attention, the GELU GEMM) -- the GEMM's main loop is LDS-DMA +
+// fragment reads + MFMAs, and the split is TWO fp16 planes:
+//     x = h + l,  h = fp16(x) (round to nearest),  l = fp16(x - h):   |x - h - l| <= 2^-24 |x|  (11 + 11 bits and l's sign)
+//     x . y = h.h' + h.l' + l.h'  (+ l.l' <= 2^-22 of the term: dropped)
+// -- THREE v_mfma_f32_32x32x16_f16 per term, products exact, sums in fp32.  That is fp32's own precision as long as l does not
+// lose bits to fp16's narrow exponent: the matrix pipe keeps fp16 subnormals (tools/experiments/mfma_f16_denorm.hip), so an l
+// below 2^-14 still carries an absolute 2^-25 -- elements of magnitude >= 2^-3 are split at full relative precision and the
+// rest at an absolute error below that of an fp32 sum of O(1) terms.  Activations (LayerNorm outputs, attention context, GELU
+// outputs: O(1), far below fp16's 65504) go in as they are; the weights (~0.02 - 0.05) are scaled by kPWeightScale = 2^6
+// before the split and the epilogue takes the factor off again (exact).  Measured against a float64 product at K = 768: rms
+// error 0.2 x that of a plain fp32 GEMM's before accumulation (numpy model), tests/test_gpu_encoder.py on the device.
 //
-// P layout of a matrix X [R, K] (K % 16 == 0), 6 bytes per element: for every 16-wide k block kb and row r six 16-byte
-// pieces (plane pl, k half kh) = the 8 bf16 of plane pl at k = 16 kb + 8 kh .. + 7, stored at
-//     piece index ((kb * R + r) * 6 + 2 * pl + (kh ^ ((r >> 3) & 1)))
-// so that (a) the 128 rows of a tile at one k block are ONE contiguous 12 KB run: twelve global_load_lds_dwordx4 move it
+// P layout of a matrix X [R, K] (K % 32 == 0), 4 bytes per element: for every 32-wide k block kb and row r eight 16-byte
+// pieces (plane pl, k quarter kq) = the 8 fp16 of plane pl at k = 32 kb + 8 kq .. + 7, stored at
+//     piece index (kb * R + r) * 8 + ((4 pl + kq) ^ ((r >> 1) & 7))
+// so that (a) the 128 rows of a tile at one k block are ONE contiguous 16 KB run: sixteen global_load_lds_dwordx4 move it
 // into LDS exactly as it lies in HBM (the LDS image of an LDS-DMA is lane-linear), and (b) a fragment read -- lane = (row,
-// k half) reads its 16 bytes at 96 row + 32 pl + 16 (kh ^ row bit 3) -- is conflict free: 96-byte rows put rows r and r + 8
-// on the same banks, the k halves swapped in rows with bit 3 set move them apart (ds_read_b128 lane groups cover 16 rows whose
-// indices are distinct modulo 16).
+// k quarter) reads 16 bytes -- is conflict free: 128-byte rows put rows r and r + 2 on the same banks, the XOR with the row's
+// bits 1..3 spreads the sixteen rows of a ds_read_b128 lane group over the sixteen 16-byte columns of the 256-byte bank line.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kPRowBytes = 96;                       // one row of one k block: 3 planes x 2 halves x 16 bytes
-constexpr int kPTile = 128 * kPRowBytes;             // one operand tile of one k step (12 KB)
+constexpr int kPRowBytes = 128;                      // one row of one k block: 2 planes x 4 quarters x 16 bytes
+constexpr int kPTile = 128 * kPRowBytes;             // one operand tile of one k step (16 KB)
 constexpr int kPPadRows = 128;                       // rows of slack behind a P matrix: the last row tile may read past R
+constexpr float kPWeightScale = 64.f;                // weights are split as 64 w (module comment)
 
-__host__ __device__ inline size_t p_bytes(int64_t R, int64_t K) { return (size_t)(R + kPPadRows) * K * 6; }
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-// four consecutive k (k % 4 == 0) of row r -> the three planes' 8-byte halves
-__device__ __forceinline__ void p_store4(void* P, int64_t R, int64_t r, int k, float x, float y, float z, float w) {
-    uint32_t a1, a2, a3, b1, b2, b3;
-    split3_bf16(x, y, a1, a2, a3);
-    split3_bf16(z, w, b1, b2, b3);
-    const int kb = k >> 4, kh = (k >> 3) & 1, half = (k >> 2) & 1;
-    char* base = (char*)P + (((size_t)kb * R + r) * 6 + (kh ^ (int)((r >> 3) & 1))) * 16 + half * 8;
-    *reinterpret_cast<uint2*>(base) = make_uint2(a1, b1);
-    *reinterpret_cast<uint2*>(base + 32) = make_uint2(a2, b2);
-    *reinterpret_cast<uint2*>(base + 64) = make_uint2(a3, b3);
+__host__ __device__ inline size_t p_bytes(int64_t R, int64_t K) { return (size_t)(R + kPPadRows) * K * 4; }
+
+// (x, y) -> packed fp16 pairs of the two planes
+__device__ __forceinline__ void split2_f16(float x, float y, uint32_t& h, uint32_t& l) {
+    const _Float16 hx = (_Float16)x, hy = (_Float16)y;
+    const _Float16 lx = (_Float16)(x - (float)hx), ly = (_Float16)(y - (float)hy);
+    h = (uint32_t)__builtin_bit_cast(uint16_t, hx) | ((uint32_t)__builtin_bit_cast(uint16_t, hy) << 16);
+    l = (uint32_t)__builtin_bit_cast(uint16_t, lx) | ((uint32_t)__builtin_bit_cast(uint16_t, ly) << 16);
 }
 
-// X [R, K] fp32 row-major (row stride ld) -> P layout: the weights at model load, and the tools' operands
-__global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ X, int64_t R, int K, int ld, void* __restrict__ P) {
+// four consecutive k (k % 4 == 0) of row r -> the two planes' 8-byte halves
+__device__ __forceinline__ void p_store4(void* P, int64_t R, int64_t r, int k, float x, float y, float z, float w) {
+    uint32_t h0, l0, h1, l1;
+    split2_f16(x, y, h0, l0);
+    split2_f16(z, w, h1, l1);
+    const int kb = k >> 5, kq = (k >> 3) & 3, half = (k >> 2) & 1, sw = (int)((r >> 1) & 7);
+    char* row = (char*)P + ((size_t)kb * R + r) * kPRowBytes + half * 8;
+    *reinterpret_cast<uint2*>(row + 16 * (kq ^ sw)) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(row + 16 * ((4 + kq) ^ sw)) = make_uint2(l0, l1);
+}
+
+// scale * X [R, K] fp32 row-major (row stride ld) -> P layout: the weights at model load, and the tools' operands
+// *too_big (optional) is raised when an element leaves fp16's range (|scale x| > 65504, or not finite)
+__global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ X, int64_t R, int K, int ld, void* __restrict__ P,
+                                                           float scale, int* __restrict__ too_big) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int k4 = K / 4;
     if (idx >= R * k4) return;
     const int64_t r = idx / k4;
     const int k = (int)(idx % k4) * 4;
     const float4 v = *reinterpret_cast<const float4*>(X + r * ld + k);
-    p_store4(P, R, r, k, v.x, v.y, v.z, v.w);
+    p_store4(P, R, r, k, scale * v.x, scale * v.y, scale * v.z, scale * v.w);
+    if (too_big && !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) * scale <= 65504.f)) *too_big = 1;
 }
 
 struct PGemmArgs {
     const void* Ap;      // P layout [M, K]
-    const void* Bp;      // P layout [N, K] (nn.Linear weight)
+    const void* Bp;      // P layout [N, K] (nn.Linear weight, scaled by kPWeightScale)
     float* C;            // fp32 [M, ldc] out (F32 epilogue)
     void* Cp;            // P layout [M, N] out (GELU_P epilogue: the next GEMM's A operand, its k dimension = N)
     const float* bias;   // [N] or null
@@ -426,9 +447,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// C = A . B^T on 128 x 128 tiles, BK = 16, four waves of 64 x 64, the six bf16 products per term of gemm_bf16x3_kernel.
-// NS-stage LDS ring filled by LDS-DMA NS - 1 tiles ahead; per k step and wave: 6 DMA pieces, 12 fragment reads, 24 MFMAs, one
-// barrier.  Order of a step: wait for the own pieces of tile t (s_waitcnt vmcnt(6 (NS - 2)): the younger tiles stay in
+// C = A . B^T on 128 x 128 tiles, BK = 32 (two 16-wide MFMA k steps), four waves of 64 x 64, three fp16 products per term.
+// NS-stage LDS ring filled by LDS-DMA NS - 1 tiles ahead; per k step and wave: 8 DMA pieces, 16 fragment reads, 24 MFMAs, one
+// barrier.  Order of a step: wait for the own pieces of tile t (s_waitcnt vmcnt(8 (NS - 2)): the younger tiles stay in
 // flight), barrier (everybody's pieces of tile t have landed AND everybody has read tile t - 1, whose slot is free now), issue
 // tile t + NS - 1 into that slot, read fragments, multiply.
 // SWAP: the MFMA's operands exchanged -- accumulator registers run along n, the lane is a row m -- for the epilogue that writes
@@ -439,9 +460,9 @@ template <int NS, int BN, bool SWAP>
 __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     constexpr int TN = BN / 64;                             // 32-column blocks per wave
     constexpr int kBTile = BN * kPRowBytes, kStage = kPTile + kBTile;
-    constexpr int kBPieces = kBTile / 1024;                 // 12 (BN = 128) or 6
-    constexpr int kBPerWave = (kBPieces + 3) / 4;           // 3 or 2 (BN = 64: waves 2, 3 repeat pieces 0, 1 -- equal counts per wave)
-    constexpr int kPerWave = 3 + kBPerWave;                 // LDS-DMA instructions per wave and stage
+    constexpr int kBPieces = kBTile / 1024;                 // 16 (BN = 128) or 8
+    constexpr int kBPerWave = kBPieces / 4;                 // 4 or 2
+    constexpr int kPerWave = 4 + kBPerWave;                 // LDS-DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -456,25 +477,27 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         by = L / gx;
     }
     const int m0 = by * 128, n0 = g.n_off + bx * BN;
-    const int nk = g.K >> 4;
+    const int nk = g.K >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)p_smem;
-    // wave w moves pieces 3 w .. 3 w + 2 (1 KB each) of the A tile and pieces w, w + 4 (, w + 8) of the B tile
-    const char* a_src = (const char*)g.Ap + (size_t)m0 * kPRowBytes + (3 * wave) * 1024 + lane * 16;
+    // wave w moves pieces 4 w .. 4 w + 3 (1 KB = 8 rows each) of the A tile and pieces w, w + 4 (, w + 8, w + 12) of the B tile
+    const char* a_src = (const char*)g.Ap + (size_t)m0 * kPRowBytes + (4 * wave) * 1024 + lane * 16;
     const char* b_src = (const char*)g.Bp + (size_t)n0 * kPRowBytes + lane * 16;
     const size_t a_step = (size_t)g.M * kPRowBytes, b_step = (size_t)g.N * kPRowBytes;
     auto issue = [&](int slot, int kb) {
         const uint32_t dst = lds0 + slot * kStage;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) glds16(a_src + kb * a_step + u * 1024, dst + (3 * wave + u) * 1024);
+        for (int u = 0; u < 4; ++u) glds16(a_src + kb * a_step + u * 1024, dst + (4 * wave + u) * 1024);
 #pragma unroll
         for (int u = 0; u < kBPerWave; ++u) {
-            const int piece = (wave + 4 * u) % kBPieces;
+            const int piece = wave + 4 * u;
             glds16(b_src + kb * b_step + piece * 1024, dst + kPTile + piece * 1024);
         }
     };
-    const uint32_t frag = 16 * (lk ^ ((lr >> 3) & 1));
-    const unsigned char* a_rd = p_smem + (wr * 64 + lr) * kPRowBytes + frag;
-    const unsigned char* b_rd = p_smem + kPTile + (wc * 32 * TN + lr) * kPRowBytes + frag;
+    // fragment (plane pl, MFMA k step s) of this lane's row: piece (4 pl + 2 s + lk) ^ ((row >> 1) & 7); the row's bits 1..3 are
+    // lr's (tiles and wave tiles start on multiples of 32)
+    const uint32_t frag0 = 16 * (lk ^ ((lr >> 1) & 7));
+    const unsigned char* a_rd = p_smem + (wr * 64 + lr) * kPRowBytes;
+    const unsigned char* b_rd = p_smem + kPTile + (wc * 32 * TN + lr) * kPRowBytes;
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -488,36 +511,39 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
     struct Frags {
-        bf16x8_t a[2][3], b[TN][3];
+        f16x8_t a[2][2][2], b[TN][2][2];       // [block][plane][k step]
     };
     auto read_frags = [&](Frags& f, int slot) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                f.a[i][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_rd + slot * kStage + i * 32 * kPRowBytes + 32 * pl));
+            for (int s = 0; s < 2; ++s) {
+                const uint32_t fo = frag0 ^ (16 * (4 * pl + 2 * s));
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                f.b[j][pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b_rd + slot * kStage + j * 32 * kPRowBytes + 32 * pl));
-        }
+                for (int i = 0; i < 2; ++i)
+                    f.a[i][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(a_rd + slot * kStage + i * 32 * kPRowBytes + fo));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    f.b[j][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(b_rd + slot * kStage + j * 32 * kPRowBytes + fo));
+            }
     };
     auto mma = [&](const Frags& f) {
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};        // the small products first
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (SWAP)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j][PB[term]], f.a[i][PA[term]], acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[term]], f.b[j][PB[term]], acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.b[j][PB[term]][s], f.a[i][PA[term]][s], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][PA[term]][s], f.b[j][PB[term]][s], acc[i][j], 0, 0, 0);
+                    }
     };
     static_assert(NS == 2 || NS == 3, "ring depth");
-    // (A second fragment register set -- tile t + 1's fragments read while tile t is multiplied, two LDS slots -- was built and
-    // measured: 8192 x 2304 x 768 177 us against 164; the MFMAs do not wait for LDS reads here.)
     auto step = [&](int t, int slot) {
         // the own pieces of tile t: everything but the NS - 2 younger tiles' pieces (none at the end of the loop)
         if (NS == 3 && nk - 1 - t >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
@@ -535,6 +561,7 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
             if (t + s < nk) step(t + s, s);
     }
 
+    constexpr float kUnscale = 1.0f / kPWeightScale;
     if constexpr (!SWAP) {
         // C/D layout of the 32 x 32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m)
 #pragma unroll
@@ -547,7 +574,7 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (m >= g.M) continue;
-                    float v = acc[i][j][r] + bv;
+                    float v = fmaf(acc[i][j][r], kUnscale, bv);
                     if (g.res) v += g.res[(size_t)m * g.ldr + n];
                     g.C[(size_t)m * g.ldc + n] = v;
                 }
@@ -565,8 +592,8 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int n = n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk;
                     const float4 bv = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    p_store4(g.Cp, g.M, m, n, gelu_erf(acc[i][j][4 * q4 + 0] + bv.x), gelu_erf(acc[i][j][4 * q4 + 1] + bv.y),
-                             gelu_erf(acc[i][j][4 * q4 + 2] + bv.z), gelu_erf(acc[i][j][4 * q4 + 3] + bv.w));
+                    p_store4(g.Cp, g.M, m, n, gelu_erf(fmaf(acc[i][j][4 * q4 + 0], kUnscale, bv.x)), gelu_erf(fmaf(acc[i][j][4 * q4 + 1], kUnscale, bv.y)),
+                             gelu_erf(fmaf(acc[i][j][4 * q4 + 2], kUnscale, bv.z)), gelu_erf(fmaf(acc[i][j][4 * q4 + 3], kUnscale, bv.w)));
                 }
         }
     }
@@ -936,9 +963,9 @@ int launch_gemm_p_ns(PGemmArgs g, int n_off, int col_tiles, hipStream_t st) {
 }
 template <bool SWAP>
 int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
-    ASPIRE_REQUIRE(g.N % 128 == 0 && g.K % 16 == 0, ASPIRE_ERR_UNSUPPORTED, "P-layout GEMM needs N %% 128 == 0 and K %% 16 == 0");
+    ASPIRE_REQUIRE(g.N % 128 == 0 && g.K % 32 == 0, ASPIRE_ERR_UNSUPPORTED, "P-layout GEMM needs N %% 128 == 0 and K %% 32 == 0");
     const int ring = tuning().gemm_ring == 3 ? 3 : 2;
-    const long long slots = ring == 2 ? 768 : 512, rows = (g.M + 127) / 128, n128 = g.N / 128;
+    const long long slots = ring == 2 ? 512 : 256, rows = (g.M + 127) / 128, n128 = g.N / 128;
     // 128 x 64 tiles (twice the workgroups) where 128 x 128 ones cannot give every workgroup slot a tile and the k loop is short
     // (measured at M = 8192: N = 768, K = 768 61 -> 58 us; K = 3072 211 -> 221 us: not there)
     int c1 = (int)n128;
@@ -995,11 +1022,10 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
     const unsigned row_blocks = (unsigned)((M + 3) / 4);
 
     // P path: the weights' planes are prepared (aspire_bert_prepare_planes), BERT-base shapes tile by 128 -- every nn.Linear GEMM
-    // streams pre-split operands (gemm_p_kernel); otherwise (ASPIRE_HIP_GEMM=f32 | bf16x3, no planes) the round-2 kernels
-    // -- from ~3000 token rows on: below, the 128 x 128 tiles of the P-layout GEMM are too few to fill the chip and its 192-step k loop
-    // (K = 3072) sets the time (measured M = 1024: FFN2 110 vs 71 us; M = 4096: 112 vs 147), while the on-the-fly kernels pick
-    // smaller tiles there
-    const bool pp = w->planes != nullptr && (tuning().gemm_form == 0 ? M >= 3072 : tuning().gemm_form == 3) && dh == 64 && !tuning().attn_gemm &&
+    // streams pre-split fp16 operands (gemm_p_kernel), from 1024 token rows on (measured B x L = 4 x 128: 2.46 vs 2.42 ms per batch,
+    // 8 x 128: 2.55 vs 2.81, 16 x 128: 2.90 vs 3.52, 32 x 256: 6.64 vs 9.8); below -- and with ASPIRE_HIP_GEMM=f32 | bf16x3, or without
+    // planes -- the round-2 kernels, which pick smaller tiles for small M
+    const bool pp = w->planes != nullptr && (tuning().gemm_form == 0 ? M >= 1024 : tuning().gemm_form == 3) && dh == 64 && !tuning().attn_gemm &&
                     w->ffn_dim % 128 == 0;
     const PlaneOffsets po = plane_offsets(w->ffn_dim);
     float* x = w->n_layers == 0 ? hidden_out : ws.x;
@@ -1089,7 +1115,7 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
     return ASPIRE_OK;
 }
 
-// The weights' bf16 planes, formed ONCE when the model is loaded: a device buffer of aspire_bert_planes_bytes(w) bytes that the
+// The weights' fp16 planes, formed ONCE when the model is loaded: a device buffer of aspire_bert_planes_bytes(w) bytes that the
 // caller keeps next to the weights and hands over as aspire_bert_weights::planes.
 extern "C" size_t aspire_bert_planes_bytes(const aspire_bert_weights* w) {
     if (!w || w->n_layers <= 0 || w->hidden != kD || w->ffn_dim <= 0) return 0;
@@ -1103,10 +1129,18 @@ extern "C" int aspire_bert_prepare_planes(const aspire_bert_weights* w, void* pl
     ASPIRE_REQUIRE(planes_bytes >= aspire_bert_planes_bytes(w), ASPIRE_ERR_INVALID_ARG, "planes buffer too small");
     hipStream_t st = (hipStream_t)stream;
     const PlaneOffsets po = plane_offsets(w->ffn_dim);
+    int* too_big = nullptr;        // a load-time call: its own 4 bytes, one synchronisation at the end
+    ASPIRE_HIP_OK(hipMalloc((void**)&too_big, sizeof(int)));
     auto split = [&](const float* X, int64_t R, int K, void* P) {
-        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((R * (K / 4) + 255) / 256)), dim3(256), 0, st, X, R, K, K, P);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((R * (K / 4) + 255) / 256)), dim3(256), 0, st, X, R, K, K, P, kPWeightScale,
+                           too_big);
     };
-    ASPIRE_HIP_OK(hipMemsetAsync(planes, 0, aspire_bert_planes_bytes(w), st));      // the slack rows behind every matrix
+    hipError_t e0 = hipMemsetAsync(too_big, 0, sizeof(int), st);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(planes, 0, aspire_bert_planes_bytes(w), st);      // the slack rows behind every matrix
+    if (e0 != hipSuccess) {
+        (void)hipFree(too_big);
+        ASPIRE_HIP_OK(e0);
+    }
     for (int l = 0; l < w->n_layers; ++l) {
         const aspire_bert_layer& ly = w->layers[l];
         char* lp = (char*)planes + (size_t)l * po.per_layer;
@@ -1114,17 +1148,25 @@ extern "C" int aspire_bert_prepare_planes(const aspire_bert_weights* w, void* pl
         split(ly.w_o, kD, kD, lp + po.o);
         split(ly.w_ffn1, w->ffn_dim, kD, lp + po.ffn1);
         split(ly.w_ffn2, kD, w->ffn_dim, lp + po.ffn2);
-        ASPIRE_LAUNCH_OK();
     }
+    int flag = 0;
+    hipError_t e1 = hipGetLastError();
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(&flag, too_big, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+    (void)hipFree(too_big);
+    ASPIRE_HIP_OK(e1);
+    ASPIRE_REQUIRE(flag == 0, ASPIRE_ERR_UNSUPPORTED,
+                   "a weight is not finite or beyond +-1023: outside the fp16-plane GEMM's range (leave aspire_bert_weights::planes NULL for such a model)");
     return ASPIRE_OK;
 }
 
-// Tuning hooks (not part of include/aspire_hip.h): an operand into the P layout, and one C = A . B^T (+bias) GEMM on P operands
+// Tuning hooks (not part of include/aspire_hip.h): an operand into the P layout (weight != 0: the B side, scaled), and one C = A . B^T (+bias) GEMM on P operands
 // (tools/gemmbench.py); swap != 0: the GELU -> P-layout epilogue (Cp [M, N]).
 extern "C" size_t aspire_debug_planes_bytes(int64_t R, int64_t K) { return p_bytes(R, K); }
-extern "C" int aspire_debug_split_planes(const float* X, int64_t R, int K, void* P, void* stream) {
-    ASPIRE_REQUIRE(K % 16 == 0, ASPIRE_ERR_UNSUPPORTED, "K %% 16");
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((R * (K / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, R, K, K, P);
+extern "C" int aspire_debug_split_planes(const float* X, int64_t R, int K, void* P, int weight, void* stream) {
+    ASPIRE_REQUIRE(K % 32 == 0, ASPIRE_ERR_UNSUPPORTED, "K %% 32");
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((R * (K / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, R, K, K, P,
+                       weight ? kPWeightScale : 1.0f, nullptr);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }

@@ -58,12 +58,17 @@ class HipBertEncoder:
             cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size,
             float(cfg.layer_norm_eps), None)
         self._ws = None
-        # the nn.Linear weights' bf16 planes, formed once (include/aspire_hip.h: aspire_bert_prepare_planes)
+        # the nn.Linear weights' fp16 planes, formed once (include/aspire_hip.h: aspire_bert_prepare_planes)
         nbytes = lib.aspire_bert_planes_bytes(ctypes.byref(self._w))
         if nbytes and cfg.intermediate_size % 128 == 0:
             self._planes = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-            check(lib.aspire_bert_prepare_planes(ctypes.byref(self._w), ops._ptr(self._planes), nbytes, ops._stream()))
-            self._w.planes = ctypes.c_void_p(self._planes.data_ptr())
+            try:
+                check(lib.aspire_bert_prepare_planes(ctypes.byref(self._w), ops._ptr(self._planes), nbytes, ops._stream()))
+                self._w.planes = ctypes.c_void_p(self._planes.data_ptr())
+            except NotImplementedError as e:        # a weight beyond the fp16 planes' range: the on-the-fly bf16x3 GEMMs take any fp32
+                import warnings
+                warnings.warn(f'HipBertEncoder: {e}; running without pre-split weights')
+                self._planes = None
 
     def eval(self):
         return self

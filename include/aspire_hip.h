@@ -93,10 +93,13 @@ typedef struct {
     const aspire_bert_layer* layers;            /* HOST array of n_layers entries (device pointers inside) */
     int32_t n_layers, n_heads, hidden, ffn_dim, vocab, max_pos, n_types;
     float ln_eps;                               /* layer_norm_eps (1e-12) */
-    /* NULL, or the nn.Linear weights' pre-split bf16 planes: a DEVICE buffer of aspire_bert_planes_bytes(w) bytes filled once
-     * by aspire_bert_prepare_planes when the model is loaded (the weights never change).  With it the forward's GEMMs stream
-     * pre-split operands -- same fp32 accuracy (three bf16 planes per operand, six products per term), no conversion work in
-     * the main loop; without it every workgroup splits its fp32 tiles on the fly. */
+    /* NULL, or the nn.Linear weights' pre-split planes: a DEVICE buffer of aspire_bert_planes_bytes(w) bytes filled once by
+     * aspire_bert_prepare_planes when the model is loaded (the weights never change; the call synchronises the stream and
+     * returns ASPIRE_ERR_UNSUPPORTED for a weight beyond +-1023 or not finite).  With it the forward's GEMMs (from 1024 token
+     * rows on) stream pre-split operands: every fp32 value as two fp16 planes h + l (24 significant bits, the weights scaled by
+     * 2^6 first), three exact matrix-pipe products per term (h.h' + h.l' + l.h') summed in fp32 -- fp32's accuracy, measured
+     * against float64 in tests/test_gpu_encoder.py -- and no conversion work in the main loop; without it every workgroup splits
+     * its fp32 tiles into three bf16 planes on the fly (six products per term). */
     const void* planes;
 } aspire_bert_weights;
 

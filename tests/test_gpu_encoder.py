@@ -155,8 +155,9 @@ def test_gemm_bf16x3_form_is_fp32_accurate():
 
 
 def test_gemm_on_presplit_operands_is_fp32_accurate():
-    """The P-layout GEMM (operands pre-split into three bf16 planes: the weights at model load, an activation by the kernel that
-    produces it; LDS-DMA tiles) against float64 and against the on-the-fly split: the same six products, the same error; M edges
+    """The P-layout GEMM (operands pre-split into two fp16 planes: the weights at model load, an activation by the kernel that
+    produces it; LDS-DMA tiles; three exact products per term) against float64 and against the on-the-fly bf16x3 split (six
+    products): no larger an error, on operands far from the encoder's comfortable ranges (activations to +-12, weights O(1)); M edges
     (rows past the matrix feed unstored outputs only), both ring depths, 128 x 64 column tiles, and the GELU -> P-layout epilogue
     of the first FFN GEMM (its output read back through a second P-layout GEMM against the identity)."""
     import ctypes
@@ -165,15 +166,15 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
     L.aspire_debug_gemm_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
     L.aspire_debug_planes_bytes.restype = ctypes.c_size_t
     L.aspire_debug_planes_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
-    L.aspire_debug_split_planes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.aspire_debug_split_planes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.aspire_debug_gemm_planes.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator().manual_seed(7)
 
-    def planes(X):
+    def planes(X, weight=0):                       # weight: the B side (split as 64 x, the GEMM's epilogue takes the factor off)
         r, k = X.shape
         P = torch.empty(L.aspire_debug_planes_bytes(r, k), dtype=torch.uint8, device='cuda')     # slack rows left uninitialised
-        assert L.aspire_debug_split_planes(X.data_ptr(), r, k, P.data_ptr(), st) == 0
+        assert L.aspire_debug_split_planes(X.data_ptr(), r, k, P.data_ptr(), weight, st) == 0
         return P
 
     for M, N, K in ((8192, 2304, 768), (1000, 768, 3072), (130, 768, 768), (4100, 3072, 768)):
@@ -185,7 +186,7 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
         C0 = torch.empty(M, N, device='cuda')
         with _lib.pinned(GEMM='bf16x3'):
             assert L.aspire_debug_gemm_f32(A.data_ptr(), B.data_ptr(), C0.data_ptr(), bias.data_ptr(), M, N, K, st) == 0
-        Ap, Bp = planes(A), planes(B)
+        Ap, Bp = planes(A), planes(B, 1)
         for pin in ({}, {'GEMM_RING': '3'}, {'GEMM_TILE': '64'}):
             C = torch.full((M, N), float('nan'), device='cuda')
             with _lib.pinned(**pin):
@@ -202,10 +203,10 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
     B = (0.05 * torch.randn(N, K, generator=g)).cuda()
     bias = torch.randn(N, generator=g).cuda()
     Hp = torch.empty(L.aspire_debug_planes_bytes(M, N), dtype=torch.uint8, device='cuda')
-    assert L.aspire_debug_gemm_planes(planes(A).data_ptr(), planes(B).data_ptr(), None, Hp.data_ptr(), bias.data_ptr(), M, N, K, 1, st) == 0
+    assert L.aspire_debug_gemm_planes(planes(A).data_ptr(), planes(B, 1).data_ptr(), None, Hp.data_ptr(), bias.data_ptr(), M, N, K, 1, st) == 0
     eye = torch.eye(N, device='cuda')
     H = torch.empty(M, N, device='cuda')
-    assert L.aspire_debug_gemm_planes(Hp.data_ptr(), planes(eye).data_ptr(), H.data_ptr(), None, None, M, N, N, 0, st) == 0
+    assert L.aspire_debug_gemm_planes(Hp.data_ptr(), planes(eye, 1).data_ptr(), H.data_ptr(), None, None, M, N, N, 0, st) == 0
     torch.cuda.synchronize()
     want = torch.nn.functional.gelu(A.double() @ B.double().T + bias.double())
     assert (H.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
@@ -230,3 +231,20 @@ def test_bert_forward_on_presplit_operands_small_shapes(n_layers, b, l):
         other = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
     assert (got - want).abs().max().item() < TOL
     assert (got - other).abs().max().item() < 2e-5
+
+
+def test_weights_beyond_the_fp16_planes_are_left_to_the_fp32_input_kernels():
+    """aspire_bert_prepare_planes rejects a weight beyond +-1023 (64 w must stay inside fp16); HipBertEncoder then runs without
+    planes -- the on-the-fly bf16x3 GEMMs take any fp32 -- and still matches HuggingFace."""
+    from aspire_amd.encoder import HipBertEncoder
+    m = _bert(1, seed=9)
+    with torch.no_grad():
+        m.encoder.layer[0].intermediate.dense.weight[5, 7] = 3000.0
+    tok, seg, mask, _ = _batch(8, 128, 3000, seed=77)
+    with pytest.warns(UserWarning, match='1023'):
+        enc = HipBertEncoder(m)
+    assert not enc._w.planes
+    with torch.no_grad():
+        want = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
+    got = enc.forward_hidden(tok.cuda(), seg.cuda(), mask.cuda()).cpu()
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())

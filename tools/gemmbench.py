@@ -36,16 +36,16 @@ def main():
             print(f'M={M} N={N} K={K} {form:7s} tile {tile or "auto":4s}: {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}% of the fp32-MFMA peak)  '
                   f'max|err| vs float64 {err:.2e}', flush=True)
         # pre-split operands (P layout): the planes are formed once (weights at model load, activations by the producing kernel)
-        if N % 128 == 0 and K % 16 == 0:
+        if N % 128 == 0 and K % 32 == 0:
             L = _lib.lib
             L.aspire_debug_planes_bytes.restype = ctypes.c_size_t
             L.aspire_debug_planes_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
-            L.aspire_debug_split_planes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            L.aspire_debug_split_planes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
             L.aspire_debug_gemm_planes.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
             Ap = torch.zeros(L.aspire_debug_planes_bytes(M, K), dtype=torch.uint8, device='cuda')
             Bp = torch.zeros(L.aspire_debug_planes_bytes(N, K), dtype=torch.uint8, device='cuda')
-            assert L.aspire_debug_split_planes(A.data_ptr(), M, K, Ap.data_ptr(), st) == 0
-            assert L.aspire_debug_split_planes(B.data_ptr(), N, K, Bp.data_ptr(), st) == 0
+            assert L.aspire_debug_split_planes(A.data_ptr(), M, K, Ap.data_ptr(), 0, st) == 0
+            assert L.aspire_debug_split_planes(B.data_ptr(), N, K, Bp.data_ptr(), 1, st) == 0
             C.zero_()
             runp = lambda: L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, None, M, N, K, 0, st)
             for ring in ('3', '2'):

@@ -20,12 +20,12 @@ if len(sys.argv) > 5 and sys.argv[5] == 'planes':
     L = _lib.lib
     L.aspire_debug_planes_bytes.restype = ctypes.c_size_t
     L.aspire_debug_planes_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
-    L.aspire_debug_split_planes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.aspire_debug_split_planes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.aspire_debug_gemm_planes.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
     Ap = torch.zeros(L.aspire_debug_planes_bytes(M, K), dtype=torch.uint8, device='cuda')
     Bp = torch.zeros(L.aspire_debug_planes_bytes(N, K), dtype=torch.uint8, device='cuda')
-    assert L.aspire_debug_split_planes(A.data_ptr(), M, K, Ap.data_ptr(), st) == 0
-    assert L.aspire_debug_split_planes(B.data_ptr(), N, K, Bp.data_ptr(), st) == 0
+    assert L.aspire_debug_split_planes(A.data_ptr(), M, K, Ap.data_ptr(), 0, st) == 0
+    assert L.aspire_debug_split_planes(B.data_ptr(), N, K, Bp.data_ptr(), 1, st) == 0
     with _lib.pinned(GEMM_RING=sys.argv[6] if len(sys.argv) > 6 else ''):
         for _ in range(reps):
             assert L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, None, M, N, K, 0, st) == 0
