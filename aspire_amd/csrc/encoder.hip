@@ -377,20 +377,36 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
 // before the split and the epilogue takes the factor off again (exact).  Measured against a float64 product at K = 768: rms
 // error 0.2 x that of a plain fp32 GEMM's before accumulation (numpy model), tests/test_gpu_encoder.py on the device.
 //
-// P layout of a matrix X [R, K] (K % 32 == 0), 4 bytes per element: for every 32-wide k block kb and row r eight 16-byte
-// pieces (plane pl, k quarter kq) = the 8 fp16 of plane pl at k = 32 kb + 8 kq .. + 7, stored at
-//     piece index (kb * R + r) * 8 + ((4 pl + kq) ^ ((r >> 1) & 7))
-// so that (a) the 128 rows of a tile at one k block are ONE contiguous 16 KB run: sixteen global_load_lds_dwordx4 move it
-// into LDS exactly as it lies in HBM (the LDS image of an LDS-DMA is lane-linear), and (b) a fragment read -- lane = (row,
-// k quarter) reads 16 bytes -- is conflict free: 128-byte rows put rows r and r + 2 on the same banks, the XOR with the row's
-// bits 1..3 spreads the sixteen rows of a ds_read_b128 lane group over the sixteen 16-byte columns of the 256-byte bank line.
+// P layout of a matrix X [R, K] (K % 32 == 0), 4 bytes per element: for every 16-wide k block kb and row r four 16-byte
+// pieces (plane pl, k half kh) = the 8 fp16 of plane pl at k = 16 kb + 8 kh .. + 7, stored at
+//     piece index (kb * R + r) * 4 + ((2 pl + kh) ^ ((r >> 2) & 3))
+// so that (a) the 128 rows of a tile at one k block are ONE contiguous 8 KB run: eight global_load_lds_dwordx4 move it into
+// LDS exactly as it lies in HBM (the LDS image of an LDS-DMA is lane-linear), and (b) a fragment read -- lane = (row, k half)
+// reads 16 bytes -- is conflict free: 64-byte rows put rows r and r + 4 on the same banks, the XOR with the row's bits 2..3
+// spreads the sixteen rows of a ds_read_b128 lane group over the sixteen 16-byte columns of the 256-byte bank line.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kPRowBytes = 128;                      // one row of one k block: 2 planes x 4 quarters x 16 bytes
-constexpr int kPTile = 128 * kPRowBytes;             // one operand tile of one k step (16 KB)
+constexpr int kPRowBytes = 64;                       // one row of one k block: 2 planes x 2 halves x 16 bytes
+constexpr int kPTile = 128 * kPRowBytes;             // 128 rows of one k block (8 KB)
 constexpr int kPPadRows = 128;                       // rows of slack behind a P matrix: the last row tile may read past R
+constexpr int kPRingDefault = 22;                    // 10 KS + NS: stages of two k blocks, two-stage ring (launch_gemm_p_ring)
 constexpr float kPWeightScale = 64.f;                // weights are split as 64 w (module comment)
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+#ifdef ASPIRE_PHASE_CLOCK
+// debug build only (tools/gemmphases.py): per-workgroup time stamps (100 MHz wall clock) of gemm_p_kernel into the buffer set by
+// aspire_debug_gemm_buffer: [workgroup][16] = start, first tile landed, main loop done, stores issued, HW_ID, XCC_ID, -, -,
+// then inside step 8: after its barrier, after its LDS-DMA issue, after its MFMAs' issue, step 9: after its vmcnt wait, after its barrier
+static __device__ long long* g_gdbg = nullptr;
+#define G_STAMP(k, v)                                                                                                \
+    do {                                                                                                             \
+        if (g_gdbg && threadIdx.x == 0) g_gdbg[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = (long long)(v); \
+    } while (0)
+#else
+#define G_STAMP(k, v) \
+    do {              \
+    } while (0)
+#endif
 
 __host__ __device__ inline size_t p_bytes(int64_t R, int64_t K) { return (size_t)(R + kPPadRows) * K * 4; }
 
@@ -407,13 +423,12 @@ __device__ __forceinline__ void p_store4(void* P, int64_t R, int64_t r, int k, f
     uint32_t h0, l0, h1, l1;
     split2_f16(x, y, h0, l0);
     split2_f16(z, w, h1, l1);
-    const int kb = k >> 5, kq = (k >> 3) & 3, half = (k >> 2) & 1, sw = (int)((r >> 1) & 7);
+    const int kb = k >> 4, kh = (k >> 3) & 1, half = (k >> 2) & 1, sw = (int)((r >> 2) & 3);
     char* row = (char*)P + ((size_t)kb * R + r) * kPRowBytes + half * 8;
-    *reinterpret_cast<uint2*>(row + 16 * (kq ^ sw)) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(row + 16 * ((4 + kq) ^ sw)) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(row + 16 * (kh ^ sw)) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(row + 16 * ((2 + kh) ^ sw)) = make_uint2(l0, l1);
 }
 
-// scale * X [R, K] fp32 row-major (row stride ld) -> P layout: the weights at model load, and the tools' operands
 // *too_big (optional) is raised when an element leaves fp16's range (|scale x| > 65504, or not finite)
 __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ X, int64_t R, int K, int ld, void* __restrict__ P,
                                                            float scale, int* __restrict__ too_big) {
@@ -436,33 +451,40 @@ struct PGemmArgs {
     const float* res;    // [M, ldr] residual or null
     int M, N, K, ldc, ldr;
     int n_off;           // first column of this launch (a GEMM may run as a launch of 128-wide and one of 64-wide column tiles)
+    int probe;           // timing probes (ASPIRE_HIP_GEMM_PROBE): 1 no MFMAs, 2 no LDS-DMA
 };
 
-// One 16-byte-per-lane LDS-DMA: 64 lanes x 16 B from the lanes' global addresses to LDS bytes [lds_dst, lds_dst + 1024).  M0 is
-// compiler-reserved: saved and restored inside the statement.  hipcc does not count this load: the caller waits with
-// s_waitcnt vmcnt(N) itself.
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+// One 16-byte-per-lane LDS-DMA: 64 lanes x 16 B from global bytes [base + IMM + voff(lane)] to LDS bytes [lds_dst + IMM, .. + 1024).
+// The address is a uniform 64-bit base in SGPRs plus a per-lane 32-bit offset that never changes (16 lane): stepping along k
+// is scalar arithmetic only -- with per-lane 64-bit addresses every issue paid a v_lshl_add_u64 that queues behind the other
+// workgroup's MFMAs on the same SIMD (measured with the phase stamps: 8 issues took 0.6 us of a 1.6 us step).  hipcc does not
+// count this load: the caller waits with s_waitcnt vmcnt(N) itself.
+// M0 is compiler-reserved: saved and restored inside the statement (scalar instructions: they do not queue behind MFMAs).
+template <int IMM>
+__device__ __forceinline__ void glds16(uint64_t base, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst), "n"(IMM)
+                 : "memory");
 }
 
-// C = A . B^T on 128 x 128 tiles, BK = 32 (two 16-wide MFMA k steps), four waves of 64 x 64, three fp16 products per term.
-// NS-stage LDS ring filled by LDS-DMA NS - 1 tiles ahead; per k step and wave: 8 DMA pieces, 16 fragment reads, 24 MFMAs, one
-// barrier.  Order of a step: wait for the own pieces of tile t (s_waitcnt vmcnt(8 (NS - 2)): the younger tiles stay in
-// flight), barrier (everybody's pieces of tile t have landed AND everybody has read tile t - 1, whose slot is free now), issue
-// tile t + NS - 1 into that slot, read fragments, multiply.
+// C = A . B^T on 128 x 128 tiles, four waves of 64 x 64, three fp16 products per term.  A stage = KS 16-wide k blocks (KS MFMA k
+// steps); NS-stage LDS ring filled by LDS-DMA NS - 1 stages ahead; per stage and wave: 4 KS DMA pieces, 8 KS fragment reads,
+// 12 KS MFMAs, one barrier.  Order of a step: wait for the own pieces of stage t (s_waitcnt vmcnt(4 KS x the younger stages in
+// flight)), barrier (everybody's pieces of stage t have landed AND everybody has read stage t - 1, whose slot is free now),
+// issue stage t + NS - 1 into that slot, read fragments, multiply.
 // SWAP: the MFMA's operands exchanged -- accumulator registers run along n, the lane is a row m -- for the epilogue that writes
 // GELU(.) straight into the P layout of the next GEMM's A operand (a lane then holds 4 consecutive k of its row: one 8-byte
 // store per plane); otherwise registers run along m, lanes along n: 128-byte coalesced fp32 stores, bias / residual fused.
 // BN = 64: 128 x 64 tiles (wave tile 64 x 32) for the columns that would otherwise leave a last round of workgroups half empty.
-template <int NS, int BN, bool SWAP>
+template <int NS, int KS, int BN, bool SWAP>
 __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     constexpr int TN = BN / 64;                             // 32-column blocks per wave
-    constexpr int kBTile = BN * kPRowBytes, kStage = kPTile + kBTile;
-    constexpr int kBPieces = kBTile / 1024;                 // 16 (BN = 128) or 8
-    constexpr int kBPerWave = kBPieces / 4;                 // 4 or 2
-    constexpr int kPerWave = 4 + kBPerWave;                 // LDS-DMA instructions per wave and stage
+    constexpr int kBTile = BN * kPRowBytes;                 // B rows of one k block
+    constexpr int kStage = KS * (kPTile + kBTile);          // [A k block 0 .. KS - 1][B k block 0 .. KS - 1]
+    constexpr int kBPerWave = kBTile / 4096;                // 1 KB pieces per wave and k block: 2 (BN = 128) or 1
+    constexpr int kPerWave = KS * (2 + kBPerWave);          // LDS-DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,27 +499,36 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         by = L / gx;
     }
     const int m0 = by * 128, n0 = g.n_off + bx * BN;
-    const int nk = g.K >> 5;
+    G_STAMP(0, __builtin_amdgcn_s_memrealtime());
+    G_STAMP(4, __builtin_amdgcn_s_getreg(31 << 11 | 4));
+    G_STAMP(5, __builtin_amdgcn_s_getreg(31 << 11 | 20));
+    const int nk = g.K / (16 * KS);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)p_smem;
-    // wave w moves pieces 4 w .. 4 w + 3 (1 KB = 8 rows each) of the A tile and pieces w, w + 4 (, w + 8, w + 12) of the B tile
-    const char* a_src = (const char*)g.Ap + (size_t)m0 * kPRowBytes + (4 * wave) * 1024 + lane * 16;
-    const char* b_src = (const char*)g.Bp + (size_t)n0 * kPRowBytes + lane * 16;
-    const size_t a_step = (size_t)g.M * kPRowBytes, b_step = (size_t)g.N * kPRowBytes;
-    auto issue = [&](int slot, int kb) {
+    // per k block wave w moves pieces 2 w, 2 w + 1 (1 KB = 16 rows each) of the A rows and pieces 2 w, 2 w + 1 (BN = 64: piece w) of B's
+    const uint64_t a_src = (uint64_t)(uintptr_t)g.Ap + (uint64_t)m0 * kPRowBytes + (2 * wave) * 1024;
+    const uint64_t b_src = (uint64_t)(uintptr_t)g.Bp + (uint64_t)n0 * kPRowBytes + (kBPerWave * wave) * 1024;
+    const uint64_t a_step = (uint64_t)g.M * kPRowBytes, b_step = (uint64_t)g.N * kPRowBytes;
+    const uint32_t lane16 = lane * 16;
+    auto issue = [&](int slot, int t) {
         const uint32_t dst = lds0 + slot * kStage;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) glds16(a_src + kb * a_step + u * 1024, dst + (4 * wave + u) * 1024);
-#pragma unroll
-        for (int u = 0; u < kBPerWave; ++u) {
-            const int piece = wave + 4 * u;
-            glds16(b_src + kb * b_step + piece * 1024, dst + kPTile + piece * 1024);
+        for (int s = 0; s < KS; ++s) {
+            const uint64_t kb = (uint64_t)t * KS + s;
+            const uint64_t ab = a_src + kb * a_step, bb = b_src + kb * b_step;
+            // (the instruction's offset moves the LDS address along with the global one: both pieces name the first one's M0)
+            glds16<0>(ab, lane16, dst + s * kPTile + (2 * wave) * 1024);
+            glds16<1024>(ab, lane16, dst + s * kPTile + (2 * wave) * 1024);
+            if (g.probe != 10) {
+                glds16<0>(bb, lane16, dst + KS * kPTile + s * kBTile + (kBPerWave * wave) * 1024);
+                if constexpr (kBPerWave == 2) glds16<1024>(bb, lane16, dst + KS * kPTile + s * kBTile + (2 * wave) * 1024);
+            }
         }
     };
-    // fragment (plane pl, MFMA k step s) of this lane's row: piece (4 pl + 2 s + lk) ^ ((row >> 1) & 7); the row's bits 1..3 are
-    // lr's (tiles and wave tiles start on multiples of 32)
-    const uint32_t frag0 = 16 * (lk ^ ((lr >> 1) & 7));
+    // fragment (plane pl) of this lane's row in a k block: piece (2 pl + lk) ^ ((row >> 2) & 3); the row's bits 2..3 are lr's (tiles
+    // and wave tiles start on multiples of 32)
+    const uint32_t frag0 = 16 * (lk ^ ((lr >> 2) & 3));
     const unsigned char* a_rd = p_smem + (wr * 64 + lr) * kPRowBytes;
-    const unsigned char* b_rd = p_smem + kPTile + (wc * 32 * TN + lr) * kPRowBytes;
+    const unsigned char* b_rd = p_smem + KS * kPTile + (wc * 32 * TN + lr) * kPRowBytes;
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -511,26 +542,26 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
     struct Frags {
-        f16x8_t a[2][2][2], b[TN][2][2];       // [block][plane][k step]
+        f16x8_t a[2][2][KS], b[TN][2][KS];       // [block][plane][k step]
     };
     auto read_frags = [&](Frags& f, int slot) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int s = 0; s < KS; ++s)           // the first MFMA k step's fragments first: its products start while the second's land
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const uint32_t fo = frag0 ^ (16 * (4 * pl + 2 * s));
+            for (int pl = 0; pl < 2; ++pl) {
+                const uint32_t fo = frag0 ^ (32 * pl);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    f.a[i][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(a_rd + slot * kStage + i * 32 * kPRowBytes + fo));
+                    f.a[i][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(a_rd + slot * kStage + s * kPTile + i * 32 * kPRowBytes + fo));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    f.b[j][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(b_rd + slot * kStage + j * 32 * kPRowBytes + fo));
+                    f.b[j][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(b_rd + slot * kStage + s * kBTile + j * 32 * kPRowBytes + fo));
             }
     };
     auto mma = [&](const Frags& f) {
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};        // the small products first
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -543,17 +574,35 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][PA[term]][s], f.b[j][PB[term]][s], acc[i][j], 0, 0, 0);
                     }
     };
-    static_assert(NS == 2 || NS == 3, "ring depth");
+    static_assert(NS >= 2 && NS <= 4 && kPerWave * (NS - 2) < 64, "ring depth");
     auto step = [&](int t, int slot) {
-        // the own pieces of tile t: everything but the NS - 2 younger tiles' pieces (none at the end of the loop)
-        if (NS == 3 && nk - 1 - t >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
+        // the own pieces of stage t: everything but the younger stages' pieces (NS - 2 of them, fewer at the end of the loop)
+        const int younger = nk - 1 - t < NS - 2 ? nk - 1 - t : NS - 2;
+        if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPerWave) : "memory");
+        else if (NS >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 9) G_STAMP(11, __builtin_amdgcn_s_memrealtime());
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + NS - 1 < nk) issue((slot + NS - 1) % NS, t + NS - 1);
+        if (t == 0) G_STAMP(1, __builtin_amdgcn_s_memrealtime());
+        if (t == 8) G_STAMP(8, __builtin_amdgcn_s_memrealtime());
+        if (t == 9) G_STAMP(12, __builtin_amdgcn_s_memrealtime());
+        if (t + NS - 1 < nk && g.probe != 2 && g.probe != 6) issue((slot + NS - 1) % NS, t + NS - 1);
+        if (t == 8) G_STAMP(9, __builtin_amdgcn_s_memrealtime());
         Frags f;
         read_frags(f, slot);
-        mma(f);
+        if (g.probe == 11) {         // LDS-DMA + fragment reads, no MFMAs
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(f.a[i][pl][s]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(f.b[j][pl][s]));
+                }
+        } else if (g.probe != 1 && g.probe != 5) mma(f);
+        if (t == 8) G_STAMP(10, __builtin_amdgcn_s_memrealtime());
     };
     for (int t = 0; t < nk; t += NS) {
 #pragma unroll
@@ -561,18 +610,43 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
             if (t + s < nk) step(t + s, s);
     }
 
+    G_STAMP(2, __builtin_amdgcn_s_memrealtime());
     constexpr float kUnscale = 1.0f / kPWeightScale;
+    if (((g.probe >= 4 && g.probe <= 6) || g.probe >= 10) && acc[0][0][0] != 12345.678f) return;      // probes 4+: no epilogue (4: all else, 5: no MFMAs, 6: no LDS-DMA)
     if constexpr (!SWAP) {
-        // C/D layout of the 32 x 32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m)
+        // C/D layout of the 32 x 32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m): a store instruction
+        // writes two full 128-byte lines.  Whole tiles (all but the last row of tiles) take the branch-free form: the residual's 16
+        // loads of a block go out together, the 16 stores follow back to back (with per-element row checks the compiler put an
+        // s_waitcnt vmcnt(0) in front of every element: 64 serialised stores per wave, 4 us per workgroup on an idle chip and
+        // 12 us when every CU stores at once -- 32 of the 120 us of an 8192 x 2304 x 768 launch)
+        const bool whole = m0 + 128 <= g.M;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wc * 32 * TN + 32 * j + lr;
                 const float bv = g.bias ? g.bias[n] : 0.f;
+                const int mb = m0 + wr * 64 + 32 * i + 4 * lk;
+                if (whole) {
+                    float* crow = g.C + (size_t)mb * g.ldc + n;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[i][j][r], kUnscale, bv);
+                    if (g.res) {
+                        const float* rrow = g.res + (size_t)mb * g.ldr + n;
+                        float rv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[r] = rrow[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] += rv[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
                     if (m >= g.M) continue;
                     float v = fmaf(acc[i][j][r], kUnscale, bv);
                     if (g.res) v += g.res[(size_t)m * g.ldr + n];
@@ -582,6 +656,14 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     } else {
         // swapped: col = lane & 31 is the row m, the registers run along n in groups of 4 consecutive: GELU(acc + bias) goes
         // straight into the P layout [M, N] (k dimension = n) of the next GEMM's A operand
+        // (the bias vectors are fetched before the first store: a load between stores makes the compiler wait for every store
+        // issued so far -- vmcnt counts both)
+        float4 bv[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                bv[j][q4] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + wr * 64 + 32 * i + lr;
@@ -591,12 +673,13 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int n = n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk;
-                    const float4 bv = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    p_store4(g.Cp, g.M, m, n, gelu_erf(fmaf(acc[i][j][4 * q4 + 0], kUnscale, bv.x)), gelu_erf(fmaf(acc[i][j][4 * q4 + 1], kUnscale, bv.y)),
-                             gelu_erf(fmaf(acc[i][j][4 * q4 + 2], kUnscale, bv.z)), gelu_erf(fmaf(acc[i][j][4 * q4 + 3], kUnscale, bv.w)));
+                    const float4 b4 = bv[j][q4];
+                    p_store4(g.Cp, g.M, m, n, gelu_erf(fmaf(acc[i][j][4 * q4 + 0], kUnscale, b4.x)), gelu_erf(fmaf(acc[i][j][4 * q4 + 1], kUnscale, b4.y)),
+                             gelu_erf(fmaf(acc[i][j][4 * q4 + 2], kUnscale, b4.z)), gelu_erf(fmaf(acc[i][j][4 * q4 + 3], kUnscale, b4.w)));
                 }
         }
     }
+    G_STAMP(3, __builtin_amdgcn_s_memrealtime());
 }
 
 // One wave per row of 768: lane holds 3 float4 (d = 4*lane + 256*c).
@@ -950,32 +1033,39 @@ Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim) {
 // of a GEMM into a launch of 128-wide tiles filling whole rounds and a launch of 64-wide ones for the rest -- 8192 x 2304: 768 +
 // 768 tiles instead of 1152 = 1.5 rounds -- was built and measured: 164 us either way.  A half-empty last round is not the
 // loss it looks like: its workgroups run faster for having the CU's matrix pipes to themselves.)
-template <int NS, int BN, bool SWAP>
+template <int NS, int KS, int BN, bool SWAP>
 int launch_gemm_p_ns(PGemmArgs g, int n_off, int col_tiles, hipStream_t st) {
-    constexpr int lds = NS * (kPTile + BN * kPRowBytes);
-    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<NS, BN, SWAP>),
+    constexpr int lds = NS * KS * (kPTile + BN * kPRowBytes);
+    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<NS, KS, BN, SWAP>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     ASPIRE_HIP_OK(raised);
     g.n_off = n_off;
-    hipLaunchKernelGGL((gemm_p_kernel<NS, BN, SWAP>), dim3(col_tiles, (g.M + 127) / 128), dim3(256), lds, st, g);
+    g.probe = tuning().gemm_probe;
+    hipLaunchKernelGGL((gemm_p_kernel<NS, KS, BN, SWAP>), dim3(col_tiles, (g.M + 127) / 128), dim3(256), lds, st, g);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
+}
+template <int BN, bool SWAP>
+int launch_gemm_p_ring(const PGemmArgs& g, int n_off, int col_tiles, hipStream_t st) {
+    // ASPIRE_HIP_GEMM_RING = 10 KS + NS pins the ring (default: kPRingDefault)
+    switch (tuning().gemm_ring ? tuning().gemm_ring : kPRingDefault) {
+    case 13: return launch_gemm_p_ns<3, 1, BN, SWAP>(g, n_off, col_tiles, st);
+    case 14: return launch_gemm_p_ns<4, 1, BN, SWAP>(g, n_off, col_tiles, st);
+    case 23: return launch_gemm_p_ns<3, 2, BN, SWAP>(g, n_off, col_tiles, st);
+    default: return launch_gemm_p_ns<2, 2, BN, SWAP>(g, n_off, col_tiles, st);
+    }
 }
 template <bool SWAP>
 int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
     ASPIRE_REQUIRE(g.N % 128 == 0 && g.K % 32 == 0, ASPIRE_ERR_UNSUPPORTED, "P-layout GEMM needs N %% 128 == 0 and K %% 32 == 0");
-    const int ring = tuning().gemm_ring == 3 ? 3 : 2;
-    const long long slots = ring == 2 ? 512 : 256, rows = (g.M + 127) / 128, n128 = g.N / 128;
+    const long long slots = 512, rows = (g.M + 127) / 128, n128 = g.N / 128;
     // 128 x 64 tiles (twice the workgroups) where 128 x 128 ones cannot give every workgroup slot a tile and the k loop is short
-    // (measured at M = 8192: N = 768, K = 768 61 -> 58 us; K = 3072 211 -> 221 us: not there)
     int c1 = (int)n128;
     if (tuning().gemm_tile == 64 || (tuning().gemm_tile == 0 && rows * n128 < slots && g.K <= 1024)) c1 = 0;
     if (c1 > 0)
-        if (int rc = ring == 2 ? launch_gemm_p_ns<2, 128, SWAP>(g, 0, c1, st) : launch_gemm_p_ns<3, 128, SWAP>(g, 0, c1, st)) return rc;
+        if (int rc = launch_gemm_p_ring<128, SWAP>(g, 0, c1, st)) return rc;
     if (c1 < n128)
-        if (int rc = ring == 2 ? launch_gemm_p_ns<2, 64, SWAP>(g, c1 * 128, (int)(n128 - c1) * 2, st)
-                               : launch_gemm_p_ns<3, 64, SWAP>(g, c1 * 128, (int)(n128 - c1) * 2, st))
-            return rc;
+        if (int rc = launch_gemm_p_ring<64, SWAP>(g, c1 * 128, (int)(n128 - c1) * 2, st)) return rc;
     return ASPIRE_OK;
 }
 // where a layer's four weight matrices sit in the prepared planes buffer
@@ -1189,3 +1279,10 @@ extern "C" int aspire_debug_gemm_f32(const float* A, const float* B, float* C, c
     g.gelu = 0;
     return launch_gemm<false>(g, 1, (hipStream_t)stream);
 }
+
+#ifdef ASPIRE_PHASE_CLOCK
+extern "C" void aspire_debug_gemm_buffer(void* p) {
+    long long* q = (long long*)p;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aspire::g_gdbg), &q, sizeof(q));
+}
+#endif

@@ -41,9 +41,12 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.gemm_tile96 = f == 96;
         t.gemm_tile = f;
     } else if (!strcmp(key, "GEMM_RING")) {
-        const int f = unset ? 0 : atoi(v);
-        if (f != 0 && f != 2 && f != 3) return false;
+        int f = unset ? 0 : atoi(v);
+        if (f == 2 || f == 3) f += 20;        // the round-3 spellings: ring depth at two k blocks per stage
+        if (f != 0 && f != 22 && f != 23 && f != 13 && f != 14) return false;
         t.gemm_ring = f;
+    } else if (!strcmp(key, "GEMM_PROBE")) {
+        t.gemm_probe = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_VALU")) {
         t.fused_valu = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_NOSOLVE")) {
@@ -79,6 +82,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : t.gemm_form == 3 ? "planes" : "";
     else if (!strcmp(key, "GEMM_TILE")) v = number(t.gemm_tile);
     else if (!strcmp(key, "GEMM_RING")) v = number(t.gemm_ring);
+    else if (!strcmp(key, "GEMM_PROBE")) v = number(t.gemm_probe);
     else if (!strcmp(key, "FUSED_VALU")) v = number(t.fused_valu);
     else if (!strcmp(key, "FUSED_NOSOLVE")) v = number(t.fused_nosolve);
     else if (!strcmp(key, "FUSED_NOSELF")) v = number(t.fused_noself);
@@ -90,7 +94,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);
