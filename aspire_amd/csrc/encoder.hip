@@ -388,10 +388,20 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
 constexpr int kPRowBytes = 64;                       // one row of one k block: 2 planes x 2 halves x 16 bytes
 constexpr int kPTile = 128 * kPRowBytes;             // 128 rows of one k block (8 KB)
 constexpr int kPPadRows = 128;                       // rows of slack behind a P matrix: the last row tile may read past R
-constexpr int kPRingDefault = 22;                    // 10 KS + NS: stages of two k blocks, two-stage ring (launch_gemm_p_ring)
+constexpr int kPRingDefault = 13;                    // 10 KS + NS: stages of one k block, three-stage ring = 48 KB, three workgroups per CU
 constexpr float kPWeightScale = 64.f;                // weights are split as 64 w (module comment)
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+// Timing probes of gemm_p_kernel (ASPIRE_HIP_GEMM_PROBE; wrong results by design) exist in the instrumented build only
+// (tools/build_clock.sh): 1 no MFMAs, 2 no LDS-DMA, 4 no epilogue, 5 / 6 = 1 / 2 without epilogue, 10 no B-tile DMA and no
+// epilogue, 11 LDS-DMA + fragment reads only, 20 stamps inside step 8.  In the product build the branches are compiled out: a
+// branch in the step splits the block in which the compiler interleaves fragment reads and MFMAs.
+#ifdef ASPIRE_PHASE_CLOCK
+#define G_PROBE(g) ((g).probe)
+#else
+#define G_PROBE(g) 0
+#endif
 
 #ifdef ASPIRE_PHASE_CLOCK
 // debug build only (tools/gemmphases.py): per-workgroup time stamps (100 MHz wall clock) of gemm_p_kernel into the buffer set by
@@ -459,20 +469,37 @@ struct PGemmArgs {
 // is scalar arithmetic only -- with per-lane 64-bit addresses every issue paid a v_lshl_add_u64 that queues behind the other
 // workgroup's MFMAs on the same SIMD (measured with the phase stamps: 8 issues took 0.6 us of a 1.6 us step).  hipcc does not
 // count this load: the caller waits with s_waitcnt vmcnt(N) itself.
-// M0 is compiler-reserved: saved and restored inside the statement (scalar instructions: they do not queue behind MFMAs).
-template <int IMM>
-__device__ __forceinline__ void glds16(uint64_t base, uint32_t voff, uint32_t lds_dst) {
+// M0 is compiler-reserved: saved and restored inside the statement.  The pieces of one k block go out in ONE statement (two
+// 1 KB pieces of A, TWO_B ? two : one of B): everything a wave issues in front of its fragment reads queues behind the MFMAs
+// its neighbour on the SIMD is streaming (a handful of issue slots per 32-cycle MFMA), so the count matters: 13 (11)
+// instructions per k block instead of 20 (15).
+template <bool TWO_B>
+__device__ __forceinline__ void glds_kblock(uint64_t a_base, uint64_t b_base, uint32_t voff, uint32_t a_dst, uint32_t b_dst) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(base), "s"(lds_dst), "n"(IMM)
-                 : "memory");
+    if constexpr (TWO_B)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3 offset:0\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(a_base), "s"(b_base), "s"(a_dst), "s"(b_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3 offset:0\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(a_base), "s"(b_base), "s"(a_dst), "s"(b_dst)
+                     : "memory");
 }
 
 // C = A . B^T on 128 x 128 tiles, four waves of 64 x 64, three fp16 products per term.  A stage = KS 16-wide k blocks (KS MFMA k
 // steps); NS-stage LDS ring filled by LDS-DMA NS - 1 stages ahead; per stage and wave: 4 KS DMA pieces, 8 KS fragment reads,
-// 12 KS MFMAs, one barrier.  Order of a step: wait for the own pieces of stage t (s_waitcnt vmcnt(4 KS x the younger stages in
-// flight)), barrier (everybody's pieces of stage t have landed AND everybody has read stage t - 1, whose slot is free now),
+// 12 KS MFMAs, one barrier.  Order of a step: wait for the own pieces of stage t (s_waitcnt vmcnt(kPerWave x the younger stages
+// in flight)), barrier (everybody's pieces of stage t have landed AND everybody has read stage t - 1, whose slot is free now),
 // issue stage t + NS - 1 into that slot, read fragments, multiply.
 // SWAP: the MFMA's operands exchanged -- accumulator registers run along n, the lane is a row m -- for the epilogue that writes
 // GELU(.) straight into the P layout of the next GEMM's A operand (a lane then holds 4 consecutive k of its row: one 8-byte
@@ -514,14 +541,9 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const uint64_t kb = (uint64_t)t * KS + s;
-            const uint64_t ab = a_src + kb * a_step, bb = b_src + kb * b_step;
-            // (the instruction's offset moves the LDS address along with the global one: both pieces name the first one's M0)
-            glds16<0>(ab, lane16, dst + s * kPTile + (2 * wave) * 1024);
-            glds16<1024>(ab, lane16, dst + s * kPTile + (2 * wave) * 1024);
-            if (g.probe != 10) {
-                glds16<0>(bb, lane16, dst + KS * kPTile + s * kBTile + (kBPerWave * wave) * 1024);
-                if constexpr (kBPerWave == 2) glds16<1024>(bb, lane16, dst + KS * kPTile + s * kBTile + (2 * wave) * 1024);
-            }
+            // (an instruction's offset moves the LDS address along with the global one)
+            glds_kblock<kBPerWave == 2>(a_src + kb * a_step, b_src + kb * b_step, lane16, dst + s * kPTile + (2 * wave) * 1024,
+                                        dst + KS * kPTile + s * kBTile + (kBPerWave * wave) * 1024);
         }
     };
     // fragment (plane pl) of this lane's row in a k block: piece (2 pl + lk) ^ ((row >> 2) & 3); the row's bits 2..3 are lr's (tiles
@@ -581,17 +603,20 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPerWave) : "memory");
         else if (NS >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (t == 9) G_STAMP(11, __builtin_amdgcn_s_memrealtime());
+        if (G_PROBE(g) == 20 && t == 9) G_STAMP(11, __builtin_amdgcn_s_memrealtime());
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t == 0) G_STAMP(1, __builtin_amdgcn_s_memrealtime());
-        if (t == 8) G_STAMP(8, __builtin_amdgcn_s_memrealtime());
-        if (t == 9) G_STAMP(12, __builtin_amdgcn_s_memrealtime());
-        if (t + NS - 1 < nk && g.probe != 2 && g.probe != 6) issue((slot + NS - 1) % NS, t + NS - 1);
-        if (t == 8) G_STAMP(9, __builtin_amdgcn_s_memrealtime());
+        if (G_PROBE(g) == 20 && t == 8) G_STAMP(8, __builtin_amdgcn_s_memrealtime());
+        if (G_PROBE(g) == 20 && t == 9) G_STAMP(12, __builtin_amdgcn_s_memrealtime());
+        if (t + NS - 1 < nk && G_PROBE(g) != 2 && G_PROBE(g) != 6) issue((slot + NS - 1) % NS, t + NS - 1);
+        if (G_PROBE(g) == 20 && t == 8) G_STAMP(9, __builtin_amdgcn_s_memrealtime());
         Frags f;
         read_frags(f, slot);
-        if (g.probe == 11) {         // LDS-DMA + fragment reads, no MFMAs
+        // all 8 KS fragment reads go out before the first MFMA (left alone the compiler reads four fragments at a time into the
+        // same registers: six exposed LDS round trips per stage)
+        __builtin_amdgcn_sched_barrier(0);
+        if (G_PROBE(g) == 11) {         // LDS-DMA + fragment reads, no MFMAs
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -601,8 +626,8 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(f.b[j][pl][s]));
                 }
-        } else if (g.probe != 1 && g.probe != 5) mma(f);
-        if (t == 8) G_STAMP(10, __builtin_amdgcn_s_memrealtime());
+        } else if (G_PROBE(g) != 1 && G_PROBE(g) != 5) mma(f);
+        if (G_PROBE(g) == 20 && t == 8) G_STAMP(10, __builtin_amdgcn_s_memrealtime());
     };
     for (int t = 0; t < nk; t += NS) {
 #pragma unroll
@@ -612,7 +637,7 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 
     G_STAMP(2, __builtin_amdgcn_s_memrealtime());
     constexpr float kUnscale = 1.0f / kPWeightScale;
-    if (((g.probe >= 4 && g.probe <= 6) || g.probe >= 10) && acc[0][0][0] != 12345.678f) return;      // probes 4+: no epilogue (4: all else, 5: no MFMAs, 6: no LDS-DMA)
+    if (((G_PROBE(g) >= 4 && G_PROBE(g) <= 6) || (G_PROBE(g) >= 10 && G_PROBE(g) < 20)) && acc[0][0][0] != 12345.678f) return;      // probes 4+: no epilogue (4: all else, 5: no MFMAs, 6: no LDS-DMA)
     if constexpr (!SWAP) {
         // C/D layout of the 32 x 32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m): a store instruction
         // writes two full 128-byte lines.  Whole tiles (all but the last row of tiles) take the branch-free form: the residual's 16
@@ -936,6 +961,202 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f32_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same fused attention on the fp16 matrix pipe at fp32 accuracy: every operand (Q, K, V, and the probabilities)
+// goes in as two fp16 planes h + l (module comment of the P-layout GEMM: 24 significant bits; Q / K / V are O(1), P is in
+// [0, 1]), three v_mfma_f32_32x32x16_f16 per term, sums and the whole soft-max in fp32.  Per 128-key tile and wave that is
+// 96 MFMAs of 32 cycles against 256 fp32-input MFMAs of 64: 3 072 matrix-pipe cycles instead of 16 384.
+//   S^T = K Q^T  : A = K planes [key][64 dims] (128-byte rows, 16-byte pieces XORed with the key's bits 1..3: conflict-free
+//                  ds_read_b128), B = this lane's query, split once into 4 k steps x (h, l) registers.
+//   O^T = V^T P^T: the MFMA's 8 consecutive k of lane half lk must be KEYS.  The S^T accumulators of lane half lk hold, per
+//                  16-key group, keys {4 lk .. 4 lk + 3} and {8 + 4 lk .. 8 + 4 lk + 3}: P^T goes back in straight from the
+//                  registers (converted to h + l in place), and the V^T image is built to match -- [dim][key slot], slots of a
+//                  16-key group ordered [0-3, 8-11, 4-7, 12-15], so that a lane's 8 keys are one 16-byte read (256-byte rows,
+//                  pieces XORed with the dim's low 4 bits).  V is transposed while it is staged: a thread owns 4 consecutive
+//                  keys x 8 dims and writes 8-byte runs of 4 keys.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8_f16(const float (&v)[8], f16x8_t& h, f16x8_t& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hj = (_Float16)v[j];
+        h[j] = hj;
+        l[j] = (_Float16)(v[j] - (float)hj);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                                  float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp,
+                                                                  int64_t rows) {
+    __shared__ __attribute__((aligned(16))) unsigned char Kp[2][128 * 128];    // [plane][key][64 dims fp16]
+    __shared__ __attribute__((aligned(16))) unsigned char Vp[2][64 * 256];     // [plane][dim][128 key slots fp16]
+    __shared__ float kbias[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lk = lane >> 5;
+    const int qblocks = (L + 127) / 128;
+    const int qb = blockIdx.x % qblocks, h = (blockIdx.x / qblocks) % H, b = blockIdx.x / (qblocks * H);
+    const size_t ld = 3 * kD;
+    const float* base = qkv + (size_t)b * L * ld + h * 64;
+    const int q_row = qb * 128 + wave * 32 + lr;                      // this lane's query
+    const bool q_ok = q_row < L;
+    f16x8_t qh[4], ql[4];                                              // k step ks: dims 16 ks + 8 lk .. + 7
+    {
+        const float* qp = base + (size_t)min(q_row, L - 1) * ld + 8 * lk;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 u = *reinterpret_cast<const float4*>(qp + 16 * ks), v = *reinterpret_cast<const float4*>(qp + 16 * ks + 4);
+            const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            split8_f16(x, qh[ks], ql[ks]);
+        }
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mb][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                              // l_run: this half-wave's share of the sum
+    constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) folded with log2(e)
+    // fragment addresses: K rows 32 rb + lr, piece (2 ks + lk) ^ ((row >> 1) & 7); V^T rows 32 mb + lr, piece (2 s16 + lk) ^ (row & 15)
+    const uint32_t k_rd = lr * 128 + 16 * (lk ^ ((lr >> 1) & 7)), k_sw = 0;
+    (void)k_sw;
+    const uint32_t v_rd = lr * 256 + 16 * (lk ^ (lr & 15));
+
+    for (int k0 = 0; k0 < L; k0 += 128) {
+        __syncthreads();                                               // previous tile fully consumed
+        {
+            // ---- K: thread -> key tid >> 1, 32 dims (tid & 1) * 32 ..: four 8-dim pieces per plane ----
+            const int key = tid >> 1, d0 = (tid & 1) * 32;
+            const bool ok = k0 + key < L;
+            const float* kp = base + kD + (size_t)min(k0 + key, L - 1) * ld + d0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 u = *reinterpret_cast<const float4*>(kp + 8 * c), v = *reinterpret_cast<const float4*>(kp + 8 * c + 4);
+                if (!ok) u = v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                f16x8_t hh, ll;
+                split8_f16(x, hh, ll);
+                const uint32_t at = key * 128 + 16 * ((d0 / 8 + c) ^ ((key >> 1) & 7));
+                *reinterpret_cast<f16x8_t*>(&Kp[0][at]) = hh;
+                *reinterpret_cast<f16x8_t*>(&Kp[1][at]) = ll;
+            }
+            // ---- V transposed: thread -> keys 4 kg .. 4 kg + 3 (kg = tid >> 3), dims 8 dg .. 8 dg + 7 (dg = tid & 7) ----
+            const int kg = tid >> 3, dg = tid & 7;
+            float vv[4][8];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int vkey = k0 + 4 * kg + kk;
+                const float* vp = base + 2 * kD + (size_t)min(vkey, L - 1) * ld + 8 * dg;
+                float4 u = *reinterpret_cast<const float4*>(vp), v = *reinterpret_cast<const float4*>(vp + 4);
+                if (vkey >= L) u = v = make_float4(0.f, 0.f, 0.f, 0.f);
+                vv[kk][0] = u.x; vv[kk][1] = u.y; vv[kk][2] = u.z; vv[kk][3] = u.w;
+                vv[kk][4] = v.x; vv[kk][5] = v.y; vv[kk][6] = v.z; vv[kk][7] = v.w;
+            }
+            const int sub = kg & 3, slot4 = sub == 1 ? 2 : sub == 2 ? 1 : sub;      // [0-3, 8-11, 4-7, 12-15] within a 16-key group
+            const int piece = 2 * (kg >> 2) + (slot4 >> 1), half = slot4 & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * dg + j;
+                typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+                f16x4_t hh, ll;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const _Float16 t = (_Float16)vv[kk][j];
+                    hh[kk] = t;
+                    ll[kk] = (_Float16)(vv[kk][j] - (float)t);
+                }
+                const uint32_t at = d * 256 + 16 * (piece ^ (d & 15)) + 8 * half;
+                *reinterpret_cast<f16x4_t*>(&Vp[0][at]) = hh;
+                *reinterpret_cast<f16x4_t*>(&Vp[1][at]) = ll;
+            }
+            if (tid < 128) {
+                const int kk = k0 + tid;
+                // additive mask; keys past L are tile padding and must weigh exactly 0
+                kbias[tid] = kk >= L ? -INFINITY : (mask[(size_t)b * L + kk] != 0 ? 0.f : -3.4028234663852886e38f);
+            }
+        }
+        __syncthreads();
+        // ---- S^T tile: 4 blocks of 32 keys x this wave's 32 queries; per k step the products l.h, h.l, h.h ----
+        f32x16 sacc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[rb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const uint32_t at = (k_rd + rb * 32 * 128) ^ (32 * ks);
+                const f16x8_t kh = *reinterpret_cast<const f16x8_t*>(&Kp[0][at]), kl = *reinterpret_cast<const f16x8_t*>(&Kp[1][at]);
+                sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc[rb], 0, 0, 0);
+                sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc[rb], 0, 0, 0);
+                sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc[rb], 0, 0, 0);
+            }
+        // ---- online soft-max over this tile's keys (registers of this lane + the other half-wave) -------------
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * rb + 8 * (r >> 2) + 4 * lk + (r & 3);
+                sacc[rb][r] = fmaf(sacc[rb][r], kScaleLog2, kbias[key] * 1.44269504088896340736f);
+                tmax = fmaxf(tmax, sacc[rb][r]);
+            }
+        tmax = fmaxf(tmax, lane_xor<32>(tmax));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // exp2(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[rb][r] = __builtin_amdgcn_exp2f(sacc[rb][r] - m_new);
+                psum += sacc[rb][r];
+            }
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[mb][r] *= alpha;
+        // ---- O^T += V^T P^T: registers 8 g .. 8 g + 7 of S^T block rb are the 8 keys of k step 2 rb + g in this lane half ----
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const float pv[8] = {sacc[rb][8 * g2 + 0], sacc[rb][8 * g2 + 1], sacc[rb][8 * g2 + 2], sacc[rb][8 * g2 + 3],
+                                     sacc[rb][8 * g2 + 4], sacc[rb][8 * g2 + 5], sacc[rb][8 * g2 + 6], sacc[rb][8 * g2 + 7]};
+                f16x8_t ph, pl;
+                split8_f16(pv, ph, pl);
+                const int s16 = 2 * rb + g2;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const uint32_t at = (v_rd + mb * 32 * 256) ^ (32 * s16);
+                    const f16x8_t vh = *reinterpret_cast<const f16x8_t*>(&Vp[0][at]), vl = *reinterpret_cast<const f16x8_t*>(&Vp[1][at]);
+                    o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[mb], 0, 0, 0);
+                    o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[mb], 0, 0, 0);
+                    o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[mb], 0, 0, 0);
+                }
+            }
+    }
+    // ---- normalise and store: lane = query, registers = head dims (4 consecutive per group) --------------------
+    const float l_tot = l_run + lane_xor<32>(l_run);
+    const float inv = 1.0f / l_tot;
+    if (q_ok && ctxp) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                p_store4(ctxp, rows, (int64_t)b * L + q_row, h * 64 + 32 * mb + 8 * g4 + 4 * lk, o[mb][4 * g4 + 0] * inv,
+                         o[mb][4 * g4 + 1] * inv, o[mb][4 * g4 + 2] * inv, o[mb][4 * g4 + 3] * inv);
+    } else if (q_ok) {
+        float* op = ctx + ((size_t)b * L + q_row) * kD + h * 64;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4*>(op + 32 * mb + 8 * g4 + 4 * lk) =
+                    make_float4(o[mb][4 * g4 + 0] * inv, o[mb][4 * g4 + 1] * inv, o[mb][4 * g4 + 2] * inv, o[mb][4 * g4 + 3] * inv);
+    }
+}
+
 // fraction of the last round of workgroups that runs empty, at 3 resident workgroups per CU
 double gemm_rounds_waste(long long blocks) {
     const double rounds = (double)blocks / 768.0;
@@ -1049,16 +1270,17 @@ template <int BN, bool SWAP>
 int launch_gemm_p_ring(const PGemmArgs& g, int n_off, int col_tiles, hipStream_t st) {
     // ASPIRE_HIP_GEMM_RING = 10 KS + NS pins the ring (default: kPRingDefault)
     switch (tuning().gemm_ring ? tuning().gemm_ring : kPRingDefault) {
-    case 13: return launch_gemm_p_ns<3, 1, BN, SWAP>(g, n_off, col_tiles, st);
+    case 12: return launch_gemm_p_ns<2, 1, BN, SWAP>(g, n_off, col_tiles, st);
     case 14: return launch_gemm_p_ns<4, 1, BN, SWAP>(g, n_off, col_tiles, st);
     case 23: return launch_gemm_p_ns<3, 2, BN, SWAP>(g, n_off, col_tiles, st);
-    default: return launch_gemm_p_ns<2, 2, BN, SWAP>(g, n_off, col_tiles, st);
+    case 22: return launch_gemm_p_ns<2, 2, BN, SWAP>(g, n_off, col_tiles, st);
+    default: return launch_gemm_p_ns<3, 1, BN, SWAP>(g, n_off, col_tiles, st);
     }
 }
 template <bool SWAP>
 int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
     ASPIRE_REQUIRE(g.N % 128 == 0 && g.K % 32 == 0, ASPIRE_ERR_UNSUPPORTED, "P-layout GEMM needs N %% 128 == 0 and K %% 32 == 0");
-    const long long slots = 512, rows = (g.M + 127) / 128, n128 = g.N / 128;
+    const long long slots = 768, rows = (g.M + 127) / 128, n128 = g.N / 128;
     // 128 x 64 tiles (twice the workgroups) where 128 x 128 ones cannot give every workgroup slot a tile and the k loop is short
     int c1 = (int)n128;
     if (tuning().gemm_tile == 64 || (tuning().gemm_tile == 0 && rows * n128 < slots && g.K <= 1024)) c1 = 0;
@@ -1144,8 +1366,12 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         // three-kernel form (QK^T GEMM, masked soft-max, PV GEMM) that the fused one is tested against.
         if (dh == 64 && !tuning().attn_gemm) {
             const unsigned qblocks = (unsigned)((L + 127) / 128);
-            hipLaunchKernelGGL(flash_attn_f32_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkv, attn_mask, ws.ctx,
-                               (int)L, H, pp ? ws.ctxp : nullptr, M);
+            if (tuning().attn_f32)
+                hipLaunchKernelGGL(flash_attn_f32_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkv, attn_mask, ws.ctx,
+                                   (int)L, H, pp ? ws.ctxp : nullptr, M);
+            else
+                hipLaunchKernelGGL(flash_attn_f16x2_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkv, attn_mask, ws.ctx,
+                                   (int)L, H, pp ? ws.ctxp : nullptr, M);
             ASPIRE_LAUNCH_OK();
         } else {
             // 2. scores[b,h] = Q_bh . K_bh^T   (scale and mask are applied by the softmax kernel)

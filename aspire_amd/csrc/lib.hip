@@ -29,8 +29,9 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "COST1_BLOCKS")) {
         t.cost1_blocks = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "ATTN")) {
-        if (!unset && strcmp(v, "gemm")) return false;
-        t.attn_gemm = unset ? 0 : 1;
+        if (!unset && strcmp(v, "gemm") && strcmp(v, "f32")) return false;
+        t.attn_gemm = !unset && !strcmp(v, "gemm");
+        t.attn_f32 = !unset && !strcmp(v, "f32");
     } else if (!strcmp(key, "GEMM")) {
         const int f = unset ? 0 : !strcmp(v, "f32") ? 1 : !strcmp(v, "bf16x3") ? 2 : !strcmp(v, "planes") ? 3 : -1;
         if (f < 0) return false;
@@ -43,7 +44,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "GEMM_RING")) {
         int f = unset ? 0 : atoi(v);
         if (f == 2 || f == 3) f += 20;        // the round-3 spellings: ring depth at two k blocks per stage
-        if (f != 0 && f != 22 && f != 23 && f != 13 && f != 14) return false;
+        if (f != 0 && f != 22 && f != 23 && f != 12 && f != 13 && f != 14) return false;
         t.gemm_ring = f;
     } else if (!strcmp(key, "GEMM_PROBE")) {
         t.gemm_probe = unset ? 0 : atoi(v);
@@ -78,7 +79,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
         v = names[t.sinkhorn_form];
     } else if (!strcmp(key, "COST_PATH")) v = t.cost_path == 1 ? "mfma" : t.cost_path == 2 ? "valu" : "";
     else if (!strcmp(key, "COST1_BLOCKS")) v = number(t.cost1_blocks);
-    else if (!strcmp(key, "ATTN")) v = t.attn_gemm ? "gemm" : "";
+    else if (!strcmp(key, "ATTN")) v = t.attn_gemm ? "gemm" : t.attn_f32 ? "f32" : "";
     else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : t.gemm_form == 3 ? "planes" : "";
     else if (!strcmp(key, "GEMM_TILE")) v = number(t.gemm_tile);
     else if (!strcmp(key, "GEMM_RING")) v = number(t.gemm_ring);

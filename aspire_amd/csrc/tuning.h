@@ -9,6 +9,7 @@ struct Tuning {
     int sinkhorn_form = 0;   // ASPIRE_HIP_SINKHORN: 0 by grid size, 1 wave, 3 block, 4 block-norepair, 5 block16, 6 block-dense, 7 block-wide (lanes per pair of the block form)
     int cost_path = 0;       // ASPIRE_HIP_COST_PATH: 0 by shape, 1 mfma (Gram kernel), 2 valu
     int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
+    int attn_f32 = 0;        // ASPIRE_HIP_ATTN=f32: the fused attention kernel on fp32-input MFMAs (round 2) instead of the fp16-plane form
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
     int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default (pre-split operands from ~3000 token rows on, else bf16x3), 1 f32 = fp32-input MFMA everywhere, 2 bf16x3 = operands split on the fly, 3 planes = pre-split operands at any size
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows

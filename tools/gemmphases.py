@@ -40,7 +40,7 @@ print(f'per workgroup: start -> first tile landed {np.mean(landed - start):.2f} 
       f'main loop {np.mean(loop_end - landed):.2f} (min {np.min(loop_end - landed):.2f}, max {np.max(loop_end - landed):.2f}); '
       f'stores issued in {np.mean(end - loop_end):.2f} (max {np.max(end - loop_end):.2f})')
 order = np.argsort(start)
-if K // 32 > 9:
+if K // 32 > 9 and os.environ.get('ASPIRE_HIP_GEMM_PROBE') == '20':
     d = lambda a, b: (t[:, b] - t[:, a]) / 100.0
     print(f'inside step 8 (wave 0): barrier -> LDS-DMA issued {d(8, 9).mean():.2f} us, -> MFMAs issued {d(9, 10).mean():.2f}, -> own pieces of the next stage landed '
           f'{d(10, 11).mean():.2f} (max {d(10, 11).max():.2f}), -> through the barrier {d(11, 12).mean():.2f} (max {d(11, 12).max():.2f}); step {d(8, 12).mean():.2f}')
