@@ -67,7 +67,7 @@ def test_encode_to_pool_is_forward_without_the_padding():
     m = _bert(2, seed=1)
     model = AspireConSent(bert_model=m)
     batches = _doc_batches(3, 23, 8, 3000, 9)
-    pool, cls = model.encode_to_pool(batches, pids=[f'd{i}' for i in range(23)], want_cls=True)
+    pool, cls = model.encode_to_pool(batches, pids=[f'd{i}' for i in range(23)], want_cls=True, docs_per_forward=None)     # one encoder call per batch, as given
     assert len(pool) == 23 and pool.pids[5] == 'd5'
     rows, start, lens = pool.repset.rows.cpu(), pool.repset.start.cpu().tolist(), pool.repset.len.cpu().tolist()
     assert pool.repset.rows.is_cuda and rows.shape[0] == sum(lens)
@@ -85,6 +85,12 @@ def test_encode_to_pool_is_forward_without_the_padding():
     want = _oracle_reps(m, batches)
     for d in range(23):
         np.testing.assert_allclose(rows[start[d]:start[d] + lens[d]].numpy(), want[d].numpy(), atol=TOL, rtol=0)
+    # by default consecutive batches are joined into encoder calls of up to 64 documents (the shorter ones' token tensors padded):
+    # the same rows -- to rounding, the joined call's row count can select other GEMM kernel forms
+    for per in (64, 16):
+        joined = model.encode_to_pool(batches, docs_per_forward=per)
+        assert torch.equal(joined.repset.start.cpu(), pool.repset.start.cpu())
+        np.testing.assert_allclose(joined.repset.rows.cpu().numpy(), rows.numpy(), atol=2e-5, rtol=0)
 
 
 def test_token_ids_to_ranked_list_end_to_end():
