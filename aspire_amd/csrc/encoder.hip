@@ -393,11 +393,11 @@ constexpr float kPWeightScale = 64.f;                // weights are split as 64 
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-// Timing probes of gemm_p_kernel (ASPIRE_HIP_GEMM_PROBE; wrong results by design) exist in the instrumented build only
-// (tools/build_clock.sh): 1 no MFMAs, 2 no LDS-DMA, 4 no epilogue, 5 / 6 = 1 / 2 without epilogue, 10 no B-tile DMA and no
-// epilogue, 11 LDS-DMA + fragment reads only, 20 stamps inside step 8.  In the product build the branches are compiled out: a
-// branch in the step splits the block in which the compiler interleaves fragment reads and MFMAs.
-#ifdef ASPIRE_PHASE_CLOCK
+// Timing probes of gemm_p_kernel (ASPIRE_HIP_GEMM_PROBE; wrong results by design) exist only in builds with -DASPIRE_GEMM_PROBES
+// (probes alone) or -DASPIRE_PHASE_CLOCK (probes + time stamps, tools/build_clock.sh; the stamps themselves cost ~30 %):
+// 1 no MFMAs, 2 no LDS-DMA, 3 every workgroup computes tile (0, 0) (operands always cache-hot), 4 no epilogue, 5 / 6 = 1 / 2
+// without epilogue, 10 no B-tile DMA and no epilogue, 11 LDS-DMA + fragment reads only, 20 stamps inside step 8.
+#if defined(ASPIRE_PHASE_CLOCK) || defined(ASPIRE_GEMM_PROBES)
 #define G_PROBE(g) ((g).probe)
 #else
 #define G_PROBE(g) 0
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         bx = L % gx;
         by = L / gx;
     }
-    const int m0 = by * 128, n0 = g.n_off + bx * BN;
+    const int m0 = G_PROBE(g) == 3 ? 0 : (int)by * 128, n0 = G_PROBE(g) == 3 ? g.n_off : g.n_off + (int)bx * BN;      // probe 3: every workgroup computes tile (0, 0)
     G_STAMP(0, __builtin_amdgcn_s_memrealtime());
     G_STAMP(4, __builtin_amdgcn_s_getreg(31 << 11 | 4));
     G_STAMP(5, __builtin_amdgcn_s_getreg(31 << 11 | 20));

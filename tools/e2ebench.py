@@ -53,7 +53,8 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
     t_encode = time.perf_counter() - t0
     # the GPU side of the same stage alone: encoder forward and pooling kernels under HIP events
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    bb, abs_lens, idxs = batches[0]
+    calls = model._merge_batches(batches, 64)                 # what encode_to_pool runs: consecutive batches joined to 64 documents
+    bb, abs_lens, idxs = calls[0]
     from aspire_amd.batch_prep import spans_to_csr
     tok_idx, span_off = spans_to_csr(idxs, S)
     tok_idx, span_off = tok_idx.to(dev), span_off.to(dev)
@@ -68,7 +69,7 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
     ev[2].record()
     torch.cuda.synchronize()
     enc_ms, pool_ms = ev[0].elapsed_time(ev[1]) / n_rep, ev[1].elapsed_time(ev[2]) / n_rep
-    n_batches = len(batches)
+    n_batches = len(calls)
     # queries: the same encoder, reps left on the GPU
     qreps = []
     for bb, abs_lens, idxs in qbatches:
@@ -98,7 +99,7 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
     cosq = torch.nn.functional.normalize(pool.repset.rows[:2048], dim=1)
     mean_cos = float((cosq @ cosq.T).mean())
     out = {
-        'what': f'config 5, one GPU slice: {n_docs} docs x {L} tokens ({S} sentences) encoded in batches of {BATCH} straight into the resident '
+        'what': f'config 5, one GPU slice: {n_docs} docs x {L} tokens ({S} sentences), prepared in batches of {BATCH}, encoded {len(calls[0][1])} per call straight into the resident '
                 f'rep store, then {n_queries} queries x otAspire + top-{kk} on it (pp_gen_nearest.py:141-202); synthetic tokens, '
                 f'random-init BERT-base',
         'docs': n_docs, 'tokens': L, 'sents': S, 'queries': n_queries,
