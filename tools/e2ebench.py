@@ -110,6 +110,12 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
         'split_ms': {'encoder_kernels': enc_ms * n_batches, 'pooling_kernels': pool_ms * n_batches,
                      'encode_host_and_gaps': t_encode * 1e3 - (enc_ms + pool_ms) * n_batches, 'ot_and_rank': t_score * 1e3},
         'encoder_share_of_total': enc_ms * n_batches / (t_encode * 1e3 + t_score * 1e3),
+        # 12 L (14 155 776 + 3072 L) flop per document; every product runs as three fp16 MFMAs (two planes per
+        # operand), so the pipe's ceiling for this arithmetic is the dense fp16 peak / 3
+        'encoder_roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 2500.0 / 3,
+                             'achieved': 12 * L * (14155776 + 3072 * L) * n_docs / t_encode / 1e12,
+                             'frac': 12 * L * (14155776 + 3072 * L) * n_docs / t_encode / 1e12 / (2500.0 / 3),
+                             'what': 'whole encode stage (GEMMs, attention, LayerNorms, pooling, host) against the fp16 MFMA peak / 3 products'},
     }
     if check:
         # three (query, candidate) pairs against HF BertModel (fp32, CPU) -> oracle pooling -> oracle OT
