@@ -52,8 +52,8 @@ def test_bert_forward_matches_transformers(n_layers, b, l):
 
 
 def test_fused_attention_matches_three_kernel_form():
-    """aspire_debug_set("ATTN", "gemm") runs attention as QK^T GEMM + masked soft-max + PV GEMM; the fused kernel (default) must
-    give the same hidden states (key tiles of 128: lengths on, just past and between tile edges, ragged masks)."""
+    """aspire_debug_set("ATTN", "gemm") runs attention as QK^T GEMM + masked soft-max + PV GEMM; the fused kernels (the default
+    on fp16 planes, and "f32") must give the same hidden states (key tiles of 128: lengths on, just past and between tile edges, ragged masks)."""
     from aspire_amd._lib import pinned
     from aspire_amd.encoder import HipBertEncoder
     m = _bert(2, seed=5)
@@ -64,6 +64,11 @@ def test_fused_attention_matches_three_kernel_form():
         with pinned(ATTN='gemm'):
             ref = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
         assert (fused - ref).abs().max().item() < 2e-5, l
+        # ... and the fused kernel's fp32-input form (round 2; the default splits Q, K, V and the probabilities into fp16 planes)
+        with pinned(ATTN='f32'):
+            f32 = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+        assert (fused - f32).abs().max().item() < 2e-5, l
+        assert (f32 - ref).abs().max().item() < 2e-5, l
 
 
 def test_bert_full_length_512():
