@@ -20,7 +20,10 @@ for case in range(n_cases):
         nc = max(1, nc // 8)
     g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
     scale = float(rng.choice([1.0, 1.0, 0.3, 2.0]))
-    mk = lambda n: scale * torch.randn(int(n), 768, generator=g)
+    # a third of the cases: every row carries a common vector (anisotropic embeddings, mean cosine 0.5 .. 0.9: the rows are centred
+    # by the kernels that can, the others redo most entries with the direct formula)
+    common = float(rng.choice([0.0, 0.0, 1.0, 3.0])) * torch.randn(768, generator=g)
+    mk = lambda n: scale * (torch.randn(int(n), 768, generator=g) + common)
     ragged = rng.random() < 0.7
     q = [mk(rng.integers(1, smax + 1) if ragged else smax) for _ in range(nq)]
     c = [mk(rng.integers(1, smax + 1) if ragged else smax) for _ in range(nc)]
@@ -38,7 +41,8 @@ for case in range(n_cases):
             j = 1
         w = orc.get_similarity(q[i], c[j])
         shared = j == 1 and len(c[1]) and torch.equal(c[1][0], q[0][0]) and i == 0
-        tol = 5e-2 * max(1.0, scale) if shared else 1e-4          # coincident sentences: geomloss's own cancellation noise (grows with the vectors' scale)
+        big = 1.0 + float(common.abs().max() > 0) * 2.0          # a common vector: the reference's own fp32 cost has more rounding to lose
+        tol = 5e-2 * max(1.0, scale) if shared else 1e-4 * big          # coincident sentences: geomloss's own cancellation noise (grows with the vectors' scale)
         e = abs(float(ot[i, j]) - w)
         assert e <= tol, (case, nq, nc, smax, i, j, float(ot[i, j]), w, len(q[i]), len(c[j]))
         if not shared:
@@ -48,20 +52,20 @@ for case in range(n_cases):
         el = abs(float(l2[i, j]) - wl)
         # coincident sentences under torch.cdist's matmul formula (a side beyond 25 rows): the reference's own value is
         # sqrt(clamp(cancellation noise)), 0 or ~3e-2 by rounding luck
-        tol_l2 = 5e-2 if (shared and max(len(q[i]), len(c[j])) > 25) else 1e-4
+        tol_l2 = 5e-2 if (shared and max(len(q[i]), len(c[j])) > 25) else 1e-4 * big
         assert el <= tol_l2, (case, nq, nc, smax, i, j, float(l2[i, j]), wl, len(q[i]), len(c[j]))
-        if tol_l2 == 1e-4:
+        if tol_l2 <= 3e-4:
             worst_l2 = max(worst_l2, el)
     k = int(min(nc, rng.choice([1, 10, 100, 128])))
     qs, cs = ops.DeviceRepSet.from_list(q), ops.DeviceRepSet.from_list(c)
     sc, ts, ti = ops.ot_rank(qs, cs, k, want=_lib.OT_SIMILARITY)
     sc, ts, ti = sc.cpu(), ts.cpu(), ti.cpu()
-    np.testing.assert_allclose(sc.numpy(), ot, atol=2e-4, rtol=0)
+    np.testing.assert_allclose(sc.numpy(), ot, atol=2e-4 * big, rtol=0)
     for i in range(nq):
         order = orc.rank_descending(sc[i].tolist())[:k]
         assert ti[i].tolist() == order, (case, nq, nc, smax, k, i)
         assert torch.equal(ts[i], sc[i][order])
-    print(f'case {case}: Q={nq} C={nc} S<={smax} ragged={ragged} k={k} ok', flush=True)
+    print(f'case {case}: Q={nq} C={nc} S<={smax} ragged={ragged} k={k} common={float(common.abs().max()) > 0} ok', flush=True)
 print(f'{n_cases} cases ok; worst |ot - oracle| {worst_ot:.2e}, worst |l2max - oracle| {worst_l2:.2e}')
 
 # ---- part 2: the padded, paired calling pattern of caching_score (disent_models.py:256-342), groups of <= 64 ----------
