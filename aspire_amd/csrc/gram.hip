@@ -53,6 +53,7 @@ struct GramArgs {
     float* cost;
     float* neg;
     float* scores;       // tsAspire: [nq][c.n]
+    int center;          // ASPIRE_OT_FLAG_CENTER / ASPIRE_CDIST_CENTER: subtract the tile's first query row from every staged row
     const float* qbox;   // fused diameter (BOX): per-query coordinate boxes [nq][2][768]
     float* diam2;        //                       out [nq][ncand]
 };
@@ -79,6 +80,15 @@ __device__ __forceinline__ float4 ldg4(unsigned long long addr, int ofs) {
 #else
     (void)addr; (void)ofs;
     return make_float4(0.f, 0.f, 0.f, 0.f);   // host pass of the single-source compile; never called
+#endif
+}
+
+__device__ __forceinline__ float ldg1(unsigned long long addr, int ofs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(reinterpret_cast<gfp>(addr) + ofs);
+#else
+    (void)addr; (void)ofs;
+    return 0.f;
 #endif
 }
 
@@ -193,6 +203,14 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     // tile t+2's loads go out into the other -- candidate rows come from HBM, and one iteration of MFMAs
     // (~1 us) does not cover that latency, two do.
     float4 ra[2][A_F4], rb[2][B_F4];
+    // Rows that share a large common component (anisotropic embeddings): x.y, |x|^2 and |y|^2 are then all dominated by it, the
+    // expansion cancels for nearly EVERY entry and the direct-formula redo below takes the kernel over (128 x 16 384 x 12: 86 ms
+    // instead of 9).  Distances do not move when every row of the tile is shifted by the same vector: with g.center the tile's
+    // first query row comes off each staged float4 before it is squared or split (one more L1-resident load per k step).
+    const unsigned long long pmu = q_ptr[0];
+    float4 rm[2];
+    rm[0] = rm[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto sub4 = [](const float4& v, const float4& m) { return make_float4(v.x - m.x, v.y - m.y, v.z - m.z, v.w - m.w); };
     float na[A_F4], nb[B_F4];
 #pragma unroll
     for (int p = 0; p < A_F4; ++p) na[p] = 0.f;
@@ -204,6 +222,7 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
         for (int p = 0; p < A_F4; ++p) ra[S][p] = ldg4(pa[p], k0 + 4 * lk4);
 #pragma unroll
         for (int p = 0; p < B_F4; ++p) rb[S][p] = ldg4(pb[p], k0 + 4 * lk4);
+        if (g.center) rm[S] = ldg4(pmu, k0 + 4 * lk4);
     };
     // one float4 piece (A piece p < A_F4, B piece p - A_F4 otherwise) of a register set -> LDS, k-major
     auto split_store = [&](uint32_t (*dst)[kLdw], uint32_t (*dst1)[kLdw], uint32_t (*dst2)[kLdw], int row, const float4& v) {
@@ -220,33 +239,37 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int p = 0; p < A_F4; ++p) {
-            split_store(As3[buf][0], As3[buf][1], As3[buf][2], lrow + 64 * p, ra[S][p]);
-            na[p] = fmaf(count, sq4f(ra[S][p]), na[p]);
+            const float4 v = sub4(ra[S][p], rm[S]);
+            split_store(As3[buf][0], As3[buf][1], As3[buf][2], lrow + 64 * p, v);
+            na[p] = fmaf(count, sq4f(v), na[p]);
         }
 #pragma unroll
         for (int p = 0; p < B_F4; ++p) {
-            split_store(Bs3[buf][0], Bs3[buf][1], Bs3[buf][2], lrow + 64 * p, rb[S][p]);
-            nb[p] = fmaf(count, sq4f(rb[S][p]), nb[p]);
+            const float4 v = sub4(rb[S][p], rm[S]);
+            split_store(Bs3[buf][0], Bs3[buf][1], Bs3[buf][2], lrow + 64 * p, v);
+            nb[p] = fmaf(count, sq4f(v), nb[p]);
         }
     };
     auto store_piece = [&](auto setc, int piece, int buf) {
         constexpr int S = decltype(setc)::value;
         if (piece < A_F4) {
             const int p = piece, row = lrow + 64 * p;
-            As[buf][4 * lk4 + 0][row] = ra[S][p].x;
-            As[buf][4 * lk4 + 1][row] = ra[S][p].y;
-            As[buf][4 * lk4 + 2][row] = ra[S][p].z;
-            As[buf][4 * lk4 + 3][row] = ra[S][p].w;
-            na[p] += sq4f(ra[S][p]);
+            const float4 v = sub4(ra[S][p], rm[S]);
+            As[buf][4 * lk4 + 0][row] = v.x;
+            As[buf][4 * lk4 + 1][row] = v.y;
+            As[buf][4 * lk4 + 2][row] = v.z;
+            As[buf][4 * lk4 + 3][row] = v.w;
+            na[p] += sq4f(v);
         } else if (piece < A_F4 + B_F4) {
             const int p = piece - A_F4;
             if (B_ALL || lrow < BN) {
                 const int row = lrow + 64 * p;
-                Bs[buf][4 * lk4 + 0][row] = rb[S][p].x;
-                Bs[buf][4 * lk4 + 1][row] = rb[S][p].y;
-                Bs[buf][4 * lk4 + 2][row] = rb[S][p].z;
-                Bs[buf][4 * lk4 + 3][row] = rb[S][p].w;
-                nb[p] += sq4f(rb[S][p]);
+                const float4 v = sub4(rb[S][p], rm[S]);
+                Bs[buf][4 * lk4 + 0][row] = v.x;
+                Bs[buf][4 * lk4 + 1][row] = v.y;
+                Bs[buf][4 * lk4 + 2][row] = v.z;
+                Bs[buf][4 * lk4 + 3][row] = v.w;
+                nb[p] += sq4f(v);
             }
         }
     };
@@ -304,6 +327,14 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
                             qmn[u] = g.qbox[(size_t)u * 2 * kD + k_cur + bk];
                             qmx[u] = g.qbox[(size_t)u * 2 * kD + kD + k_cur + bk];
                         }
+                    if (g.center) {                // the queries' boxes move with their rows
+                        const float mub = ldg1(pmu, k_cur + bk);
+#pragma unroll
+                        for (int u = 0; u < kBoxQ; ++u) {
+                            qmn[u] -= mub;
+                            qmx[u] -= mub;
+                        }
+                    }
                 }
             }
             if (kk == 0 && do_load) load_tiles(load_set, k_load);
@@ -684,6 +715,7 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
     int bn = 128;
     if (int rc = fill_geometry(g, a, mr_q, mr_c, bn)) return rc;
     g.E = 64 * T * T;
+    g.center = a.center;
     g.ld = 8 * T;
     g.cost = cost;
     g.neg = neg;
@@ -715,6 +747,7 @@ int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t s
     b.cand1 = a.c.n;
     if (int rc = fill_geometry(g, b, mr_q, mr_c, bn)) return rc;
     g.scores = a.scores;
+    g.center = a.center;
     return launch_gram<true>(g, bn, stream);
 }
 

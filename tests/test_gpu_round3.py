@@ -159,6 +159,17 @@ def test_rows_with_a_common_component_are_centred(amd):
                                                                             orc.RepLen(c_[None].permute(0, 2, 1), [len(c_)])).item())):
         got = amd.scorer.score_pool([long_q], long_c, method=method).cpu().numpy()[0]
         np.testing.assert_allclose(got[[0, 299, 599]], [ref(long_c[i]) for i in (0, 299, 599)], atol=TOL, rtol=0)
+    # many queries against one pool: the matrix-pipe cost tiles (gram.hip) centre every tile on its first query row
+    many_q = [mk(n) for n in (8, 3, 12, 5, 8, 1, 7, 6)]
+    for method in ('ot', 'l2max'):
+        got = amd.scorer.score_pool(many_q, cands, method=method).cpu().numpy()
+        for qi, ci in ((0, 0), (2, 1), (5, 2099), (7, 4199)):
+            if method == 'ot':
+                want_v = orc.get_similarity(many_q[qi], cands[ci])
+            else:
+                want_v = -orc.allpair_masked_dist_l2max(orc.RepLen(many_q[qi][None].permute(0, 2, 1), [len(many_q[qi])]),
+                                                        orc.RepLen(cands[ci][None].permute(0, 2, 1), [len(cands[ci])])).item()
+            assert abs(got[qi, ci] - want_v) < TOL, (method, qi, ci, got[qi, ci], want_v)
     # batched jobs: 8-row documents (fused kernel) and abstracts of up to 20 rows (CHUNK items)
     for cmax in (8, 20, 32):                               # 32: the 16-row tile kernels' record items
         lens2 = torch.randint(1, cmax + 1, (1600,), generator=g).tolist()

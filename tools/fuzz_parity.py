@@ -80,6 +80,8 @@ for case in range(n2):
     creps = [torch.randn(int(rng.integers(1, smax + 1)), 768, generator=g).numpy() for _ in range(b)]
     qd, cds = {'sent_reps': qrep}, [{'sent_reps': r} for r in creps]
     for agg in ('l2max', 'l2top2', 'l2wasserstein'):
+        if agg == 'l2top2' and qlen * max(len(r) for r in creps) < 2:
+            continue                       # torch.topk(k=2) over a single entry raises in the reference too (pair_distances.py:308)
         got = scorer.caching_score(qd, cds, score_agg_type=agg)
         if agg == 'l2top2':
             qt = orc.RepLen(torch.stack([torch.nn.functional.pad(torch.as_tensor(qrep), (0, 0, 0, 0))] * b).permute(0, 2, 1), [qlen] * b)
