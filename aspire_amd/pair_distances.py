@@ -72,6 +72,9 @@ def allpair_masked_dist_l2topk(query, cand, return_pair_sims=False):
     """pair_distances.py:295-345 (score_agg_type 'l2top2').
     :return: positive distances [batch_size] (minus the sum of the two largest -cdist entries), or with
         return_pair_sims (sims [batch_size], pair_sims [batch_size, q_max_sents, c_max_sents])."""
+    if query.embed.shape[-1] * cand.embed.shape[-1] < 2:
+        # torch.topk(k=2) over the [batch, q_max_sents * c_max_sents] view raises for a single entry (pair_distances.py:333)
+        raise RuntimeError('selected index k out of range')
     q, c, out_dev = _to_repsets(query, cand)
     if return_pair_sims:
         sims, pair = ops.l2agg_scores(q, c, _lib.AGG_TOP2, pairing=_lib.PAIR_PAIRED, want_pair_sims=True)

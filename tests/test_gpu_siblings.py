@@ -92,3 +92,17 @@ def test_pool_scoring_and_caching_score(amd):
             assert first.shape == (8, 12)
     with pytest.raises(AssertionError):
         amd.ops.l2agg_scores(amd.ops.DeviceRepSet.from_list(queries), amd.ops.DeviceRepSet.from_list(cands), 7)
+
+
+def test_a_single_padded_entry_raises_like_torch_topk(amd):
+    """pair_distances.py:333: torch.topk(k=2) over the [batch, q_max_sents * c_max_sents] view raises RuntimeError when that view has
+    one column (both sides padded to one sentence)."""
+    g = torch.Generator().manual_seed(4)
+    q, c = torch.randn(2, 1, 768, generator=g), torch.randn(2, 1, 768, generator=g)
+    qt = amd.pd.rep_len_tup(embed=q.permute(0, 2, 1), abs_lens=[1, 1])
+    ct = amd.pd.rep_len_tup(embed=c.permute(0, 2, 1), abs_lens=[1, 1])
+    with pytest.raises(RuntimeError):
+        amd.pd.allpair_masked_dist_l2topk(qt, ct)
+    with pytest.raises(RuntimeError):
+        from oracle import aspire_oracle as orc
+        orc.allpair_masked_dist_l2topk(orc.RepLen(q.permute(0, 2, 1), [1, 1]), orc.RepLen(c.permute(0, 2, 1), [1, 1]))
