@@ -85,8 +85,8 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
     torch.cuda.synchronize()
     t_score = time.perf_counter() - t0
     # the same score + rank stage on i.i.d. N(0, 1) reps of the same shapes: random-init BERT puts every sentence rep almost on
-    # one line (cosine ~0.99), where the matrix-pipe cost kernel's |x|^2 - 2 x.y + |y|^2 cancels and nearly every entry is redone
-    # with the direct formula (NOTES.md section 3: pair_gram_kernel) -- trained reps are not like that
+    # one line (cosine ~0.97), where |x|^2 - 2 x.y + |y|^2 cancels unless the rows are centred first (ASPIRE_OT_FLAG_CENTER, set by
+    # aspire_amd.ops from a sample of the pool: NOTES.md, round-3 log)
     g = torch.Generator().manual_seed(seed + 7)
     iid_c = ops.DeviceRepSet(torch.randn(n_docs * S, 768, generator=g).to(dev), pool.repset.start, pool.repset.len, ext=0, max_len=S)
     iid_q = ops.DeviceRepSet(torch.randn(n_queries * S, 768, generator=g).to(dev), q.start, q.len, ext=0, max_len=S)
