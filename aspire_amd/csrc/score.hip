@@ -81,13 +81,15 @@ __device__ __forceinline__ float lds_wave_reduce(const float (&v)[N], float* xp,
 }
 
 // Load N sentence rows (this lane's float4 slice) of one document; rows >= navail read as zero.
-template <int N, bool BBOX>
+template <int N, bool BBOX, bool CENTER = false>
 __device__ __forceinline__ void load_rows(float4 (&r)[N], const float* doc, int row0, int navail, int dofs, int nbox,
-                                          float4& mn, float4& mx) {
+                                          float4& mn, float4& mx, const float4& mu) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int row = row0 + i;
         r[i] = row < navail ? ld4(doc + (size_t)row * kD + dofs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (CENTER)                 // ASPIRE_OT_FLAG_CENTER (a row past the document stays a zero row: masked downstream)
+            if (row < navail) { r[i].x -= mu.x; r[i].y -= mu.y; r[i].z -= mu.z; r[i].w -= mu.w; }
         if (BBOX && row < nbox) {
             mn.x = fminf(mn.x, r[i].x); mn.y = fminf(mn.y, r[i].y); mn.z = fminf(mn.z, r[i].z); mn.w = fminf(mn.w, r[i].w);
             mx.x = fmaxf(mx.x, r[i].x); mx.y = fmaxf(mx.y, r[i].y); mx.z = fmaxf(mx.z, r[i].z); mx.w = fmaxf(mx.w, r[i].w);
@@ -132,10 +134,14 @@ __device__ __forceinline__ void half_tile_partials(const float4 (&x)[4], const f
 // ---------------------------------------------------------------------------------------------
 // Phase 1: all three waves form the partial sums of (query doc, candidate doc) for every tile.
 // ---------------------------------------------------------------------------------------------
-template <int T, bool NEED_G, bool NEED_D2, bool BBOX>
+template <int T, bool NEED_G, bool NEED_D2, bool BBOX, bool CENTER = false>
 __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, int q_box, const float* cdoc, int c_avail,
                                               int c_box, float* lds, int wave, int lane) {
     const int dofs = wave * 256 + lane * 4;
+    // CENTER -- rows sharing a large common component (include/aspire_hip.h: ASPIRE_OT_FLAG_CENTER): the query's first row comes
+    // off every row before anything is multiplied; distances and the bounding box's extent do not move, the expansion stops
+    // cancelling.  A compile-time form: four more live registers push the plain kernels over their three-per-CU budget.
+    const float4 mu = CENTER ? ld4(qdoc + dofs) : make_float4(0.f, 0.f, 0.f, 0.f);
     float* red = lds + wave * (T * T * 128);
     float* rednorm = lds + Lds<T>::kRed + wave * (T * 16);
     float* xp = lds + Lds<T>::kXp + wave * kXpWave;
@@ -147,9 +153,9 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
         // (the j-outer loops below wait per row with counted vmcnt).  Both query halves are resident, so the
         // second half starts without another exposed load latency.
         float4 x0[4], x1[4], y[8];
-        load_rows<4, BBOX>(x0, qdoc, 0, q_avail, dofs, q_box, mn, mx);
-        load_rows<4, BBOX>(x1, qdoc, 4, q_avail, dofs, q_box, mn, mx);
-        load_rows<8, BBOX>(y, cdoc, 0, c_avail, dofs, c_box, mn, mx);
+        load_rows<4, BBOX, CENTER>(x0, qdoc, 0, q_avail, dofs, q_box, mn, mx, mu);
+        load_rows<4, BBOX, CENTER>(x1, qdoc, 4, q_avail, dofs, q_box, mn, mx, mu);
+        load_rows<8, BBOX, CENTER>(y, cdoc, 0, c_avail, dofs, c_box, mn, mx, mu);
         half_tile_partials<NEED_G, NEED_D2>(x0, y, red, xp, lane);
         half_tile_partials<NEED_G, NEED_D2>(x1, y, red + 32, xp, lane);
         if (NEED_G) {
@@ -172,7 +178,7 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
 #pragma unroll 1
     for (int tj = 0; tj < Tc; ++tj) {
         float4 y[8];
-        load_rows<8, BBOX>(y, cdoc, tj * 8, c_avail, dofs, c_box, mn, mx);
+        load_rows<8, BBOX, CENTER>(y, cdoc, tj * 8, c_avail, dofs, c_box, mn, mx, mu);
 #pragma unroll 1
         for (int ti = 0; ti < Tq; ++ti) {
             float nrm[16];  // |x_i|^2 of the 8 query rows, |y_j|^2 of the 8 candidate rows (first row / column of tiles only)
@@ -180,7 +186,7 @@ __device__ __forceinline__ void pair_partials(const float* qdoc, int q_avail, in
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
                 float4 x[4];
-                load_rows<4, BBOX>(x, qdoc, ti * 8 + half * 4, q_avail, dofs, q_box, mn, mx);  // min/max idempotent
+                load_rows<4, BBOX, CENTER>(x, qdoc, ti * 8 + half * 4, q_avail, dofs, q_box, mn, mx, mu);  // min/max idempotent
                 half_tile_partials<NEED_G, NEED_D2>(x, y, red + (ti * T + tj) * 128 + half * 32, xp, lane);
                 if (want_norms) {
 #pragma unroll
@@ -891,7 +897,7 @@ __device__ void sinkhorn_pair(const ScoreArgs& a, const PairState<T>& s, int q_l
 // DIRECT: both L2 formulas accumulated (padded reference tensors: their pair matrices are compared at 1e-5).  !DIRECT
 // (CSR inputs): x.y only, -cdist from the expansion with the cancelled entries redone -- half the arithmetic and
 // half the cross-lane reductions of the T x T tile loop.
-template <int T, bool DIRECT>
+template <int T, bool DIRECT, bool CENTER = false>
 __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairWs<T> ws) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -911,9 +917,9 @@ __global__ void __launch_bounds__(kBlock, 3) pair_cost_kernel(ScoreArgs a, PairW
         const int q_avail = a.q.ext > 0 ? a.q.ext : q_len;
         const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
         if (own_diam) {
-            pair_partials<T, true, DIRECT, true>(qdoc, q_avail, q_len, cdoc, c_avail, c_len, lds, wave, lane);
+            pair_partials<T, true, DIRECT, true, CENTER>(qdoc, q_avail, q_len, cdoc, c_avail, c_len, lds, wave, lane);
         } else {
-            pair_partials<T, true, DIRECT, false>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
+            pair_partials<T, true, DIRECT, false, CENTER>(qdoc, q_avail, 0, cdoc, c_avail, 0, lds, wave, lane);
         }
         __syncthreads();
         const int64_t slot = paired ? (c_idx - a.cand0) : q_idx * ncand + (c_idx - a.cand0);
@@ -1022,7 +1028,18 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
 
     // One item: accumulate, reduce, finish, hand over.  `r` is one of two register sets that take turns (the loop
     // below is unrolled by two so that the set being prefetched into is never copied).
-    auto process = [&](const RowSet& rs, int q_len, int c_len, uint32_t item) {
+    auto process = [&](RowSet& rs, int q_len, int c_len, uint32_t item) {
+        if (a.center) {          // ASPIRE_OT_FLAG_CENTER: the tile's first query row comes off every row (see pair_partials)
+            const float4 mu = rs.x0[0];
+            auto sub = [&](float4& v) { v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w; };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sub(rs.x0[i]);
+                sub(rs.x1[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sub(rs.y[j]);
+        }
         // ---- accumulate + reduce the current item (register operands only).  Only the x.y sums are accumulated:
         // geomloss's cost is the expansion anyway, and torch.cdist's direct (x - y)^2 form (the marginals' -cdist)
         // is met by the same expansion to a few 1e-5 except where it cancels -- those entries (d^2 below 1e-4 of the
@@ -2255,6 +2272,9 @@ int launch_cost_stage(const ScoreArgs& a, const aspire_repset* q, const aspire_r
         const int64_t items = n_slots * T * T;
         hipLaunchKernelGGL(pair_cost1_sub_kernel, dim3((unsigned)(items < 1024 ? items : 1024)), dim3(kBlock),
                            Lds<1>::kTotal * sizeof(float), stream, a, ws1, (uint32_t)T);
+    } else if (csr && a.center) {        // rows with a large common component: the same kernel on centred rows
+        hipLaunchKernelGGL((pair_cost_kernel<T, false, true>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
+                           Lds<T>::kTotal * sizeof(float), stream, a, ws);
     } else if (csr) {
         hipLaunchKernelGGL((pair_cost_kernel<T, false>), dim3((unsigned)(a.cand1 - a.cand0), (unsigned)qchunks, 1), dim3(kBlock),
                            Lds<T>::kTotal * sizeof(float), stream, a, ws);

@@ -211,8 +211,9 @@ typedef struct {
  * direct-formula fix-up that otherwise redoes nearly every entry (5 x slower at mean cosine 0.8) is back to the exception.
  * Same results to rounding (closer to the float64 value than the un-centred expansion).  Honoured by the streaming kernels
  * (fused / chunk forms, the 16-row tiles: centre = mean of the staged query rows) and by the matrix-pipe cost tiles of the
- * many-query calls (centre = the tile's first query row: 128 x 16 384 x 12 at mean cosine 0.97 86 -> 8 ms); the small-pool and
- * 33 .. 128-row kernels ignore it.  aspire_amd.ops sets it from a sample of the pool. */
+ * many-query calls and the small-pool cost kernels (centre = the tile's / the query's first row: 128 x 16 384 x 12 at mean cosine
+ * 0.97 86 -> 8 ms; 1 x 1000 x 12 at 0.8 123 -> 49 us); the 33 .. 128-row kernel and padded reference tensors ignore it.
+ * aspire_amd.ops sets it from a sample of the pool. */
 #define ASPIRE_OT_FLAG_CENTER 2
 #define ASPIRE_CDIST_CENTER 0x200
 
