@@ -202,6 +202,27 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
             err0 = (C0.double() - ref).abs().max().item()
             assert err <= max(1.5 * err0, 3e-7 * scale), (M, N, K, pin, err, err0)
             assert (C - C0).abs().max().item() <= 2e-6 * scale, (M, N, K, pin)
+    # outliers, as trained encoders have them: a few activation columns in the hundreds, a few weight rows in the tens, most entries
+    # small (their low planes sit in fp16's subnormal range: an absolute 2^-25 each) -- still no worse than the fp32-input forms
+    M, N, K = 2048, 768, 3072
+    A = 0.05 * torch.randn(M, K, generator=g)
+    A[:, ::257] *= 4000.0
+    B = 0.02 * torch.randn(N, K, generator=g)
+    B[::97] *= 400.0
+    A, B = A.cuda(), B.cuda()
+    ref = A.double() @ B.double().T
+    scale = ref.abs().max().item()
+    C0, C = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    with _lib.pinned(GEMM='bf16x3'):
+        assert L.aspire_debug_gemm_f32(A.data_ptr(), B.data_ptr(), C0.data_ptr(), None, M, N, K, st) == 0
+    assert L.aspire_debug_gemm_planes(planes(A).data_ptr(), planes(B, 1).data_ptr(), C.data_ptr(), None, None, M, N, K, 0, st) == 0
+    torch.cuda.synchronize()
+    err, err0 = (C.double() - ref).abs().max().item(), (C0.double() - ref).abs().max().item()
+    assert torch.isfinite(C).all() and err <= max(1.5 * err0, 3e-7 * scale), (err, err0, scale)
+    # ... and row by row against the row's own magnitude (small outputs next to big ones)
+    rel = ((C.double() - ref).abs().amax(1) / ref.abs().amax(1)).max().item()
+    rel0 = ((C0.double() - ref).abs().amax(1) / ref.abs().amax(1)).max().item()
+    assert rel <= max(1.5 * rel0, 1e-6), (rel, rel0)
     # GELU epilogue into the P layout: H = GELU(A . B^T + bias) as planes, read back as H . I^T
     M, N, K = 300, 256, 768
     A = torch.randn(M, K, generator=g).cuda()
