@@ -89,8 +89,9 @@ class RepStore:
         return self
 
     def resident(self, pids):
+        """Every id of `pids` (any iterable; a set is fastest) is in the resident matrix."""
         idx = getattr(self, '_dev_index', None)
-        return idx is not None and all(p in idx for p in pids)
+        return idx is not None and idx.keys() >= (pids if isinstance(pids, (set, frozenset)) else set(pids))
 
     def pool_batch(self, pid_lists):
         """The pools of several queries (each a list of paper ids, pool order) as ONE scorer.PoolBatch over the resident matrix:
