@@ -29,10 +29,16 @@ OT_DISTANCE, OT_PLAN_SIM, OT_SIMILARITY = 0, 1, 2
 AGG_MAX, AGG_TOP2, AGG_ATTENTION = 0, 1, 2
 
 
+class RepPlanes(ctypes.Structure):
+    """struct aspire_rep_planes"""
+    _fields_ = [('planes', c_void_p), ('row_nrm', c_void_p), ('row_iscale', c_void_p), ('mu', c_void_p),
+                ('total_rows', c_int64), ('plane_rows', c_int64)]
+
+
 class RepSet(ctypes.Structure):
     """struct aspire_repset"""
     _fields_ = [('rows', c_void_p), ('start', c_void_p), ('len', c_void_p), ('n', c_int64),
-                ('ext', c_int32), ('max_len', c_int32)]
+                ('ext', c_int32), ('max_len', c_int32), ('planes', ctypes.POINTER(RepPlanes))]
 
 
 class OtParams(ctypes.Structure):
@@ -74,6 +80,9 @@ SIGNATURES = {
     'aspire_bert_workspace_bytes': (c_size_t, [ctypes.POINTER(BertWeights), c_int64, c_int64]),
     'aspire_bert_forward_f32': (c_int, [ctypes.POINTER(BertWeights), c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    'aspire_rep_planes_bytes': (c_size_t, [c_int64]),
+    'aspire_rep_planes_prepare': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, ctypes.POINTER(RepPlanes),
+                                          c_void_p]),
     'aspire_l2max_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
     'aspire_l2agg_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int, c_int,
@@ -107,6 +116,7 @@ SIGNATURES = {
     'aspire_debug_ot_rank_batch_stages_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_void_p, c_int64,
                                                       ctypes.POINTER(OtParams), c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                                       c_void_p, c_size_t, c_void_p, c_int]),
+    'aspire_debug_clock_probe': (c_int, [c_void_p, ctypes.c_longlong, c_void_p]),
     'aspire_selftest_xlane': (c_int, [ctypes.POINTER(c_int)]),
 }
 

@@ -662,6 +662,16 @@ int fill_geometry(GramArgs& g, const ScoreArgs& a, int mr_q, int mr_c, int& bn) 
     return ASPIRE_OK;
 }
 
+// the fp16-plane tiles (gramp.hip) of a call whose queries fill more than 64 rows.  128 x 128 by default: the 128 x 256 and
+// 256 x 256 forms move fewer bytes per product and hold a higher clock, but end at the same matrix-pipe rate (the kernel is power
+// bound: NOTES.md, round 4) and lose on calls with few query rows or few candidate tiles
+GramGeometry planes_geometry(const GramArgs& g) {
+    const int t = tuning().gram_tile;
+    const int bn = t ? t % 1000 : 128, bm = t ? t / 1000 : 128;
+    const int dpt_q = bn / g.mr_q, dpt_c = bm / g.mr_c;
+    return GramGeometry{g.mr_q, g.mr_c, dpt_q, dpt_c, (int)((g.nq + dpt_q - 1) / dpt_q), (int)((g.ncand + dpt_c - 1) / dpt_c), g.E, g.ld, bm, bn};
+}
+
 template <bool L2MAX>
 int launch_gram(const GramArgs& g, int bn, hipStream_t stream) {
     const dim3 grid((unsigned)(g.n_ct * g.n_qt));
@@ -728,7 +738,9 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
         g.diam2 = diam2;
         return launch_gram<false>(g, bn, stream);
     }
-    if (int rc = launch_gram<false>(g, bn, stream)) return rc;
+    if (bn == 128 && gram_planes_ok(a)) {
+        if (int rc = launch_pair_gram_planes(a, planes_geometry(g), false, cost, neg, stream)) return rc;
+    } else if (int rc = launch_gram<false>(g, bn, stream)) return rc;
     if (diam2) {
         hipLaunchKernelGGL(doc_box_range_kernel, dim3(g.ncand), dim3(192), 0, stream, a.c, a.cand0, cbox);
         ASPIRE_LAUNCH_OK();
@@ -748,6 +760,7 @@ int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t s
     if (int rc = fill_geometry(g, b, mr_q, mr_c, bn)) return rc;
     g.scores = a.scores;
     g.center = a.center;
+    if (bn == 128 && gram_planes_ok(b)) return launch_pair_gram_planes(b, planes_geometry(g), true, nullptr, nullptr, stream);
     return launch_gram<true>(g, bn, stream);
 }
 

@@ -56,6 +56,14 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.fused_noself = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_WAVES")) {
         t.fused_waves = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "GRAM_TILE")) {
+        const int f = unset ? 0 : atoi(v);
+        if (f != 0 && f != 128128 && f != 128256 && f != 256256) return false;
+        t.gram_tile = f;
+    } else if (!strcmp(key, "GRAM_RING")) {
+        const int f = unset ? 0 : atoi(v);
+        if (f != 0 && f != 3 && f != 4) return false;
+        t.gram_ring = f;
     } else if (!strcmp(key, "OT_FORM")) {
         const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : !strcmp(v, "fused") ? 3 : !strcmp(v, "chunk") ? 4 : -1;
         if (f < 0) return false;
@@ -88,6 +96,8 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "FUSED_NOSOLVE")) v = number(t.fused_nosolve);
     else if (!strcmp(key, "FUSED_NOSELF")) v = number(t.fused_noself);
     else if (!strcmp(key, "FUSED_WAVES")) v = number(t.fused_waves);
+    else if (!strcmp(key, "GRAM_TILE")) v = number(t.gram_tile);
+    else if (!strcmp(key, "GRAM_RING")) v = number(t.gram_ring);
     else if (!strcmp(key, "OT_FORM")) v = t.ot_form == 1 ? "small" : t.ot_form == 2 ? "tile" : t.ot_form == 3 ? "fused" : t.ot_form == 4 ? "chunk" : "";
     if (!v || strlen(v) + 1 > len) return false;
     strcpy(buf, v);
@@ -95,7 +105,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF", "GRAM_TILE", "GRAM_RING"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);
@@ -186,6 +196,33 @@ extern "C" int aspire_debug_get(const char* key, char* buf, size_t len) {
     return ASPIRE_OK;
 }
 extern "C" const char* aspire_last_error(void) { return g_err; }
+
+namespace aspire {
+namespace {
+// out[0] = shader-clock ticks (s_memtime), out[1] = 100 MHz wall ticks (s_memrealtime) over ~wall_ticks of spinning by one wave
+__global__ void clock_probe_kernel(long long* out, long long wall_ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    long long r1 = r0;
+    while (r1 - r0 < wall_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (long long)__builtin_amdgcn_s_memtime() - t0;
+        out[1] = r1 - r0;
+    }
+}
+}  // namespace
+}  // namespace aspire
+
+/* debug: one wave spins for wall_us microseconds on `stream` and reports the clock the shader engines ran at meanwhile
+ * (launch it beside the kernel under study, on another stream): out[0] / out[1] x 100 MHz */
+extern "C" int aspire_debug_clock_probe(long long* out, long long wall_us, void* stream) {
+    ASPIRE_REQUIRE(out, ASPIRE_ERR_INVALID_ARG, "null output");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, wall_us * 100);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
 
 extern "C" int aspire_selftest_xlane(int* out_mismatch_host) {
     ASPIRE_REQUIRE(out_mismatch_host, ASPIRE_ERR_INVALID_ARG, "null output");

@@ -2080,6 +2080,8 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
+    a.q_planes = q->planes;
+    a.c_planes = c->planes;
     a.pairing = pairing;
     a.cdist_mode = cdist_mode;
     a.agg = agg;
@@ -2187,6 +2189,8 @@ void fill_ot_args(ScoreArgs& a, const aspire_repset* q, const aspire_repset* c, 
                   const float* diameter, int64_t diam_group, int want, float* scores) {
     a.q = to_dev(q);
     a.c = to_dev(c);
+    a.q_planes = q->planes;
+    a.c_planes = c->planes;
     a.pairing = pairing;
     a.cdist_mode = prm->cdist_mode;
     a.blur = prm->blur;
@@ -3068,6 +3072,8 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
+    a.q_planes = q->planes;
+    a.c_planes = c->planes;
     a.pairing = kPairMapped;
     a.cdist_mode = cdist_mode;
     a.center = center;
@@ -3188,6 +3194,8 @@ extern "C" int aspire_group_diameter_f32(const aspire_repset* q, const aspire_re
     ScoreArgs a{};
     a.q = to_dev(q);
     a.c = to_dev(c);
+    a.q_planes = q->planes;
+    a.c_planes = c->planes;
     a.pairing = pairing;
     const int64_t ngroups = (c->n + group - 1) / group;
     const int64_t blocks = pairing == ASPIRE_PAIR_PAIRED ? ngroups : ngroups * q->n;     // (query, group) folded into grid.x

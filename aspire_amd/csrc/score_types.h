@@ -22,6 +22,10 @@ struct ScoreArgs {
     double blur, scaling, temp;
     double log_blur, log_scaling;        // natural logs, float64, formed on the host (schedule lengths)
     float log2_blur, log2_scaling;       // the same in log2 units, fp32
+    // fp16 planes of the two row matrices (include/aspire_hip.h: aspire_rep_planes; HOST structs, null = none): the launchers of
+    // gramp.hip read them, no kernel does
+    const aspire_rep_planes* q_planes;
+    const aspire_rep_planes* c_planes;
     const float* diameter;
     int64_t diam_group;
     int64_t n_groups;
@@ -123,6 +127,14 @@ size_t gram_extra_bytes_per_cand(void);
 int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* cost, float* neg, float* diam2, float* qbox,
                         float* cbox, hipStream_t stream);
 int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t stream);
+
+// gramp.hip: the 128-column Gram tiles on pre-split fp16 planes (three matrix-pipe products per term, operands by LDS-DMA)
+bool gram_planes_ok(const ScoreArgs& a);
+struct GramGeometry {
+    int mr_q, mr_c, dpt_q, dpt_c, n_qt, n_ct, E, ld;
+    int bm, bn;  // candidate / query rows per tile: 128 x 128, 128 x 256, 256 x 256
+};
+int launch_pair_gram_planes(const ScoreArgs& a, const GramGeometry& geo, bool l2max, float* cost, float* neg, hipStream_t stream);
 
 // generic.hip: one workgroup per pair for documents beyond the tile kernels' 32 rows (mode 0 otAspire, 1 max-sim)
 int generic_max_rows(void);

@@ -34,6 +34,22 @@ def _i32(t, name):
     return t
 
 
+class RowPlanes:
+    """struct aspire_rep_planes of a row matrix + the device blob it points into."""
+
+    def __init__(self, rows, mu=None):
+        _f32(rows, 'rows')
+        n = int(rows.shape[0])
+        nbytes = lib.aspire_rep_planes_bytes(n)
+        self.blob = torch.empty(nbytes, device=rows.device, dtype=torch.uint8)
+        self.mu = mu                       # tensor [768] (the store's common vector); None: formed from these rows
+        self.c = _lib.RepPlanes()
+        check(lib.aspire_rep_planes_prepare(_ptr(rows), n, D, _ptr(_f32(mu, 'mu')) if mu is not None else None, _ptr(self.blob),
+                                            nbytes, ctypes.byref(self.c), _stream()))
+        if mu is None:
+            self.mu = self.blob[:4 * D].view(torch.float32)
+
+
 class DeviceRepSet:
     """Rows + CSR view of sentence reps resident in HBM (struct aspire_repset).
 
@@ -80,11 +96,32 @@ class DeviceRepSet:
         return cls(rows, start.to(dev), lens.to(dev), ext=0, max_len=max(lens_host) if lens_host else 0, lens_host=lens_host)
 
     def struct(self):
-        return RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len)
+        planes = getattr(self.rows, '_aspire_planes', None)      # kept on the matrix: index lists and slices of it share them
+        return RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len,
+                      ctypes.pointer(planes.c) if planes is not None else None)
 
     def slice(self, lo, hi):
         return DeviceRepSet(self.rows, self.start[lo:hi].contiguous(), self.len[lo:hi].contiguous(), self.ext,
                             self.max_len, lens_host=self.lens_host[lo:hi] if self.lens_host is not None else None)
+
+    @property
+    def planes(self):
+        return getattr(self.rows, '_aspire_planes', None)
+
+    def prepare_planes(self, like=None, mu=None):
+        """The row matrix a second time as fp16 planes (include/aspire_hip.h: aspire_rep_planes): once per resident store;
+        for query sets that are not part of the store, per call with like = the store's rep set (its common vector).  The
+        many-query cost tiles then run on the fp16 matrix pipe.  Returns self."""
+        if like is not None:
+            assert like.planes is not None, 'prepare the store\'s planes first'
+            mu = like.planes.mu
+        self.rows._aspire_planes = RowPlanes(self.rows, mu)
+        return self
+
+    def drop_planes(self):
+        if getattr(self.rows, '_aspire_planes', None) is not None:
+            self.rows._aspire_planes = None
+        return self
 
     def center_hint(self):
         """True when the rows share a large common component (|mean row|^2 > 0.25 x the mean squared norm, i.e. a mean cosine of
@@ -342,3 +379,26 @@ def selftest_xlane():
     n = (ctypes.c_int * 16)()
     check(lib.aspire_selftest_xlane(n))
     return sum(n), list(n)
+
+
+def clock_under(fn, wall_us=4000, reps=None):
+    """GHz the shader engines hold while fn() runs repeatedly on the current stream (aspire_debug_clock_probe on a side stream)."""
+    side = torch.cuda.Stream()
+    out = torch.zeros(2, device='cuda', dtype=torch.int64)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    check(lib.aspire_debug_clock_probe(_ptr(out), int(wall_us), ctypes.c_void_p(side.cuda_stream)))
+    if reps is None:
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        fn()
+        t1.record()
+        t1.synchronize()
+        reps = max(2, int(1.3 * wall_us / 1e3 / max(t0.elapsed_time(t1), 1e-3)))
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    ticks, wall = out.tolist()
+    return ticks / max(wall, 1) * 0.1

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASPIRE_ABI_VERSION 4
+#define ASPIRE_ABI_VERSION 5
 
 typedef enum {
     ASPIRE_OK = 0,
@@ -132,6 +132,42 @@ int aspire_cls_l2_f32(const float* q_cls, int64_t Q, const float* c_cls, int64_t
 #define ASPIRE_PAIR_CROSS 0
 #define ASPIRE_PAIR_PAIRED 1
 
+/* ---------------------------------------------------------------------------------------------
+ * fp16 planes of a rep store's row matrix: the many-query cost tiles (pair_distances.py:48-55 with >= ~8 query
+ * documents: torch.cdist of every query sentence against every candidate sentence is a [sum S_c, sum S_q] x 768 GEMM)
+ * run on v_mfma_f32_32x32x16_f16 at fp32 accuracy when both rep sets carry their rows a second time as two fp16
+ * planes.  Row r is stored as h + l of s_r * (rows[r] - mu): mu = one vector per store (L2 distances do not change
+ * under a common shift: the anisotropic common component of sentence embeddings comes off before anything is
+ * rounded), s_r = the power of two that puts the row's largest entry into [2^14, 2^15) (any finite fp32 row fits:
+ * nothing is rejected), h = fp16(.), l = fp16(. - h): 22+ significant bits per element, three exact matrix-pipe
+ * products per term (h.h' + h.l' + l.h') accumulated in fp32 -- the encoder's scheme (aspire_bert_prepare_planes).
+ * Layout: 48 k blocks of 16 coordinates; k block kb, row r: 64 bytes = pieces (plane pl, k half kh) at
+ * ((kb * plane_rows + r) * 4 + 2 pl + kh) * 16, each the 8 fp16 of plane pl at coordinates 16 kb + 8 kh .. + 7;
+ * rows [total_rows, plane_rows) are zero (what the tiles read for the rows a short document does not have).
+ * The planes are prepared ONCE per resident store (4 B per element, like the fp32 rows: one more copy in HBM) and
+ * per call for queries that are not part of the store, with the STORE's mu: two rep sets can meet in one call iff
+ * their `mu` pointers are equal.  A rep set without planes (planes == NULL), or one whose mu differs, takes the
+ * kernels that read the fp32 rows -- same results to rounding.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* planes;      /* [48][plane_rows][64 B] */
+    const float* row_nrm;    /* [plane_rows]  |rows[r] - mu|^2 (0 for the zero rows) */
+    const float* row_iscale; /* [plane_rows]  1 / s_r */
+    const float* mu;         /* [D] */
+    int64_t total_rows;      /* rows of the fp32 matrix the planes were made of */
+    int64_t plane_rows;      /* > total_rows, a multiple of 16 */
+} aspire_rep_planes;
+
+/* bytes of the device blob aspire_rep_planes_prepare fills for a matrix of total_rows rows */
+size_t aspire_rep_planes_bytes(int64_t total_rows);
+/* rows [total_rows, D] -> blob; *out_host (a HOST struct) receives the pointers into it.
+ *   mu   device [D] or NULL.  NULL: the mean of a sample of up to 4096 of the rows is formed (deterministic: rows
+ *        k * stride) and kept in the blob.  Given: used as it is and out_host->mu == mu -- pass the store's mu when
+ *        preparing query rows, and rank 0's mu on every shard of a sharded store (then sharded and un-sharded
+ *        scores are the same bits). */
+int aspire_rep_planes_prepare(const float* rows, int64_t total_rows, int64_t D, const float* mu, void* blob,
+                              size_t blob_bytes, aspire_rep_planes* out_host, void* stream);
+
 typedef struct {
     const float* rows;     /* [total_rows, D] */
     const int32_t* start;  /* [n] first row of each document */
@@ -146,6 +182,8 @@ typedef struct {
      * empty dimension, pair_distances.py:57) -- lens live on the device, so the HOST layer rejects it
      * (aspire_amd.ops.DeviceRepSet raises ValueError); the library does not look. */
     int32_t max_len;
+    /* optional (NULL): fp16 planes of `rows` (aspire_rep_planes above; a HOST pointer, read during the call) */
+    const aspire_rep_planes* planes;
 } aspire_repset;
 
 /* ---------------------------------------------------------------------------------------------
@@ -373,6 +411,11 @@ int aspire_debug_ot_rank_batch_stages_f32(const aspire_repset* q, const aspire_r
                                           int64_t max_job, const aspire_ot_params* prm, int want, float* scores, int64_t k,
                                           float* top_scores, int64_t* top_idx, void* workspace, size_t workspace_bytes,
                                           void* stream, int stages);
+
+/* Measurement aid: one wave spins for wall_us microseconds on `stream` and writes out[0] = shader-clock ticks, out[1] = 100 MHz
+ * wall ticks: launched beside a kernel under study (another stream), out[0] / out[1] x 100 MHz is the clock the chip held under
+ * it (the matrix-pipe kernels run power-limited well below the nominal 2.4 GHz; rooflines quote both). */
+int aspire_debug_clock_probe(long long* out, long long wall_us, void* stream);
 
 /* Cross-lane primitive self test (DPP / permlane forms vs ds_bpermute); out_mismatch_host[16] receives
  * the number of mismatching lanes per check (all 0 = ok; order: xor 1,2,4,8,16,32, row sum, col sum,

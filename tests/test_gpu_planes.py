@@ -1,0 +1,190 @@
+"""The many-query cost tiles on pre-split fp16 planes (aspire_amd/csrc/gramp.hip; include/aspire_hip.h: aspire_rep_planes)
+against the oracle, against float64, and against the forms that read the fp32 rows.  Reference arithmetic:
+src/learning/facetid_models/pair_distances.py:48-55, 138-186.  Every call goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aspire_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def amd():
+    from aspire_amd import ops, scorer, _lib
+    assert torch.cuda.is_available()
+    return type('NS', (), dict(ops=ops, scorer=scorer, lib=_lib))
+
+
+def _set(amd, docs):
+    return amd.ops.DeviceRepSet.from_list(docs)
+
+
+def _docs(seed, lens, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return [scale * torch.randn(int(n), 768, generator=g) + shift for n in lens]
+
+
+def _l2max_oracle(q, c):
+    return -orc.allpair_masked_dist_l2max(orc.RepLen(q[None].permute(0, 2, 1), [len(q)]),
+                                          orc.RepLen(c[None].permute(0, 2, 1), [len(c)])).item()
+
+
+def _with_planes(amd, qdocs, cdocs):
+    c = _set(amd, cdocs).prepare_planes()
+    q = _set(amd, qdocs).prepare_planes(like=c)
+    return q, c
+
+
+def test_planes_blob_is_the_rows(amd):
+    """h + l planes, per-row scale, norms and the store's mean as the header describes them"""
+    g = torch.Generator().manual_seed(3)
+    rows = (torch.randn(37, 768, generator=g) * torch.logspace(-3, 2, 37)[:, None] + 0.5).cuda()
+    rows[5] = 0
+    rp = amd.ops.RowPlanes(rows)
+    pr, n = rp.c.plane_rows, 37
+    assert pr % 16 == 0 and pr > n and rp.c.total_rows == n
+    mu = rp.mu.cpu()
+    np.testing.assert_allclose(mu.numpy(), rows.cpu().mean(0).numpy(), atol=1e-5)       # fewer than 4096 rows: all of them
+    blob = rp.blob.cpu()
+    nrm = blob[4096:4096 + 4 * pr].view(torch.float32)
+    isc = blob[4096 + 4 * pr:4096 + 8 * pr].view(torch.float32)
+    planes = blob[4096 + 8 * pr:].view(torch.float16).view(48, pr, 2, 2, 8)           # [kb][row][plane][k half][8]
+    v = rows.cpu() - mu
+    np.testing.assert_allclose(nrm[:n].numpy(), (v.double() ** 2).sum(1).numpy(), rtol=1e-5)
+    assert (nrm[n:] == 0).all() and (isc[n:] == 0).all() and (planes[:, n:] == 0).all()
+    rec = (planes[:, :, 0].double() + planes[:, :, 1].double()).permute(1, 0, 2, 3).reshape(pr, 768)[:n] * isc[:n, None].double()
+    err = (rec - v.double()).abs().max(1).values / v.abs().max(1).values.clamp(min=1e-30).double()
+    assert err.max() < 2.0 ** -21, err.max()
+    s = 1.0 / isc[:n].double()
+    top = (v.double().abs().max(1).values * s)
+    live = v.abs().max(1).values > 0
+    assert ((top[live] >= 2 ** 14) & (top[live] < 2 ** 15)).all()
+    assert (np.log2(s.numpy()) % 1 == 0).all()
+
+
+@pytest.mark.parametrize('qlens,clens', [
+    ([8] * 12, [8] * 40),                                     # 96 query rows: one 128-column tile
+    ([5, 8, 1, 7, 3] * 4, [8, 3, 1, 6, 7, 2, 8, 5] * 5),      # ragged
+    ([12] * 11, [12] * 23),                                   # 12-row slots, 10 per tile, two query tiles
+    ([9, 16, 13] * 3, [11, 1, 16, 4] * 6),                    # T = 2 ragged
+    ([20, 3, 24, 17], [17, 24, 2, 9] * 3),                    # T = 3
+    ([32, 30, 27], [32, 1, 30, 26, 25] * 2),                  # T = 4, crosses the cdist 25/26 switch
+])
+def test_planes_ot_and_l2max_match_oracle(amd, qlens, clens):
+    from aspire_amd._lib import pinned
+    qd, cd = _docs(11, qlens), _docs(12, clens)
+    q, c = _with_planes(amd, qd, cd)
+    with pinned(COST_PATH='mfma'):
+        l2 = amd.ops.l2max_scores(q, c).view(len(qd), len(cd)).cpu().numpy()
+        ot = -amd.ops.ot_sinkhorn(q, c).view(len(qd), len(cd)).cpu().numpy()
+    want_l2 = np.array([[_l2max_oracle(x, y) for y in cd] for x in qd], dtype=np.float32)
+    want_ot = np.array([[orc.get_similarity(x, y) for y in cd] for x in qd], dtype=np.float32)
+    np.testing.assert_allclose(l2, want_l2, atol=TOL, rtol=0)
+    np.testing.assert_allclose(ot, want_ot, atol=TOL, rtol=0)
+
+
+def test_planes_near_duplicates_and_scales(amd):
+    """a candidate that repeats a query sentence exactly / nearly (direct-formula work list from the fp32 rows); rows of very
+    different magnitudes (per-row scales); an all-zero row"""
+    from aspire_amd._lib import pinned
+    g = torch.Generator().manual_seed(5)
+    qd = _docs(31, [8] * 10)
+    cd = _docs(32, [8] * 24)
+    cd[3][2] = qd[1][5]
+    cd[7][0] = qd[2][0] + 1e-3 * torch.randn(768, generator=g)
+    cd[9][7] = qd[0][1] + 1e-2 * torch.randn(768, generator=g)
+    cd[11] = cd[11] * 1e-3
+    cd[12] = cd[12] * 300.0
+    cd[13][4] = 0
+    qd[4] = qd[4] * 50.0
+    q, c = _with_planes(amd, qd, cd)
+    with pinned(COST_PATH='mfma'):
+        l2 = amd.ops.l2max_scores(q, c).view(len(qd), len(cd)).cpu().numpy()
+    want = np.array([[-torch.cdist(x.double(), y.double()).min().item() for y in cd] for x in qd])
+    np.testing.assert_allclose(l2, want, atol=0, rtol=3e-6)
+    assert l2[1, 3] == 0.0
+
+
+@pytest.mark.parametrize('shift', [0.0, 2.0])
+def test_planes_agree_with_fp32_row_forms_at_size(amd, shift):
+    """bench-sized grid with tail tiles, i.i.d. rows and rows with a large common component (mean cosine 0.8): the plane
+    tiles against the bf16x3 tiles and against float64 on a sample"""
+    from aspire_amd._lib import pinned
+    nq, nc, s = 32, 4001, 8
+    g = torch.Generator().manual_seed(77)
+    qrows = (torch.randn(nq * s, 768, generator=g) * torch.linspace(0.3, 2.0, 768) + shift).cuda()
+    crows = (torch.randn(nc * s, 768, generator=g) + shift).cuda()
+    mk = lambda rows, n: amd.ops.DeviceRepSet(rows, (torch.arange(n, device='cuda', dtype=torch.int32) * s).contiguous(),
+                                              torch.full((n,), s, device='cuda', dtype=torch.int32), ext=0, max_len=s)
+    q, c = mk(qrows, nq), mk(crows, nc)
+    c.prepare_planes()
+    q.prepare_planes(like=c)
+    out = {}
+    for form in ('', 'bf16x3'):
+        with pinned(COST_PATH='mfma', GEMM=form):
+            out[form] = (amd.ops.l2max_scores(q, c).view(nq, nc).cpu().numpy(), amd.ops.ot_sinkhorn(q, c).view(nq, nc).cpu().numpy())
+    assert not np.array_equal(out[''][0], out['bf16x3'][0])          # two different kernels ran
+    # both against float64 (the bf16x3 tiles centre on the tile's first query row, the planes on the store's mean: on rows with a
+    # common component the planes are the closer of the two -- tools/planeerr.py)
+    d = torch.cdist(qrows.double(), crows.double())
+    want = -d.view(nq, s, nc, s).permute(0, 2, 1, 3).reshape(nq, nc, s * s).min(-1).values.cpu().numpy()
+    assert np.abs(out[''][0] - want).max() < 1e-5
+    assert np.abs(out['bf16x3'][0] - want).max() < 6e-5
+    np.testing.assert_allclose(out[''][1], out['bf16x3'][1], atol=5e-5, rtol=0)
+
+
+def test_without_planes_or_with_another_centre_the_fp32_forms_run(amd):
+    """the fallback: a rep set without planes, or one prepared around another vector, takes the kernels that read the fp32
+    rows -- same scores to rounding, never an error"""
+    from aspire_amd._lib import pinned
+    qd, cd = _docs(41, [8] * 16), _docs(42, [8] * 300)
+    q, c = _with_planes(amd, qd, cd)
+    with pinned(COST_PATH='mfma'):
+        a = amd.ops.l2max_scores(q, c).cpu().numpy()
+        q2 = _set(amd, qd)                                   # no planes on the query side
+        b = amd.ops.l2max_scores(q2, c).cpu().numpy()
+        q3 = _set(amd, qd).prepare_planes()                  # its own centre
+        b3 = amd.ops.l2max_scores(q3, c).cpu().numpy()
+        with pinned(GEMM='bf16x3'):
+            b4 = amd.ops.l2max_scores(q, c).cpu().numpy()
+    assert np.array_equal(b, b3) and np.array_equal(b, b4)
+    assert not np.array_equal(a, b)
+    np.testing.assert_allclose(a, b, atol=2e-5, rtol=0)
+
+
+def test_pools_as_index_lists_share_the_store_planes(amd):
+    """a pool = an index list into the resident matrix (RepStore.pool): the tiles gather its rows from the store's planes"""
+    from aspire_amd._lib import pinned
+    docs = _docs(51, np.random.RandomState(1).randint(1, 9, size=400))
+    store = _set(amd, docs).prepare_planes()
+    pick = np.random.RandomState(2).permutation(400)[:300]
+    idx = torch.as_tensor(pick, device='cuda')
+    pool = amd.ops.DeviceRepSet(store.rows, store.start[idx].contiguous(), store.len[idx].contiguous(), ext=0, max_len=8)
+    qsel = torch.as_tensor(np.arange(20), device='cuda')
+    q = amd.ops.DeviceRepSet(store.rows, store.start[qsel].contiguous(), store.len[qsel].contiguous(), ext=0, max_len=8)
+    assert pool.planes is store.planes and q.planes is store.planes
+    with pinned(COST_PATH='mfma'):
+        got = amd.ops.l2max_scores(q, pool).view(20, 300).cpu().numpy()
+    want = np.array([[_l2max_oracle(docs[i], docs[j]) for j in pick] for i in range(20)], dtype=np.float32)
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('tile', ['128256', '256256'])
+def test_wider_tile_forms_give_the_same_scores(amd, tile):
+    """GRAM_TILE pins the 128 x 256 / 256 x 256 tiles (wider wave tiles, one or two workgroups per CU; kept for A/B runs):
+    same products in the same order per entry, so max-sim is the same bits; ragged documents and tail tiles included"""
+    from aspire_amd._lib import pinned
+    qd = _docs(61, np.random.RandomState(3).randint(1, 13, size=50))
+    cd = _docs(62, np.random.RandomState(4).randint(1, 13, size=700))
+    q, c = _with_planes(amd, qd, cd)
+    with pinned(COST_PATH='mfma'):
+        a = amd.ops.l2max_scores(q, c).cpu().numpy()
+        ot_a = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+        with pinned(GRAM_TILE=tile):
+            b = amd.ops.l2max_scores(q, c).cpu().numpy()
+            ot_b = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(ot_a, ot_b)
