@@ -134,7 +134,7 @@ class AspireConSent:
         flush()
         return out
 
-    def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64):
+    def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64, planes=False):
         """Encode document batches straight into a resident candidate pool.
 
         batches: iterable of (bert_batch, abs_lens, sent_tok_idxs) as prepare_abstracts returns them (it is consumed
@@ -143,6 +143,8 @@ class AspireConSent:
         document's rows (aspire_span_mean_pool_rows_f32) -- no padded tensor, no copy back to the host.
         docs_per_forward: consecutive batches are joined into encoder calls of up to this many documents (_merge_batches; None or 0:
         one call per batch as given).
+        planes: also keep the rows as fp16 planes (CandidatePool.prepare_planes: one more pass over the finished store, ~2.5 ms per
+        GB) for the many-query cost tiles.
         Returns a scorer.CandidatePool (and the [N, 768] CLS reps on the GPU with want_cls)."""
         from .scorer import CandidatePool
         dev = ops.require_gpu()
@@ -202,4 +204,6 @@ class AspireConSent:
         repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0,
                                   lens_host=all_lens)
         pool = CandidatePool.from_repset(repset, pids=pids)
+        if planes and total:
+            pool.prepare_planes()
         return (pool, cls_all) if want_cls else pool

@@ -34,6 +34,28 @@ def _i32(t, name):
     return t
 
 
+# None: every rep set decides from a sample of its rows (center_hint: a few small kernels + one host sync per NEW row matrix);
+# True / False: the answer for every call (set_center_hint) -- e.g. False for a process that knows its vectors are isotropic,
+# True for one that scores a sentence-embedding space, so that all shards and call forms of a job use one arithmetic.
+CENTER_HINT = None
+
+
+def set_center_hint(mode):
+    global CENTER_HINT
+    assert mode in (None, True, False)
+    CENTER_HINT = mode
+
+
+def _match_planes(q, c, pairing):
+    """A many-query all-against-all call on a pool that carries fp16 planes (DeviceRepSet.prepare_planes): the queries get
+    theirs, around the pool's centre, unless they are rows of the same matrix already (then nothing happens) or carry planes of
+    another store (left alone: the call takes the kernels that read the fp32 rows).  ~10 us for 256 query rows."""
+    if pairing != _lib.PAIR_CROSS or c.planes is None or q.ext or c.ext or q.n * max(8, (q.max_len + 3) // 4 * 4) <= 64:
+        return
+    if q.planes is None:
+        q.prepare_planes(like=c)
+
+
 class RowPlanes:
     """struct aspire_rep_planes of a row matrix + the device blob it points into."""
 
@@ -124,6 +146,11 @@ class DeviceRepSet:
         return self
 
     def center_hint(self):
+        if CENTER_HINT is not None:
+            return CENTER_HINT
+        return self._center_hint_sampled()
+
+    def _center_hint_sampled(self):
         """True when the rows share a large common component (|mean row|^2 > 0.25 x the mean squared norm, i.e. a mean cosine of
         roughly 0.25 between unrelated rows -- sentence-embedding spaces are usually far above that): the scoring calls then set
         ASPIRE_OT_FLAG_CENTER / ASPIRE_CDIST_CENTER (include/aspire_hip.h).  From a sample of up to 512 rows, once per rep set."""
@@ -195,6 +222,7 @@ def l2max_scores(q, c, pairing=_lib.PAIR_CROSS, cdist_mode=_lib.CDIST_AUTO, want
     dev = q.rows.device
     scores = torch.empty(p, device=dev, dtype=torch.float32)
     pair = torch.empty(p, q.ext, c.ext, device=dev, dtype=torch.float32) if want_pair_sims else None
+    _match_planes(q, c, pairing)
     qs, cs = q.struct(), c.struct()
     check(lib.aspire_l2max_scores_f32(ctypes.byref(qs), ctypes.byref(cs), D, pairing, cdist_mode, _ptr(scores),
                                       _ptr(pair), _stream()))
@@ -241,6 +269,7 @@ def ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, blur=0.05, scaling=0.9, sent_sm_t
         extras = [torch.empty(p, q.ext, device=dev), torch.empty(p, c.ext, device=dev),
                   torch.empty(p, q.ext, c.ext, device=dev), torch.empty(p, q.ext, c.ext, device=dev)]
     prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, (_lib.OT_FLAG_ONE_FORM if one_form else 0) | (_lib.OT_FLAG_CENTER if c.center_hint() else 0))
+    _match_planes(q, c, pairing)
     qs, cs = q.struct(), c.struct()
     nbytes = lib.aspire_ot_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), pairing)
     ws = workspace if workspace is not None else torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
@@ -259,6 +288,7 @@ def ot_rank(q, c, k, blur=0.05, scaling=0.9, sent_sm_temp=1.0, cdist_mode=_lib.C
     dev = q.rows.device
     scores = torch.empty(q.n, c.n, device=dev, dtype=torch.float32)
     prm = OtParams(float(blur), float(scaling), float(sent_sm_temp), cdist_mode, (_lib.OT_FLAG_ONE_FORM if one_form else 0) | (_lib.OT_FLAG_CENTER if c.center_hint() else 0))
+    _match_planes(q, c, _lib.PAIR_CROSS)
     qs, cs = q.struct(), c.struct()
     nbytes = lib.aspire_ot_rank_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), k)
     ws = torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)

@@ -105,6 +105,48 @@ class ShardedPoolRanker:
             block = pool_reps[self.lo:hi]
         self.pool = CandidatePool(block, pids=list(range(self.lo, self.lo + len(block))))
 
+    @classmethod
+    def from_resident(cls, pool, global_offset, n_total, multiple=64, group=None, planes=False):
+        """Wrap a block that is ALREADY resident on this rank's GPU -- what AspireConSent.encode_to_pool or RepStore.pool return
+        (config 5: every rank encodes its own block of the corpus straight into HBM, src/pre_process/pp_gen_nearest.py:141-202
+        per rank) -- as this rank's shard: documents [global_offset, global_offset + len(pool)) of a pool of n_total.  No copy.
+        planes: keep the block's rows as fp16 planes too (CandidatePool.prepare_planes), centred on RANK 0's common vector,
+        broadcast once: every shard then rounds its rows around the same point."""
+        self = cls.__new__(cls)
+        self.group, self.multiple, self.n_total = group, multiple, n_total
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.lo = int(global_offset)
+        self.pool = pool
+        pool.pids = list(range(self.lo, self.lo + len(pool)))
+        if planes:
+            self.prepare_planes()
+        return self
+
+    def prepare_planes(self):
+        """fp16 planes of this rank's block around ONE centre for all shards: rank 0 forms it from a sample of its rows, one
+        768-float broadcast hands it to the others (an empty rank-0 block: zeros)."""
+        from . import ops
+        dev = ops.require_gpu()
+        mu = None
+        if self.world > 1:
+            if self.rank == 0 and len(self.pool) > 0:
+                mu = ops.RowPlanes(self.pool.repset.rows).mu.clone()
+            elif self.rank == 0:
+                mu = torch.zeros(768, device=dev)
+            else:
+                mu = torch.empty(768, device=dev)
+            if dist.get_backend(self.group) == 'gloo':
+                host = mu.cpu()
+                dist.broadcast(host, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                mu = host.to(dev)
+            else:
+                dist.broadcast(mu, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        if len(self.pool) > 0:
+            self.pool.prepare_planes(mu=mu)
+        self.mu = mu
+        return self
+
     def rank_queries(self, query_reps_list, k, **score_kw):
         from . import ops
         from .scorer import score_pool

@@ -144,13 +144,15 @@ def test_without_planes_or_with_another_centre_the_fp32_forms_run(amd):
     q, c = _with_planes(amd, qd, cd)
     with pinned(COST_PATH='mfma'):
         a = amd.ops.l2max_scores(q, c).cpu().numpy()
-        q2 = _set(amd, qd)                                   # no planes on the query side
-        b = amd.ops.l2max_scores(q2, c).cpu().numpy()
-        q3 = _set(amd, qd).prepare_planes()                  # its own centre
-        b3 = amd.ops.l2max_scores(q3, c).cpu().numpy()
+        q2 = _set(amd, qd)                                   # no planes on the query side: ops prepares them around the pool's centre
+        a2 = amd.ops.l2max_scores(q2, c).cpu().numpy()
+        assert q2.planes is not None and q2.planes.c.mu == c.planes.c.mu and np.array_equal(a, a2)
+        q3 = _set(amd, qd).prepare_planes()                  # its own centre: left alone
+        b = amd.ops.l2max_scores(q3, c).cpu().numpy()
         with pinned(GEMM='bf16x3'):
             b4 = amd.ops.l2max_scores(q, c).cpu().numpy()
-    assert np.array_equal(b, b3) and np.array_equal(b, b4)
+        b5 = amd.ops.l2max_scores(_set(amd, qd), _set(amd, cd)).cpu().numpy()      # no planes anywhere
+    assert np.array_equal(b, b4) and np.array_equal(b, b5)
     assert not np.array_equal(a, b)
     np.testing.assert_allclose(a, b, atol=2e-5, rtol=0)
 

@@ -179,3 +179,44 @@ def test_rows_with_a_common_component_are_centred(amd):
         for j in range(2):
             for pid, s in ranked[j][:3]:
                 assert abs(s - orc.get_similarity(queries[j], pools[j][pid])) < TOL, (cmax, j, pid)
+
+
+def test_pool_batch_reused_with_longer_queries_grows_its_workspace():
+    """RepStore.pool_batch advertises re-use of the cached batch for another facet: a later call whose queries are LONGER than
+    the candidates (crossing an 8-row boundary of the pair slots) needs more workspace than the first call sized
+    ('workspace too small'); the size is asked for on every call"""
+    from aspire_amd import scorer
+    from aspire_amd.repstore import RepStore
+    from oracle import aspire_oracle as orc
+    g = torch.Generator().manual_seed(3)
+    store = RepStore({f'p{i}': torch.randn(int(n), 768, generator=g).numpy() for i, n in enumerate(torch.randint(1, 8, (60,), generator=g))})
+    store.to_device()
+    pools = [[f'p{i}' for i in range(0, 30)], [f'p{i}' for i in range(20, 60)]]
+    batch = store.pool_batch(pools)
+    short = [torch.randn(3, 768, generator=g).numpy(), torch.randn(5, 768, generator=g).numpy()]
+    long_ = [torch.randn(20, 768, generator=g).numpy(), torch.randn(11, 768, generator=g).numpy()]
+    for queries in (short, long_, short):
+        for method in ('ot', 'l2max'):
+            ranked = scorer.rank_pool_batch(queries, batch, method=method)
+            assert store.pool_batch(pools) is batch
+            for q, pids, r in zip(queries, pools, ranked):
+                if method == 'ot':
+                    want = [orc.get_similarity(torch.as_tensor(q), torch.as_tensor(store.get(p))) for p in pids]
+                    got = dict(r)
+                    np.testing.assert_allclose([got[p] for p in pids], want, atol=1e-4, rtol=0)
+                assert sorted(p for p, _ in r) == sorted(pids)
+
+
+def test_repstore_chunked_upload_and_planes():
+    """to_device through the pinned staging buffer (chunks smaller than the store, a document never split) gives the rows of the
+    one-shot upload; planes=True prepares the fp16 planes next to them"""
+    from aspire_amd.repstore import RepStore
+    g = torch.Generator().manual_seed(4)
+    store = RepStore({f'p{i}': torch.randn(int(n), 768, generator=g).numpy() for i, n in enumerate(torch.randint(1, 13, (300,), generator=g))})
+    store.to_device(chunk_rows=100, planes=True)
+    want = np.concatenate([store.get(p) for p in store.pid2reps], 0)
+    assert np.array_equal(store._dev_rows.cpu().numpy(), want)
+    pool = store.pool([f'p{i}' for i in (5, 250, 17)])
+    assert pool.repset.planes is not None and pool.repset.planes.c.total_rows == want.shape[0]
+    s, n = store._dev_index['p250']
+    assert np.array_equal(store._dev_rows[s:s + n].cpu().numpy(), store.get('p250'))
