@@ -44,6 +44,11 @@ import time
 import torch
 import torch.distributed as dist
 
+
+def _pinned(**kw):
+    from aspire_amd._lib import pinned
+    return pinned(**kw)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -62,43 +67,186 @@ def algorithmic_bytes(n_jobs):
     return n_jobs * (4 * D * (NC * S + S) + 4 * NC)
 
 
-def cpu_baseline(query, cands, budget_s=18.0):
-    """The oracle on this box's host cores, same workload (one job's pairs), bounded wall time."""
+_CPU_WORKER = r"""
+import sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from oracle import aspire_oracle as orc
+torch.set_num_threads(1)
+g = torch.Generator().manual_seed(int(sys.argv[2]))
+q = torch.randn(8, 768, generator=g)
+c = torch.randn(64, 8, 768, generator=g)
+orc.get_similarity(q, c[0])
+print('ready', flush=True)
+sys.stdin.readline()
+t0 = time.perf_counter()
+n = 0
+while time.perf_counter() - t0 < float(sys.argv[3]):
+    orc.get_similarity(q, c[n % 64])
+    n += 1
+print(n, time.perf_counter() - t0, flush=True)
+"""
+
+
+def cpu_baseline(query, cands, budget_s=30.0):
+    """The oracle (a PyTorch CPU port of the reference path) on this box's host cores, same workload (one job's pairs), bounded
+    wall time.  Both calling patterns of the reference -- one pair per call (evaluate.py:72-74 via models.py:190-197) and
+    caching_score groups of 64 (pp_gen_nearest.py:182-202) -- over a sweep of intra-op thread counts, plus the process-parallel
+    form of the per-pair pattern (one single-threaded worker per core, what a user with many cores would run).  `value` is the
+    fastest single-process figure."""
+    import subprocess
     from oracle import aspire_oracle as orc
     ncpu = os.cpu_count() or 1
     q = query.cpu().view(S, D)
     c = cands.cpu().view(NC, S, D)
-    per = {}
-    for nt in sorted({1, ncpu}):
+    qn = q.numpy()
+    sweep = sorted({t for t in (1, 8, 32, ncpu) if t <= ncpu})
+    slice_s = budget_s / (2 * len(sweep) + 3)
+    pair, batch = {}, {}
+    for nt in sweep:
         torch.set_num_threads(nt)
         orc.get_similarity(q, c[0])
         t0 = time.perf_counter()
         n = 0
-        while n < NC and time.perf_counter() - t0 < budget_s / 3:
+        while n < NC and time.perf_counter() - t0 < slice_s:
             orc.get_similarity(q, c[n])
             n += 1
-        per[nt] = (n, time.perf_counter() - t0)
-    best = max(per, key=lambda nt: per[nt][0] / per[nt][1])
-    torch.set_num_threads(best)
-    # the reference's other calling pattern: groups of 64 through caching_score (pp_gen_nearest.py:182)
-    t0 = time.perf_counter()
-    nb = 0
-    qn = q.numpy()
-    while nb < NC and time.perf_counter() - t0 < budget_s / 3:
-        orc.caching_score(qn, [c[i].numpy() for i in range(nb, min(NC, nb + 64))])
-        nb = min(NC, nb + 64)
-    dt_batch = time.perf_counter() - t0
-    n, dt = per[best]
+        pair[nt] = n / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        nb = 0
+        while time.perf_counter() - t0 < slice_s:
+            lo = nb % NC
+            orc.caching_score(qn, [c[i].numpy() for i in range(lo, min(NC, lo + 64))])
+            nb += min(NC, lo + 64) - lo
+        batch[nt] = nb / (time.perf_counter() - t0)
+    best_pair, best_batch = max(pair, key=pair.get), max(batch, key=batch.get)
+    # process-parallel: min(cores, 32) workers (each imports torch: memory bounds the count), one thread each, released together
+    n_workers = min(ncpu, 32)
+    procs = [subprocess.Popen([sys.executable, '-c', _CPU_WORKER, ROOT, str(w), str(slice_s)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                              text=True, env=dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES=''))
+             for w in range(n_workers)]
+    par = None
+    try:
+        for pr in procs:
+            assert pr.stdout.readline().strip() == 'ready'
+        for pr in procs:
+            pr.stdin.write('go\n')
+            pr.stdin.flush()
+        res = [pr.stdout.readline().split() for pr in procs]
+        par = sum(int(n) / float(dt) for n, dt in res)
+    except Exception as e:          # a reported baseline, not the measurement: never fail the bench over it
+        par = None
+        par_err = repr(e)
+    finally:
+        for pr in procs:
+            pr.kill()
+    torch.set_num_threads(ncpu)
+    value = max(batch[best_batch], pair[best_pair])
     return {
-        'value': n / dt, 'unit': 'alignments/s', 'cores': best, 'kind': 'port',
-        'sample': f'{n} of the {NC} pairs of one step, one pair per call (models.py:190-197 pattern), {dt:.1f} s, '
-                  f'torch.set_num_threads({best})',
-        'by_threads': {str(nt): per[nt][0] / per[nt][1] for nt in per},
+        'value': value, 'unit': 'alignments/s', 'cores': best_batch if batch[best_batch] >= pair[best_pair] else best_pair, 'kind': 'port',
+        'sample': f'caching_score groups of 64 (disent_models.py:256, pp_gen_nearest.py:182) of one step\'s {NC} pairs for {slice_s:.1f} s per '
+                  f'thread count, torch.set_num_threads({best_batch}) the fastest; one pair per call in per_pair_by_threads',
         'host_cores': ncpu,
-        'batched64_value': nb / dt_batch,
-        'batched64_sample': f'{nb} pairs in caching_score groups of 64 (disent_models.py:256), {dt_batch:.1f} s, {best} threads',
+        'batched64_by_threads': {str(t): batch[t] for t in sweep},
+        'per_pair_by_threads': {str(t): pair[t] for t in sweep},
+        'per_pair_value': pair[best_pair],
+        'process_parallel': {'value': par, 'workers': n_workers, 'threads_per_worker': 1,
+                             'what': f'{n_workers} processes x one thread, one pair per call (models.py:190-197), {slice_s:.1f} s, released together'}
+                            if par is not None else {'value': None, 'error': par_err},
         'note': 'oracle = PyTorch CPU port of the reference path; Sinkhorn = restated geomloss 0.2.4 (parity unpinned)',
     }
+
+
+def cpu_l2max(device_q_rows, device_c_rows, nq, s, budget_s=4.0):
+    """tsAspire on the host cores (config 3's CPU leg): the oracle's allpair_masked_dist_l2max through caching_score's groups of 64
+    candidates per query (disent_models.py:294-295), all cores, on a bounded sample of the same rows."""
+    from oracle import aspire_oracle as orc
+    ncpu = min(os.cpu_count() or 1, 8)          # more intra-op threads than that are slower on these tensor sizes (cpu_baseline's sweep)
+    torch.set_num_threads(ncpu)
+    q = device_q_rows[:nq * s].cpu().view(nq, s, D).numpy()
+    c = device_c_rows[:64 * 64 * s].cpu().view(64 * 64, s, D)
+    groups = [[c[i].numpy() for i in range(g0, g0 + 64)] for g0 in range(0, 64 * 64, 64)]
+    orc.caching_score(q[0], groups[0], score_agg_type='l2lse')
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        orc.caching_score(q[n % nq], groups[(n // nq) % len(groups)], score_agg_type='l2lse')
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': 64 * n / dt, 'unit': 'pairs/s', 'cores': ncpu, 'kind': 'port',
+            'sample': f'{n} caching_score(l2lse) calls of 64 candidates each, {dt:.1f} s, torch.set_num_threads({ncpu})'}
+
+
+def config3_probe(device, Q=32, C=50000, s=8, reps=30, cpu=True):
+    """BASELINE config 3 on one GPU (outside the timed headline): tsAspire, a batch of 32 queries x 50 000 candidates of 8
+    sentences, max-sim single match (pair_distances.py:138-186 via disent_models.py:294-295) -- ONE aspire_l2max_scores_f32
+    call over a resident store that carries its rows as fp16 planes (aspire_rep_planes, prepared once), timed with HIP events;
+    every call prepares the planes of a fresh batch of queries (~10 us) as a serving loop would.  The x.y term of the 102 M
+    sentence pairs is a [400 000 x 256] x 768 GEMM: matrix-pipe bound.  Roofline: algorithmic flops 2 Sq Sc D per pair
+     against the dense fp16 MFMA peak / 3 -- fp32 accuracy on the fp16 pipe takes three products per term -- and,
+    beside it, the executed MFMA rate against what the pipe sustains on random operands with NO data movement (tools/ubench/mfmapeak:
+    the chip is power-limited there to ~1.6 PFLOP/s at ~1.65 GHz: profiles/r04_mfmapeak.txt)."""
+    from aspire_amd import ops
+    g = torch.Generator().manual_seed(1)
+    crows = torch.empty(C * s, D, device=device)
+    for lo in range(0, C * s, 1 << 16):
+        crows[lo:lo + (1 << 16)] = torch.randn(min(1 << 16, C * s - lo), D, generator=g).to(device)
+    qrows = torch.randn(Q * s, D, generator=g).to(device)
+    mk = lambda rows, n: ops.DeviceRepSet(rows, (torch.arange(n, device=device, dtype=torch.int32) * s).contiguous(),
+                                          torch.full((n,), s, device=device, dtype=torch.int32), ext=0, max_len=s, lens_host=[s] * n)
+    c, q = mk(crows, C), mk(qrows, Q)
+    t0 = time.perf_counter()
+    c.prepare_planes()
+    torch.cuda.synchronize()
+    t_prepare = time.perf_counter() - t0
+
+    def call():
+        q.drop_planes()                 # a new batch of queries each call: their planes are part of the call
+        return ops.l2max_scores(q, c)
+    for _ in range(3):
+        sc = call()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        call()
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / reps * 1e3
+    ghz = ops.clock_under(call)
+    with _pinned(GEMM='bf16x3'):
+        for _ in range(2):
+            ops.l2max_scores(q, c)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(10):
+            ops.l2max_scores(q, c)
+        b.record()
+        torch.cuda.synchronize()
+        us_rows = a.elapsed_time(b) / 10 * 1e3
+    # spot check against float64 on the first rows
+    want = -torch.cdist(qrows[:s].double(), crows[:64 * s].double()).view(s, 64, s).permute(1, 0, 2).reshape(64, -1).min(1).values
+    err = float((sc.view(Q, C)[0, :64].double() - want).abs().max())
+    flop = 2.0 * s * s * D * Q * C
+    nbytes = 4 * D * (C * s + Q * s) + 4 * Q * C
+    peak = 2500.0 / 3
+    res = {
+        'workload': f'tsAspire biomed: {Q} queries x {C} candidates, {s} sents x {D}d, max-sim single match, one call; resident store with fp16 '
+                    f'planes (prepared once: {t_prepare * 1e3:.1f} ms), query planes prepared per call; reps ~ N(0,1); {nbytes / 2**20:.0f} MiB > L3',
+        'us_per_call': us, 'pairs_per_s': Q * C / (us * 1e-6), 'clock_ghz_under_kernel': ghz,
+        'us_per_call_fp32_row_tiles': us_rows, 'max_abs_err_vs_float64_on_64_pairs': err,
+        'roofline': {'bound': 'mfma', 'achieved': flop / (us * 1e-6) / 1e12, 'peak': peak, 'unit': 'TFLOP/s', 'frac': flop / (us * 1e-6) / 1e12 / peak,
+                     'kernel': 'pair_gram_p_kernel<128,128,3,true>', 'algorithmic_flop_per_call': flop,
+                     'denominator': 'dense fp16 MFMA peak 2500 TFLOP/s / 3 products per term (h.h + h.l + l.h: fp32 accuracy on the fp16 pipe)',
+                     'executed_mfma_tflops': 3 * flop / (us * 1e-6) / 1e12,
+                     'executed_frac_of_random_operand_ceiling': 3 * flop / (us * 1e-6) / 1e12 / 1600.0,
+                     'random_operand_ceiling': '1600 TFLOP/s: v_mfma_f32_32x32x16_f16 from registers, random operands, no memory traffic, 1.65 GHz '
+                                               'under power limit (profiles/r04_mfmapeak.txt)',
+                     'hbm_view': {'achieved_GBs': nbytes / (us * 1e-6) / 1e9, 'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  'algorithmic_bytes_per_call': nbytes}},
+    }
+    if cpu:
+        res['cpu_baseline'] = cpu_l2max(qrows, crows, Q, s)
+    return res
 
 
 def config4_probe(device, J=50, NCAND=125, smax=20, reps=40):
@@ -136,7 +284,26 @@ def config4_probe(device, J=50, NCAND=125, smax=20, reps=40):
         res[name] = {'us_per_call': us, 'pairs_per_s': J * NCAND / (us * 1e-6),
                      'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                   'algorithmic_bytes_per_call': nbytes,
-                                  'what': 'the whole call (item sort + scoring launch + overflow scan + rank), back to back on one stream'}}
+                                  'what': 'the whole call (item sort + scoring launch + rank), back to back on one stream; the data (< 256 MiB) sits in the Infinity Cache: HBM is not what bounds it -- see issue_floor'}}
+    # the scoring kernel against its VALU issue floor (the data sits in the Infinity Cache; what bounds the launch is issue slots and
+    # the 1.5 rounds of items): SQ_ACTIVE_INST_VALU of the committed counter pass = cycles in which some wave of a SIMD issued a
+    # VALU instruction, summed over SIMDs; spread evenly over 1024 SIMDs at 2.4 GHz it is the time below which no schedule of the
+    # same instruction stream gets
+    for name in ('r04_csf_50x125_ot_sq_counters.txt', 'r03_csf_50x125_ot_sq_counters.txt'):
+        cpath = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(cpath):
+            continue
+        in_kernel, quad = False, None
+        for line in open(cpath):
+            if 'dispatches' in line:
+                in_kernel = 'pair_fused_kernel' in line
+            elif in_kernel and 'SQ_ACTIVE_INST_VALU' in line:
+                quad = float(line.split()[-1])
+        if quad:
+            floor_us = quad * 4 / 1024 / 2.4e3
+            res['otAspire']['issue_floor'] = {'bound': 'valu-issue', 'floor_us': floor_us, 'frac': floor_us / res['otAspire']['us_per_call'],
+                                              'source': f'profiles/{name}: SQ_ACTIVE_INST_VALU {quad:.0f} quad-cycles per launch x 4 / (1024 SIMDs x 2.4 GHz)'}
+            break
     res['workload'] = (f'{J} jobs x {NCAND} candidates of 3 .. {smax} sentence rows, facet-selected queries of 1 .. 8 rows, k = {NCAND} '
                        f'(full ranking), reps resident; data {sum(r["roofline"]["algorithmic_bytes_per_call"] for r in res.values()) // 2 / 2**20:.0f} MiB'
                        f' < L3: warm')
@@ -373,6 +540,14 @@ def main():
         t = sorted(a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs)
         rccl['all_gather_us'] = {'median': t[len(t) // 2] * 1e3, 'min': t[0] * 1e3, 'bytes_per_rank': K * TOPK * 8,
                                  'what': f'all_gather_into_tensor of {K} x {TOPK} int64 keys per rank on the lane stream, 20 in a row'}
+    e2e_ranks = None
+    if world > 1 and not args.no_probes and not os.environ.get('ASPIRE_BENCH_NO_E2E'):
+        # config 5's flow on every rank (outside the timed headline)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import e2ebench
+        mine = e2ebench.run_sharded(rank, world, n_docs=int(os.environ.get('ASPIRE_BENCH_E2E_DOCS', '8192')))
+        e2e_ranks = [None] * world
+        dist.all_gather_object(e2e_ranks, mine)
     out = None
     if rank == 0:
         # ---- per-stage kernel durations, live: HIP events on the launch stream around launches of ONE stage alone, on the
@@ -487,10 +662,18 @@ def main():
             out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r3.sh)'
         if rccl is not None:
             out['rccl'] = rccl
+            if e2e_ranks is not None:
+                out['e2e'] = {'what': 'config 5 per rank (tools/e2ebench.py: run_sharded): each rank encodes its own block into HBM (fp16 planes '
+                                      'kept), ranks 128 replicated queries with otAspire against it, merges the top-100 over one all-gather; weak '
+                                      'scaling, the job\'s rates are the sums over ranks',
+                              'docs_per_s': sum(r['docs_per_s'] for r in e2e_ranks),
+                              'pairs_per_s': sum(r['pairs_per_s'] for r in e2e_ranks),
+                              'merged_top1_agrees': len({r['top1_of_query0'] for r in e2e_ranks}) == 1, 'ranks': e2e_ranks}
         out['cross_check'] = ('per-kernel durations (roofline.kernel_ms, profiles/*_kernel_stats.csv) add up to one_stream.ms_per_call; '
                               '`value` has calls in flight on several streams, where per-kernel durations of overlapping launches mean '
                               'nothing -- verify `one_stream`, treat `value` as the whole-job rate the driver can time from outside')
         if world == 1 and not args.no_probes:
+            out['config3'] = config3_probe(device, cpu=not args.no_cpu_baseline)
             out['config4'] = config4_probe(device)
             if not os.environ.get('ASPIRE_BENCH_NO_E2E'):
                 sys.path.insert(0, os.path.join(ROOT, 'tools'))

@@ -122,7 +122,7 @@ def test_empty_shard(tmp_path):
 def test_bench_two_ranks_on_one_gpu():
     """bench.py --gpus 2 with both ranks on cuda:0 over gloo: sharded global indices, all-gather layout, merge kernel,
     and the checks bench.py itself makes on the merged ranking (every rank identical, candidates of both shards)"""
-    env = dict(os.environ, ASPIRE_BENCH_ONE_GPU='1', MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, ASPIRE_BENCH_ONE_GPU='1', MASTER_ADDR='127.0.0.1', ASPIRE_BENCH_E2E_DOCS='256')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
            '--repeats', '6']
@@ -137,3 +137,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert r['ranks_seen'] == [0, 1] and r['world_size'] == 2 and r['backend'] == 'gloo'
     assert r['merged_ranking_agrees_on_all_ranks'] is True and r['shards_in_merged_top_k'] == 2
     assert r['all_gather_us']['median'] > 0 and len(r['devices']) == 2
+    # config 5's flow on every rank: each encodes its own block, ranks the replicated queries, merges
+    e = j['e2e']
+    assert len(e['ranks']) == 2 and e['merged_top1_agrees'] and e['docs_per_s'] > 0 and e['pairs_per_s'] > 0
+    assert all(r['shards_in_top_k'] == 2 for r in e['ranks'])

@@ -47,7 +47,9 @@ def test_cdist_formula_follows_the_group_extents_ot(amd):
     query = torch.randn(8, 768, generator=g)
     got = amd.scorer.score_pool([query], cands, method='ot', schedule='batch').cpu().numpy()[0]
     want = np.array(orc.rank_pool_caching(query.numpy(), [c.numpy() for c in cands]), dtype=np.float32)
-    np.testing.assert_allclose(got, want, atol=1e-2, rtol=0)            # plan-weighted similarity: fp32 conditioning
+    import plan_sim_floor
+    truth = np.array(orc.rank_pool_caching(query.numpy(), [c.numpy() for c in cands], dtype=torch.float64))
+    plan_sim_floor.check(got, want, truth, 'long-document groups')       # plan-weighted similarity: against float64, per case
     # the marginals are where the cdist formula enters: compare them through the drop-in caching_score on the long group
     qd = {'sent_reps': query.numpy()}
     cds = [{'sent_reps': c.numpy()} for c in cands[64:128]]

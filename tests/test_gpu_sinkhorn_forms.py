@@ -8,6 +8,14 @@ import torch
 from oracle import aspire_oracle as orc
 
 pytestmark = pytest.mark.gpu
+
+
+def _plan_sim(x, y, dtype):
+    """AllPairMaskedWasserstein.compute_distance(..., return_pair_sims=True)[0] of one pair (pair_distances.py:61-86), in `dtype`"""
+    from oracle import aspire_oracle as orc
+    xt = orc.RepLen(x[None].to(dtype).permute(0, 2, 1), [len(x)])
+    yt = orc.RepLen(y[None].to(dtype).permute(0, 2, 1), [len(y)])
+    return orc.AllPairMaskedWasserstein({}).compute_distance(xt, yt, return_pair_sims=True)[0][0]
 TOL = 1e-4
 
 
@@ -88,7 +96,28 @@ def test_forms_agree_at_size(amd, nq, nc, s, want):
         with pinned(SINKHORN=form, OT_FORM='tile'):
             out[form] = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
     dflt = amd.ops.ot_sinkhorn(q, c, want=w).cpu().numpy()
-    tol = 5e-5 if want == 'distance' else 1e-2     # plan-weighted similarity: see test_gpu_scoring.PLAN_SIM_TOL
+    if want == 'distance':
+        tol = 5e-5
+    else:
+        # plan-weighted similarity: the bound of this case from a sample of its pairs -- the reference's fp32 path against the
+        # same arithmetic in float64 (tests/plan_sim_floor.py); every form must sit inside it, two forms inside twice that
+        import plan_sim_floor
+        rows_q, rows_c = q.rows.cpu(), c.rows.cpu()
+        sq, sc = q.start.cpu().tolist(), c.start.cpu().tolist()
+        lq, lc = q.len.cpu().tolist(), c.len.cpu().tolist()
+        pick = np.random.RandomState(nq + s).choice(nc, 24, replace=False)
+        w32, w64, idx = [], [], []
+        for qi in range(nq):
+            x = rows_q[sq[qi]:sq[qi] + lq[qi]]
+            for ci in pick:
+                y = rows_c[sc[ci]:sc[ci] + lc[ci]]
+                w32.append(float(_plan_sim(x, y, torch.float32)))
+                w64.append(float(_plan_sim(x, y, torch.float64)))
+                idx.append(qi * nc + int(ci))
+        b = plan_sim_floor.bound(w32, w64)
+        for form in forms:
+            plan_sim_floor.check(out[form].reshape(-1)[idx], w32, w64, form)
+        tol = 2 * b
     for form in forms[1:]:
         assert np.isfinite(out[form]).all()
         np.testing.assert_allclose(out[form], out['wave'], atol=tol, rtol=0)

@@ -31,7 +31,7 @@ def synthetic_batches(n_docs, L, S, seed):
     return batches
 
 
-def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
+def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2, planes=True):
     from transformers import BertConfig, BertModel
     from aspire_amd import ops, scorer, _lib
     from aspire_amd.consent import AspireConSent
@@ -48,7 +48,7 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
     model.encode_to_pool(batches[:2])             # warm-up (workspace allocation, clocks)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pool = model.encode_to_pool(batches)
+    pool = model.encode_to_pool(batches, planes=planes)      # planes: + one pass over the finished store (inside the timed stage)
     torch.cuda.synchronize()
     t_encode = time.perf_counter() - t0
     # the GPU side of the same stage alone: encoder forward and pooling kernels under HIP events
@@ -89,6 +89,8 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
     # aspire_amd.ops from a sample of the pool: NOTES.md, round-3 log)
     g = torch.Generator().manual_seed(seed + 7)
     iid_c = ops.DeviceRepSet(torch.randn(n_docs * S, 768, generator=g).to(dev), pool.repset.start, pool.repset.len, ext=0, max_len=S)
+    if planes:
+        iid_c.prepare_planes()
     iid_q = ops.DeviceRepSet(torch.randn(n_queries * S, 768, generator=g).to(dev), q.start, q.len, ext=0, max_len=S)
     ops.ot_rank(iid_q, iid_c, kk, want=_lib.OT_SIMILARITY)
     torch.cuda.synchronize()
@@ -102,7 +104,7 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
         'what': f'config 5, one GPU slice: {n_docs} docs x {L} tokens ({S} sentences), prepared in batches of {BATCH}, encoded {len(calls[0][1])} per call straight into the resident '
                 f'rep store, then {n_queries} queries x otAspire + top-{kk} on it (pp_gen_nearest.py:141-202); synthetic tokens, '
                 f'random-init BERT-base',
-        'docs': n_docs, 'tokens': L, 'sents': S, 'queries': n_queries,
+        'docs': n_docs, 'tokens': L, 'sents': S, 'queries': n_queries, 'store_carries_fp16_planes': bool(planes),
         'encode_s': t_encode, 'docs_per_s': n_docs / t_encode,
         'score_rank_s': t_score, 'pairs_per_s': n_queries * n_docs / t_score,
         'score_rank_on_iid_reps_s': t_score_iid, 'pairs_per_s_on_iid_reps': n_queries * n_docs / t_score_iid,
@@ -136,6 +138,51 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2):
                 worst = max(worst, abs(float(sc[qi, ci]) - want))
         out['spot_check'] = {'pairs': 3, 'max_abs_diff_vs_hf_plus_oracle': worst, 'tolerance': 2e-4, 'ok': worst < 2e-4}
     return out
+
+
+def run_sharded(rank, world, group=None, n_docs=8192, L=256, S=12, n_queries=128, k=100, seed=2):
+    """Config 5 as the 8-GPU job runs it, per rank (weak scaling: every rank n_docs documents of a corpus of world x n_docs): encode
+    THIS rank's block straight into its HBM (with fp16 planes), wrap it as the rank's shard (ShardedPoolRanker.from_resident: one
+    768-float broadcast fixes the planes' common centre), rank the replicated queries (otAspire) against it and merge the per-query
+    top-k over ONE all-gather + one merge launch.  Returns this rank's numbers; bench.py gathers them from every rank."""
+    from transformers import BertConfig, BertModel
+    from aspire_amd import ops
+    from aspire_amd.consent import AspireConSent
+    from aspire_amd.parallel import ShardedPoolRanker
+    import torch.distributed as dist
+    dev = ops.require_gpu()
+    torch.manual_seed(0)
+    model = AspireConSent(bert_model=BertModel(BertConfig(vocab_size=31090), add_pooling_layer=False).eval())
+    batches = synthetic_batches(n_docs, L, S, seed + 100 * (rank + 1))       # this rank's documents
+    qbatches = synthetic_batches(n_queries, L, S, seed + 1)                  # the same queries on every rank
+    for bb, _, _ in batches + qbatches:
+        for key in ('tokid_tt', 'seg_tt', 'attnmask_tt'):
+            bb[key] = bb[key].to(dev)
+    model.encode_to_pool(batches[:2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(group)
+    t0 = time.perf_counter()
+    block = model.encode_to_pool(batches)
+    torch.cuda.synchronize()
+    t_encode = time.perf_counter() - t0
+    ranker = ShardedPoolRanker.from_resident(block, rank * n_docs, world * n_docs, group=group, planes=True)
+    qreps = []
+    for bb, abs_lens, idxs in qbatches:
+        _, sent = model.forward_device(bb, abs_lens, idxs)
+        qreps.extend(sent[i, :abs_lens[i]] for i in range(len(abs_lens)))
+    kk = min(k, n_docs)
+    ranker.rank_queries(qreps, kk, method='ot')
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(group)
+    t0 = time.perf_counter()
+    top_s, top_i = ranker.rank_queries(qreps, kk, method='ot')
+    torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0
+    return {'rank': rank, 'docs': n_docs, 'docs_per_s': n_docs / t_encode, 'encode_s': t_encode, 'score_rank_merge_s': t_rank,
+            'pairs_per_s': n_queries * n_docs / t_rank, 'queries': n_queries, 'k': kk,
+            'shards_in_top_k': int(len(torch.unique(top_i // n_docs))), 'top1_of_query0': int(top_i[0, 0])}
 
 
 if __name__ == '__main__':
