@@ -58,7 +58,7 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
     return r;
 }
 
-// mode 0: otAspire (a.want, extras);  mode 1: tsAspire max-sim (a.scores = max over valid entries of -cdist, pair_sims);
+// mode 0: otAspire (a.want, extras);  mode 1: the aggregations of -cdist (a.agg: tsAspire max-sim, top-2, attention; pair outputs);
 __device__ __forceinline__ void pair_generic_body(const ScoreArgs& a, int mode, int skip_up_to, int rows_q, int rows_c, int64_t p,
                                                   float* lds) {
     const int tid = threadIdx.x;
@@ -124,15 +124,64 @@ __device__ __forceinline__ void pair_generic_body(const ScoreArgs& a, int mode, 
     __syncthreads();
 
     if (mode == 1) {
-        // ---- tsAspire: max over the valid block (pair_distances.py:167-176) -----------------------------------------------
-        float best = -INFINITY;
-        for (int e = tid; e < q_len * c_len; e += kGenThreads) best = fmaxf(best, neg[(e / c_len) * ld + e % c_len]);
-        best = block_reduce(best, lds + L.red, true);
-        if (tid == 0) a.scores[p] = best;
+        // ---- the aggregations of the masked -cdist block -------------------------------------------------------------------
+        float score;
+        if (a.agg == ASPIRE_AGG_MAX) {
+            // tsAspire: max over the valid block (pair_distances.py:167-176)
+            float best = -INFINITY;
+            for (int e = tid; e < q_len * c_len; e += kGenThreads) best = fmaxf(best, neg[(e / c_len) * ld + e % c_len]);
+            score = block_reduce(best, lds + L.red, true);
+        } else if (a.agg == ASPIRE_AGG_TOP2) {
+            // torch.topk(k = 2) over the padded [q.ext, c.ext] block, masked entries taking part with -cdist - 10e8
+            // (pair_distances.py:295-345); without padded extents over the valid block, a missing second entry counting -10e8.
+            // The largest value, then: the same again if it occurs twice, else the largest value below it.
+            const int eq = a.q.ext > 0 ? a.q.ext : q_len, ec = a.c.ext > 0 ? a.c.ext : c_len;
+            auto entry = [&](int e) {
+                const int i = e / ec, j = e - i * ec;
+                return neg[i * ld + j] + ((i < q_len && j < c_len) ? 0.f : -10e8f);
+            };
+            float m1 = -INFINITY;
+            for (int e = tid; e < eq * ec; e += kGenThreads) m1 = fmaxf(m1, entry(e));
+            m1 = block_reduce(m1, lds + L.red, true);
+            float cnt = 0.f, below = -INFINITY;
+            for (int e = tid; e < eq * ec; e += kGenThreads) {
+                const float v = entry(e);
+                if (v == m1) cnt += 1.f;
+                else below = fmaxf(below, v);
+            }
+            cnt = block_reduce(cnt, lds + L.red, false);
+            below = block_reduce(below, lds + L.red, true);
+            float m2 = cnt >= 2.f ? m1 : below;
+            if (m2 == -INFINITY) m2 = -10e8f;
+            score = m1 + m2;
+        } else {
+            // AllPairMaskedAttention (pair_distances.py:95-135): soft-max of -d / temp over the valid block, sum p * (-d)
+            const float temp = (float)a.temp;
+            float mx = -INFINITY;
+            for (int e = tid; e < q_len * c_len; e += kGenThreads) mx = fmaxf(mx, neg[(e / c_len) * ld + e % c_len] / temp);
+            mx = block_reduce(mx, lds + L.red, true);
+            float se = 0.f, sn = 0.f;
+            for (int e = tid; e < q_len * c_len; e += kGenThreads) {
+                const float v = neg[(e / c_len) * ld + e % c_len];
+                const float w = expf(v / temp - mx);
+                se += w;
+                sn = fmaf(w, v, sn);
+            }
+            se = block_reduce(se, lds + L.red, false);
+            sn = block_reduce(sn, lds + L.red, false);
+            score = sn / se;
+            if (a.out_plan)
+                for (int e = tid; e < a.q.ext * a.c.ext; e += kGenThreads) {
+                    const int i = e / a.c.ext, j = e - i * a.c.ext;
+                    a.out_plan[(p * a.q.ext + i) * a.c.ext + j] = (i < q_len && j < c_len) ? expf(neg[i * ld + j] / temp - mx) / se : 0.f;
+                }
+        }
+        if (tid == 0) a.scores[p] = score;
         if (a.out_pairsims)
             for (int e = tid; e < a.q.ext * a.c.ext; e += kGenThreads) {
                 const int i = e / a.c.ext, j = e - i * a.c.ext;
-                a.out_pairsims[(p * a.q.ext + i) * a.c.ext + j] = neg[i * ld + j] + ((i < q_len && j < c_len) ? 0.f : -10e8f);
+                a.out_pairsims[(p * a.q.ext + i) * a.c.ext + j] =
+                    neg[i * ld + j] + (((i < q_len && j < c_len) || a.agg == ASPIRE_AGG_ATTENTION) ? 0.f : -10e8f);
             }
         return;
     }

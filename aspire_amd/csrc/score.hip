@@ -2119,9 +2119,6 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     // documents) and the long-document kernel then rewrites the pairs that hold a longer one.
     const int rows_q = q->ext > 0 ? q->ext : q->max_len, rows_c = c->ext > 0 ? c->ext : c->max_len;
     const bool long_docs = max_rows_of(q, c) > 8 * kMaxT;
-    ASPIRE_REQUIRE(!long_docs || agg == ASPIRE_AGG_MAX, ASPIRE_ERR_UNSUPPORTED,
-                   "documents with more than %d sentence rows: only the max-sim and otAspire scores are built (got %d)", 8 * kMaxT,
-                   max_rows_of(q, c));
     if (long_docs && (q->ext > 0 || c->ext > 0)) return launch_pair_generic(a, 1, 0, rows_q, rows_c, (hipStream_t)stream);
     dim3 grid;
     grid = dim3((unsigned)a.c.n, (unsigned)query_chunks(a), 1);

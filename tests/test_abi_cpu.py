@@ -148,6 +148,31 @@ def test_integration_md_stub_passes_every_argument():
         assert _top_level_args(call) == _top_level_args(decl), (fn, _top_level_args(call), _top_level_args(decl))
 
 
+def _header_struct_fields(hdr, name):
+    body = re.search(r'typedef struct \{((?:(?!typedef struct).)*?)\}\s*' + name + r'\s*;', hdr, flags=re.S).group(1)
+    names = []
+    for decl in body.split(';'):
+        if decl.strip():      # "const float *w_qkv, *b_qkv" declares two
+            parts = decl.strip().split(',')
+            names += [re.sub(r'\[.*\]', '', p.strip().split()[-1].lstrip('*')) for p in parts]
+    return names
+
+
+def test_struct_fields_match_the_header():
+    """every ctypes.Structure of aspire_amd/_lib.py AND of the stub in INTEGRATION.md lists the header's fields, in order
+    (INTEGRATION.md's OtParams once stopped at cdist_mode: it only worked because ctypes zero-fills the tail)"""
+    from aspire_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(root, 'include', 'aspire_hip.h')).read(), flags=re.S)
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    for cname, cls in (('aspire_repset', _lib.RepSet), ('aspire_ot_params', _lib.OtParams), ('aspire_rep_planes', _lib.RepPlanes),
+                       ('aspire_bert_layer', _lib.BertLayer), ('aspire_bert_weights', _lib.BertWeights)):
+        assert [f[0] for f in cls._fields_] == _header_struct_fields(hdr, cname), cname
+    for cname, pyname in (('aspire_repset', 'RepSet'), ('aspire_ot_params', 'OtParams')):
+        block = re.search(r'class ' + pyname + r'\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\s*(?:#.*)?\n(?:class|\n|def)', doc, flags=re.S).group(1)
+        assert re.findall(r"\('(\w+)'", block) == _header_struct_fields(hdr, cname), pyname
+
+
 def test_compute_requires_gpu():
     from aspire_amd import ops
     if torch.cuda.is_available():

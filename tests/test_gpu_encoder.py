@@ -274,3 +274,54 @@ def test_weights_beyond_the_fp16_planes_are_left_to_the_fp32_input_kernels():
         want = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
     got = enc.forward_hidden(tok.cuda(), seg.cuda(), mask.cuda()).cpu()
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_checkpoint_path_from_a_local_save_pretrained_directory(tmp_path):
+    """AspireConSent(hf_model_name) as examples/ex_aspire_consent.py:33 calls it -- AutoModel.from_pretrained -- on a LOCAL
+    directory (no network): a BERT-base-geometry model with SciBERT's vocabulary size (31 090) saved WITH its pooler, as the
+    published Aspire checkpoints are.  The forward equals HF's at 1e-4; the pooler is computed by the reference and unused
+    (ex_aspire_consent.py:72-76), here it is not even loaded."""
+    from transformers import BertConfig, BertModel, AutoModel
+    from aspire_amd import AspireConSent
+    torch.manual_seed(5)
+    cfg = BertConfig(vocab_size=31090, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                     max_position_embeddings=512)
+    src = BertModel(cfg, add_pooling_layer=True).eval()
+    src.save_pretrained(str(tmp_path / 'ckpt'))
+    model = AspireConSent(str(tmp_path / 'ckpt'))
+    assert model.bert_encoder.config.vocab_size == 31090
+    g = torch.Generator().manual_seed(6)
+    tok = torch.randint(0, 31090, (3, 40), generator=g)
+    tok[:, -1] = 31089                                           # the last row of the embedding table
+    mask = torch.ones_like(tok)
+    mask[1, 30:] = 0
+    hf = AutoModel.from_pretrained(str(tmp_path / 'ckpt')).eval()
+    with torch.no_grad():
+        want = hf(tok, token_type_ids=torch.zeros_like(tok), attention_mask=mask).last_hidden_state
+    got = model.bert_encoder.forward_hidden(tok, torch.zeros_like(tok), mask).cpu()
+    np.testing.assert_allclose(got[0].numpy(), want[0].numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(got[1, :30].numpy(), want[1, :30].numpy(), atol=1e-4, rtol=0)
+    # the drop-in forward on top of it
+    bert_batch = {'tokid_tt': tok, 'seg_tt': torch.zeros_like(tok), 'attnmask_tt': mask, 'seq_lens': [40, 30, 40]}
+    cls, sent = model.forward(bert_batch, [2, 1, 2], [[list(range(3, 9)), list(range(9, 20))], [list(range(2, 7))],
+                                                        [list(range(1, 5)), list(range(5, 39))]])
+    np.testing.assert_allclose(cls.numpy(), want[:, 0].numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(sent[2, 1].numpy(), want[2, 5:39].mean(0).numpy(), atol=1e-4, rtol=0)
+
+
+def test_state_dict_with_the_bert_prefix():
+    """a BertForPreTraining-style module: every encoder weight under 'bert.' (+ heads the encoder ignores) -- the weight-name
+    mapping of HipBertEncoder finds them"""
+    from transformers import BertConfig, BertForPreTraining
+    from aspire_amd.encoder import HipBertEncoder
+    torch.manual_seed(7)
+    cfg = BertConfig(vocab_size=500, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                     max_position_embeddings=64)
+    full = BertForPreTraining(cfg).eval()
+    assert all(k.startswith(('bert.', 'cls.')) for k in full.state_dict())
+    enc = HipBertEncoder(full)
+    tok = torch.randint(0, 500, (2, 16), generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        want = full.bert(tok, token_type_ids=torch.zeros_like(tok), attention_mask=torch.ones_like(tok)).last_hidden_state
+    got = enc.forward_hidden(tok, torch.zeros_like(tok), torch.ones_like(tok)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-4, rtol=0)

@@ -106,3 +106,37 @@ def test_a_single_padded_entry_raises_like_torch_topk(amd):
     with pytest.raises(RuntimeError):
         from oracle import aspire_oracle as orc
         orc.allpair_masked_dist_l2topk(orc.RepLen(q.permute(0, 2, 1), [1, 1]), orc.RepLen(c.permute(0, 2, 1), [1, 1]))
+
+
+def test_siblings_on_documents_of_33_to_128_rows(amd):
+    """beyond the tile kernels' 32 rows (the one-workgroup-per-pair kernel, generic.hip): padded reference tensors with the pair
+    outputs, and a CSR pool that mixes short and long documents -- as otAspire / l2max have accepted since round 2"""
+    g = torch.Generator().manual_seed(13)
+    # padded [B, D, S] tensors, 40 x 70 rows, ragged lengths (torch.cdist's matmul formula: both sides beyond 25 rows)
+    q, c = torch.randn(3, 40, 768, generator=g), torch.randn(3, 70, 768, generator=g)
+    qlens, clens = [40, 33, 7], [70, 1, 64]
+    for b in range(3):
+        q[b, qlens[b]:] = 0
+        c[b, clens[b]:] = 0
+    qt, ct = amd.pd.rep_len_tup(q.permute(0, 2, 1), qlens), amd.pd.rep_len_tup(c.permute(0, 2, 1), clens)
+    oq, oc = orc.RepLen(q.permute(0, 2, 1), qlens), orc.RepLen(c.permute(0, 2, 1), clens)
+    sims, pair = amd.pd.allpair_masked_dist_l2topk(qt, ct, return_pair_sims=True)
+    wsims, wpair = orc.allpair_masked_dist_l2topk(oq, oc, return_pair_sims=True)
+    np.testing.assert_allclose(sims.numpy(), wsims.numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(pair.numpy(), wpair.numpy(), atol=TOL, rtol=1e-7)
+    att, oatt = amd.pd.AllPairMaskedAttention({'cdatt_sm_temp': 0.7}), orc.AllPairMaskedAttention({'cdatt_sm_temp': 0.7})
+    ds, (ps, sm, ms) = att.compute_distance(qt, ct, return_pair_sims=True)
+    wds, (wps, wsm, wms) = oatt.compute_distance(oq, oc, return_pair_sims=True)
+    np.testing.assert_allclose(ds.numpy(), wds.numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(ps.numpy(), wps.numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(sm.numpy(), wsm.numpy(), atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(ms.numpy(), wms.numpy(), atol=TOL, rtol=1e-4)
+    # CSR pool: 128-row and 33-row documents among short ones
+    queries = [torch.randn(n, 768, generator=g) for n in (8, 50)]
+    cands = [torch.randn(int(n), 768, generator=g) for n in (8, 128, 2, 33, 20, 90)]
+    for method, fn in (('l2top2', lambda a, b: -orc.allpair_masked_dist_l2topk(a, b)),
+                       ('l2attention', lambda a, b: -orc.AllPairMaskedAttention({'cdatt_sm_temp': 0.5}).compute_distance(a, b))):
+        got = amd.scorer.score_pool(queries, cands, method=method, hparams={'cdatt_sm_temp': 0.5}).cpu().numpy()
+        want = np.array([[fn(orc.RepLen(x[None].permute(0, 2, 1), [len(x)]), orc.RepLen(y[None].permute(0, 2, 1), [len(y)])).item()
+                          for y in cands] for x in queries], dtype=np.float32)
+        np.testing.assert_allclose(got, want, atol=TOL, rtol=0)

@@ -96,3 +96,20 @@ def test_evaluate_step_reads_scores_json(tmp_path):
     assert os.path.exists(os.path.join(tmp_path, 'aggregated-evaluations.csv'))
     assert ev.get_scores_filename('r', 'background') == os.path.join('r', 'scores-background.json')
     assert ev.get_evaluations_filename('r', 'method', True) == os.path.join('r', 'aggregated-evaluations-method.csv')
+
+
+def test_from_h5_reads_the_reference_layout(tmp_path):
+    """the reference's encodings.h5: one dataset per paper id holding [num_sents, 768] (src/evaluation/utils/models.py:68-95,
+    file name from utils/utils.py:63-64).  h5py is not in the build image: the test runs wherever it is installed."""
+    h5py = pytest.importorskip('h5py')
+    from aspire_amd.repstore import RepStore
+    rs = np.random.RandomState(0)
+    want = {f'pid{i}': rs.randn(n, 768).astype(np.float32) for i, n in enumerate((3, 1, 12))}
+    path = str(tmp_path / 'encodings.h5')
+    with h5py.File(path, 'w') as f:
+        for pid, reps in want.items():
+            f.create_dataset(pid, data=reps)
+    store = RepStore.from_h5(path)
+    assert sorted(store.pid2reps) == sorted(want)
+    for pid, reps in want.items():
+        assert store.get(pid).dtype == np.float32 and np.array_equal(store.get(pid), reps)
