@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) mfma_loop(float* out, long long* clk, int
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    f16x8 a, b, a2[4], b2[4];
+    f16x8 a, b, a2[4], b2[4], a3[16], b3[12];
     bf16x8 ab, bb;
     unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
     auto rnd = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (float)(int)(h & 0xFFFF) * (1.0f / 32768.f) - 1.0f; };
@@ -28,6 +28,8 @@ __global__ void __launch_bounds__(256) mfma_loop(float* out, long long* clk, int
             a2[u][r] = (_Float16)(RANDOM ? rnd() : 1.0f);
             b2[u][r] = (_Float16)(RANDOM ? rnd() : 1.0f);
         }
+        for (int u = 0; u < 16; ++u) a3[u][r] = (_Float16)(RANDOM ? rnd() : 1.0f);
+        for (int u = 0; u < 12; ++u) b3[u][r] = (_Float16)(RANDOM ? rnd() : 1.0f);
     }
     long long t0 = 0, r0 = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -39,7 +41,8 @@ __global__ void __launch_bounds__(256) mfma_loop(float* out, long long* clk, int
         for (int u = 0; u < 8; ++u) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if constexpr (KIND == 3) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[(u + i) & 3], b2[u & 3], acc[i], 0, 0, 0);
+                if constexpr (KIND == 4) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[(4 * u + i) & 15], b3[(5 * u + 3 * i) % 12], acc[i], 0, 0, 0);
+                else if constexpr (KIND == 3) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[(u + i) & 3], b2[u & 3], acc[i], 0, 0, 0);
                 else if constexpr (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
                 else if constexpr (KIND == 1) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[i], 0, 0, 0);
                 else {
@@ -81,7 +84,7 @@ void run(const char* name, double flop_per_mfma, int waves_per_simd, int iters) 
     long long h[2];
     hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
     const double n_mfma = (double)blocks * 4 * iters * 32;
-    printf("%-36s waves/SIMD %d  %8.3f ms  %8.1f TFLOP/s  %6.2f G MFMA/s  clock %.2f GHz  cycles per MFMA and SIMD %.1f\n", name, waves_per_simd, ms,
+    printf("%-44s waves/SIMD %d  %8.3f ms  %8.1f TFLOP/s  %6.2f G MFMA/s  clock %.2f GHz  cycles per MFMA and SIMD %.1f\n", name, waves_per_simd, ms,
            n_mfma * flop_per_mfma / ms / 1e9, n_mfma / ms / 1e6, (double)h[0] / h[1] * 0.1,
            ms * 1e-3 * ((double)h[0] / h[1] * 1e8) / (n_mfma / 1024));
     hipFree(out);
@@ -95,6 +98,7 @@ int main() {
         run<2>("v_mfma_f32_16x16x32_f16", 2.0 * 16 * 16 * 32, w, 4000);
         run<3, 0>("32x32x16_f16 4 operand sets, ones", 2.0 * 32 * 32 * 16, w, 4000);
         run<3, 1>("32x32x16_f16 4 operand sets, random", 2.0 * 32 * 32 * 16, w, 4000);
+        run<4, 1>("32x32x16_f16 16 x 12 operand sets, random", 2.0 * 32 * 32 * 16, w, 4000);
     }
     return 0;
 }
