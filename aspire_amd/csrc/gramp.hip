@@ -45,6 +45,12 @@ constexpr int kMuSample = 4096;
 #ifndef GRAMP_SPREAD
 #define GRAMP_SPREAD 1   // 1: the LDS-DMA pieces of a stage go out one at a time between runs of MFMAs, 0: together behind the barrier
 #endif
+#ifndef GRAMP_GRP_SHIFT
+#define GRAMP_GRP_SHIFT 2   // ping-pong groups: bit of the wave index that tells the two waves of a SIMD apart
+#endif
+#ifndef GRAMP_PROBE
+#define GRAMP_PROBE 0   // timing probes of the ping-pong loop (wrong results): 1 no MFMAs, 2 no reads / LDS-DMA, 3 no LDS-DMA, 4 no reads
+#endif
 #ifndef GRAMP_PRE
 #define GRAMP_PRE 4      // MFMAs of a stage issued in front of the next stage's barrier
 #endif
@@ -131,8 +137,16 @@ __device__ __forceinline__ float4 ldrow4(const float* rows, int32_t row, int ofs
 //   256 x 256: eight waves of 64 x 128, one per CU -- a row is moved into LDS once per 256 rows of the other side: half the LDS-DMA
 //              bytes per product of the 128 x 128 form, which is what that form runs out of (16 KB per workgroup and stage through
 //              the CU's vector-memory path for 384 matrix-pipe cycles per SIMD), and two thirds of its fragment reads
-template <int BM, int BN, int RING, bool L2MAX>
+// PP (256 x 256 only): ping-pong.  The eight waves are two groups of four (waves w and w + 4 share a SIMD); every k block is two
+// segments with a workgroup barrier between segments, and group 1 runs ONE segment behind group 0 (it passes one extra barrier up
+// front): while one wave of a SIMD is in its load segment -- fragment reads of stage t out of LDS, its LDS-DMA pieces of stage
+// t + RING - 1 into the slot stage t - 1 has left, wait for both and for its pieces of stage t + 1 -- the other is in its MFMA
+// segment (24 MFMAs at raised priority, nothing else): the matrix pipe of a SIMD always has exactly one wave feeding it, without a
+// second fragment set or MFMAs threaded between loads.  (All waves in step -- the non-PP form of this tile -- leaves both waves of a
+// SIMD loading at the same time, then both competing for the pipe: 45 % busy.)
+template <int BM, int BN, int RING, bool L2MAX, bool PP = false>
 __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 128 ? 2 : 1) pair_gram_p_kernel(GramPArgs g) {
+    static_assert(!PP || (BM == 256 && BN == 256), "ping-pong: two groups of four waves");
     constexpr int NT = 2 * BM;                      // threads
     constexpr int TN = BN / 64;                     // 32-column blocks per wave
     constexpr int NB = 2 * BN / BM;                 // 1 KB pieces of the query tile per wave and k block (the candidate tile's: 2)
@@ -281,6 +295,49 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][PA[term]], f.b[j][PB[term]], acc[i][j], 0, 0, 0);
         }
     };
+    if constexpr (PP) {
+        const int grp = (wave >> GRAMP_GRP_SHIFT) & 1;
+        Frags& f = F[0];
+#pragma unroll
+        for (int st = 0; st < RING - 1; ++st) issue(st, st);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * kPerWave) : "memory");
+        __builtin_amdgcn_s_barrier();                  // everybody's pieces of stage 0 have landed
+        if (grp == 1) __builtin_amdgcn_s_barrier();    // the stagger: group 1 starts one segment late
+        asm volatile("" ::: "memory");
+        auto pp_step = [&](int t, auto slotc) {
+            constexpr int slot = decltype(slotc)::value;
+            // ---- load segment: stage t -> registers; the wave's pieces of stage t + RING - 1 into the slot of stage t - 1 (both
+            // groups read that one at least a segment ago and waited for the reads before their barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            if (GRAMP_PROBE != 2 && GRAMP_PROBE != 4) read_frags(f, slot);
+            if (GRAMP_PROBE != 2 && GRAMP_PROBE != 3 && t + RING - 1 < kKBlocks) issue((slot + RING - 1) % RING, t + RING - 1);
+            // reads done (the slot may be refilled by whoever passes the next barrier), own pieces of stage t + 1 landed: all
+            // but the younger stages' (RING - 2 of them, fewer at the end)
+            const int younger = kKBlocks - 2 - t < RING - 2 ? (kKBlocks - 2 - t < 0 ? 0 : kKBlocks - 2 - t) : RING - 2;
+            if (RING >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * kPerWave) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kPerWave) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- MFMA segment
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if (GRAMP_PROBE != 1) mma(f, 0, NMMA);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        static_assert(kKBlocks % RING == 0, "ring depth");
+#pragma unroll 1
+        for (int t = 0; t < kKBlocks; t += RING) {
+            pp_step(t, std::integral_constant<int, 0>{});
+            pp_step(t + 1, std::integral_constant<int, 1>{});
+            pp_step(t + 2, std::integral_constant<int, 2>{});
+            if constexpr (RING == 4) pp_step(t + 3, std::integral_constant<int, 3>{});
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();    // as many barriers as group 1
+    } else {
     constexpr int kPre = GRAMP_PRE;
 #pragma unroll
     for (int st = 0; st < RING; ++st) issue(st, st);
@@ -328,6 +385,7 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
 #pragma unroll 1
     for (int t = 0; t < kKBlocks; t += kUnroll) {
         unrolled_steps(step, t, std::make_integer_sequence<int, kUnroll>{}, std::integral_constant<int, RING>{});
+    }
     }
     __syncthreads();      // every wave is done with the ring: the epilogue's scratch lives there
 
@@ -627,7 +685,13 @@ int launch_pair_gram_planes(const ScoreArgs& a, const GramGeometry& geo, bool l2
     };
     const int form = geo.bm * 1000 + geo.bn;
     if (form == 256256) {
-        if (tuning().gram_ring == 4) {
+        if (tuning().gram_pp && tuning().gram_ring == 4) {
+            if (l2max) launch(pair_gram_p_kernel<256, 256, 4, true, true>, 256, 256, 4);
+            else launch(pair_gram_p_kernel<256, 256, 4, false, true>, 256, 256, 4);
+        } else if (tuning().gram_pp) {
+            if (l2max) launch(pair_gram_p_kernel<256, 256, 3, true, true>, 256, 256, 3);
+            else launch(pair_gram_p_kernel<256, 256, 3, false, true>, 256, 256, 3);
+        } else if (tuning().gram_ring == 4) {
             if (l2max) launch(pair_gram_p_kernel<256, 256, 4, true>, 256, 256, 4);
             else launch(pair_gram_p_kernel<256, 256, 4, false>, 256, 256, 4);
         } else {

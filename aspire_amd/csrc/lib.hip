@@ -60,6 +60,8 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         const int f = unset ? 0 : atoi(v);
         if (f != 0 && f != 128128 && f != 128256 && f != 256256) return false;
         t.gram_tile = f;
+    } else if (!strcmp(key, "GRAM_PP")) {
+        t.gram_pp = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "GRAM_RING")) {
         const int f = unset ? 0 : atoi(v);
         if (f != 0 && f != 3 && f != 4) return false;
@@ -98,6 +100,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "FUSED_WAVES")) v = number(t.fused_waves);
     else if (!strcmp(key, "GRAM_TILE")) v = number(t.gram_tile);
     else if (!strcmp(key, "GRAM_RING")) v = number(t.gram_ring);
+    else if (!strcmp(key, "GRAM_PP")) v = number(t.gram_pp);
     else if (!strcmp(key, "OT_FORM")) v = t.ot_form == 1 ? "small" : t.ot_form == 2 ? "tile" : t.ot_form == 3 ? "fused" : t.ot_form == 4 ? "chunk" : "";
     if (!v || strlen(v) + 1 > len) return false;
     strcpy(buf, v);
@@ -105,7 +108,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF", "GRAM_TILE", "GRAM_RING"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF", "GRAM_TILE", "GRAM_RING", "GRAM_PP"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

@@ -22,6 +22,7 @@ struct Tuning {
     int fused_nosolve = 0;   // ASPIRE_HIP_FUSED_NOSOLVE=1: the fused kernel's cost phase alone (timing experiments)
     int fused_noself = 0;    // ASPIRE_HIP_FUSED_NOSELF=1: batches of <= 64 jobs also take the tables launch + the table-driven kernel (A/B)
     int gram_tile = 0;       // ASPIRE_HIP_GRAM_TILE=128128 | 128256 | 256256: candidate x query rows per tile of the fp16-plane cost tiles (0: by shape)
+    int gram_pp = 0;         // ASPIRE_HIP_GRAM_PP=1: the 256 x 256 tiles in the ping-pong form (two wave groups a segment apart)
     int gram_ring = 0;       // ASPIRE_HIP_GRAM_RING=4: four-stage ring for the 256 x 256 tiles (default 3)
     int fused_waves = 0;     // ASPIRE_HIP_FUSED_WAVES: cap on the fused kernel's resident waves (0 = default; grid experiments)
 };

@@ -174,10 +174,11 @@ def test_pools_as_index_lists_share_the_store_planes(amd):
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize('tile', ['128256', '256256'])
-def test_wider_tile_forms_give_the_same_scores(amd, tile):
-    """GRAM_TILE pins the 128 x 256 / 256 x 256 tiles (wider wave tiles, one or two workgroups per CU; kept for A/B runs):
-    same products in the same order per entry, so max-sim is the same bits; ragged documents and tail tiles included"""
+@pytest.mark.parametrize('tile,pp', [('128256', ''), ('256256', ''), ('256256', '1')])
+def test_wider_tile_forms_give_the_same_scores(amd, tile, pp):
+    """GRAM_TILE pins the 128 x 256 / 256 x 256 tiles (wider wave tiles, one or two workgroups per CU), GRAM_PP the ping-pong
+    schedule of the 256 x 256 form -- kept for A/B runs, none beats the 128 x 128 default (NOTES.md, round 4): the same
+    products in the same order per entry, so the same bits; ragged documents and tail tiles included"""
     from aspire_amd._lib import pinned
     qd = _docs(61, np.random.RandomState(3).randint(1, 13, size=50))
     cd = _docs(62, np.random.RandomState(4).randint(1, 13, size=700))
@@ -185,7 +186,7 @@ def test_wider_tile_forms_give_the_same_scores(amd, tile):
     with pinned(COST_PATH='mfma'):
         a = amd.ops.l2max_scores(q, c).cpu().numpy()
         ot_a = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
-        with pinned(GRAM_TILE=tile):
+        with pinned(GRAM_TILE=tile, GRAM_PP=pp):
             b = amd.ops.l2max_scores(q, c).cpu().numpy()
             ot_b = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
     assert np.array_equal(a, b)
