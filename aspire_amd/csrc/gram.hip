@@ -697,6 +697,19 @@ int launch_gram(const GramArgs& g, int bn, hipStream_t stream) {
 
 // The matrix-core form serves CSR inputs (no padded extents) scored all-against-all, once the query side fills
 // a useful part of an MFMA tile or documents are longer than the 8-row VALU tile.
+// Max-sim on the fp16-plane tiles whatever the number of queries: both rep sets carry planes around one centre, the pool fills the
+// chip (>= 128 candidate tiles), and it is not the one case the streaming kernel wins (ONE query of <= 8 rows against documents of
+// <= 8: the fused kernel's max-sim form reads each row once at 6 TB/s and has no wasted columns -- 81 against 95 us at 1 x 20 000 x 8)
+bool gram_planes_wanted_l2max(const aspire_repset* q, const aspire_repset* c, int pairing) {
+    if (pairing != ASPIRE_PAIR_CROSS || q->ext != 0 || c->ext != 0 || !q->planes || !c->planes) return false;
+    if (q->max_len <= 0 || c->max_len <= 0 || q->max_len > 32 || c->max_len > 32) return false;
+    if (tuning().cost_path == 2 || tuning().gemm_form == 1 || tuning().gemm_form == 2) return false;
+    if (q->planes->mu != c->planes->mu || !q->planes->planes || !c->planes->planes) return false;
+    const int64_t tiles = (c->n + kBM / slot_rows(c->max_len) - 1) / (kBM / slot_rows(c->max_len));
+    if (tiles < 128) return false;
+    return !(q->n == 1 && q->max_len <= 8 && c->max_len <= 8);
+}
+
 bool gram_path_wanted(const aspire_repset* q, const aspire_repset* c, int pairing) {
     if (pairing != ASPIRE_PAIR_CROSS || q->ext != 0 || c->ext != 0) return false;
     if (q->max_len <= 0 || c->max_len <= 0 || q->max_len > 32 || c->max_len > 32) return false;
@@ -760,7 +773,9 @@ int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t s
     if (int rc = fill_geometry(g, b, mr_q, mr_c, bn)) return rc;
     g.scores = a.scores;
     g.center = a.center;
-    if (bn == 128 && gram_planes_ok(b)) return launch_pair_gram_planes(b, planes_geometry(g), true, nullptr, nullptr, stream);
+    // (with few query rows too: most of the 128 query columns of a tile are then zero rows, and the tiles still run at the rate the
+    // candidate planes stream in -- 1 x 20 000 x 12: 137 us = 5.4 TB/s against 192 on the 16-row streaming kernel)
+    if (gram_planes_ok(b)) return launch_pair_gram_planes(b, planes_geometry(g), true, nullptr, nullptr, stream);
     return launch_gram<true>(g, bn, stream);
 }
 

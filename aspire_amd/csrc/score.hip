@@ -2092,6 +2092,9 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     a.center = center;
     if (one_form)      // every pair through the long-form kernel, whatever the size of the call (include/aspire_hip.h)
         return launch_pair_generic(a, 1, 0, q->ext > 0 ? q->ext : q->max_len, c->ext > 0 ? c->ext : c->max_len, (hipStream_t)stream);
+    // both sides carry fp16 planes: the matrix-pipe tiles (gramp.hip) whatever the number of queries
+    if (agg == ASPIRE_AGG_MAX && !pair_sims && gram_planes_wanted_l2max(q, c, pairing))
+        return launch_pair_gram_l2max(a, q->max_len, c->max_len, (hipStream_t)stream);
     // ONE query against a big pool of 9 .. 16-row documents: the streaming kernel's max-sim form (tile16.hip)
     if (agg == ASPIRE_AGG_MAX && !pair_sims && q->n == 1 && c->n >= 4096 && tile16_path_ok(q, c, pairing) &&
         pairing == ASPIRE_PAIR_CROSS && tuning().cost_path != 1 && tuning().ot_form != 1) {

@@ -47,10 +47,13 @@ def set_center_hint(mode):
 
 
 def _match_planes(q, c, pairing):
-    """A many-query all-against-all call on a pool that carries fp16 planes (DeviceRepSet.prepare_planes): the queries get
+    """An all-against-all call on a big pool that carries fp16 planes (DeviceRepSet.prepare_planes): the queries get
     theirs, around the pool's centre, unless they are rows of the same matrix already (then nothing happens) or carry planes of
     another store (left alone: the call takes the kernels that read the fp32 rows).  ~10 us for 256 query rows."""
-    if pairing != _lib.PAIR_CROSS or c.planes is None or q.ext or c.ext or q.n * max(8, (q.max_len + 3) // 4 * 4) <= 64:
+    if pairing != _lib.PAIR_CROSS or c.planes is None or q.ext or c.ext:
+        return
+    slot = max(8, (c.max_len + 3) // 4 * 4)
+    if c.n * slot < 128 * 128 or max(q.max_len, c.max_len) > 32:          # fewer than 128 candidate tiles: the small-pool kernels
         return
     if q.planes is None:
         q.prepare_planes(like=c)

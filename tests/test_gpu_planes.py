@@ -140,7 +140,7 @@ def test_without_planes_or_with_another_centre_the_fp32_forms_run(amd):
     """the fallback: a rep set without planes, or one prepared around another vector, takes the kernels that read the fp32
     rows -- same scores to rounding, never an error"""
     from aspire_amd._lib import pinned
-    qd, cd = _docs(41, [8] * 16), _docs(42, [8] * 300)
+    qd, cd = _docs(41, [8] * 16), _docs(42, [8] * 2100)          # 131 candidate tiles: a pool the plane tiles are used on
     q, c = _with_planes(amd, qd, cd)
     with pinned(COST_PATH='mfma'):
         a = amd.ops.l2max_scores(q, c).cpu().numpy()
@@ -191,3 +191,23 @@ def test_wider_tile_forms_give_the_same_scores(amd, tile, pp):
             ot_b = amd.ops.ot_sinkhorn(q, c).cpu().numpy()
     assert np.array_equal(a, b)
     assert np.array_equal(ot_a, ot_b)
+
+
+@pytest.mark.parametrize('nq,s', [(1, 12), (4, 8), (2, 20), (1, 32)])
+def test_few_queries_on_a_big_plane_pool_take_the_plane_tiles(amd, nq, s):
+    """max-sim with both sides on planes runs on the matrix-pipe tiles whatever the number of queries (most query columns of a
+    tile are then zero rows): ragged documents, against float64 and against the streaming kernels that read the fp32 rows"""
+    g = torch.Generator().manual_seed(100 * nq + s)
+    nc = 128 * 128 // (((s + 3) // 4) * 4) + 37
+    cd = [torch.randn(int(n), 768, generator=g) for n in torch.randint(1, s + 1, (nc,), generator=g)]
+    qd = [torch.randn(int(n), 768, generator=g) for n in torch.randint(max(1, s - 3), s + 1, (nq,), generator=g)]
+    c = _set(amd, cd).prepare_planes()
+    q = _set(amd, qd)
+    got = amd.ops.l2max_scores(q, c).view(nq, nc).cpu().numpy()
+    assert q.planes is not None                                   # ops gave the queries the pool's centre
+    ref = amd.ops.l2max_scores(_set(amd, qd), _set(amd, cd)).view(nq, nc).cpu().numpy()
+    assert not np.array_equal(got, ref)                           # another kernel ran
+    np.testing.assert_allclose(got, ref, atol=5e-5, rtol=0)
+    for ci in (0, 17, nc - 1):
+        want = -torch.cdist(qd[0].double(), cd[ci].double()).min().item()
+        assert abs(got[0, ci] - want) < 2e-5

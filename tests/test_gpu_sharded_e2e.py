@@ -94,7 +94,7 @@ def test_many_queries_on_plane_shards_equal_the_plane_store_bit_for_bit(tmp_path
     import torch.multiprocessing as mp
     world = 2
     g = torch.Generator().manual_seed(9)
-    docs = [torch.randn(int(n), 768, generator=g) + 0.7 for n in torch.randint(1, 9, (4000,), generator=g)]
+    docs = [torch.randn(int(n), 768, generator=g) + 0.7 for n in torch.randint(1, 9, (9000,), generator=g)]          # each shard well beyond 128 candidate tiles
     queries = [torch.randn(8, 768, generator=g) + 0.7 for _ in range(40)]
     torch.save({'docs': docs, 'queries': queries}, os.path.join(str(tmp_path), 'in.pt'))
     mp.spawn(_plane_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
