@@ -75,6 +75,10 @@ class AspireConSent:
         tok_idx, span_off = spans_to_csr(batch_senttok_idxs, max_sents)
         dev = final_hidden_state.device
         doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
+        if not bool(torch.isfinite(sent_reps).all()):
+            # an activation beyond the fp16 planes' range (encoder.py: forward_full_range): once more on the full-range kernels
+            final_hidden_state = self.bert_encoder.forward_full_range(tokid_tt, seg_tt, attnmask_tt)
+            doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
         # the reference squeezes and re-unsqueezes (:76, :46-49): shapes are [B,768] and [B,S,768] for every B.
         return doc_cls_reps.to(out_dev), sent_reps.to(out_dev)
 
@@ -134,7 +138,7 @@ class AspireConSent:
         flush()
         return out
 
-    def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64, planes=False):
+    def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64, planes=False, _full_range=False):
         """Encode document batches straight into a resident candidate pool.
 
         batches: iterable of (bert_batch, abs_lens, sent_tok_idxs) as prepare_abstracts returns them (it is consumed
@@ -201,6 +205,15 @@ class AspireConSent:
                                                           attention_mask=bert_batch['attnmask_tt'], check_ids=False)
                 ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows,
                                         cls_all[d0:d0 + b] if want_cls else None)
+        if total and not bool(torch.isfinite(rows).all()) and not _full_range:
+            # an activation left the fp16 planes' range somewhere (one check over the finished store): encode again on the kernels
+            # that take any fp32 value
+            from ._lib import pinned
+            import warnings
+            warnings.warn('AspireConSent.encode_to_pool: non-finite sentence reps on the fp16-plane encoder path; encoding again with '
+                          'ASPIRE_HIP_GEMM=bf16x3, ASPIRE_HIP_ATTN=f32')
+            with pinned(GEMM='bf16x3', ATTN='f32'):
+                return self.encode_to_pool(batches, pids=pids, want_cls=want_cls, docs_per_forward=None, planes=planes, _full_range=True)
         repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0,
                                   lens_host=all_lens)
         pool = CandidatePool.from_repset(repset, pids=pids)

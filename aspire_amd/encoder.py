@@ -73,6 +73,15 @@ class HipBertEncoder:
     def eval(self):
         return self
 
+    def forward_full_range(self, tokid_tt, token_type_ids=None, attention_mask=None):
+        """The forward on the kernels that take ANY fp32 activation: GEMM operands split into three bf16 planes on the fly, attention
+        on the fp32-input MFMA.  The default path keeps activations as two fp16 planes (|x| <= 65504: far above what BERT-base
+        checkpoints produce, but a fine-tuned model with an outlier feature beyond it turns into inf there); callers that find
+        non-finite hidden states (AspireConSent.forward / encode_to_pool check what they hand out) come here."""
+        from ._lib import pinned
+        with pinned(GEMM='bf16x3', ATTN='f32'):
+            return self.forward_hidden(tokid_tt, token_type_ids, attention_mask, check_ids=False)
+
     def forward_hidden(self, tokid_tt, token_type_ids=None, attention_mask=None, check_ids=True):
         """int64 [B, L] tensors (any device) -> last_hidden_state [B, L, 768] on the GPU.  check_ids=False: the caller has
         validated the token ids already (encode_to_pool checks all its batches with one device round trip)."""

@@ -78,6 +78,20 @@ class PoolBatch:
         self._out = {}          # (k, key_form) -> preallocated outputs + workspace of the last call with that k
 
 
+_WORKSPACE = {}
+
+
+def _shared_workspace(dev, nbytes):
+    """ONE grow-only scratch buffer per device for the batched score + rank calls of this module: they run on the caller's stream
+    and hand their results to the host before they return, so consecutive calls can share it (a cached PoolBatch used to keep
+    its own -- slot_bytes x candidates, ~8 KB per candidate at 32 rows -- for as long as the RepStore cached the batch)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _WORKSPACE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WORKSPACE[key] = torch.empty(max(int(nbytes), 16), device=dev, dtype=torch.uint8)
+    return ws
+
+
 def rank_pool_batch(query_reps_list, batch, k=None, hparams=None, method='ot', deterministic=False, sign=1.0):
     """rank_pools on a prepared PoolBatch (RepStore.pool_batch): ONE upload of the queries (rows + index list), one library call,
     two small downloads.  Returns per query [(pid, sign * score), ...] as rank_pools does (evaluate.py:77 stores -similarity:
@@ -104,14 +118,13 @@ def rank_pool_batch(query_reps_list, batch, k=None, hparams=None, method='ot', d
     if slot is None:
         slot = batch._out[(k, method)] = {
             'out': (torch.empty(batch.c.n, device=dev), torch.empty(j, k, device=dev), torch.empty(j, k, device=dev, dtype=torch.int64)),
-            'ws': None}
+            }
     # the workspace depends on the QUERIES too (longest document of the call: slot size, record count): asked for on every call
     # -- a host-side computation -- and grown when another facet's queries need more than the last call's
     qs, cs = q.struct(), batch.c.struct()
     need = (_lib.lib.aspire_l2max_rank_batch_workspace_bytes if method == 'l2max' else _lib.lib.aspire_ot_rank_batch_workspace_bytes)(
         ctypes.byref(qs), ctypes.byref(cs), batch.max_job, k)
-    if slot['ws'] is None or slot['ws'].numel() < need:
-        slot['ws'] = torch.empty(max(need, 16), device=dev, dtype=torch.uint8)
+    slot['ws'] = _shared_workspace(dev, need)
     if method == 'l2max':
         _, top_s, top_i = ops.l2max_rank_batch(q, batch.c, batch.job_off, batch.max_job, k, out=slot['out'], workspace=slot['ws'],
                                                one_form=deterministic)
@@ -209,9 +222,12 @@ def _score_run(q, c, method, schedule, hparams, score_batch_size, cdist_mode, de
             # entry would take the Gram tiles + a Sinkhorn launch, built for many queries)
             dev = c.rows.device
             cc = ops.DeviceRepSet(c.rows, c.start.repeat(q.n), c.len.repeat(q.n), ext=0, max_len=c.max_len)
-            job_off = (torch.arange(q.n + 1, dtype=torch.int64) * c.n).to(torch.int32).to(dev)
-            sims, _, _ = ops.ot_rank_batch(q, cc, job_off, c.n, 0, want=_lib.OT_SIMILARITY, **kw)
-            return sims.view(q.n, c.n)
+            qs, cs = q.struct(), cc.struct()
+            need = _lib.lib.aspire_ot_rank_batch_workspace_bytes(ctypes.byref(qs), ctypes.byref(cs), c.n, 0)
+            if need <= (1 << 30):      # (the batched entry reserves pair slots for EVERY candidate: beyond 1 GiB the chunked path below)
+                job_off = (torch.arange(q.n + 1, dtype=torch.int64) * c.n).to(torch.int32).to(dev)
+                sims, _, _ = ops.ot_rank_batch(q, cc, job_off, c.n, 0, want=_lib.OT_SIMILARITY, workspace=_shared_workspace(dev, need), **kw)
+                return sims.view(q.n, c.n)
         dist = ops.ot_sinkhorn(q, c, pairing=_lib.PAIR_CROSS, want=_lib.OT_DISTANCE, one_form=deterministic, **kw)
         return (-dist).view(q.n, c.n)
     diam = ops.group_diameter(q, c, _lib.PAIR_CROSS, group=score_batch_size)

@@ -659,7 +659,7 @@ def main():
             out['roofline']['sinkhorn'] = {k: {f: v[f] for f in ('what', 'kernel', 'ns_per_pair', 'valu_wave_instructions_per_pair', 'bound',
                                                                   'achieved_frac', 'issue_floor_us', 'kernel_us_per_call', 'algorithmic_floor') if f in v}
                                            for k, v in sj.items() if isinstance(v, dict)}
-            out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r3.sh)'
+            out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r4.sh)'
         if rccl is not None:
             out['rccl'] = rccl
             if e2e_ranks is not None:

@@ -325,3 +325,42 @@ def test_state_dict_with_the_bert_prefix():
         want = full.bert(tok, token_type_ids=torch.zeros_like(tok), attention_mask=torch.ones_like(tok)).last_hidden_state
     got = enc.forward_hidden(tok, torch.zeros_like(tok), torch.ones_like(tok)).cpu()
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-4, rtol=0)
+
+
+def test_activation_beyond_the_fp16_planes_falls_back_to_the_full_range_kernels():
+    """the default encoder path keeps activations as two fp16 planes (|x| <= 65504).  A checkpoint with an outlier
+    feature beyond that -- here one channel of the embedding LayerNorm scaled by 2e5, its input weights scaled down so that the
+    layer stays well conditioned -- produces inf on that path; AspireConSent.forward notices the non-finite reps and runs the
+    forward again on the kernels that take any fp32 value (bf16x3 GEMMs, fp32-input attention), which match HF"""
+    from transformers import BertConfig, BertModel
+    from aspire_amd import AspireConSent
+    torch.manual_seed(11)
+    cfg = BertConfig(vocab_size=400, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                     max_position_embeddings=64)
+    m = BertModel(cfg, add_pooling_layer=False).eval()
+    ch = 5
+    with torch.no_grad():
+        m.embeddings.LayerNorm.weight[ch] = 2e5
+        lyr = m.encoder.layer[0]
+        for lin in (lyr.attention.self.query, lyr.attention.self.key, lyr.attention.self.value, lyr.intermediate.dense):
+            lin.weight[:, ch] *= 1e-5
+    model = AspireConSent(bert_model=m)
+    tok = torch.randint(0, 400, (4, 32), generator=torch.Generator().manual_seed(12))
+    mask = torch.ones_like(tok)
+    hidden_default = model.bert_encoder.forward_hidden(tok, torch.zeros_like(tok), mask)
+    assert not bool(torch.isfinite(hidden_default).all())            # the fp16-plane path does overflow on this model
+    with torch.no_grad():
+        want = m(tok, token_type_ids=torch.zeros_like(tok), attention_mask=mask).last_hidden_state
+    full = model.bert_encoder.forward_full_range(tok, torch.zeros_like(tok), mask).cpu()
+    scale = float(want.abs().max())
+    assert torch.isfinite(full).all() and float((full - want).abs().max()) < 2e-5 * scale
+    bert_batch = {'tokid_tt': tok, 'seg_tt': torch.zeros_like(tok), 'attnmask_tt': mask, 'seq_lens': [32] * 4}
+    idxs = [[list(range(1, 12)), list(range(12, 31))]] * 4
+    cls, sent = model.forward(bert_batch, [2] * 4, idxs)
+    assert torch.isfinite(sent).all() and torch.isfinite(cls).all()
+    np.testing.assert_allclose(sent[1, 1].numpy(), want[1, 12:31].mean(0).numpy(), atol=2e-5 * scale, rtol=0)
+    with pytest.warns(UserWarning, match='non-finite'):
+        pool = model.encode_to_pool([(bert_batch, [2] * 4, idxs)])
+    rows = pool.repset.rows.cpu()
+    assert torch.isfinite(rows).all()
+    np.testing.assert_allclose(rows[3].numpy(), want[1, 12:31].mean(0).numpy(), atol=2e-5 * scale, rtol=0)

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from aspire_amd import ops
 J, NC, S = 20, 1000, 8
