@@ -40,8 +40,8 @@ def test_size_limits(amd):
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
     with pytest.raises(NotImplementedError):      # beyond the long-document kernel's 128 rows
         amd.scorer.score_pool([q], _docs(5, [129]), method='ot')
-    with pytest.raises(NotImplementedError):      # the sibling aggregations stop at the tile kernels' 32 rows
-        amd.scorer.score_pool(_docs(6, [40]), c, method='l2top2')
+    with pytest.raises(NotImplementedError):      # the sibling aggregations share that limit (33 .. 128 rows: tests/test_gpu_siblings.py)
+        amd.scorer.score_pool(_docs(6, [129]), c, method='l2top2')
     with pytest.raises(AssertionError):      # encoding dim != 768
         amd.ops.DeviceRepSet.from_list([torch.zeros(3, 512)])
 
