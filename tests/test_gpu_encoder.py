@@ -336,7 +336,7 @@ def test_activation_beyond_the_fp16_planes_falls_back_to_the_full_range_kernels(
     from aspire_amd import AspireConSent
     torch.manual_seed(11)
     cfg = BertConfig(vocab_size=400, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
-                     max_position_embeddings=64)
+                     max_position_embeddings=128)
     m = BertModel(cfg, add_pooling_layer=False).eval()
     ch = 5
     with torch.no_grad():
@@ -345,7 +345,7 @@ def test_activation_beyond_the_fp16_planes_falls_back_to_the_full_range_kernels(
         for lin in (lyr.attention.self.query, lyr.attention.self.key, lyr.attention.self.value, lyr.intermediate.dense):
             lin.weight[:, ch] *= 1e-5
     model = AspireConSent(bert_model=m)
-    tok = torch.randint(0, 400, (4, 32), generator=torch.Generator().manual_seed(12))
+    tok = torch.randint(0, 400, (8, 128), generator=torch.Generator().manual_seed(12))      # 1024 token rows: the fp16-plane GEMMs
     mask = torch.ones_like(tok)
     hidden_default = model.bert_encoder.forward_hidden(tok, torch.zeros_like(tok), mask)
     assert not bool(torch.isfinite(hidden_default).all())            # the fp16-plane path does overflow on this model
@@ -354,13 +354,13 @@ def test_activation_beyond_the_fp16_planes_falls_back_to_the_full_range_kernels(
     full = model.bert_encoder.forward_full_range(tok, torch.zeros_like(tok), mask).cpu()
     scale = float(want.abs().max())
     assert torch.isfinite(full).all() and float((full - want).abs().max()) < 2e-5 * scale
-    bert_batch = {'tokid_tt': tok, 'seg_tt': torch.zeros_like(tok), 'attnmask_tt': mask, 'seq_lens': [32] * 4}
-    idxs = [[list(range(1, 12)), list(range(12, 31))]] * 4
-    cls, sent = model.forward(bert_batch, [2] * 4, idxs)
+    bert_batch = {'tokid_tt': tok, 'seg_tt': torch.zeros_like(tok), 'attnmask_tt': mask, 'seq_lens': [128] * 8}
+    idxs = [[list(range(1, 12)), list(range(12, 31))]] * 8
+    cls, sent = model.forward(bert_batch, [2] * 8, idxs)
     assert torch.isfinite(sent).all() and torch.isfinite(cls).all()
     np.testing.assert_allclose(sent[1, 1].numpy(), want[1, 12:31].mean(0).numpy(), atol=2e-5 * scale, rtol=0)
     with pytest.warns(UserWarning, match='non-finite'):
-        pool = model.encode_to_pool([(bert_batch, [2] * 4, idxs)])
+        pool = model.encode_to_pool([(bert_batch, [2] * 8, idxs)])
     rows = pool.repset.rows.cpu()
     assert torch.isfinite(rows).all()
     np.testing.assert_allclose(rows[3].numpy(), want[1, 12:31].mean(0).numpy(), atol=2e-5 * scale, rtol=0)
