@@ -38,7 +38,7 @@ class RepPlanes(ctypes.Structure):
 class RepSet(ctypes.Structure):
     """struct aspire_repset"""
     _fields_ = [('rows', c_void_p), ('start', c_void_p), ('len', c_void_p), ('n', c_int64),
-                ('ext', c_int32), ('max_len', c_int32), ('planes', ctypes.POINTER(RepPlanes))]
+                ('ext', c_int32), ('max_len', c_int32), ('planes', ctypes.POINTER(RepPlanes)), ('doc_box', c_void_p)]
 
 
 class OtParams(ctypes.Structure):
@@ -83,6 +83,7 @@ SIGNATURES = {
     'aspire_rep_planes_bytes': (c_size_t, [c_int64]),
     'aspire_rep_planes_prepare': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, ctypes.POINTER(RepPlanes),
                                           c_void_p]),
+    'aspire_repset_boxes_f32': (c_int, [ctypes.POINTER(RepSet), c_int64, c_void_p, c_void_p]),
     'aspire_l2max_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
     'aspire_l2agg_scores_f32': (c_int, [ctypes.POINTER(RepSet), ctypes.POINTER(RepSet), c_int64, c_int, c_int, c_int,

@@ -755,8 +755,12 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
         if (int rc = launch_pair_gram_planes(a, planes_geometry(g), false, cost, neg, stream)) return rc;
     } else if (int rc = launch_gram<false>(g, bn, stream)) return rc;
     if (diam2) {
-        hipLaunchKernelGGL(doc_box_range_kernel, dim3(g.ncand), dim3(192), 0, stream, a.c, a.cand0, cbox);
-        ASPIRE_LAUNCH_OK();
+        if (a.c_box) {        // a resident pool brought its documents' boxes along (aspire_repset.doc_box)
+            cbox = const_cast<float*>(a.c_box) + (size_t)a.cand0 * 2 * kD;
+        } else {
+            hipLaunchKernelGGL(doc_box_range_kernel, dim3(g.ncand), dim3(192), 0, stream, a.c, a.cand0, cbox);
+            ASPIRE_LAUNCH_OK();
+        }
         hipLaunchKernelGGL(pair_box_kernel, dim3((g.ncand + 31) / 32, (g.nq + 31) / 32), dim3(256), 0, stream, qbox, cbox,
                            g.nq, g.ncand, diam2);
         ASPIRE_LAUNCH_OK();
@@ -780,3 +784,15 @@ int launch_pair_gram_l2max(const ScoreArgs& a, int mr_q, int mr_c, hipStream_t s
 }
 
 }  // namespace aspire
+
+extern "C" int aspire_repset_boxes_f32(const aspire_repset* set, int64_t D, float* boxes, void* stream) {
+    using namespace aspire;
+    ASPIRE_REQUIRE(set && (boxes || set->n == 0), ASPIRE_ERR_INVALID_ARG, "null argument");
+    ASPIRE_REQUIRE(D == kD, ASPIRE_ERR_UNSUPPORTED, "encoding dim must be %d", kD);
+    if (set->n == 0) return ASPIRE_OK;
+    ASPIRE_REQUIRE(set->n < ((int64_t)1 << 31), ASPIRE_ERR_UNSUPPORTED, "too many documents for one launch");
+    const RepSet d{set->rows, set->start, set->len, set->n, set->ext};
+    hipLaunchKernelGGL(doc_box_range_kernel, dim3((unsigned)set->n), dim3(192), 0, (hipStream_t)stream, d, (int64_t)0, boxes);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}

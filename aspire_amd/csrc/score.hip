@@ -2082,6 +2082,7 @@ extern "C" int aspire_l2agg_scores_f32(const aspire_repset* q, const aspire_reps
     a.c = to_dev(c);
     a.q_planes = q->planes;
     a.c_planes = c->planes;
+    a.c_box = c->doc_box;
     a.pairing = pairing;
     a.cdist_mode = cdist_mode;
     a.agg = agg;
@@ -2191,6 +2192,7 @@ void fill_ot_args(ScoreArgs& a, const aspire_repset* q, const aspire_repset* c, 
     a.c = to_dev(c);
     a.q_planes = q->planes;
     a.c_planes = c->planes;
+    a.c_box = c->doc_box;
     a.pairing = pairing;
     a.cdist_mode = prm->cdist_mode;
     a.blur = prm->blur;
@@ -3074,6 +3076,7 @@ extern "C" int aspire_l2max_rank_batch_f32(const aspire_repset* q, const aspire_
     a.c = to_dev(c);
     a.q_planes = q->planes;
     a.c_planes = c->planes;
+    a.c_box = c->doc_box;
     a.pairing = kPairMapped;
     a.cdist_mode = cdist_mode;
     a.center = center;
@@ -3196,6 +3199,7 @@ extern "C" int aspire_group_diameter_f32(const aspire_repset* q, const aspire_re
     a.c = to_dev(c);
     a.q_planes = q->planes;
     a.c_planes = c->planes;
+    a.c_box = c->doc_box;
     a.pairing = pairing;
     const int64_t ngroups = (c->n + group - 1) / group;
     const int64_t blocks = pairing == ASPIRE_PAIR_PAIRED ? ngroups : ngroups * q->n;     // (query, group) folded into grid.x

@@ -26,6 +26,7 @@ struct ScoreArgs {
     // gramp.hip read them, no kernel does
     const aspire_rep_planes* q_planes;
     const aspire_rep_planes* c_planes;
+    const float* c_box;      // the candidates' cached per-document boxes (aspire_repset.doc_box: device [c.n][2][768]) or null
     const float* diameter;
     int64_t diam_group;
     int64_t n_groups;

@@ -123,11 +123,25 @@ class DeviceRepSet:
     def struct(self):
         planes = getattr(self.rows, '_aspire_planes', None)      # kept on the matrix: index lists and slices of it share them
         return RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len,
-                      ctypes.pointer(planes.c) if planes is not None else None)
+                      ctypes.pointer(planes.c) if planes is not None else None, _ptr(getattr(self, 'doc_box', None)))
+
+    def prepare_boxes(self):
+        """The documents' per-coordinate bounding boxes [n, 2, 768], kept with this rep set (include/aspire_hip.h:
+        aspire_repset.doc_box): the many-query otAspire calls on a resident pool then skip their pass over every candidate row
+        (geomloss's diameter).  6 KB per document.  Returns self."""
+        if self.n and getattr(self, 'doc_box', None) is None:
+            box = torch.empty(self.n, 2, D, device=self.rows.device, dtype=torch.float32)
+            s = RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len, None, None)
+            check(lib.aspire_repset_boxes_f32(ctypes.byref(s), D, _ptr(box), _stream()))
+            self.doc_box = box
+        return self
 
     def slice(self, lo, hi):
-        return DeviceRepSet(self.rows, self.start[lo:hi].contiguous(), self.len[lo:hi].contiguous(), self.ext,
-                            self.max_len, lens_host=self.lens_host[lo:hi] if self.lens_host is not None else None)
+        r = DeviceRepSet(self.rows, self.start[lo:hi].contiguous(), self.len[lo:hi].contiguous(), self.ext,
+                         self.max_len, lens_host=self.lens_host[lo:hi] if self.lens_host is not None else None)
+        if getattr(self, 'doc_box', None) is not None:
+            r.doc_box = self.doc_box[lo:hi]
+        return r
 
     @property
     def planes(self):

@@ -46,6 +46,7 @@ class CandidatePool:
         32 queries x 50 000 candidates max-sim 1.08 -> 0.49 ms.  Once per resident pool; 4 B per element more HBM.
         mu: the common vector to centre on (a [768] GPU tensor); default: the mean of a sample of the pool's rows."""
         self.repset.prepare_planes(mu=mu)
+        self.repset.prepare_boxes()          # + the documents' boxes (geomloss's diameter in the many-query otAspire calls): 6 KB each
         return self
 
 

@@ -184,7 +184,15 @@ typedef struct {
     int32_t max_len;
     /* optional (NULL): fp16 planes of `rows` (aspire_rep_planes above; a HOST pointer, read during the call) */
     const aspire_rep_planes* planes;
+    /* optional (NULL): the documents' per-coordinate bounding boxes, device [n][2][D] (min row, max row), as
+     * aspire_repset_boxes_f32 forms them.  geomloss's epsilon schedule starts at the diameter of the two documents' joint box;
+     * the many-query otAspire calls form every candidate's box per call (a pass over all its rows) unless a resident pool
+     * brings them along. */
+    const float* doc_box;
 } aspire_repset;
+
+/* boxes [n][2][D] of the documents of `set` (len[] >= 1): boxes[k][0] = per-coordinate minimum over document k's rows, [k][1] = maximum */
+int aspire_repset_boxes_f32(const aspire_repset* set, int64_t D, float* boxes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A9  tsAspire max-sim.  Replaces allpair_masked_dist_l2max,

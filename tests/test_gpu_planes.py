@@ -211,3 +211,27 @@ def test_few_queries_on_a_big_plane_pool_take_the_plane_tiles(amd, nq, s):
     for ci in (0, 17, nc - 1):
         want = -torch.cdist(qd[0].double(), cd[ci].double()).min().item()
         assert abs(got[0, ci] - want) < 2e-5
+
+
+def test_cached_document_boxes_give_the_same_ot_scores(amd):
+    """aspire_repset.doc_box: a resident pool's per-document boxes, formed once (CandidatePool.prepare_planes does) instead of per
+    call -- the same values, so the many-query otAspire scores are the same bits; the boxes themselves against torch"""
+    from aspire_amd._lib import pinned
+    g = torch.Generator().manual_seed(21)
+    cd = [torch.randn(int(n), 768, generator=g) for n in torch.randint(1, 13, (2000,), generator=g)]
+    qd = [torch.randn(int(n), 768, generator=g) for n in torch.randint(1, 13, (30,), generator=g)]
+    c = _set(amd, cd).prepare_planes()
+    q = _set(amd, qd)
+    with pinned(COST_PATH='mfma'):
+        a = amd.ops.ot_sinkhorn(q, c).cpu()
+        c.prepare_boxes()
+        box = c.doc_box.cpu()
+        b = amd.ops.ot_sinkhorn(q, c).cpu()
+        tail = amd.ops.ot_sinkhorn(q, c.slice(1500, 2000)).cpu()
+    for k in (0, 7, 1999):
+        assert torch.equal(box[k, 0], cd[k].min(0).values) and torch.equal(box[k, 1], cd[k].max(0).values)
+    assert torch.equal(a, b)
+    # a slice of the pool takes its slice of the boxes (another grid size: another Sinkhorn layout, so to rounding)
+    np.testing.assert_allclose(tail.view(30, 500).numpy(), b.view(30, 2000)[:, 1500:].numpy(), atol=5e-5, rtol=0)
+    want = np.array([[orc.get_similarity(qd[i], cd[j]) for j in (0, 1999)] for i in (0, 29)], dtype=np.float32)
+    np.testing.assert_allclose(-b.view(30, 2000)[[0, 29]][:, [0, 1999]].numpy(), want, atol=TOL, rtol=0)

@@ -18,6 +18,7 @@ def main():
     res = {}
     for name, form in (('bf16x3 (fp32 rows)', 'bf16x3'), ('fp16 planes', '')):
         if form == '':
+            c.prepare_boxes()
             us = timeit(lambda: c.prepare_planes(), n=5, warm=1)
             print(f'prepare_planes({C * S} rows): {us:9.1f} us')
             us = timeit(lambda: q.prepare_planes(like=c), n=20, warm=2)
