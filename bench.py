@@ -545,9 +545,14 @@ def main():
         # config 5's flow on every rank (outside the timed headline)
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import e2ebench
-        mine = e2ebench.run_sharded(rank, world, n_docs=int(os.environ.get('ASPIRE_BENCH_E2E_DOCS', '8192')))
+        try:
+            mine = e2ebench.run_sharded(rank, world, n_docs=int(os.environ.get('ASPIRE_BENCH_E2E_DOCS', '8192')))
+        except Exception as e:          # a side measurement: it must not take the headline line with it
+            mine = {'rank': rank, 'error': repr(e)}
         e2e_ranks = [None] * world
         dist.all_gather_object(e2e_ranks, mine)
+        if any('error' in r for r in e2e_ranks):
+            e2e_ranks = {'errors': [r for r in e2e_ranks if 'error' in r]}
     out = None
     if rank == 0:
         # ---- per-stage kernel durations, live: HIP events on the launch stream around launches of ONE stage alone, on the
@@ -662,7 +667,9 @@ def main():
             out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r4.sh)'
         if rccl is not None:
             out['rccl'] = rccl
-            if e2e_ranks is not None:
+            if isinstance(e2e_ranks, dict):
+                out['e2e'] = e2e_ranks
+            elif e2e_ranks is not None:
                 out['e2e'] = {'what': 'config 5 per rank (tools/e2ebench.py: run_sharded): each rank encodes its own block into HBM (fp16 planes '
                                       'kept), ranks 128 replicated queries with otAspire against it, merges the top-100 over one all-gather; weak '
                                       'scaling, the job\'s rates are the sums over ranks',
