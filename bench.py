@@ -244,6 +244,17 @@ def config3_probe(device, Q=32, C=50000, s=8, reps=30, cpu=True):
                      'hbm_view': {'achieved_GBs': nbytes / (us * 1e-6) / 1e9, 'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                   'algorithmic_bytes_per_call': nbytes}},
     }
+    # HBM traffic of the kernel from the committed counter passes (not measured in this run): 2 x FETCH_SIZE + WRITE_SIZE
+    tpath = os.path.join(ROOT, 'profiles', 'r04_planes_32x50000x8_fetch_write_size.txt')
+    if os.path.exists(tpath) and (Q, C, s) == (32, 50000, 8):
+        kb = {}
+        for line in open(tpath):
+            f = line.split()
+            if len(f) >= 5 and f[0] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                kb[f[0]] = float(f[-1])
+        if len(kb) == 2:
+            res['roofline']['traffic'] = int((2 * kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024)
+            res['roofline']['traffic_source'] = 'profiles/r04_planes_32x50000x8_fetch_write_size.txt (2 x FETCH_SIZE + WRITE_SIZE, KB per launch)'
     if cpu:
         res['cpu_baseline'] = cpu_l2max(qrows, crows, Q, s)
     return res
