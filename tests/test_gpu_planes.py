@@ -235,3 +235,30 @@ def test_cached_document_boxes_give_the_same_ot_scores(amd):
     np.testing.assert_allclose(tail.view(30, 500).numpy(), b.view(30, 2000)[:, 1500:].numpy(), atol=5e-5, rtol=0)
     want = np.array([[orc.get_similarity(qd[i], cd[j]) for j in (0, 1999)] for i in (0, 29)], dtype=np.float32)
     np.testing.assert_allclose(-b.view(30, 2000)[[0, 29]][:, [0, 1999]].numpy(), want, atol=TOL, rtol=0)
+
+
+def test_batch_schedule_on_a_plane_pool(amd):
+    """caching_score's grouping (one epsilon schedule per 64 candidates, plan-weighted similarity: pp_gen_nearest.py:182-202) with
+    the costs from the plane tiles: against the float64 oracle, no further from it than the reference's own fp32 path
+    (tests/plan_sim_floor.py), and the ranking step on top of it"""
+    import plan_sim_floor
+    from aspire_amd._lib import pinned
+    g = torch.Generator().manual_seed(31)
+    cd = [torch.randn(int(n), 768, generator=g) for n in torch.randint(1, 9, (2200,), generator=g)]
+    qd = [torch.randn(int(n), 768, generator=g) for n in (8, 6, 8, 7, 5, 8, 8, 3, 8)]
+    pool = amd.scorer.CandidatePool(cd).prepare_planes()
+    with pinned(COST_PATH='mfma'):
+        got = amd.scorer.score_pool(qd, pool, method='ot', schedule='batch').cpu().numpy()
+        ranked = amd.scorer.rank_pool(qd[:2], pool, k=30, method='ot', schedule='batch')
+    for qi in (0, 7):
+        sub = cd[:192]
+        want = np.array(orc.rank_pool_caching(qd[qi].numpy(), [c.numpy() for c in sub]), dtype=np.float32)
+        truth = np.array(orc.rank_pool_caching(qd[qi].numpy(), [c.numpy() for c in sub], dtype=torch.float64))
+        plan_sim_floor.check(got[qi, :192], want, truth, 'plane tiles, batch schedule')
+    # the ranking step (a 2-query call: another kernel family forms its costs, so the scores agree to the plan-similarity's
+    # rounding and near-ties may swap): descending, and every listed candidate's score is the 9-query call's to that rounding
+    sc = [v for _, v in ranked[0]]
+    assert sc == sorted(sc, reverse=True) and len(sc) == 30
+    for i, v in ranked[0]:
+        assert abs(v - got[0, i]) < 5e-3
+    assert ranked[0][0][0] == int(np.argmax(got[0]))
