@@ -638,6 +638,53 @@ __global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__
         }
 }
 
+// The same for FEW queries (nq <= 8): the general kernel's 32 x 32 document blocks would run 1/32 .. 1/4 full and re-stage every
+// candidate box through LDS (120 us at 1 .. 4 x 20 000).  Here the queries' boxes sit in LDS (6 KB each), a wave walks candidates --
+// six coalesced 1 KB loads per candidate box, the lane's twelve coordinates against every query -- and reduces over its lanes.
+constexpr int kBoxFewQ = 8;
+__global__ void __launch_bounds__(256) pair_box_few_kernel(const float* __restrict__ qbox, const float* __restrict__ cbox, uint32_t nq,
+                                                           uint32_t ncand, float* __restrict__ diam2) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];      // [nq][2][768]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < nq * 2 * kD / 4; i += 256) reinterpret_cast<float4*>(qs)[i] = reinterpret_cast<const float4*>(qbox)[i];
+    __syncthreads();
+    for (uint32_t c = blockIdx.x * 4 + wave; c < ncand; c += gridDim.x * 4) {
+        const float* cb = cbox + (size_t)c * 2 * kD + 4 * lane;
+        float4 cn[3], cx[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            cn[t] = ld4_stream(cb + 256 * t);
+            cx[t] = ld4_stream(cb + kD + 256 * t);
+        }
+        for (uint32_t u = 0; u < nq; ++u) {
+            const float* qb = qs + (size_t)u * 2 * kD + 4 * lane;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float4 qn = *reinterpret_cast<const float4*>(qb + 256 * t), qx = *reinterpret_cast<const float4*>(qb + kD + 256 * t);
+                const float dx = fmaxf(qx.x, cx[t].x) - fminf(qn.x, cn[t].x);
+                const float dy = fmaxf(qx.y, cx[t].y) - fminf(qn.y, cn[t].y);
+                const float dz = fmaxf(qx.z, cx[t].z) - fminf(qn.z, cn[t].z);
+                const float dw = fmaxf(qx.w, cx[t].w) - fminf(qn.w, cn[t].w);
+                acc = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, acc))));
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) diam2[(size_t)u * ncand + c] = acc;
+        }
+    }
+}
+
+int launch_pair_box(const float* qbox, const float* cbox, uint32_t nq, uint32_t ncand, float* diam2, hipStream_t stream) {
+    if (nq <= (uint32_t)kBoxFewQ) {
+        const uint32_t wgs = (ncand + 3) / 4 < 2048 ? (ncand + 3) / 4 : 2048;
+        hipLaunchKernelGGL(pair_box_few_kernel, dim3(wgs), dim3(256), nq * 2 * kD * sizeof(float), stream, qbox, cbox, nq, ncand, diam2);
+    } else {
+        hipLaunchKernelGGL(pair_box_kernel, dim3((ncand + 31) / 32, (nq + 31) / 32), dim3(256), 0, stream, qbox, cbox, nq, ncand, diam2);
+    }
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
 int slot_rows(int max_len) {
     const int r = (max_len + 3) / 4 * 4;
     return r < 8 ? 8 : r;
@@ -710,6 +757,17 @@ bool gram_planes_wanted_l2max(const aspire_repset* q, const aspire_repset* c, in
     return !(q->n == 1 && q->max_len <= 8 && c->max_len <= 8);
 }
 
+// otAspire's cost stage on the plane tiles with FEW queries too: as above, and the pairs' diameters must not cost a pass over every
+// candidate row -- the pool brings its documents' boxes along (aspire_repset.doc_box) or the caller its own diameters.  Two to eight
+// queries against 20 000 documents of 8 rows then take cost tiles (~90 us) + pair_box + the block Sinkhorn kernel instead of the
+// fused kernel re-staging every candidate group per query (Q = 4: 335 us, Q = 8: 626).  ONE query of <= 8 rows stays on the fused /
+// chunk kernels.
+bool gram_planes_wanted_ot(const aspire_repset* q, const aspire_repset* c, int pairing, bool caller_diameters) {
+    if (!gram_planes_wanted_l2max(q, c, pairing)) return false;
+    if (!c->doc_box && !caller_diameters) return false;
+    return !(q->n == 1 && q->max_len <= 8);
+}
+
 bool gram_path_wanted(const aspire_repset* q, const aspire_repset* c, int pairing) {
     if (pairing != ASPIRE_PAIR_CROSS || q->ext != 0 || c->ext != 0) return false;
     if (q->max_len <= 0 || c->max_len <= 0 || q->max_len > 32 || c->max_len > 32) return false;
@@ -742,6 +800,16 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
     g.ld = 8 * T;
     g.cost = cost;
     g.neg = neg;
+    if (gram_planes_ok(a) && bn < 128 && (a.c_box || !diam2)) {
+        // few queries on a plane pool (gram_planes_wanted_ot): the 128-column plane tiles, diameters from the cached boxes
+        if (diam2 && a.cand0 == 0) {
+            hipLaunchKernelGGL(doc_box_range_kernel, dim3((unsigned)g.nq), dim3(192), 0, stream, a.q, (int64_t)0, qbox);
+            ASPIRE_LAUNCH_OK();
+        }
+        if (int rc = launch_pair_gram_planes(a, planes_geometry(g), false, cost, neg, stream)) return rc;
+        if (diam2) return launch_pair_box(qbox, a.c_box + (size_t)a.cand0 * 2 * kD, g.nq, g.ncand, diam2, stream);
+        return ASPIRE_OK;
+    }
     if (diam2 && a.cand0 == 0) {   // per-coordinate boxes of the queries, once per call
         hipLaunchKernelGGL(doc_box_range_kernel, dim3((unsigned)g.nq), dim3(192), 0, stream, a.q, (int64_t)0, qbox);
         ASPIRE_LAUNCH_OK();
@@ -761,9 +829,7 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
             hipLaunchKernelGGL(doc_box_range_kernel, dim3(g.ncand), dim3(192), 0, stream, a.c, a.cand0, cbox);
             ASPIRE_LAUNCH_OK();
         }
-        hipLaunchKernelGGL(pair_box_kernel, dim3((g.ncand + 31) / 32, (g.nq + 31) / 32), dim3(256), 0, stream, qbox, cbox,
-                           g.nq, g.ncand, diam2);
-        ASPIRE_LAUNCH_OK();
+        if (int rc = launch_pair_box(qbox, cbox, g.nq, g.ncand, diam2, stream)) return rc;
     }
     return ASPIRE_OK;
 }

@@ -2428,7 +2428,9 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     // ONE query against a big pool of 9 .. 16-row documents: the streaming kernel (tile16.hip) beats the 32-column Gram tiles,
     // whose 12 .. 16 real query rows fill a third to a half of the MFMA tile (1 x 20 000 x 12 otAspire: 247 vs 363 us; at two
     // queries they tie, from three the Gram tiles win: 623 vs 565 us)
-    const bool stream16 = q->n == 1 && c->n >= 4096 && tile16_path_ok(q, c, pairing) && tuning().cost_path != 1 &&
+    // both sides on fp16 planes, the pool's boxes cached: the plane tiles whatever the number of queries (gram.hip)
+    const bool planes_ot = !extra && gram_planes_wanted_ot(q, c, pairing, diameter != nullptr) && tuning().ot_form == 0;
+    const bool stream16 = !planes_ot && q->n == 1 && c->n >= 4096 && tile16_path_ok(q, c, pairing) && tuning().cost_path != 1 &&
                           tuning().ot_form != 1;
     const int form_t = tuning().ot_form;
     // ONE short query (facet-selected rows) against a pool of abstracts of up to 32 rows: the fused kernel's CHUNK form, as in
@@ -2439,7 +2441,7 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
                         (form_t == 0 || form_t == 4) && prm->scaling >= 0.25 && !tuning().fused_nosolve && !tuning().fused_valu &&
                         tuning().cost_path == 0 && workspace &&
                         (size_t)(chunk_items_bound(1, c->n, c->n) + 2) * 64 + 256 + qbox_bytes(q) + 64 <= workspace_bytes;
-    const bool gram = gram_path_wanted(q, c, pairing) && !stream16 && !chunk1;
+    const bool gram = (gram_path_wanted(q, c, pairing) || planes_ot) && !stream16 && !chunk1;
     ASPIRE_REQUIRE(workspace && workspace_bytes >= per_cand + qbox_bytes(q) + kWsSlack, ASPIRE_ERR_INVALID_ARG,
                    "workspace too small: %zu bytes given, at least %zu needed (aspire_ot_workspace_bytes suggests %zu)",
                    workspace_bytes, per_cand, aspire_ot_workspace_bytes(q, c, pairing));

@@ -125,6 +125,7 @@ __device__ __forceinline__ bool use_mm_formula(int mode, int nq, int nc) {
 // gram.hip: matrix-core form of the pairwise-cost stage (host launchers; see the file header)
 bool gram_path_wanted(const aspire_repset* q, const aspire_repset* c, int pairing);
 bool gram_planes_wanted_l2max(const aspire_repset* q, const aspire_repset* c, int pairing);
+bool gram_planes_wanted_ot(const aspire_repset* q, const aspire_repset* c, int pairing, bool caller_diameters);
 size_t gram_extra_bytes_per_cand(void);
 int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* cost, float* neg, float* diam2, float* qbox,
                         float* cbox, hipStream_t stream);

@@ -262,3 +262,26 @@ def test_batch_schedule_on_a_plane_pool(amd):
     for i, v in ranked[0]:
         assert abs(v - got[0, i]) < 5e-3
     assert ranked[0][0][0] == int(np.argmax(got[0]))
+
+
+@pytest.mark.parametrize('nq,s', [(1, 12), (3, 8), (8, 8), (2, 20)])
+def test_few_query_otaspire_on_a_plane_pool_with_cached_boxes(amd, nq, s):
+    """otAspire's cost stage on the plane tiles with FEW queries (gram_planes_wanted_ot): the pool carries planes and its
+    documents' boxes, the pairs' diameters come from pair_box_few_kernel -- against the oracle, ragged documents"""
+    g = torch.Generator().manual_seed(300 + 10 * nq + s)
+    nc = 128 * 128 // (((s + 3) // 4) * 4) + 21
+    cd = [torch.randn(int(n), 768, generator=g) for n in torch.randint(1, s + 1, (nc,), generator=g)]
+    qd = [torch.randn(int(n), 768, generator=g) for n in torch.randint(max(1, s - 3), s + 1, (nq,), generator=g)]
+    if nq == 1:
+        qd[0] = torch.randn(s, 768, generator=g)            # (one query of <= 8 rows would stay on the fused kernel)
+    pool = amd.scorer.CandidatePool(cd).prepare_planes()
+    assert pool.repset.doc_box is not None
+    got = amd.scorer.score_pool(qd, pool, method='ot', schedule='pair').cpu().numpy()
+    ref = amd.scorer.score_pool(qd, cd, method='ot', schedule='pair').cpu().numpy()       # no planes: the default kernels
+    assert not np.array_equal(got, ref)
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
+    for qi in (0, nq - 1):
+        for ci in (0, 5, nc - 1):
+            assert abs(got[qi, ci] - orc.get_similarity(qd[qi], cd[ci])) < 1e-4
+    ranked = amd.scorer.rank_pool(qd, pool, k=10, method='ot')
+    assert [i for i, _ in ranked[0]] == np.argsort(-got[0].astype(np.float64), kind='stable')[:10].tolist()
