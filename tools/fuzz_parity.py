@@ -1,6 +1,8 @@
 """Randomised parity sweep across the dispatch thresholds (pool sizes, document lengths, query counts):
 GPU otAspire / tsAspire scores of sampled pairs against the oracle, and the rank of every query against the stable
-descending sort of its own scores.   python tools/fuzz_parity.py [n_cases] [seed]"""
+descending sort of its own scores.   python tools/fuzz_parity.py [n_cases] [seed] [planes]
+planes: the pool is a resident CandidatePool that carries fp16 planes and cached boxes (the plane tiles of gramp.hip wherever the
+library takes them: pools of >= 128 tiles, any number of queries), query counts up to 40."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,14 +11,15 @@ from oracle import aspire_oracle as orc
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+planes = len(sys.argv) > 3 and sys.argv[3] == 'planes'
 rng = np.random.default_rng(seed)
 sizes = [1, 5, 100, 256, 257, 511, 512, 1000, 1024, 1025, 2047, 2049, 2500, 4096, 4097, 7001, 8192, 10001, 16001]
 worst_ot = worst_l2 = 0.0
 for case in range(n_cases):
-    nq = int(rng.choice([1, 1, 1, 2, 3, 5]))
-    nc = int(rng.choice(sizes))
+    nq = int(rng.choice([1, 2, 3, 5, 9, 17, 40] if planes else [1, 1, 1, 2, 3, 5]))
+    nc = int(rng.choice([2047, 2049, 2500, 4096, 4097, 7001, 8192] if planes else sizes))
     smax = int(rng.choice([8, 8, 8, 12, 16, 20, 32]))
-    if nq * nc * (smax // 8 + (smax % 8 > 0)) ** 2 > 120000:
+    if not planes and nq * nc * (smax // 8 + (smax % 8 > 0)) ** 2 > 120000:
         nc = max(1, nc // 8)
     g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
     scale = float(rng.choice([1.0, 1.0, 0.3, 2.0]))
@@ -29,8 +32,9 @@ for case in range(n_cases):
     c = [mk(rng.integers(1, smax + 1) if ragged else smax) for _ in range(nc)]
     if rng.random() < 0.3 and nc > 2:          # a candidate sharing sentences with the query
         c[1] = torch.cat([q[0][:1], c[1]])[:smax]
-    ot = scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
-    l2 = scorer.score_pool(q, c, method='l2max').cpu().numpy()
+    pool = scorer.CandidatePool(c).prepare_planes() if planes else c
+    ot = scorer.score_pool(q, pool, method='ot', schedule='pair').cpu().numpy()
+    l2 = scorer.score_pool(q, pool, method='l2max').cpu().numpy()
     if not (np.isfinite(ot).all() and np.isfinite(l2).all()):
         bad_ot, bad_l2 = np.argwhere(~np.isfinite(ot)), np.argwhere(~np.isfinite(l2))
         raise AssertionError(('non-finite scores', case, nq, nc, smax, scale, ragged, 'ot', bad_ot[:6].tolist(), len(bad_ot), 'l2max', bad_l2[:6].tolist(),
@@ -57,10 +61,14 @@ for case in range(n_cases):
         if tol_l2 <= 3e-4:
             worst_l2 = max(worst_l2, el)
     k = int(min(nc, rng.choice([1, 10, 100, 128])))
-    qs, cs = ops.DeviceRepSet.from_list(q), ops.DeviceRepSet.from_list(c)
+    qs, cs = ops.DeviceRepSet.from_list(q), (pool.repset if planes else ops.DeviceRepSet.from_list(c))
     sc, ts, ti = ops.ot_rank(qs, cs, k, want=_lib.OT_SIMILARITY)
     sc, ts, ti = sc.cpu(), ts.cpu(), ti.cpu()
-    np.testing.assert_allclose(sc.numpy(), ot, atol=2e-4 * big, rtol=0)
+    same = np.ones_like(ot, dtype=bool)
+    if nc > 2 and len(c[1]) and torch.equal(c[1][0], q[0][0]):
+        same[0, 1] = False            # a coincident sentence: cancellation noise of the cost, another value per kernel family (see above)
+        assert abs(float(sc[0, 1]) - float(ot[0, 1])) <= 5e-2 * max(1.0, scale)
+    np.testing.assert_allclose(sc.numpy()[same], ot[same], atol=2e-4 * big, rtol=0)
     for i in range(nq):
         order = orc.rank_descending(sc[i].tolist())[:k]
         assert ti[i].tolist() == order, (case, nq, nc, smax, k, i)
