@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
     auto step = [&](int t, auto slotc, auto parc) {
         constexpr int slot = decltype(slotc)::value, par = decltype(parc)::value;     // stage t lives in ring slot `slot`, fragment set `par`
         __builtin_amdgcn_sched_barrier(0);
-        mma(F[par], 0, kPre);
+        if (GRAMP_PROBE != 6) mma(F[par], 0, kPre);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < kKBlocks) {
             // own pieces of stage t + 1: everything but the younger stages' (RING - 2 of them, fewer at the end of the loop)
@@ -372,12 +372,12 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
             const bool more = t + RING < kKBlocks;
             unrolled_pieces([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
-                mma(F[par], kPre + p * kRun, kPre + (p + 1) * kRun);
+                if (GRAMP_PROBE != 6) mma(F[par], kPre + p * kRun, kPre + (p + 1) * kRun);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_piece(slot, t + RING, pc);
+                if (more && GRAMP_PROBE != 7) issue_piece(slot, t + RING, pc);
                 __builtin_amdgcn_sched_barrier(0);
             }, std::make_integer_sequence<int, kPerWave>{});
-            mma(F[par], kPre + kPerWave * kRun, NMMA);
+            if (GRAMP_PROBE != 6) mma(F[par], kPre + kPerWave * kRun, NMMA);
         }
     };
     constexpr int kUnroll = RING % 2 ? 2 * RING : RING;      // ring slots x fragment sets
@@ -387,6 +387,7 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
         unrolled_steps(step, t, std::make_integer_sequence<int, kUnroll>{}, std::integral_constant<int, RING>{});
     }
     }
+    if (GRAMP_PROBE == 5 && acc[0][0][0] != 12345.678f) return;      // timing probe: no epilogue
     __syncthreads();      // every wave is done with the ring: the epilogue's scratch lives there
 
     // ---- epilogue (gram.hip's, on the stores' precomputed norms).  C/D layout of the 32x32 MFMA: col = lane & 31 (query row),

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for v in probe1 probe2 probe3 probe4; do echo "== $v"; ASPIRE_HIP_LIB=build/variants/$v/libaspire_hip.so ASPIRE_HIP_GRAM_TILE=256256 ASPIRE_HIP_GRAM_PP=1 python tools/planebench.py 2>&1 | grep "l2max fp16 planes"; done
+echo "== product"; python tools/planebench.py 2>&1 | grep "l2max fp16 planes"
+for v in gp5 gp6 gp7; do echo "== $v (5 no epilogue, 6 no MFMAs, 7 no LDS-DMA after the prologue)"; ASPIRE_HIP_LIB=build/variants/$v/libaspire_hip.so python tools/planebench.py 2>&1 | grep "l2max fp16 planes"; done
