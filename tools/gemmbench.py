@@ -48,9 +48,10 @@ def main():
             assert L.aspire_debug_split_planes(B.data_ptr(), N, K, Bp.data_ptr(), 1, st) == 0
             C.zero_()
             runp = lambda: L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, None, M, N, K, 0, st)
-            for ring in ('3', '2'):
+            # ASPIRE_HIP_GEMM_RING = 10 x (k blocks per stage) + (stages in the ring): 13 = the default (48 KB, three workgroups per CU)
+            for ring in ('13', '12'):
                 with _lib.pinned(GEMM_RING=ring):
-                    for _ in range(3): assert runp() == 0
+                    for _ in range(10): assert runp() == 0
                     torch.cuda.synchronize()
                     n, us = 20, 1e30
                     for _ in range(3):
@@ -61,7 +62,7 @@ def main():
                         us = min(us, a.elapsed_time(b) / n * 1e3)
                 err = (C[:64].double() - ref).abs().max().item()
                 errl = (C[-64:].double() - (A[-64:].double() @ B.double().T)).abs().max().item()
-                print(f'M={M} N={N} K={K} planes  ring {ring}   : {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}% of the fp32-MFMA peak)  '
+                print(f'M={M} N={N} K={K} planes  ring {ring}  : {us:8.1f} us  {2 * M * N * K / us / 1e6:6.1f} TFLOP/s ({2 * M * N * K / us / 1e6 / 157.3 * 100:.0f}% of the fp32-MFMA peak)  '
                       f'max|err| vs float64 {err:.2e} / last rows {errl:.2e}', flush=True)
 
 if __name__ == '__main__':
