@@ -462,6 +462,7 @@ struct PGemmArgs {
     int M, N, K, ldc, ldr;
     int n_off;           // first column of this launch (a GEMM may run as a launch of 128-wide and one of 64-wide column tiles)
     int probe;           // timing probes (ASPIRE_HIP_GEMM_PROBE): 1 no MFMAs, 2 no LDS-DMA
+    int tiles_x, tiles_y;   // PERSIST: the tile grid (a workgroup walks several tiles; the launch grid is the resident workgroups)
 };
 
 // One 16-byte-per-lane LDS-DMA: 64 lanes x 16 B from global bytes [base + IMM + voff(lane)] to LDS bytes [lds_dst + IMM, .. + 1024).
@@ -505,8 +506,13 @@ __device__ __forceinline__ void glds_kblock(uint64_t a_base, uint64_t b_base, ui
 // GELU(.) straight into the P layout of the next GEMM's A operand (a lane then holds 4 consecutive k of its row: one 8-byte
 // store per plane); otherwise registers run along m, lanes along n: 128-byte coalesced fp32 stores, bias / residual fused.
 // BN = 64: 128 x 64 tiles (wave tile 64 x 32) for the columns that would otherwise leave a last round of workgroups half empty.
-template <int NS, int KS, int BN, bool SWAP>
+// PERSIST (K / 16 a multiple of NS): the launch is the RESIDENT workgroups (three per CU) and a workgroup walks its XCD's share of
+// the tiles; the k-block stream runs on across a tile boundary -- the first NS - 1 stages of the NEXT tile go out during the last
+// steps of this one and land under its epilogue's stores, so a tile's prologue (address set-up, the first DMA round trips, the
+// workgroup's own launch) is paid once per workgroup instead of once per tile.
+template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false>
 __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
+    static_assert(!PERSIST || KS == 1, "persistent form: one k block per stage");
     constexpr int TN = BN / 64;                             // 32-column blocks per wave
     constexpr int kBTile = BN * kPRowBytes;                 // B rows of one k block
     constexpr int kStage = KS * (kPTile + kBTile);          // [A k block 0 .. KS - 1][B k block 0 .. KS - 1]
@@ -516,36 +522,39 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lk = lane >> 5;
-    uint32_t bx, by;       // XCD-aware tile order, as gemm_f32_kernel
-    {
-        const uint32_t gx = gridDim.x, nb = gx * gridDim.y;
-        const uint32_t b = blockIdx.x + gx * blockIdx.y;
-        const uint32_t x = b & 7, q8 = nb >> 3, r8 = nb & 7;
-        const uint32_t L = x * q8 + (x < r8 ? x : r8) + (b >> 3);
-        bx = L % gx;
-        by = L / gx;
-    }
-    const int m0 = G_PROBE(g) == 3 ? 0 : (int)by * 128, n0 = G_PROBE(g) == 3 ? g.n_off : g.n_off + (int)bx * BN;      // probe 3: every workgroup computes tile (0, 0)
+    // XCD-aware tile order, as gemm_f32_kernel: XCD x = workgroup id mod 8 owns a contiguous run of the tile sequence.  PERSIST: the
+    // workgroups of an XCD share its run round-robin (tile_i = this workgroup's place among them, + tile_stride per tile)
+    const uint32_t gx = PERSIST ? (uint32_t)g.tiles_x : gridDim.x, nb = gx * (PERSIST ? (uint32_t)g.tiles_y : gridDim.y);
+    const uint32_t wg = blockIdx.x + gridDim.x * blockIdx.y;
+    const uint32_t xcd = wg & 7, q8 = nb >> 3, r8 = nb & 7;
+    const uint32_t tile_lo = xcd * q8 + (xcd < r8 ? xcd : r8), tile_n = PERSIST ? q8 + (xcd < r8 ? 1u : 0u) : 0u;
+    const uint32_t tile_stride = PERSIST ? (gridDim.x - xcd + 7) >> 3 : 0u;
+    uint32_t tile_i = wg >> 3;
+    if (PERSIST && tile_i >= tile_n) return;
+    uint32_t bx = (tile_lo + tile_i) % gx, by = (tile_lo + tile_i) / gx;
+    int m0 = G_PROBE(g) == 3 ? 0 : (int)by * 128, n0 = G_PROBE(g) == 3 ? g.n_off : g.n_off + (int)bx * BN;      // probe 3: every workgroup computes tile (0, 0)
     G_STAMP(0, __builtin_amdgcn_s_memrealtime());
     G_STAMP(4, __builtin_amdgcn_s_getreg(31 << 11 | 4));
     G_STAMP(5, __builtin_amdgcn_s_getreg(31 << 11 | 20));
     const int nk = g.K / (16 * KS);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)p_smem;
     // per k block wave w moves pieces 2 w, 2 w + 1 (1 KB = 16 rows each) of the A rows and pieces 2 w, 2 w + 1 (BN = 64: piece w) of B's
-    const uint64_t a_src = (uint64_t)(uintptr_t)g.Ap + (uint64_t)m0 * kPRowBytes + (2 * wave) * 1024;
-    const uint64_t b_src = (uint64_t)(uintptr_t)g.Bp + (uint64_t)n0 * kPRowBytes + (kBPerWave * wave) * 1024;
+    const uint64_t a_wave = (uint64_t)(uintptr_t)g.Ap + (2 * wave) * 1024, b_wave = (uint64_t)(uintptr_t)g.Bp + (kBPerWave * wave) * 1024;
+    uint64_t a_src = a_wave + (uint64_t)m0 * kPRowBytes, b_src = b_wave + (uint64_t)n0 * kPRowBytes;
+    uint64_t a_nxt = 0, b_nxt = 0;                            // PERSIST: the same of the workgroup's next tile
     const uint64_t a_step = (uint64_t)g.M * kPRowBytes, b_step = (uint64_t)g.N * kPRowBytes;
     const uint32_t lane16 = lane * 16;
-    auto issue = [&](int slot, int t) {
+    auto issue_from = [&](uint64_t a_from, uint64_t b_from, int slot, int t) {
         const uint32_t dst = lds0 + slot * kStage;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const uint64_t kb = (uint64_t)t * KS + s;
             // (an instruction's offset moves the LDS address along with the global one)
-            glds_kblock<kBPerWave == 2>(a_src + kb * a_step, b_src + kb * b_step, lane16, dst + s * kPTile + (2 * wave) * 1024,
+            glds_kblock<kBPerWave == 2>(a_from + kb * a_step, b_from + kb * b_step, lane16, dst + s * kPTile + (2 * wave) * 1024,
                                         dst + KS * kPTile + s * kBTile + (kBPerWave * wave) * 1024);
         }
     };
+    auto issue = [&](int slot, int t) { issue_from(a_src, b_src, slot, t); };
     // fragment (plane pl) of this lane's row in a k block: piece (2 pl + lk) ^ ((row >> 2) & 3); the row's bits 2..3 are lr's (tiles
     // and wave tiles start on multiples of 32)
     const uint32_t frag0 = 16 * (lk ^ ((lr >> 2) & 3));
@@ -563,6 +572,8 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
+    bool first_tile = true, has_next = false;
+    (void)first_tile;
     struct Frags {
         f16x8_t a[2][2][KS], b[TN][2][KS];       // [block][plane][k step]
     };
@@ -598,18 +609,26 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     };
     static_assert(NS >= 2 && NS <= 4 && kPerWave * (NS - 2) < 64, "ring depth");
     auto step = [&](int t, int slot) {
-        // the own pieces of stage t: everything but the younger stages' pieces (NS - 2 of them, fewer at the end of the loop)
-        const int younger = nk - 1 - t < NS - 2 ? nk - 1 - t : NS - 2;
-        if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPerWave) : "memory");
-        else if (NS >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the own pieces of stage t: everything but the younger stages' pieces (NS - 2 of them, fewer at the end of the loop --
+        // PERSIST: of the workgroup's last tile).  PERSIST, a later tile's first NS - 1 stages: waited for in front of the previous
+        // tile's epilogue (whose stores count in vmcnt too and may be acknowledged late: a vmcnt(N) here would wait for them).
+        // lgkmcnt(0): this wave's fragment reads of the previous stage are done before anybody may refill that slot.
+        const int younger = (PERSIST && has_next) || nk - 1 - t >= NS - 2 ? NS - 2 : nk - 1 - t;
+        if (PERSIST && !first_tile && t < NS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * kPerWave) : "memory");
+        else if (NS >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (G_PROBE(g) == 20 && t == 9) G_STAMP(11, __builtin_amdgcn_s_memrealtime());
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t == 0) G_STAMP(1, __builtin_amdgcn_s_memrealtime());
         if (G_PROBE(g) == 20 && t == 8) G_STAMP(8, __builtin_amdgcn_s_memrealtime());
         if (G_PROBE(g) == 20 && t == 9) G_STAMP(12, __builtin_amdgcn_s_memrealtime());
-        if (t + NS - 1 < nk && G_PROBE(g) != 2 && G_PROBE(g) != 6) issue((slot + NS - 1) % NS, t + NS - 1);
+        if (t + NS - 1 < nk) {
+            if (G_PROBE(g) != 2 && G_PROBE(g) != 6) issue((slot + NS - 1) % NS, t + NS - 1);
+        } else if (PERSIST && has_next) {
+            issue_from(a_nxt, b_nxt, (slot + NS - 1) % NS, t + NS - 1 - nk);      // the next tile's first stages (nk % NS == 0: its stage s lives in slot s)
+        }
         if (G_PROBE(g) == 20 && t == 8) G_STAMP(9, __builtin_amdgcn_s_memrealtime());
         Frags f;
         read_frags(f, slot);
@@ -629,11 +648,32 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         } else if (G_PROBE(g) != 1 && G_PROBE(g) != 5) mma(f);
         if (G_PROBE(g) == 20 && t == 8) G_STAMP(10, __builtin_amdgcn_s_memrealtime());
     };
-    for (int t = 0; t < nk; t += NS) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (t + s < nk) step(t + s, s);
+  for (;;) {            // PERSIST: the workgroup's tiles; otherwise once
+    if constexpr (PERSIST) {
+        has_next = tile_i + tile_stride < tile_n;
+        if (has_next) {
+            const uint32_t L = tile_lo + tile_i + tile_stride;
+            a_nxt = a_wave + (uint64_t)((L / gx) * 128) * kPRowBytes;
+            b_nxt = b_wave + (uint64_t)(g.n_off + (int)(L % gx) * BN) * kPRowBytes;
+        }
     }
+    if constexpr (PERSIST) {
+        static_assert(!PERSIST || NS == 3, "persistent form: the default ring");
+#pragma unroll 1
+        for (int t = 0; t < nk; t += 3) {
+            step(t, 0);
+            step(t + 1, 1);
+            step(t + 2, 2);
+        }
+    } else {
+        for (int t = 0; t < nk; t += NS) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (t + s < nk) step(t + s, s);
+        }
+    }
+    // PERSIST: this wave's pieces of the next tile's first stages have landed before its stores go out (see step)
+    if (PERSIST && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     G_STAMP(2, __builtin_amdgcn_s_memrealtime());
     constexpr float kUnscale = 1.0f / kPWeightScale;
@@ -705,6 +745,23 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         }
     }
     G_STAMP(3, __builtin_amdgcn_s_memrealtime());
+    if (!PERSIST || !has_next) break;
+    tile_i += tile_stride;
+    first_tile = false;
+    a_src = a_nxt;
+    b_src = b_nxt;
+    {
+        const uint32_t L = tile_lo + tile_i;
+        m0 = (int)(L / gx) * 128;
+        n0 = g.n_off + (int)(L % gx) * BN;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 }
 
 // One wave per row of 768: lane holds 3 float4 (d = 4*lane + 256*c).
@@ -1254,6 +1311,22 @@ Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim) {
 // of a GEMM into a launch of 128-wide tiles filling whole rounds and a launch of 64-wide ones for the rest -- 8192 x 2304: 768 +
 // 768 tiles instead of 1152 = 1.5 rounds -- was built and measured: 164 us either way.  A half-empty last round is not the
 // loss it looks like: its workgroups run faster for having the CU's matrix pipes to themselves.)
+// the persistent form of the default ring: 768 resident workgroups (three per CU) walk the tiles
+template <int BN, bool SWAP>
+int launch_gemm_p_persist(PGemmArgs g, int n_off, int col_tiles, hipStream_t st) {
+    constexpr int NS = 3, lds = NS * (kPTile + BN * kPRowBytes);
+    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<NS, 1, BN, SWAP, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    ASPIRE_HIP_OK(raised);
+    g.n_off = n_off;
+    g.probe = 0;
+    g.tiles_x = col_tiles;
+    g.tiles_y = (g.M + 127) / 128;
+    const long long tiles = (long long)g.tiles_x * g.tiles_y;
+    hipLaunchKernelGGL((gemm_p_kernel<NS, 1, BN, SWAP, true>), dim3((unsigned)(tiles < 768 ? tiles : 768)), dim3(256), lds, st, g);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
 template <int NS, int KS, int BN, bool SWAP>
 int launch_gemm_p_ns(PGemmArgs g, int n_off, int col_tiles, hipStream_t st) {
     constexpr int lds = NS * KS * (kPTile + BN * kPRowBytes);
@@ -1268,8 +1341,10 @@ int launch_gemm_p_ns(PGemmArgs g, int n_off, int col_tiles, hipStream_t st) {
 }
 template <int BN, bool SWAP>
 int launch_gemm_p_ring(const PGemmArgs& g, int n_off, int col_tiles, hipStream_t st) {
-    // ASPIRE_HIP_GEMM_RING = 10 KS + NS pins the ring (default: kPRingDefault)
-    switch (tuning().gemm_ring ? tuning().gemm_ring : kPRingDefault) {
+    // ASPIRE_HIP_GEMM_RING = 10 KS + NS pins the ring (default: kPRingDefault); 113: the default ring's persistent form
+    if (tuning().gemm_ring == 113 && (g.K / 16) % 3 == 0 && (long long)col_tiles * ((g.M + 127) / 128) > 768)
+        return launch_gemm_p_persist<BN, SWAP>(g, n_off, col_tiles, st);
+    switch (tuning().gemm_ring ? tuning().gemm_ring % 100 : kPRingDefault) {
     case 12: return launch_gemm_p_ns<2, 1, BN, SWAP>(g, n_off, col_tiles, st);
     case 14: return launch_gemm_p_ns<4, 1, BN, SWAP>(g, n_off, col_tiles, st);
     case 23: return launch_gemm_p_ns<3, 2, BN, SWAP>(g, n_off, col_tiles, st);

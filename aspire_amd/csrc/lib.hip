@@ -44,7 +44,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "GEMM_RING")) {
         int f = unset ? 0 : atoi(v);
         if (f == 2 || f == 3) f += 20;        // the round-3 spellings: ring depth at two k blocks per stage
-        if (f != 0 && f != 22 && f != 23 && f != 12 && f != 13 && f != 14) return false;
+        if (f != 0 && f != 22 && f != 23 && f != 12 && f != 13 && f != 14 && f != 113) return false;
         t.gemm_ring = f;
     } else if (!strcmp(key, "GEMM_PROBE")) {
         t.gemm_probe = unset ? 0 : atoi(v);

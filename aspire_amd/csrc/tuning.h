@@ -14,7 +14,7 @@ struct Tuning {
     int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default (pre-split operands from 1024 token rows on, else bf16x3), 1 f32 = fp32-input MFMA everywhere, 2 bf16x3 = operands split on the fly, 3 planes = pre-split operands at any size
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
     int gemm_probe = 0;      // ASPIRE_HIP_GEMM_PROBE=1: the P-layout GEMM without its MFMAs, 2: without its LDS-DMA (timing probes, wrong results)
-    int gemm_ring = 0;       // ASPIRE_HIP_GEMM_RING=22 | 23 | 13 | 14: 10 x (k blocks per stage) + (stages in the LDS ring) of the P-layout GEMM
+    int gemm_ring = 0;       // ASPIRE_HIP_GEMM_RING=22 | 23 | 13 | 14: 10 x (k blocks per stage) + (stages in the LDS ring) of the P-layout GEMM; 113: ring 13 as a persistent tile loop
     int gemm_tile = 0;       // ASPIRE_HIP_GEMM_TILE=128 | 64: force 128 x 128 / 128 x 64 tiles in the bf16x3 form (tuning)
     int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
                              // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch

@@ -192,7 +192,7 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
         with _lib.pinned(GEMM='bf16x3'):
             assert L.aspire_debug_gemm_f32(A.data_ptr(), B.data_ptr(), C0.data_ptr(), bias.data_ptr(), M, N, K, st) == 0
         Ap, Bp = planes(A), planes(B, 1)
-        for pin in ({}, {'GEMM_RING': '3'}, {'GEMM_TILE': '64'}):
+        for pin in ({}, {'GEMM_RING': '3'}, {'GEMM_TILE': '64'}, {'GEMM_RING': '113'}):      # 113: the persistent tile loop (> 768 tiles)
             C = torch.full((M, N), float('nan'), device='cuda')
             with _lib.pinned(**pin):
                 assert L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, bias.data_ptr(), M, N, K, 0, st) == 0
@@ -236,6 +236,24 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
     torch.cuda.synchronize()
     want = torch.nn.functional.gelu(A.double() @ B.double().T + bias.double())
     assert (H.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+    # the same epilogue from the persistent tile loop (780 tiles on 768 resident workgroups, a ragged last row of tiles): the same bits
+    M, N, K = 8300, 1536, 768
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (0.05 * torch.randn(N, K, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Ap, Bp, eyep = planes(A), planes(B, 1), planes(torch.eye(N, device='cuda'), 1)
+    out = []
+    for pin in ({}, {'GEMM_RING': '113'}):
+        Hp = torch.zeros(L.aspire_debug_planes_bytes(M, N), dtype=torch.uint8, device='cuda')
+        H = torch.empty(M, N, device='cuda')
+        with _lib.pinned(**pin):
+            assert L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), None, Hp.data_ptr(), bias.data_ptr(), M, N, K, 1, st) == 0
+        assert L.aspire_debug_gemm_planes(Hp.data_ptr(), eyep.data_ptr(), H.data_ptr(), None, None, M, N, N, 0, st) == 0
+        torch.cuda.synchronize()
+        out.append(H)
+    assert torch.equal(out[0], out[1])
+    want = torch.nn.functional.gelu(A[-200:].double() @ B.double().T + bias.double())
+    assert (out[1][-200:].double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize('n_layers,b,l', [(2, 4, 128), (12, 2, 64), (1, 2, 300), (2, 2, 502), (1, 3, 37)])

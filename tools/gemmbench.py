@@ -49,7 +49,7 @@ def main():
             C.zero_()
             runp = lambda: L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, None, M, N, K, 0, st)
             # ASPIRE_HIP_GEMM_RING = 10 x (k blocks per stage) + (stages in the ring): 13 = the default (48 KB, three workgroups per CU)
-            for ring in ('13', '12'):
+            for ring in ('13', '113', '12'):
                 with _lib.pinned(GEMM_RING=ring):
                     for _ in range(10): assert runp() == 0
                     torch.cuda.synchronize()
