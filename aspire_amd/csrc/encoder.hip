@@ -648,6 +648,29 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         } else if (G_PROBE(g) != 1 && G_PROBE(g) != 5) mma(f);
         if (G_PROBE(g) == 20 && t == 8) G_STAMP(10, __builtin_amdgcn_s_memrealtime());
     };
+    // the tile's bias values: fetched in front of the epilogue -- PERSIST: when the tile begins (no load may sit between one tile's
+    // stores and the next tile's first steps: whoever waits for it waits for every store's acknowledgement, vmcnt counts both)
+    float bias_n[TN];
+    float4 bias_m[TN][4];
+    auto load_bias = [&]() {       // (one uniform branch around ALL the loads: a per-value select would wait for each load where it is issued)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bias_n[j] = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) bias_m[j][q4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!PERSIST && g.bias == nullptr) return;       // PERSIST: the launcher insists on a bias (a join behind the branch makes the compiler wait for the loads there)
+        if constexpr (!SWAP) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bias_n[j] = g.bias[n0 + wc * 32 * TN + 32 * j + lr];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) bias_m[j][q4] = *reinterpret_cast<const float4*>(g.bias + n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk);
+        }
+    };
+    if constexpr (PERSIST) load_bias();
   for (;;) {            // PERSIST: the workgroup's tiles; otherwise once
     if constexpr (PERSIST) {
         has_next = tile_i + tile_stride < tile_n;
@@ -677,6 +700,19 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 
     G_STAMP(2, __builtin_amdgcn_s_memrealtime());
     constexpr float kUnscale = 1.0f / kPWeightScale;
+    if constexpr (!PERSIST) load_bias();
+    // every bias register is consumed HERE, in front of the first store: the compiler waits for the bias loads once, now, instead of
+    // in front of the first use of each -- behind stores, where it can only wait with vmcnt(0) = for every store's acknowledgement
+    if constexpr (!SWAP) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias_n[j]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                asm volatile("" : "+v"(bias_m[j][q4].x), "+v"(bias_m[j][q4].y), "+v"(bias_m[j][q4].z), "+v"(bias_m[j][q4].w));
+    }
     if (((G_PROBE(g) >= 4 && G_PROBE(g) <= 6) || (G_PROBE(g) >= 10 && G_PROBE(g) < 20)) && acc[0][0][0] != 12345.678f) return;      // probes 4+: no epilogue (4: all else, 5: no MFMAs, 6: no LDS-DMA)
     if constexpr (!SWAP) {
         // C/D layout of the 32 x 32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m): a store instruction
@@ -690,14 +726,14 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wc * 32 * TN + 32 * j + lr;
-                const float bv = g.bias ? g.bias[n] : 0.f;
+                const float bv = bias_n[j];
                 const int mb = m0 + wr * 64 + 32 * i + 4 * lk;
                 if (whole) {
                     float* crow = g.C + (size_t)mb * g.ldc + n;
                     float v[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[i][j][r], kUnscale, bv);
-                    if (g.res) {
+                    if (!PERSIST && g.res) {
                         const float* rrow = g.res + (size_t)mb * g.ldr + n;
                         float rv[16];
 #pragma unroll
@@ -714,21 +750,15 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
                     if (m >= g.M) continue;
                     float v = fmaf(acc[i][j][r], kUnscale, bv);
-                    if (g.res) v += g.res[(size_t)m * g.ldr + n];
+                    if (!PERSIST && g.res) v += g.res[(size_t)m * g.ldr + n];
                     g.C[(size_t)m * g.ldc + n] = v;
                 }
             }
     } else {
         // swapped: col = lane & 31 is the row m, the registers run along n in groups of 4 consecutive: GELU(acc + bias) goes
         // straight into the P layout [M, N] (k dimension = n) of the next GEMM's A operand
-        // (the bias vectors are fetched before the first store: a load between stores makes the compiler wait for every store
+        // (the bias vectors were fetched before the first store: a load between stores makes the compiler wait for every store
         // issued so far -- vmcnt counts both)
-        float4 bv[TN][4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-                bv[j][q4] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + wr * 64 + 32 * i + lr;
@@ -738,7 +768,7 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int n = n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk;
-                    const float4 b4 = bv[j][q4];
+                    const float4 b4 = bias_m[j][q4];
                     p_store4(g.Cp, g.M, m, n, gelu_erf(fmaf(acc[i][j][4 * q4 + 0], kUnscale, b4.x)), gelu_erf(fmaf(acc[i][j][4 * q4 + 1], kUnscale, b4.y)),
                              gelu_erf(fmaf(acc[i][j][4 * q4 + 2], kUnscale, b4.z)), gelu_erf(fmaf(acc[i][j][4 * q4 + 3], kUnscale, b4.w)));
                 }
@@ -755,6 +785,7 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         m0 = (int)(L / gx) * 128;
         n0 = g.n_off + (int)(L % gx) * BN;
     }
+    load_bias();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1342,7 +1373,7 @@ int launch_gemm_p_ns(PGemmArgs g, int n_off, int col_tiles, hipStream_t st) {
 template <int BN, bool SWAP>
 int launch_gemm_p_ring(const PGemmArgs& g, int n_off, int col_tiles, hipStream_t st) {
     // ASPIRE_HIP_GEMM_RING = 10 KS + NS pins the ring (default: kPRingDefault); 113: the default ring's persistent form
-    if (tuning().gemm_ring == 113 && (g.K / 16) % 3 == 0 && (long long)col_tiles * ((g.M + 127) / 128) > 768)
+    if (tuning().gemm_ring == 113 && !g.res && g.bias && (g.K / 16) % 3 == 0 && (long long)col_tiles * ((g.M + 127) / 128) > 768)
         return launch_gemm_p_persist<BN, SWAP>(g, n_off, col_tiles, st);
     switch (tuning().gemm_ring ? tuning().gemm_ring % 100 : kPRingDefault) {
     case 12: return launch_gemm_p_ns<2, 1, BN, SWAP>(g, n_off, col_tiles, st);

@@ -47,7 +47,8 @@ def main():
             assert L.aspire_debug_split_planes(A.data_ptr(), M, K, Ap.data_ptr(), 0, st) == 0
             assert L.aspire_debug_split_planes(B.data_ptr(), N, K, Bp.data_ptr(), 1, st) == 0
             C.zero_()
-            runp = lambda: L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, None, M, N, K, 0, st)
+            zb = torch.zeros(N, device='cuda')          # (the persistent form, ring 113, wants a bias)
+            runp = lambda: L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, zb.data_ptr(), M, N, K, 0, st)
             # ASPIRE_HIP_GEMM_RING = 10 x (k blocks per stage) + (stages in the ring): 13 = the default (48 KB, three workgroups per CU)
             for ring in ('13', '113', '12'):
                 with _lib.pinned(GEMM_RING=ring):
