@@ -775,23 +775,21 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
         }
     }
     G_STAMP(3, __builtin_amdgcn_s_memrealtime());
-    if (!PERSIST || !has_next) break;
-    tile_i += tile_stride;
-    first_tile = false;
-    a_src = a_nxt;
-    b_src = b_nxt;
-    {
+    if constexpr (!PERSIST) {
+        break;
+    } else {
+        if (!has_next) break;
+        tile_i += tile_stride;
+        first_tile = false;
+        a_src = a_nxt;
+        b_src = b_nxt;
         const uint32_t L = tile_lo + tile_i;
         m0 = (int)(L / gx) * 128;
         n0 = g.n_off + (int)(L % gx) * BN;
+        load_bias();
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{};      // (constant trip counts: unrolled without being asked)
     }
-    load_bias();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 }
 
