@@ -88,9 +88,22 @@ def test_encode_to_pool_is_forward_without_the_padding():
     # by default consecutive batches are joined into encoder calls of up to 64 documents (the shorter ones' token tensors padded):
     # the same rows -- to rounding, the joined call's row count can select other GEMM kernel forms
     for per in (64, 16):
-        joined = model.encode_to_pool(batches, docs_per_forward=per)
+        joined = model.encode_to_pool(batches, docs_per_forward=per, sort_by_length=False)
         assert torch.equal(joined.repset.start.cpu(), pool.repset.start.cpu())
         np.testing.assert_allclose(joined.repset.rows.cpu().numpy(), rows.numpy(), atol=2e-5, rtol=0)
+    # sort_by_length (the default): the documents of all batches regrouped by token length (fewer pad tokens per encoder call); the store keeps
+    # the corpus order, CLS rows included
+    for per in (64, 8, 5):
+        regrouped, rcls = model.encode_to_pool(batches, pids=[f'd{i}' for i in range(23)], want_cls=True, docs_per_forward=per, sort_by_length=True)
+        assert regrouped.pids == pool.pids
+        assert torch.equal(regrouped.repset.start.cpu(), pool.repset.start.cpu()) and torch.equal(regrouped.repset.len.cpu(), pool.repset.len.cpu())
+        np.testing.assert_allclose(regrouped.repset.rows.cpu().numpy(), rows.numpy(), atol=2e-5, rtol=0)
+        np.testing.assert_allclose(rcls.cpu().numpy(), cls.cpu().numpy(), atol=2e-5, rtol=0)
+    groups, ids = AspireConSent._regroup_by_length(batches, 5)
+    assert sorted(i for g in ids for i in g) == list(range(23)) and [len(g) for g in ids] == [5, 5, 5, 5, 3]
+    lens_sorted = [n for bb, _, _ in groups for n in bb['seq_lens']]
+    assert lens_sorted == sorted(lens_sorted, reverse=True)
+    assert all(bb['tokid_tt'].shape[1] == max(bb['seq_lens']) for bb, _, _ in groups)
 
 
 def test_token_ids_to_ranked_list_end_to_end():
