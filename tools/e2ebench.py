@@ -31,6 +31,52 @@ def synthetic_batches(n_docs, L, S, seed):
     return batches
 
 
+def ragged_batches(n_docs, S, seed):
+    """The same batches on documents of abstract-like, UNEVEN token length (log-normal around 220, clipped to [60, 500]), 32 at a
+    time in corpus order, each batch padded to its longest document as prepare_abstracts pads."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.exp(rng.normal(np.log(220), 0.35, n_docs)).astype(int), 60, 500)
+    batches = []
+    for lo in range(0, n_docs, BATCH):
+        ls = lens[lo:lo + BATCH]
+        b, L = len(ls), int(ls.max())
+        tok = torch.zeros(b, L, dtype=torch.long)
+        mask = torch.zeros(b, L, dtype=torch.long)
+        idxs = []
+        for i, n in enumerate(ls):
+            tok[i, :n] = torch.from_numpy(rng.integers(1000, 30000, n))
+            mask[i, :n] = 1
+            edges = np.linspace(1, n - 1, S + 1).astype(int)
+            idxs.append([list(range(edges[s], edges[s + 1])) for s in range(S)])
+        batches.append(({'tokid_tt': tok, 'seg_tt': torch.zeros_like(tok), 'attnmask_tt': mask, 'seq_lens': [int(n) for n in ls]}, [S] * b, idxs))
+    return batches, lens
+
+
+def run_ragged(model, n_docs=2048, S=8, seed=5):
+    """encode_to_pool on documents of uneven length: the caller's corpus-order batches joined as given against the default
+    (documents regrouped by token length, the store in corpus order)."""
+    batches, lens = ragged_batches(n_docs, S, seed)
+    for bb, _, _ in batches:
+        for key in ('tokid_tt', 'seg_tt', 'attnmask_tt'):
+            bb[key] = bb[key].cuda()
+    rows_given = sum(len(a) * bb['tokid_tt'].shape[1] for bb, a, _ in batches)
+    out = {'what': f'{n_docs} documents of 60 .. 500 tokens (log-normal around 220), {S} sentences, given {BATCH} at a time in corpus order '
+                   f'(pp_gen_nearest.py:141-160); encode_to_pool with the batches joined as given / regrouped by token length (default)',
+           'real_tokens': int(lens.sum()), 'token_rows_in_the_given_batches': int(rows_given)}
+    stores = {}
+    for name, sort in (('as_given', False), ('by_length', True)):
+        model.encode_to_pool(batches[:4], sort_by_length=sort)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pool = model.encode_to_pool(batches, sort_by_length=sort)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stores[name] = pool.repset.rows
+        out[f'docs_per_s_{name}'] = n_docs / dt
+    out['max_abs_diff_between_the_stores'] = float((stores['as_given'] - stores['by_length']).abs().max())
+    return out
+
+
 def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2, planes=True):
     from transformers import BertConfig, BertModel
     from aspire_amd import ops, scorer, _lib
@@ -119,6 +165,10 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2, pla
                              'frac': 12 * L * (14155776 + 3072 * L) * n_docs / t_encode / 1e12 / (2500.0 / 3),
                              'what': 'whole encode stage (GEMMs, attention, LayerNorms, pooling, host) against the fp16 MFMA peak / 3 products'},
     }
+    try:
+        out['ragged'] = run_ragged(model)
+    except Exception as e:      # (a side measurement: never takes the block with it)
+        out['ragged'] = {'error': repr(e)}
     if check:
         # three (query, candidate) pairs against HF BertModel (fp32, CPU) -> oracle pooling -> oracle OT
         from oracle import aspire_oracle as orc
