@@ -193,17 +193,23 @@ def test_prepare_abstracts_matches_reference(golden_dir, tmp_path):
     500-word-piece cap hit mid sentence, hit exactly (sentence dropped), and a one-piece remainder."""
     from aspire_amd import prepare_abstracts
     z = json.load(open(os.path.join(golden_dir, 'prep.json')))
-    tok = _tokenizer(z['vocab'], tmp_path)
-    for case in z['cases']:
-        batch = [z['docs'][i] for i in case['doc_ids']]
-        bert_batch, abs_lens, sent_token_idxs = prepare_abstracts(batch, tok)
-        assert bert_batch['tokid_tt'].tolist() == case['tokid_tt']
-        assert bert_batch['seg_tt'].tolist() == case['seg_tt']
-        assert bert_batch['attnmask_tt'].tolist() == case['attnmask_tt']
-        assert bert_batch['seq_lens'] == case['seq_lens']
-        assert abs_lens == case['abs_lens']
-        assert sent_token_idxs == case['sent_token_idxs']
-        assert bert_batch['tokid_tt'].dtype == torch.int64
+    from transformers import BertTokenizerFast
+    slow = _tokenizer(z['vocab'], tmp_path)
+    # a fast (Rust) tokenizer goes through ONE batched call per prepare_abstracts instead of tokenize() per sentence: the same outputs
+    for tok in (slow, BertTokenizerFast(str(tmp_path / 'vocab.txt'), do_lower_case=True)):
+        for case in z['cases']:
+            batch = [z['docs'][i] for i in case['doc_ids']]
+            bert_batch, abs_lens, sent_token_idxs = prepare_abstracts(batch, tok)
+            assert bert_batch['tokid_tt'].tolist() == case['tokid_tt']
+            assert bert_batch['seg_tt'].tolist() == case['seg_tt']
+            assert bert_batch['attnmask_tt'].tolist() == case['attnmask_tt']
+            assert bert_batch['seq_lens'] == case['seq_lens']
+            assert abs_lens == case['abs_lens']
+            assert sent_token_idxs == case['sent_token_idxs']
+            assert bert_batch['tokid_tt'].dtype == torch.int64
+    from aspire_amd.batch_prep import prepare_bert_sentences
+    sents = [[d['TITLE'] + ' [SEP] '] + list(d['ABSTRACT']) for d in z['docs'][:4]]
+    assert prepare_bert_sentences(sents, slow)[1] == prepare_bert_sentences(sents, BertTokenizerFast(str(tmp_path / 'vocab.txt'), do_lower_case=True))[1]
 
 
 def test_spans_to_csr():
