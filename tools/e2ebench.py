@@ -124,12 +124,18 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2, pla
     q = ops.DeviceRepSet(torch.cat(qreps, 0).contiguous(), (torch.arange(n_queries, dtype=torch.int32) * S).to(dev),
                          torch.full((n_queries,), S, dtype=torch.int32, device=dev), ext=0, max_len=S, lens_host=[S] * n_queries)
     kk = min(k, n_docs)
-    ops.ot_rank(q, pool.repset, kk, want=_lib.OT_SIMILARITY)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    scores, top_s, top_i = ops.ot_rank(q, pool.repset, kk, want=_lib.OT_SIMILARITY)
-    torch.cuda.synchronize()
-    t_score = time.perf_counter() - t0
+    def timed(qq, cc):          # three warm-up calls (the clock governor settles over the first ~15 ms of a new load), median of three
+        for _ in range(3):
+            ops.ot_rank(qq, cc, kk, want=_lib.OT_SIMILARITY)
+        torch.cuda.synchronize()
+        ts, res = [], None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = ops.ot_rank(qq, cc, kk, want=_lib.OT_SIMILARITY)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[1], ts, res
+    t_score, t_score_all, (scores, top_s, top_i) = timed(q, pool.repset)
     # the same score + rank stage on i.i.d. N(0, 1) reps of the same shapes: random-init BERT puts every sentence rep almost on
     # one line (cosine ~0.97), where |x|^2 - 2 x.y + |y|^2 cancels unless the rows are centred first (ASPIRE_OT_FLAG_CENTER, set by
     # aspire_amd.ops from a sample of the pool: NOTES.md, round-3 log)
@@ -138,12 +144,7 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2, pla
     if planes:
         iid_c.prepare_planes()
     iid_q = ops.DeviceRepSet(torch.randn(n_queries * S, 768, generator=g).to(dev), q.start, q.len, ext=0, max_len=S)
-    ops.ot_rank(iid_q, iid_c, kk, want=_lib.OT_SIMILARITY)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ops.ot_rank(iid_q, iid_c, kk, want=_lib.OT_SIMILARITY)
-    torch.cuda.synchronize()
-    t_score_iid = time.perf_counter() - t0
+    t_score_iid, _, _ = timed(iid_q, iid_c)
     cosq = torch.nn.functional.normalize(pool.repset.rows[:2048], dim=1)
     mean_cos = float((cosq @ cosq.T).mean())
     out = {
@@ -152,7 +153,7 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2, pla
                 f'random-init BERT-base',
         'docs': n_docs, 'tokens': L, 'sents': S, 'queries': n_queries, 'store_carries_fp16_planes': bool(planes),
         'encode_s': t_encode, 'docs_per_s': n_docs / t_encode,
-        'score_rank_s': t_score, 'pairs_per_s': n_queries * n_docs / t_score,
+        'score_rank_s': t_score, 'score_rank_s_calls': t_score_all, 'pairs_per_s': n_queries * n_docs / t_score,
         'score_rank_on_iid_reps_s': t_score_iid, 'pairs_per_s_on_iid_reps': n_queries * n_docs / t_score_iid,
         'mean_cosine_of_encoded_reps': mean_cos,
         'split_ms': {'encoder_kernels': enc_ms * n_batches, 'pooling_kernels': pool_ms * n_batches,
