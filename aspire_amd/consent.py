@@ -209,40 +209,42 @@ class AspireConSent:
             lo_hi = torch.stack([torch.stack([bb['tokid_tt'].min(), bb['tokid_tt'].max()]).to(dev) for bb, _, _ in batches])
             if int(lo_hi[:, 0].min()) < 0 or int(lo_hi[:, 1].max()) >= self.bert_encoder.config.vocab_size:
                 raise IndexError('token id out of range')
-        # Pass 1 (host): every batch's pooling tables -- token positions (CSR), slot -> store row -- built up front and uploaded in
-        # groups of batches as ONE int32 buffer.  (Uploaded batch by batch from pageable memory, each copy waited behind the
-        # encoder kernels queued before it, and the next batch's kernels were launched late: the GPU sat idle ~0.5 ms per
-        # batch of 32 documents, 5 % of the encode stage.)
+        # Per group of batches: (host) every batch's pooling tables -- token positions (CSR), slot -> store row -- uploaded as ONE int32
+        # buffer, then the group's kernels.  (Uploaded batch by batch from pageable memory, each copy waited behind the encoder
+        # kernels queued before it, and the next batch's kernels were launched late: the GPU sat idle ~0.5 ms per batch of 32
+        # documents, 5 % of the encode stage.)  A group's tables are built while the GPU works on the group before it; the first
+        # groups are small so that it starts at once (all tables up front: ~80 ms of host loops per 16 384 documents with the GPU idle).
         start_np = start_t.numpy()
-        tables, doc0 = [], 0
-        for bi, (bert_batch, abs_lens, sent_tok_idxs) in enumerate(batches):
-            b = len(abs_lens)
-            ids = np.asarray(doc_ids[bi], dtype=np.int64) if doc_ids is not None else np.arange(doc0, doc0 + b)
-            max_sents = max(abs_lens)
-            max_seq_len = max(bert_batch['seq_lens'])
-            assert bert_batch['tokid_tt'].shape == (b, max_seq_len)
-            tok_idx, span_off = spans_to_csr(sent_tok_idxs, max_sents)
-            if tok_idx.numel() and (int(tok_idx.min()) < 0 or int(tok_idx.max()) >= max_seq_len):
-                raise IndexError('sentence token index out of range')
-            # slot (b, s) -> row of the store, -1 beyond the document's sentence count
-            lens_b = np.asarray(abs_lens, dtype=np.int32)[:, None]
-            slot = np.arange(max_sents, dtype=np.int32)[None, :]
-            out_row = np.where(slot < lens_b, start_np[ids, None] + slot, -1).astype(np.int32)
-            tables.append((tok_idx.numpy(), span_off.numpy(), out_row.reshape(-1), max_sents, doc0, b))
-            doc0 += b
-        group = 64                                             # batches per upload (a few MB of int32)
-        for g0 in range(0, len(batches), group):
-            chunk = tables[g0:g0 + group]
-            parts, offs, o = [], [], 0
-            for tok_idx, span_off, out_row, _, _, _ in chunk:
-                for arr in (tok_idx, span_off, out_row):
+        bounds, nxt = [0], 2
+        while bounds[-1] < len(batches):
+            bounds.append(min(len(batches), bounds[-1] + nxt))
+            nxt = min(64, nxt * 4)
+        doc0 = 0
+        for g0, g1 in zip(bounds[:-1], bounds[1:]):
+            chunk, parts, offs, o = [], [], [], 0
+            for bi in range(g0, g1):
+                bert_batch, abs_lens, sent_tok_idxs = batches[bi]
+                b = len(abs_lens)
+                ids = np.asarray(doc_ids[bi], dtype=np.int64) if doc_ids is not None else np.arange(doc0, doc0 + b)
+                max_sents = max(abs_lens)
+                max_seq_len = max(bert_batch['seq_lens'])
+                assert bert_batch['tokid_tt'].shape == (b, max_seq_len)
+                tok_idx, span_off = spans_to_csr(sent_tok_idxs, max_sents)
+                if tok_idx.numel() and (int(tok_idx.min()) < 0 or int(tok_idx.max()) >= max_seq_len):
+                    raise IndexError('sentence token index out of range')
+                # slot (b, s) -> row of the store, -1 beyond the document's sentence count
+                lens_b = np.asarray(abs_lens, dtype=np.int32)[:, None]
+                slot = np.arange(max_sents, dtype=np.int32)[None, :]
+                out_row = np.where(slot < lens_b, start_np[ids, None] + slot, -1).astype(np.int32)
+                for arr in (tok_idx.numpy(), span_off.numpy(), out_row.reshape(-1)):
                     offs.append((o, o + arr.size))
                     parts.append(arr.astype(np.int32, copy=False))
                     o += arr.size
+                chunk.append((max_sents, doc0, b))
+                doc0 += b
             flat = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.int32)).to(dev)
-            # Pass 2: kernels only
-            for i, (bert_batch, _, _) in enumerate(batches[g0:g0 + group]):
-                _, _, _, max_sents, d0, b = chunk[i]
+            for i, (bert_batch, _, _) in enumerate(batches[g0:g1]):
+                max_sents, d0, b = chunk[i]
                 (t0, t1), (s0, s1), (r0, r1) = offs[3 * i:3 * i + 3]
                 hidden = self.bert_encoder.forward_hidden(bert_batch['tokid_tt'], token_type_ids=bert_batch['seg_tt'],
                                                           attention_mask=bert_batch['attnmask_tt'], check_ids=False)
