@@ -1,0 +1,629 @@
+// NOT BUILT: an experiment of round 5 that lost (NOTES.md, round 5 log; profiles/r05_split_*).  To try it again: copy it to aspire_amd/csrc/, declare
+// split_path_ok / launch_pair_split in score_types.h, add `int fused_split, split_prio` to tuning.h, and call it where score.hip launches the
+// fused kernel's SELF / QBOX forms (git history of this round shows the hooks).  This is build 2 (buffer loads, 147 us); build 1 (117 us)
+// differs in the streamer only: 64-bit row pointers + per-stage v_lshl_add_u64, fminf / fmaxf box, one stage loop with a run-time have_box.
+// otAspire throughput kernel, role-split form: the fused kernel's two halves on DIFFERENT waves of one workgroup (A5-A8; reference
+// arithmetic: src/learning/facetid_models/pair_distances.py:21-92 + geomloss 0.2.4's sinkhorn_tensorized, restated -- fused_solve.h).
+//
+// Why.  pair_fused_kernel (fused.hip) lets the wave that streamed an item solve it, in slices inside the next item's stages: one
+// wave carries the staging registers AND the solve state (239 VGPRs: two waves per SIMD), and its issue stream alternates between
+// a stage's side products and a slice of ~7 epsilon steps.  Measured (NOTES.md round 4): the stream is then bound by the wave's own
+// issue slots -- ~30 us per item whether the chip is full or not -- and a 20 x 1000 call takes 102 us where its cost phase alone
+// takes 77.  Here the streaming waves keep only staging state (<= 168 VGPRs: THREE waves per SIMD), hand an item's finished 8 x 8
+// blocks through an LDS ring to solver waves of the same workgroup, and go on streaming; the solver waves never wait for memory and
+// fill the issue slots the streamers leave.
+//
+// Work decomposition (gfx950), documents of <= 8 sentence rows, CSR inputs, batches of <= 64 jobs (or ONE query against a pool):
+//   * one workgroup of 12 waves per CU: waves 0 .. 7 stream (two per SIMD), waves 8 .. 11 solve (one per SIMD); a streamer that
+//     runs out of items turns solver, so the launch's tail -- the last items' solves -- is spread over all twelve;
+//   * a workgroup owns a contiguous run of items (item = four consecutive candidates of one job, as in fused.hip); its streamers
+//     claim them one at a time from an LDS counter;
+//   * the query's per-coordinate box (geomloss's diameter) is formed ONCE per workgroup and job by the solver waves while the
+//     streamers' first loads are in flight (fused.hip's SELF form: every wave, from its staged query rows, during its first item);
+//   * addresses: a scalar base per item (the first row of its lowest candidate) + one 32-bit offset per row and lane, the stage in
+//     the load's immediate offset -- no address arithmetic in the stage loop.  An item whose four candidates lie further apart in
+//     the store than 32-bit offsets reach (an index-list pool over a > 4 GB store) is streamed in four passes, one candidate each;
+//   * hand-over: the four pairs' 8 x 8 costs and -cdist entries row-major + 16 words (lengths, candidates, diam^2) into one of 12
+//     ring slots; sequence numbers per slot (a bounded multi-producer / multi-consumer queue), polled with s_sleep.
+#include <mutex>
+#include <type_traits>
+
+#include "fused_solve.h"
+#include "tuning.h"
+
+namespace aspire {
+namespace {
+
+constexpr int kSpStreamers = 8;
+constexpr int kSpSolvers = 4;
+constexpr int kSpWaves = kSpStreamers + kSpSolvers;
+constexpr int kSpJobs = 3;             // query boxes a workgroup keeps (its run of items rarely touches more jobs; beyond: formed in-wave)
+constexpr int kSpSlots = 12;           // hand-over ring
+constexpr int kSpItemWords = 2 * 256 + 16;      // a slot: cost [4][64] | neg [4][64] | meta: q_len, then per pair c_len | real << 8, c_idx, diam^2
+#ifndef ASPIRE_SPLIT_UNROLL
+#define ASPIRE_SPLIT_UNROLL 4
+#endif
+constexpr int kSpUnroll = ASPIRE_SPLIT_UNROLL;      // stages per block of the stage loop (the loads' immediate offsets carry the stage inside a block)
+static_assert(kStages % kSpUnroll == 0, "stage blocks");
+// LDS, in floats: control words | boxes [kSpJobs][2][768] | ring [kSpSlots][kSpItemWords] | stage buffers [kSpStreamers][kWaveLds]
+constexpr int kSpCtl = 64;
+constexpr int kSpBoxOfs = kSpCtl;
+constexpr int kSpRingOfs = kSpBoxOfs + kSpJobs * 2 * kD;
+constexpr int kSpStageOfs = kSpRingOfs + kSpSlots * kSpItemWords;
+constexpr int kSpLdsFloats = kSpStageOfs + kSpStreamers * kWaveLds;
+// control words
+constexpr int kCtlClaim = 0, kCtlTail = 1, kCtlHead = 2, kCtlBox = 3, kCtlDone = 4, kCtlSeq = 8;
+static_assert(kCtlSeq + kSpSlots <= kSpCtl, "control block");
+constexpr int kFarRows = 1 << 19;      // (signed 32-bit byte offsets) candidates of an item further apart than this many store rows: one pass per candidate
+
+#ifdef ASPIRE_PHASE_CLOCK
+// debug build only (tools/splitphases.py): per-wave time stamps (100 MHz wall clock): [workgroup * 12 + wave][16] = start, then
+// per streamed item its hand-over; [8] = the wave turns solver, [9 ..] = end of each solve (up to 6), [15] = end
+static __device__ long long* g_sdbg = nullptr;
+#define S_STAMP(k)                                                                                                   \
+    do {                                                                                                             \
+        if (g_sdbg && lane == 0 && (k) < 16) g_sdbg[(size_t)(blockIdx.x * kSpWaves + wave) * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define S_STAMP(k) \
+    do {           \
+    } while (0)
+#endif
+
+__device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p) {
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// 16-byte buffer load: resource + 32-bit lane offset (+ a compile-time part, folded into the instruction's immediate) + scalar offset;
+// AUX 2 = non-temporal
+template <int AUX>
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    // (a whole-vector cast: __builtin_bit_cast on a vector ELEMENT reads element 0 with this clang -- common.h, swap_add)
+    const v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
+// SINGLE: ONE query (q.n == 1, CROSS pairing) against candidates [cand0, cand1) -- one job; else MAPPED jobs [job0, job1) of a batch.
+// PRIO: s_setprio of the streaming waves (the solver waves stay at 0).
+template <bool SINGLE, int PRIO>
+__global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    uint32_t* ctl = reinterpret_cast<uint32_t*>(lds_all);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // lane l holds job l's candidate range and the items (groups of four) up to and including it
+    int jo0 = 0, jo1 = 0;
+    if constexpr (SINGLE) {
+        if (lane == 0) {
+            jo0 = (int)a.cand0;
+            jo1 = (int)a.cand1;
+        }
+    } else if (lane < a.job1 - a.job0) {
+        jo0 = a.job_off[a.job0 + lane];
+        jo1 = a.job_off[a.job0 + lane + 1];
+    }
+    int gend = (jo1 - jo0 + 3) >> 2;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int t = __shfl_up(gend, m);
+        if (lane >= m) gend += t;
+    }
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readlane(gend, 63);
+    // this workgroup's run of items
+    const uint32_t nb = gridDim.x, per = n_items / nb, rem = n_items % nb;
+    const uint32_t lo = blockIdx.x * per + min((uint32_t)blockIdx.x, rem);
+    const uint32_t cnt = per + (blockIdx.x < rem ? 1u : 0u);
+    const int job_lo = __popcll(__ballot(gend <= (int)lo));              // job of the run's first item
+    if (threadIdx.x < kSpCtl) ctl[threadIdx.x] = (threadIdx.x >= kCtlSeq && threadIdx.x < kCtlSeq + kSpSlots) ? threadIdx.x - kCtlSeq : 0u;
+    __syncthreads();
+    if (cnt == 0) return;
+    S_STAMP(0);
+
+    if (wave < kSpStreamers) {
+        if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+        float* lds = lds_all + kSpStageOfs + wave * kWaveLds;
+        float* nscr = lds + kNormOfs;
+        // lane roles as in fused.hip: p = candidate of this lane (compute AND staging); (li, lj) = its 2 x 2 block of the 8 x 8 entries;
+        // the 16 lanes of group p stage the 8 rows of candidate p and query rows 2 p, 2 p + 1, chunk sc each
+        const int p = lane >> 4, lp = lane & 15, li = lp >> 2, lj = lp & 3;
+        const int sg = p, sc = lp;
+        // an item's documents, fetched one item AHEAD (the table round trips run under the current item's stages); the query's
+        // part is wave-uniform and lives in scalar registers
+        struct Ctx {
+            int c_idx, c_start, c_lr;      // per lane group: candidate, its first row, its length | real << 8
+            int q_len, q_start, job;       // wave-uniform
+        };
+        auto load_ctx = [&](uint32_t item) {
+            Ctx x;
+            const int job = SINGLE ? 0 : __popcll(__ballot(gend <= (int)item));
+            const int g0 = job > 0 ? __builtin_amdgcn_readlane(gend, job - 1) : 0;
+            const int cj0 = __builtin_amdgcn_readlane(jo0, job), cj1 = __builtin_amdgcn_readlane(jo1, job);
+            const int first = cj0 + 4 * ((int)item - g0);
+            const int cand = min(first + p, cj1 - 1);
+            const int q_idx = SINGLE ? 0 : a.job0 + job;
+            x.job = job;
+            x.q_len = __builtin_amdgcn_readfirstlane(a.q.len[q_idx]);
+            x.q_start = __builtin_amdgcn_readfirstlane(a.q.start[q_idx]);
+            x.c_idx = cand;
+            x.c_lr = a.c.len[cand] | (first + p < cj1 ? 256 : 0);
+            x.c_start = a.c.start[cand];
+            return x;
+        };
+        auto claim = [&]() {
+            uint32_t t = 0;
+            if (lane == 0) t = lds_fetch_add(&ctl[kCtlClaim]);
+            return (uint32_t)__builtin_amdgcn_readfirstlane(t);
+        };
+        uint32_t cur_it = claim();
+        Ctx next = load_ctx(lo + min(cur_it, cnt - 1));
+        bool box_ready = false;
+        int n_done = 0;
+        (void)n_done;
+
+        while (cur_it < cnt) {
+            const Ctx cur = next;
+            const uint32_t nxt_it = claim();
+            next = load_ctx(lo + (nxt_it < cnt ? nxt_it : cur_it));          // (the last item fetches itself again)
+            const int q_len = cur.q_len;
+            const int bslot = cur.job - job_lo;
+            // the item's four first rows: near each other (the usual case) -> one pass; else one pass per candidate, every lane group
+            // on the same one, the other three groups' results dropped
+            int smin = __builtin_amdgcn_readlane(cur.c_start, 0), smax = smin;
+#pragma unroll
+            for (int g = 1; g < 4; ++g) {
+                const int v = __builtin_amdgcn_readlane(cur.c_start, 16 * g);
+                smin = min(smin, v);
+                smax = max(smax, v);
+            }
+            const bool far = smax - smin > kFarRows;
+#pragma unroll 1
+            for (int pass = 0; pass < (far ? 4 : 1); ++pass) {
+            int c_idx = cur.c_idx, c_start = cur.c_start, c_len = cur.c_lr & 255;
+            bool real = (cur.c_lr & 256) != 0;
+            int row_base = smin;
+            if (far) {
+                c_idx = __builtin_amdgcn_readlane(cur.c_idx, 16 * pass);
+                c_start = __builtin_amdgcn_readlane(cur.c_start, 16 * pass);
+                const int lr = __builtin_amdgcn_readlane(cur.c_lr, 16 * pass);
+                c_len = lr & 255;
+                real = (lr & 256) != 0 && p == pass;
+                row_base = c_start;
+            }
+            const char* cbase = reinterpret_cast<const char*>(a.c.rows + (size_t)row_base * kD);
+            const char* qbase = reinterpret_cast<const char*>(a.q.rows + (size_t)cur.q_start * kD);
+
+            mfma4_t macc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) macc[m] = mfma4_t{0.f, 0.f, 0.f, 0.f};
+            f2_t ny[8], nx[2], dsq = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ny[k] = f2_t{0.f, 0.f};
+            nx[0] = nx[1] = f2_t{0.f, 0.f};
+            float4 vy[8], vx[2];
+            int oy[8], ox[2];                // byte offsets of this lane's chunk of stage 0 in its rows (pad rows: copies of the last row)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oy[j] = ((c_start - row_base + min(j, c_len - 1)) * kD + sc * 4) * 4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) ox[k] = (min(2 * sg + k, q_len - 1) * kD + sc * 4) * 4;
+            // loads as buffer loads: resource (scalar base of the item) + 32-bit lane offset + scalar block offset + immediate stage
+            // offset -- nothing for the VALU to add in the stage loop, ten offset registers instead of twenty for pointers
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cbase), 0, -1, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qbase), 0, -1, 0x00020000);
+            auto issue_loads = [&](int blk, int u) {       // stage blk * kSpUnroll + u (u == kSpUnroll: the next block's first)
+                const int so = blk * (kSpUnroll * 16 * kCh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vy[j] = buf_ld4<2>(rc, oy[j] + u * 16 * kCh, so);      // candidate rows: read once (nt)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) vx[k] = buf_ld4<0>(rq, ox[k] + u * 16 * kCh, so);
+            };
+            auto sq_acc = [](f2_t acc, const float4& v) {
+                acc = __builtin_elementwise_fma(f2_t{v.x, v.y}, f2_t{v.x, v.y}, acc);
+                return __builtin_elementwise_fma(f2_t{v.z, v.w}, f2_t{v.z, v.w}, acc);
+            };
+            issue_loads(0, 0);
+            // the boxes are formed by the solver waves while the first loads fly; a wave whose first item gets here before them forms
+            // the query's box itself, from its staged rows (as an item of a job beyond the workgroup's kSpJobs boxes does)
+            if (!box_ready) {
+                box_ready = lds_load(&ctl[kCtlBox]) == (uint32_t)kSpSolvers;
+                if (box_ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            const bool have_box = box_ready && bslot < kSpJobs;                 // wave-uniform
+            const float* qcb = lds_all + kSpBoxOfs + (have_box ? bslot : 0) * 2 * kD + sc * 4;
+            const bool center = a.center != 0;
+
+            // one stage: registers -> LDS with the norm / box side products, the next stage's loads, the dot products on the matrix pipe
+            auto stage = [&](auto cached_tag, int sb, int u) {
+                constexpr bool CACHED = decltype(cached_tag)::value;
+                float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 qn, qx;
+                if constexpr (CACHED) {
+                    qn = *reinterpret_cast<const float4*>(qcb + (sb * kSpUnroll + u) * 4 * kCh);
+                    qx = *reinterpret_cast<const float4*>(qcb + kD + (sb * kSpUnroll + u) * 4 * kCh);
+                }
+                if (center) {
+                    // centre of the rows at this lane's chunk: the mean of the eight staged query rows (fused.hip)
+                    mu = make_float4(vx[0].x + vx[1].x, vx[0].y + vx[1].y, vx[0].z + vx[1].z, vx[0].w + vx[1].w);
+                    mu.x += lane_xor<16>(mu.x); mu.y += lane_xor<16>(mu.y); mu.z += lane_xor<16>(mu.z); mu.w += lane_xor<16>(mu.w);
+                    mu.x += lane_xor<32>(mu.x); mu.y += lane_xor<32>(mu.y); mu.z += lane_xor<32>(mu.z); mu.w += lane_xor<32>(mu.w);
+                    mu.x *= 0.125f; mu.y *= 0.125f; mu.z *= 0.125f; mu.w *= 0.125f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        vy[j].x -= mu.x; vy[j].y -= mu.y; vy[j].z -= mu.z; vy[j].w -= mu.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        vx[k].x -= mu.x; vx[k].y -= mu.y; vx[k].z -= mu.z; vx[k].w -= mu.w;
+                    }
+                    if constexpr (CACHED) {          // the workgroup's box is that of the raw rows: the centre comes off here
+                        qn.x -= mu.x; qn.y -= mu.y; qn.z -= mu.z; qn.w -= mu.w;
+                        qx.x -= mu.x; qx.y -= mu.y; qx.z -= mu.z; qx.w -= mu.w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ny[j] = sq_acc(ny[j], vy[j]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) nx[k] = sq_acc(nx[k], vx[k]);
+                // the candidate's per-coordinate box over its eight rows (v_min3 / v_max3: four instructions per component and side),
+                // CACHED: the query's joined in the same chain
+                float4 mn, mx;
+                if constexpr (CACHED) {
+                    mn = vmin3_4(qn, vy[0], vy[1]);
+                    mx = vmax3_4(qx, vy[0], vy[1]);
+                } else {
+                    mn = vmin3_4(vy[0], vy[0], vy[1]);
+                    mx = vmax3_4(vy[0], vy[0], vy[1]);
+                }
+                mn = vmin3_4(mn, vy[2], vy[3]); mx = vmax3_4(mx, vy[2], vy[3]);
+                mn = vmin3_4(mn, vy[4], vy[5]); mx = vmax3_4(mx, vy[4], vy[5]);
+                mn = vmin3_4(mn, vy[6], vy[7]); mx = vmax3_4(mx, vy[6], vy[7]);
+                if constexpr (CACHED) {
+                    const f2_t dlo = {mx.x - mn.x, mx.y - mn.y}, dhi = {mx.z - mn.z, mx.w - mn.w};
+                    dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(lds + (2 * sg + k) * kRowStride + sc * 4) = vx[k];
+                // pin the side products HERE (the optimiser otherwise sinks these loop-carried sums below the loads)
+                if constexpr (CACHED)
+                    asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
+                                      "+v"(nx[0]), "+v"(nx[1]), "+v"(dsq) : : "memory");
+                else
+                    asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
+                                      "+v"(nx[0]), "+v"(nx[1]), "+v"(mn.x), "+v"(mn.y), "+v"(mn.z), "+v"(mn.w), "+v"(mx.x), "+v"(mx.y),
+                                      "+v"(mx.z), "+v"(mx.w) : : "memory");
+                if (sb * kSpUnroll + u + 1 < kStages) issue_loads(sb, u + 1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if constexpr (!CACHED) {
+                    // the query's box at this lane's chunk from the eight staged query rows (rows past the document's end are copies of
+                    // its last row), joined with the candidate's
+                    qn = qx = *reinterpret_cast<const float4*>(lds + sc * 4);
+#pragma unroll
+                    for (int r = 1; r < 8; r += 2) {
+                        const float4 q0 = *reinterpret_cast<const float4*>(lds + r * kRowStride + sc * 4);
+                        const float4 q1 = *reinterpret_cast<const float4*>(lds + min(r + 1, 7) * kRowStride + sc * 4);
+                        qn = vmin3_4(qn, q0, q1);
+                        qx = vmax3_4(qx, q0, q1);
+                    }
+                    const f2_t dlo = {vmax1(mx.x, qx.x) - vmin1(mn.x, qn.x), vmax1(mx.y, qx.y) - vmin1(mn.y, qn.y)};
+                    const f2_t dhi = {vmax1(mx.z, qx.z) - vmin1(mn.z, qn.z), vmax1(mx.w, qx.w) - vmin1(mn.w, qn.w)};
+                    dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
+                }
+                // ---- dot products on the matrix pipe: block b = lane >> 2 = (p, iq, jq) is the 4 x 4 sub-block (rows 4 iq .., columns
+                // 4 jq ..) of pair p; lane t = lane & 3 feeds query row 4 iq + t as A and candidate row 4 jq + t as B (fused.hip) ----
+                {
+                    const int mb = lane >> 2, mt = lane & 3, miq = (mb >> 1) & 1, mjq = mb & 1;
+                    const float* xm = lds + (4 * miq + mt) * kRowStride;
+                    const float* ym = lds + (8 + p * 8 + 4 * mjq + mt) * kRowStride;
+#pragma unroll
+                    for (int c = 0; c < kCh; ++c) {
+                        const float4 xa = *reinterpret_cast<const float4*>(xm + c * 4);
+                        const float4 yb = *reinterpret_cast<const float4*>(ym + c * 4);
+                        macc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.x, yb.x, macc[0], 0, 0, 0);
+                        macc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.y, yb.y, macc[1], 0, 0, 0);
+                        macc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.z, yb.z, macc[2], 0, 0, 0);
+                        macc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.w, yb.w, macc[3], 0, 0, 0);
+                        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (operand reads stay four chunks ahead at most: registers)
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
+                __builtin_amdgcn_wave_barrier();
+            };
+            auto stages = [&](auto cached_tag) {
+#pragma unroll 1
+                for (int sb = 0; sb < kStages / kSpUnroll; ++sb) {
+#pragma unroll
+                    for (int u = 0; u < kSpUnroll; ++u) stage(cached_tag, sb, u);
+                }
+            };
+            if (have_box) stages(std::true_type{});
+            else stages(std::false_type{});
+
+            // block columns -> the solve's 2 x 2 layout, through the (idle) stage buffer: pair p's 8 x 8 entries row-major
+            float accg[2][2];
+            {
+                const int mb = lane >> 2, mt = lane & 3, miq = (mb >> 1) & 1, mjq = mb & 1;
+                float* tr = lds + p * 64;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tr[(4 * miq + r) * 8 + 4 * mjq + mt] = (macc[0][r] + macc[1][r]) + (macc[2][r] + macc[3][r]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(tr + (2 * li + x) * 8 + 2 * lj);
+                    accg[x][0] = t2.x;
+                    accg[x][1] = t2.y;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // norms: sum the staging lanes' partials through the scratch table nscr[value][lane] (fused.hip)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) nscr[k * kNormLd + lane] = ny[k].x + ny[k].y;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) nscr[(8 + k) * kNormLd + lane] = nx[k].x + nx[k].y;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            auto table_sum = [&](int value, int lane0) {
+                const float4* src = reinterpret_cast<const float4*>(nscr + value * kNormLd + lane0);
+                float t = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 u = src[m];
+                    t += (u.x + u.y) + (u.z + u.w);
+                }
+                return t;
+            };
+            float xx[2], yy[2];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) yy[y] = table_sum(2 * lj + y, p * 16);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) xx[x] = table_sum(8 + ((2 * li + x) & 1), ((2 * li + x) >> 1) * 16);
+            float diam2 = dsq.x + dsq.y;
+            diam2 += lane_xor<1>(diam2); diam2 += lane_xor<2>(diam2); diam2 += lane_xor<4>(diam2); diam2 += lane_xor<8>(diam2);
+
+            // finish the entries.  Only x.y was accumulated: -cdist comes from the same expansion as geomloss's cost, and the
+            // entries where it cancels (torch.cdist's direct formula differs there) are redone below
+            const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+            float cost[2][2], neg[2][2];
+            bool redo[2][2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const int i = 2 * li + x, j = 2 * lj + y;
+                    const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
+                    const float ns = xx[x] + yy[y];
+                    redo[x][y] = !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
+                    cost[x][y] = sqrtf(fmaxf(sq, 1e-8f));
+                    neg[x][y] = -sqrtf(fmaxf(sq, 0.f));
+                }
+            {
+                // direct-formula redo, the whole wave on one entry (12 coordinates per lane), two entries per memory round trip
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        unsigned long long wm = __ballot(redo[x][y]);
+                        while (wm != 0) {
+                            int owner[2];
+                            float part[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                owner[e] = wm != 0 ? (int)__builtin_ctzll(wm) : -1;
+                                wm = wm != 0 ? wm & (wm - 1) : 0;
+                            }
+                            float4 u[2][3], v[2][3];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int o = owner[e] >= 0 ? owner[e] : owner[0];
+                                const int ol = o & 15, i = 2 * (ol >> 2) + x;
+                                const int j = 2 * (ol & 3) + y;
+                                const int cs_e = __builtin_amdgcn_readlane(c_start, o);
+                                const float* qrow = reinterpret_cast<const float*>(qbase) + (size_t)i * kD + 4 * lane;
+                                const float* crow = a.c.rows + ((size_t)cs_e + j) * kD + 4 * lane;
+#pragma unroll
+                                for (int t = 0; t < 3; ++t) {
+                                    u[e][t] = ld4(qrow + 256 * t);
+                                    v[e][t] = ld4(crow + 256 * t);
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                part[e] = 0.f;
+#pragma unroll
+                                for (int t = 0; t < 3; ++t) {
+                                    const float d0 = u[e][t].x - v[e][t].x, d1 = u[e][t].y - v[e][t].y, d2 = u[e][t].z - v[e][t].z, d3 = u[e][t].w - v[e][t].w;
+                                    part[e] = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, part[e]))));
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 2; ++e)
+                                if (owner[e] >= 0) {
+                                    const float tot = wave_sum(part[e]);
+                                    if (lane == owner[e]) neg[x][y] = -sqrtf(tot);
+                                }
+                        }
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch table is rewritten by the next item
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- hand the item over: ticket, wait for the slot (twelve items behind), payload, publish --------------------------
+            uint32_t t = 0;
+            if (lane == 0) t = lds_fetch_add(&ctl[kCtlTail]);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane(t);
+            const uint32_t slot = t % kSpSlots;
+            while (lds_load(&ctl[kCtlSeq + slot]) != t) __builtin_amdgcn_s_sleep(2);
+            float* pl = lds_all + kSpRingOfs + slot * kSpItemWords;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                *reinterpret_cast<float2*>(pl + p * 64 + (2 * li + x) * 8 + 2 * lj) = make_float2(cost[x][0], cost[x][1]);
+                *reinterpret_cast<float2*>(pl + 256 + p * 64 + (2 * li + x) * 8 + 2 * lj) = make_float2(neg[x][0], neg[x][1]);
+            }
+            if (lane == 0) pl[512] = __builtin_bit_cast(float, q_len);
+            if (lp == 0) {
+                pl[512 + 4 + p] = __builtin_bit_cast(float, c_len | (real ? 256 : 0));
+                pl[512 + 8 + p] = __builtin_bit_cast(float, c_idx);
+                pl[512 + 12 + p] = diam2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) lds_store(&ctl[kCtlSeq + slot], t + 1);
+            }      // pass
+            ++n_done;
+            S_STAMP(n_done);
+            cur_it = nxt_it;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_fetch_add(&ctl[kCtlDone]);           // (after the wave's last publication)
+        if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
+    } else {
+        // ---- the solver waves first form the query boxes of the run's jobs (256 threads, three coordinates each) --------------------
+        const int tid = threadIdx.x - kSpStreamers * 64;
+        const int job_hi = SINGLE ? 0 : __popcll(__ballot(gend <= (int)(lo + cnt - 1)));
+#pragma unroll 1
+        for (int s = 0; s < kSpJobs; ++s) {
+            const int job = job_lo + s;
+            if (job > job_hi) break;
+            const int q_idx = SINGLE ? 0 : a.job0 + job;
+            const int q_len = a.q.len[q_idx];
+            const float* qdoc = a.q.rows + (size_t)a.q.start[q_idx] * kD;
+            float* qb = lds_all + kSpBoxOfs + s * 2 * kD;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int d = tid + 256 * t;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = qdoc[(size_t)min(r, q_len - 1) * kD + d];
+                float mn = v[0], mx = v[0];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) {
+                    mn = fminf(mn, v[r]);
+                    mx = fmaxf(mx, v[r]);
+                }
+                qb[d] = mn;
+                qb[kD + d] = mx;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_fetch_add(&ctl[kCtlBox]);
+    }
+    S_STAMP(8);
+
+    // ---- solve: pop an item, solve its four pairs, store the scores -------------------------------------------------------------------
+    {
+        const int p = lane >> 4, lp = lane & 15, li = lp >> 2, lj = lp & 3;
+        int n_solved = 0;
+        (void)n_solved;
+        for (;;) {
+            uint32_t h = 0;
+            if (lane == 0) h = lds_fetch_add(&ctl[kCtlHead]);
+            h = (uint32_t)__builtin_amdgcn_readfirstlane(h);
+            const uint32_t slot = h % kSpSlots;
+            bool none = false;
+            while (lds_load(&ctl[kCtlSeq + slot]) != h + 1) {
+                // no more items: every streamer is through and this ticket is past the last publication
+                if (lds_load(&ctl[kCtlDone]) == (uint32_t)kSpStreamers && h >= lds_load(&ctl[kCtlTail])) {
+                    none = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (none) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float* pl = lds_all + kSpRingOfs + slot * kSpItemWords;
+            float cost[2][2], neg[2][2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const float2 c2 = *reinterpret_cast<const float2*>(pl + p * 64 + (2 * li + x) * 8 + 2 * lj);
+                const float2 n2 = *reinterpret_cast<const float2*>(pl + 256 + p * 64 + (2 * li + x) * 8 + 2 * lj);
+                cost[x][0] = c2.x; cost[x][1] = c2.y;
+                neg[x][0] = n2.x; neg[x][1] = n2.y;
+            }
+            const int q_len = __builtin_bit_cast(int, pl[512]);
+            const int lr = __builtin_bit_cast(int, pl[512 + 4 + p]);
+            const int c_idx = __builtin_bit_cast(int, pl[512 + 8 + p]);
+            const float diam2 = pl[512 + 12 + p];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the payload is in registers before the slot is released
+            if (lane == 0) lds_store(&ctl[kCtlSeq + slot], h + kSpSlots);
+            const int c_len = lr & 255;
+            const bool real = (lr & 256) != 0;
+            bool rv[2], cv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                rv[t] = 2 * li + t < q_len;
+                cv[t] = 2 * lj + t < c_len;
+            }
+            Solve s;
+            solve_begin<false>(s, a, cost, neg, rv, cv, fmaxf(sqrtf(diam2), kMinDiameter));
+            s.out = real ? (int64_t)c_idx : (int64_t)-1;
+            if (q_len > 8 || c_len > 8) s.valid |= 16u;
+            solve_finish<false>(s, a);
+            ++n_solved;
+            S_STAMP(8 + n_solved);
+        }
+    }
+    S_STAMP(15);
+}
+
+int cu_count() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+template <bool SINGLE, int PRIO>
+int launch_split_as(const ScoreArgs& a, hipStream_t stream) {
+    static std::once_flag raised;
+    static hipError_t raise_rc = hipSuccess;
+    std::call_once(raised, [] {
+        raise_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_split_kernel<SINGLE, PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kSpLdsFloats * (int)sizeof(float));
+    });
+    ASPIRE_HIP_OK(raise_rc);
+    hipLaunchKernelGGL((pair_split_kernel<SINGLE, PRIO>), dim3((unsigned)cu_count()), dim3(kSpWaves * 64), kSpLdsFloats * sizeof(float), stream, a);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+
+}  // namespace
+
+// the role-split form pays once every CU's eight streamers have a couple of items each
+bool split_path_ok(int64_t groups_bound, const aspire_ot_params* prm) {
+    const int f = tuning().fused_split;
+    if (f == 2) return false;
+    return (f == 1 || groups_bound >= (int64_t)cu_count() * kSpStreamers) && prm->scaling >= 0.25 && tuning().fused_nosolve == 0 && !tuning().fused_valu &&
+           !tuning().fused_noself;
+}
+
+// a: MAPPED jobs [job0, job1) (<= 64 of them), or CROSS with ONE query against candidates [cand0, cand1)
+int launch_pair_split(const ScoreArgs& a, hipStream_t stream) {
+    const bool single = a.pairing == ASPIRE_PAIR_CROSS;
+    const int prio = tuning().split_prio;
+    if (single) return prio == 1 ? launch_split_as<true, 1>(a, stream) : prio == 2 ? launch_split_as<true, 2>(a, stream) : launch_split_as<true, 0>(a, stream);
+    return prio == 1 ? launch_split_as<false, 1>(a, stream) : prio == 2 ? launch_split_as<false, 2>(a, stream) : launch_split_as<false, 0>(a, stream);
+}
+
+}  // namespace aspire
+#ifdef ASPIRE_PHASE_CLOCK
+extern "C" void aspire_debug_split_buffer(void* p) {
+    long long* q = (long long*)p;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aspire::g_sdbg), &q, sizeof(q));
+}
+#endif
