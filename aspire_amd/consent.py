@@ -75,7 +75,7 @@ class AspireConSent:
         tok_idx, span_off = spans_to_csr(batch_senttok_idxs, max_sents)
         dev = final_hidden_state.device
         doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
-        if not bool(torch.isfinite(sent_reps).all()):
+        if not bool(torch.isfinite(sent_reps).all() & torch.isfinite(doc_cls_reps).all()):      # (the CLS token belongs to no sentence span)
             # an activation beyond the fp16 planes' range (encoder.py: forward_full_range): once more on the full-range kernels
             final_hidden_state = self.bert_encoder.forward_full_range(tokid_tt, seg_tt, attnmask_tt)
             doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
@@ -255,7 +255,7 @@ class AspireConSent:
                 else:
                     ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows,
                                             cls_all[d0:d0 + b] if want_cls else None)
-        if total and not bool(torch.isfinite(rows).all()) and not _full_range:
+        if total and not _full_range and not bool(torch.isfinite(rows).all() & (torch.isfinite(cls_all).all() if want_cls else True)):
             # an activation left the fp16 planes' range somewhere (one check over the finished store): encode again on the kernels
             # that take any fp32 value
             from ._lib import pinned

@@ -552,7 +552,10 @@ __global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel
                         for (int e = 0; e < 4; ++e)
                             if (owner[e] >= 0) {
                                 const float tot = wave_sum(part[e]);
-                                if (lane == owner[e]) neg[x][y] = -sqrtf(tot);
+                                if (lane == owner[e]) {
+                                    neg[x][y] = -sqrtf(tot);
+                                    cost[x][y] = sqrtf(fmaxf(tot, 1e-8f));      // geomloss's cost from the same exact sum (see the header of this block)
+                                }
                             }
                     }
                 }

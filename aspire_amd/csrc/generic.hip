@@ -118,7 +118,10 @@ __device__ __forceinline__ void pair_generic_body(const ScoreArgs& a, int mode, 
             d1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, d1))));
         }
         const float sq = fmaf(-2.f, g0 + g1, lds[L.xx + i]) + lds[L.yy + j];
-        cost[i * ld + j] = sqrtf(fmaxf(sq, 1e-8f));
+        const float ns = lds[L.xx + i] + lds[L.yy + j];
+        // (where the expansion cancels -- the streaming kernels' test -- geomloss's cost comes from the exact sum too: what its own
+        // formula gives in float64; in fp32 the reference returns the square root of rounding noise there)
+        cost[i * ld + j] = sqrtf(fmaxf(sq < 1e-4f * ns * ns ? d0 + d1 : sq, 1e-8f));
         neg[i * ld + j] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d0 + d1);
     }
     __syncthreads();

@@ -506,7 +506,12 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
                     if (redo[k]) {
                         const uint32_t slot = atomicAdd(&wl_count, 1u);
                         if (slot < (uint32_t)kCap) wlist[slot] = ((uint32_t)(m0 + k) << 16) | (uint32_t)n;
-                        else { neg[k] = -sqrtf(direct_d2(qp, c_ptr[m0 + k])); redo[k] = false; }   // list full: lane-local
+                        else {   // list full: lane-local
+                            const float d2 = direct_d2(qp, c_ptr[m0 + k]);
+                            neg[k] = -sqrtf(d2);
+                            cost[k] = sqrtf(fmaxf(d2, 1e-8f));
+                            redo[k] = false;
+                        }
                     }
                     any_redo |= redo[k];
                 }
@@ -517,13 +522,16 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
                         if (!redo[k] && qp != zrow && c_ptr[m0 + k] != zrow) best = fmaxf(best, neg[k]);
                     if (best > -INFINITY) atomicMax(&pairmax[(int)co * 16 + (int)qo], order_key(best));
                 } else {
-                    *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
                     if (!any_redo) {
+                        *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
                         *reinterpret_cast<float4*>(g.neg + qo + co) = make_float4(neg[0], neg[1], neg[2], neg[3]);
-                    } else {   // the work-list pass writes the flagged ones: no address is stored twice
+                    } else {   // the work-list pass writes the flagged ones (-cdist AND geomloss's cost, from the same exact sum): no address is stored twice
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (!redo[k]) g.neg[qo + co + k] = neg[k];
+                            if (!redo[k]) {
+                                g.cost[qo + co + k] = cost[k];
+                                g.neg[qo + co + k] = neg[k];
+                            }
                     }
                 }
             }
@@ -558,7 +566,10 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
             const float negd = -sqrtf(part);
             if (live && l16 == 0) {
                 if constexpr (L2MAX) atomicMax(&pairmax[(int)c_off[m] * 16 + (int)q_off[n]], order_key(negd));
-                else g.neg[q_off[n] + c_off[m]] = negd;
+                else {
+                    g.neg[q_off[n] + c_off[m]] = negd;
+                    g.cost[q_off[n] + c_off[m]] = sqrtf(fmaxf(part, 1e-8f));
+                }
             }
         }
     }

@@ -383,8 +383,13 @@ __device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want
         }
         const float sq = fmaf(-2.f, g, xx) + yy;
         const int64_t o = slot * (64 * T * T) + (ta * 8 + li) * (8 * T) + tb * 8 + lj;
-        ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
+        // geomloss's cost: its expansion -- except where that cancels (the test the streaming kernels use), where the exact sum
+        // stands in: what the reference's own formula gives in float64 (in fp32 it returns the square root of rounding noise there)
+        float costv = sqrtf(fmaxf(sq, 1e-8f));
         if constexpr (DIRECT) {
+            const float ns = xx + yy;
+            if (sq < 1e-4f * ns * ns) costv = sqrtf(fmaxf(d2, 1e-8f));
+            ws.cost[o] = costv;
             ws.neg[o] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);
         } else {
             // only x.y was accumulated (see pair_cost1_kernel): -cdist from the expansion, except where it cancels
@@ -403,7 +408,9 @@ __device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want
                     s1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, s1))));
                 }
                 negv = -sqrtf(s0 + s1);
+                costv = sqrtf(fmaxf(s0 + s1, 1e-8f));
             }
+            ws.cost[o] = costv;
             ws.neg[o] = negv;
         }
     }
@@ -1122,8 +1129,10 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
             const int gi = 8 * ta + li, gj = 8 * tb + lj;                  // entry of the pair's 8T x 8T slot
             const bool redo = !mm && gi < q_len && gj < c_len && sq < 1e-4f * ns * ns;
             const int64_t o = slot * n_ent + gi * ld_e + gj;
-            ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
-            if (!redo) ws.neg[o] = -sqrtf(fmaxf(sq, 0.f));
+            if (!redo) {
+                ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
+                ws.neg[o] = -sqrtf(fmaxf(sq, 0.f));
+            }
             const unsigned long long m = __ballot(redo);
             if (lane == 0) {
                 *redo_mask = m;
@@ -1167,7 +1176,10 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
                     part += lane_xor<2>(part);
                     part += lane_xor<4>(part);
                     part += lane_xor<8>(part);
-                    if (live && l16 == 0) ws.neg[slot * n_ent + gi * ld_e + gj] = -sqrtf(part);
+                    if (live && l16 == 0) {       // geomloss's cost from the same exact sum (kCostFloor2: its clamp_min)
+                        ws.neg[slot * n_ent + gi * ld_e + gj] = -sqrtf(part);
+                        ws.cost[slot * n_ent + gi * ld_e + gj] = sqrtf(fmaxf(part, 1e-8f));
+                    }
                 }
             }
         }
@@ -1490,9 +1502,9 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
                 const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
                 const float ns = xx[x] + yy[y];
                 redo[x][y] = my_c_real && !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
-                if (my_c_real) {
+                if (my_c_real && !redo[x][y]) {
                     ws.cost[slot * 64 + i * 8 + j] = sqrtf(fmaxf(sq, 1e-8f));
-                    if (!redo[x][y]) ws.neg[slot * 64 + i * 8 + j] = -sqrtf(fmaxf(sq, 0.f));
+                    ws.neg[slot * 64 + i * 8 + j] = -sqrtf(fmaxf(sq, 0.f));
                 }
             }
         if (my_c_real && own_diam && lp == 0) ws.diam2[slot] = diam2;
@@ -1537,7 +1549,10 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
                             if (owner[e] >= 0) {
                                 const float tot = wave_sum(part);
                                 const int ol = owner[e] & 15, i = R * (ol >> 2) + x, j = R * (ol & 3) + y;
-                                if (lane == owner[e]) ws.neg[slot * 64 + i * 8 + j] = -sqrtf(tot);
+                                if (lane == owner[e]) {
+                                    ws.neg[slot * 64 + i * 8 + j] = -sqrtf(tot);
+                                    ws.cost[slot * 64 + i * 8 + j] = sqrtf(fmaxf(tot, 1e-8f));      // geomloss's cost from the same exact sum
+                                }
                             }
                         }
                     }
@@ -1558,6 +1573,7 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
                             d2s = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, d2s))));
                         }
                         ws.neg[slot * 64 + i * 8 + j] = -sqrtf(d2s);
+                        ws.cost[slot * 64 + i * 8 + j] = sqrtf(fmaxf(d2s, 1e-8f));
                     }
         }
         if constexpr (DS == 1) {

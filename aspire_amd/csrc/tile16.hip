@@ -354,7 +354,13 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
                             const int o = owner[e], ob = o >> 2;
                             const int oi = 8 * s + 4 * ((ob >> 1) & 1) + r, oj = 8 * ((ob >> 2) & 1) + 4 * (ob & 1) + (o & 3);
                             (void)oi; (void)oj;
-                            if (lane == o) negv[s][r] = -sqrtf(tot);
+                            if (lane == o) {
+                                negv[s][r] = -sqrtf(tot);
+                                if constexpr (!L2MAX) {      // geomloss's cost from the same exact sum (this lane wrote the expansion's value above)
+                                    const int i = qrow0 + 8 * s + 4 * miq + r;
+                                    if (!REC || (i < LDW && j < LDW)) ws.cost[slot * EW + i * LDW + j] = sqrtf(fmaxf(tot, 1e-8f));
+                                }
+                            }
                         }
                     }
                 }

@@ -46,17 +46,33 @@ def set_center_hint(mode):
     CENTER_HINT = mode
 
 
+def _rows_key(rows):
+    """What a cache derived from a row matrix is valid for: the same memory, the same number of rows, not written since.  torch
+    counts in-place writes (rows._version, shared by a matrix and its views); the entry points of this module that write rows
+    through the C ABI report theirs (_rows_written)."""
+    return (rows.data_ptr(), int(rows.shape[0]), rows._version)
+
+
+def _rows_written(t):
+    """The library wrote into `t` behind torch's back (a kernel given its data pointer): caches keyed by _rows_key(t) are stale."""
+    torch.autograd.graph.increment_version(t)
+
+
 def _match_planes(q, c, pairing):
     """An all-against-all call on a big pool that carries fp16 planes (DeviceRepSet.prepare_planes): the queries get
-    theirs, around the pool's centre, unless they are rows of the same matrix already (then nothing happens) or carry planes of
-    another store (left alone: the call takes the kernels that read the fp32 rows).  ~10 us for 256 query rows."""
+    theirs, around the pool's centre, unless they are rows of the same matrix already (then nothing happens) or carry planes the
+    CALLER prepared around another store's centre (left alone: the call takes the kernels that read the fp32 rows).  Planes this
+    function made earlier are kept on the query matrix and reused only while they are valid: same rows, not written since
+    (_rows_key), same centre as THIS pool -- otherwise they are made again.  ~10 us for 256 query rows."""
     if pairing != _lib.PAIR_CROSS or c.planes is None or q.ext or c.ext:
         return
     slot = max(8, (c.max_len + 3) // 4 * 4)
     if c.n * slot < 128 * 128 or max(q.max_len, c.max_len) > 32:          # fewer than 128 candidate tiles: the small-pool kernels
         return
-    if q.planes is None:
+    qp = q.planes
+    if qp is None or (qp.auto and qp.mu.data_ptr() != c.planes.mu.data_ptr()):
         q.prepare_planes(like=c)
+        q.planes.auto = True
 
 
 class RowPlanes:
@@ -68,6 +84,9 @@ class RowPlanes:
         nbytes = lib.aspire_rep_planes_bytes(n)
         self.blob = torch.empty(nbytes, device=rows.device, dtype=torch.uint8)
         self.mu = mu                       # tensor [768] (the store's common vector); None: formed from these rows
+        self.mu_given = mu is not None
+        self.auto = False                  # made by _match_planes for a call (not by the caller)
+        self.key = _rows_key(rows)
         self.c = _lib.RepPlanes()
         check(lib.aspire_rep_planes_prepare(_ptr(rows), n, D, _ptr(_f32(mu, 'mu')) if mu is not None else None, _ptr(self.blob),
                                             nbytes, ctypes.byref(self.c), _stream()))
@@ -121,31 +140,47 @@ class DeviceRepSet:
         return cls(rows, start.to(dev), lens.to(dev), ext=0, max_len=max(lens_host) if lens_host else 0, lens_host=lens_host)
 
     def struct(self):
-        planes = getattr(self.rows, '_aspire_planes', None)      # kept on the matrix: index lists and slices of it share them
+        planes = self.planes                                     # kept on the matrix: index lists and slices of it share them
         return RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len,
-                      ctypes.pointer(planes.c) if planes is not None else None, _ptr(getattr(self, 'doc_box', None)))
+                      ctypes.pointer(planes.c) if planes is not None else None, _ptr(self._fresh_boxes()))
+
+    def _fresh_boxes(self):
+        box = getattr(self, 'doc_box', None)
+        if box is not None and getattr(self, '_doc_box_key', None) not in (None, _rows_key(self.rows)):
+            self.doc_box = None                                  # the rows were written since: formed again
+            self.prepare_boxes()
+            box = self.doc_box
+        return box
 
     def prepare_boxes(self):
         """The documents' per-coordinate bounding boxes [n, 2, 768], kept with this rep set (include/aspire_hip.h:
         aspire_repset.doc_box): the many-query otAspire calls on a resident pool then skip their pass over every candidate row
-        (geomloss's diameter).  6 KB per document.  Returns self."""
+        (geomloss's diameter).  6 KB per document; formed again when the rows have been written since (_rows_key).  Returns self."""
         if self.n and getattr(self, 'doc_box', None) is None:
             box = torch.empty(self.n, 2, D, device=self.rows.device, dtype=torch.float32)
             s = RepSet(_ptr(self.rows), _ptr(self.start), _ptr(self.len), self.n, self.ext, self.max_len, None, None)
             check(lib.aspire_repset_boxes_f32(ctypes.byref(s), D, _ptr(box), _stream()))
             self.doc_box = box
+            self._doc_box_key = _rows_key(self.rows)
         return self
 
     def slice(self, lo, hi):
         r = DeviceRepSet(self.rows, self.start[lo:hi].contiguous(), self.len[lo:hi].contiguous(), self.ext,
                          self.max_len, lens_host=self.lens_host[lo:hi] if self.lens_host is not None else None)
-        if getattr(self, 'doc_box', None) is not None:
+        if self._fresh_boxes() is not None:
             r.doc_box = self.doc_box[lo:hi]
+            r._doc_box_key = self._doc_box_key
         return r
 
     @property
     def planes(self):
-        return getattr(self.rows, '_aspire_planes', None)
+        """The matrix's fp16 planes, or None.  Planes are a cache of the rows: when the rows have been written since they were
+        made (or the tensor now points elsewhere), planes the caller prepared are made again the same way (own centre / the centre
+        given then), planes made for a call (_match_planes) are dropped."""
+        pl = getattr(self.rows, '_aspire_planes', None)
+        if pl is not None and pl.key != _rows_key(self.rows):
+            self.rows._aspire_planes = pl = None if pl.auto else RowPlanes(self.rows, pl.mu if pl.mu_given else None)
+        return pl
 
     def prepare_planes(self, like=None, mu=None):
         """The row matrix a second time as fp16 planes (include/aspire_hip.h: aspire_rep_planes): once per resident store;
@@ -180,7 +215,7 @@ class DeviceRepSet:
                 else:
                     sample = self.rows[::max(1, n // 512)][:512]
                     m = sample.mean(0)
-                    hint = bool((m @ m) > 0.25 * (sample * sample).sum(1).mean())
+                    hint = bool((m * m).sum() > 0.25 * (sample * sample).sum(1).mean())      # (elementwise + reductions: no rocBLAS in the product path)
                 self.rows._aspire_center_hint = hint
             self._center_hint = hint
         return self._center_hint
@@ -216,6 +251,7 @@ def span_mean_pool_rows(hidden, tok_idx, span_off, max_sents, out_row, rows, cls
     assert out_row.numel() == b * max_sents
     check(lib.aspire_span_mean_pool_rows_f32(_ptr(hidden), b, l, d, _ptr(_i32(tok_idx, 'tok_idx')), _ptr(_i32(span_off, 'span_off')),
                                              max_sents, _ptr(_i32(out_row, 'out_row')), _ptr(rows), _ptr(cls), _stream()))
+    _rows_written(rows)
 
 
 def cls_l2(q_cls, c_cls, pairing=_lib.PAIR_PAIRED, eps=1e-6):

@@ -117,8 +117,7 @@ class ShardedPoolRanker:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.lo = int(global_offset)
-        self.pool = pool
-        pool.pids = list(range(self.lo, self.lo + len(pool)))
+        self.pool = pool          # (its pids stay the caller's; the rankings carry GLOBAL positions lo + i: rank_queries, idx_base)
         if planes:
             self.prepare_planes()
         return self
@@ -131,7 +130,10 @@ class ShardedPoolRanker:
         mu = None
         if self.world > 1:
             if self.rank == 0 and len(self.pool) > 0:
-                mu = ops.RowPlanes(self.pool.repset.rows).mu.clone()
+                # rank 0 prepares its planes ONCE, around the centre it forms from its own rows; the others get that centre (given
+                # the same vector the split is the same arithmetic: one pass here, not a sample pass and then the real one)
+                self.pool.prepare_planes()
+                mu = self.pool.repset.planes.mu.clone()
             elif self.rank == 0:
                 mu = torch.zeros(768, device=dev)
             else:
@@ -142,8 +144,10 @@ class ShardedPoolRanker:
                 mu = host.to(dev)
             else:
                 dist.broadcast(mu, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-        if len(self.pool) > 0:
-            self.pool.prepare_planes(mu=mu)
+            if self.rank != 0 and len(self.pool) > 0:
+                self.pool.prepare_planes(mu=mu)
+        elif len(self.pool) > 0:
+            self.pool.prepare_planes()
         self.mu = mu
         return self
 

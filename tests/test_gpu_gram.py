@@ -211,6 +211,52 @@ def test_baseline_config3_full_size_properties(amd):
         assert top_i[qi].cpu().tolist() == order
 
 
+def test_baseline_config3_full_size_on_the_plane_tiles(amd):
+    """The kernel the bench's `config3` key times, at the size it times it: pair_gram_p_kernel on a 50 000-document store with fp16
+    planes (gramp.hip), ALL 1.6 M max-sim scores against torch.cdist in float64 on the GPU (pair_distances.py:138-186), five
+    calls with fresh query planes each -- the race of round 4 (NOTES.md round 4, item 4: a stale k block, 1.3e-4 in ONE tile of
+    ~3000, run-dependent) was invisible below this size.  Beside it the tiles that read the fp32 rows (bf16x3), and the otAspire
+    cost slots of the same tiles through the Sinkhorn stage against the fp32-row tiles and the oracle."""
+    from aspire_amd._lib import pinned
+    g = torch.Generator().manual_seed(1)
+    nq, nc, s = 32, 50_000, 8
+    qrows = torch.randn(nq * s, 768, generator=g).cuda()
+    crows = torch.randn(nc * s, 768, generator=g).cuda()
+    mk = lambda rows, n: amd.ops.DeviceRepSet(rows, (torch.arange(n, device='cuda', dtype=torch.int32) * s).contiguous(),
+                                              torch.full((n,), s, device='cuda', dtype=torch.int32), ext=0, max_len=s)
+    q, c = mk(qrows, nq), mk(crows, nc)
+    want = torch.empty(nq, nc, device='cuda', dtype=torch.float64)
+    q64 = qrows.double()
+    for lo in range(0, nc, 10_000):                     # [256, 80 000] float64 distances per block
+        d = torch.cdist(q64, crows[lo * s:(lo + 10_000) * s].double())
+        want[:, lo:lo + 10_000] = -d.view(nq, s, 10_000, s).permute(0, 2, 1, 3).reshape(nq, 10_000, s * s).min(-1).values
+    rows_form = amd.ops.l2max_scores(q, c).view(nq, nc).double()                  # no planes: the bf16x3 tiles
+    assert (rows_form - want).abs().max().item() < 6e-5
+    c.prepare_planes()
+    worst = 0.0
+    for rep in range(5):
+        q.drop_planes()
+        got = amd.ops.l2max_scores(q, c).view(nq, nc)
+        assert q.planes is not None                                              # the plane tiles ran
+        err = (got.double() - want).abs()
+        worst = max(worst, err.max().item())
+        assert err.max().item() < 1e-5, (rep, err.max().item(), int((err > 1e-5).sum()), torch.nonzero(err > 1e-5)[:4].tolist())
+    print(f'plane tiles 32 x 50 000 x 8, five calls: max |score - float64| {worst:.2e}')
+    # otAspire: the same tiles write the pairs' cost / -cdist slots for the Sinkhorn stage
+    ot_p = amd.ops.ot_sinkhorn(q, c, want=amd.lib.OT_SIMILARITY).view(nq, nc)
+    assert torch.isfinite(ot_p).all()
+    q.drop_planes()
+    c.drop_planes()
+    ot_r = amd.ops.ot_sinkhorn(q, c, want=amd.lib.OT_SIMILARITY).view(nq, nc)
+    diff = (ot_p - ot_r).abs()
+    # (a pair whose diameter sits on a step of geomloss's schedule length flips between summation orders: see the config-5 test below)
+    assert diff.median().item() < 1e-5 and int((diff > 5e-5).sum()) <= 40 and diff.max().item() < 2e-3, \
+        (diff.median().item(), int((diff > 5e-5).sum()), diff.max().item())
+    for qi, ci in [(0, 0), (31, 49_999), (7, 12_345), (19, 33_333), (3, 25_000)]:
+        w = orc.get_similarity(qrows[qi * s:(qi + 1) * s].cpu(), crows[ci * s:(ci + 1) * s].cpu())
+        assert ot_p[qi, ci].item() == pytest.approx(w, abs=TOL)
+
+
 def test_baseline_config5_slice_properties(amd):
     """BASELINE config 5 shape (128 queries, 12 x 768 sentences) on a slice of one GPU's shard (8192 candidates): subset
     consistency of the otAspire similarities, agreement of the kernel families, and the oracle on a few pairs."""
