@@ -172,7 +172,7 @@ class AspireConSent:
         return out, ids
 
     def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64, planes=False, sort_by_length=True,
-                       _full_range=False):
+                       _full_range=False, stage_events=None):
         """Encode document batches straight into a resident candidate pool.
 
         batches: iterable of (bert_batch, abs_lens, sent_tok_idxs) as prepare_abstracts returns them (it is consumed
@@ -187,6 +187,8 @@ class AspireConSent:
         given (_merge_batches).
         planes: also keep the rows as fp16 planes (CandidatePool.prepare_planes: one more pass over the finished store, ~2.5 ms per
         GB) for the many-query cost tiles.
+        stage_events: a list that receives one (start, encoded, pooled) triple of HIP events per encoder call, recorded on the
+        current stream INSIDE this call (tools/e2ebench.py: the stage's own time split; the caller reads them after a sync).
         Returns a scorer.CandidatePool (and the [N, 768] CLS reps on the GPU with want_cls)."""
         from .scorer import CandidatePool
         dev = ops.require_gpu()
@@ -246,8 +248,13 @@ class AspireConSent:
             for i, (bert_batch, _, _) in enumerate(batches[g0:g1]):
                 max_sents, d0, b = chunk[i]
                 (t0, t1), (s0, s1), (r0, r1) = offs[3 * i:3 * i + 3]
+                if stage_events is not None:
+                    evs = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    evs[0].record()
                 hidden = self.bert_encoder.forward_hidden(bert_batch['tokid_tt'], token_type_ids=bert_batch['seg_tt'],
                                                           attention_mask=bert_batch['attnmask_tt'], check_ids=False)
+                if stage_events is not None:
+                    evs[1].record()
                 if want_cls and doc_ids is not None:       # regrouped documents: the forward's CLS rows go to their corpus positions
                     cls_b = torch.empty(b, 768, device=dev, dtype=torch.float32)
                     ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows, cls_b)
@@ -255,6 +262,9 @@ class AspireConSent:
                 else:
                     ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows,
                                             cls_all[d0:d0 + b] if want_cls else None)
+                if stage_events is not None:
+                    evs[2].record()
+                    stage_events.append(evs)
         if total and not _full_range and not bool(torch.isfinite(rows).all() & (torch.isfinite(cls_all).all() if want_cls else True)):
             # an activation left the fp16 planes' range somewhere (one check over the finished store): encode again on the kernels
             # that take any fp32 value
@@ -263,8 +273,10 @@ class AspireConSent:
             warnings.warn('AspireConSent.encode_to_pool: non-finite sentence reps on the fp16-plane encoder path; encoding again with '
                           'ASPIRE_HIP_GEMM=bf16x3, ASPIRE_HIP_ATTN=f32')
             with pinned(GEMM='bf16x3', ATTN='f32'):
+                if stage_events is not None:
+                    del stage_events[:]
                 return self.encode_to_pool(given, pids=pids, want_cls=want_cls, docs_per_forward=docs_per_forward, planes=planes,
-                                           sort_by_length=sort_by_length, _full_range=True)
+                                           sort_by_length=sort_by_length, _full_range=True, stage_events=stage_events)
         repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0,
                                   lens_host=all_lens)
         pool = CandidatePool.from_repset(repset, pids=pids)

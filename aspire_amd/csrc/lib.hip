@@ -56,6 +56,10 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.fused_noself = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_WAVES")) {
         t.fused_waves = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "FUSED_SPLIT")) {
+        t.fused_split = unset ? 0 : atoi(v);
+    } else if (!strcmp(key, "SPLIT_PRIO")) {
+        t.split_prio = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "GRAM_TILE")) {
         const int f = unset ? 0 : atoi(v);
         if (f != 0 && f != 128128 && f != 128256 && f != 256256) return false;
@@ -98,6 +102,8 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "FUSED_NOSOLVE")) v = number(t.fused_nosolve);
     else if (!strcmp(key, "FUSED_NOSELF")) v = number(t.fused_noself);
     else if (!strcmp(key, "FUSED_WAVES")) v = number(t.fused_waves);
+    else if (!strcmp(key, "FUSED_SPLIT")) v = number(t.fused_split);
+    else if (!strcmp(key, "SPLIT_PRIO")) v = number(t.split_prio);
     else if (!strcmp(key, "GRAM_TILE")) v = number(t.gram_tile);
     else if (!strcmp(key, "GRAM_RING")) v = number(t.gram_ring);
     else if (!strcmp(key, "GRAM_PP")) v = number(t.gram_pp);
@@ -108,7 +114,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_NOSELF", "GRAM_TILE", "GRAM_RING", "GRAM_PP"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_SPLIT", "SPLIT_PRIO", "FUSED_NOSELF", "GRAM_TILE", "GRAM_RING", "GRAM_PP"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

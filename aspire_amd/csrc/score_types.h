@@ -149,6 +149,10 @@ bool fused_inbox_ok(const aspire_repset* q, const float* diameter);
 bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 // (a pair whose shifted sums leave fp32 range is solved again in the max-shifted form by the wave that finds it: fused.hip, solve_safe)
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
+// split.hip: the same work with streaming waves and solver waves as two roles of one workgroup (where the fused kernel's SELF / QBOX
+// forms apply and the launch fills the chip)
+bool split_path_ok(int64_t groups_bound, const aspire_ot_params* prm);
+int launch_pair_split(const ScoreArgs& a, hipStream_t stream);
 // CHUNK form: items = four 8-row chunks (chunk_prep_kernel's records in a.grp_rec, their count in a.grp_off[0])
 int launch_pair_fused_chunk(const ScoreArgs& a, int64_t items_bound, const float* qbox, hipStream_t stream);
 int launch_pair_fused_chunk_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);

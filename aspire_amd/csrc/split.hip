@@ -1,7 +1,6 @@
-// NOT BUILT: an experiment of round 5 that lost (NOTES.md, round 5 log; profiles/r05_split_*).  To try it again: copy it to aspire_amd/csrc/, declare
-// split_path_ok / launch_pair_split in score_types.h, add `int fused_split, split_prio` to tuning.h, and call it where score.hip launches the
-// fused kernel's SELF / QBOX forms (git history of this round shows the hooks).  This is build 2 (buffer loads, 147 us); build 1 (117 us)
-// differs in the streamer only: 64-bit row pointers + per-stage v_lshl_add_u64, fminf / fmaxf box, one stage loop with a run-time have_box.
+// EXPERIMENT, off by default (ASPIRE_HIP_FUSED_SPLIT=1 turns it on; tests/test_gpu_fused.py pins its bits to the fused kernel's): round 5's attempt
+// to take the Sinkhorn solves off the streaming waves.  On par with the fused kernel (106.5 - 109 us per 20 x 1000 call against 105 - 107); with the
+// solves skipped (ASPIRE_HIP_SPLIT_PRIO=3) 91.5 -- the structure's floor.  NOTES.md, round 5 log; profiles/r05_split_*.
 // otAspire throughput kernel, role-split form: the fused kernel's two halves on DIFFERENT waves of one workgroup (A5-A8; reference
 // arithmetic: src/learning/facetid_models/pair_distances.py:21-92 + geomloss 0.2.4's sinkhorn_tensorized, restated -- fused_solve.h).
 //
@@ -20,13 +19,9 @@
 //     claim them one at a time from an LDS counter;
 //   * the query's per-coordinate box (geomloss's diameter) is formed ONCE per workgroup and job by the solver waves while the
 //     streamers' first loads are in flight (fused.hip's SELF form: every wave, from its staged query rows, during its first item);
-//   * addresses: a scalar base per item (the first row of its lowest candidate) + one 32-bit offset per row and lane, the stage in
-//     the load's immediate offset -- no address arithmetic in the stage loop.  An item whose four candidates lie further apart in
-//     the store than 32-bit offsets reach (an index-list pool over a > 4 GB store) is streamed in four passes, one candidate each;
 //   * hand-over: the four pairs' 8 x 8 costs and -cdist entries row-major + 16 words (lengths, candidates, diam^2) into one of 12
 //     ring slots; sequence numbers per slot (a bounded multi-producer / multi-consumer queue), polled with s_sleep.
 #include <mutex>
-#include <type_traits>
 
 #include "fused_solve.h"
 #include "tuning.h"
@@ -40,11 +35,6 @@ constexpr int kSpWaves = kSpStreamers + kSpSolvers;
 constexpr int kSpJobs = 3;             // query boxes a workgroup keeps (its run of items rarely touches more jobs; beyond: formed in-wave)
 constexpr int kSpSlots = 12;           // hand-over ring
 constexpr int kSpItemWords = 2 * 256 + 16;      // a slot: cost [4][64] | neg [4][64] | meta: q_len, then per pair c_len | real << 8, c_idx, diam^2
-#ifndef ASPIRE_SPLIT_UNROLL
-#define ASPIRE_SPLIT_UNROLL 4
-#endif
-constexpr int kSpUnroll = ASPIRE_SPLIT_UNROLL;      // stages per block of the stage loop (the loads' immediate offsets carry the stage inside a block)
-static_assert(kStages % kSpUnroll == 0, "stage blocks");
 // LDS, in floats: control words | boxes [kSpJobs][2][768] | ring [kSpSlots][kSpItemWords] | stage buffers [kSpStreamers][kWaveLds]
 constexpr int kSpCtl = 64;
 constexpr int kSpBoxOfs = kSpCtl;
@@ -54,7 +44,6 @@ constexpr int kSpLdsFloats = kSpStageOfs + kSpStreamers * kWaveLds;
 // control words
 constexpr int kCtlClaim = 0, kCtlTail = 1, kCtlHead = 2, kCtlBox = 3, kCtlDone = 4, kCtlSeq = 8;
 static_assert(kCtlSeq + kSpSlots <= kSpCtl, "control block");
-constexpr int kFarRows = 1 << 19;      // (signed 32-bit byte offsets) candidates of an item further apart than this many store rows: one pass per candidate
 
 #ifdef ASPIRE_PHASE_CLOCK
 // debug build only (tools/splitphases.py): per-wave time stamps (100 MHz wall clock): [workgroup * 12 + wave][16] = start, then
@@ -78,16 +67,6 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) {
 }
 __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// 16-byte buffer load: resource + 32-bit lane offset (+ a compile-time part, folded into the instruction's immediate) + scalar offset;
-// AUX 2 = non-temporal
-template <int AUX>
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    // (a whole-vector cast: __builtin_bit_cast on a vector ELEMENT reads element 0 with this clang -- common.h, swap_add)
-    const v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
-    return make_float4(t.x, t.y, t.z, t.w);
 }
 
 // SINGLE: ONE query (q.n == 1, CROSS pairing) against candidates [cand0, cand1) -- one job; else MAPPED jobs [job0, job1) of a batch.
@@ -174,32 +153,12 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
             next = load_ctx(lo + (nxt_it < cnt ? nxt_it : cur_it));          // (the last item fetches itself again)
             const int q_len = cur.q_len;
             const int bslot = cur.job - job_lo;
-            // the item's four first rows: near each other (the usual case) -> one pass; else one pass per candidate, every lane group
-            // on the same one, the other three groups' results dropped
-            int smin = __builtin_amdgcn_readlane(cur.c_start, 0), smax = smin;
-#pragma unroll
-            for (int g = 1; g < 4; ++g) {
-                const int v = __builtin_amdgcn_readlane(cur.c_start, 16 * g);
-                smin = min(smin, v);
-                smax = max(smax, v);
-            }
-            const bool far = smax - smin > kFarRows;
-#pragma unroll 1
-            for (int pass = 0; pass < (far ? 4 : 1); ++pass) {
-            int c_idx = cur.c_idx, c_start = cur.c_start, c_len = cur.c_lr & 255;
-            bool real = (cur.c_lr & 256) != 0;
-            int row_base = smin;
-            if (far) {
-                c_idx = __builtin_amdgcn_readlane(cur.c_idx, 16 * pass);
-                c_start = __builtin_amdgcn_readlane(cur.c_start, 16 * pass);
-                const int lr = __builtin_amdgcn_readlane(cur.c_lr, 16 * pass);
-                c_len = lr & 255;
-                real = (lr & 256) != 0 && p == pass;
-                row_base = c_start;
-            }
-            const char* cbase = reinterpret_cast<const char*>(a.c.rows + (size_t)row_base * kD);
-            const char* qbase = reinterpret_cast<const char*>(a.q.rows + (size_t)cur.q_start * kD);
-
+            const int c_idx = cur.c_idx, c_start = cur.c_start, c_len = cur.c_lr & 255;
+            const bool real = (cur.c_lr & 256) != 0;
+            const float* qdoc = a.q.rows + (size_t)cur.q_start * kD;
+            const float* sy_doc = a.c.rows + (size_t)c_start * kD;
+            const char* qbase = reinterpret_cast<const char*>(qdoc);
+            {
             mfma4_t macc[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) macc[m] = mfma4_t{0.f, 0.f, 0.f, 0.f};
@@ -208,48 +167,28 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
             for (int k = 0; k < 8; ++k) ny[k] = f2_t{0.f, 0.f};
             nx[0] = nx[1] = f2_t{0.f, 0.f};
             float4 vy[8], vx[2];
-            int oy[8], ox[2];                // byte offsets of this lane's chunk of stage 0 in its rows (pad rows: copies of the last row)
+            auto issue_loads = [&](int st) {
+                const int dofs = (st * kCh + sc) * 4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) oy[j] = ((c_start - row_base + min(j, c_len - 1)) * kD + sc * 4) * 4;
+                for (int j = 0; j < 8; ++j) vy[j] = ld4_stream(sy_doc + (size_t)min(j, c_len - 1) * kD + dofs);   // pad rows: copies of the last row
 #pragma unroll
-            for (int k = 0; k < 2; ++k) ox[k] = (min(2 * sg + k, q_len - 1) * kD + sc * 4) * 4;
-            // loads as buffer loads: resource (scalar base of the item) + 32-bit lane offset + scalar block offset + immediate stage
-            // offset -- nothing for the VALU to add in the stage loop, ten offset registers instead of twenty for pointers
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cbase), 0, -1, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qbase), 0, -1, 0x00020000);
-            auto issue_loads = [&](int blk, int u) {       // stage blk * kSpUnroll + u (u == kSpUnroll: the next block's first)
-                const int so = blk * (kSpUnroll * 16 * kCh);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vy[j] = buf_ld4<2>(rc, oy[j] + u * 16 * kCh, so);      // candidate rows: read once (nt)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) vx[k] = buf_ld4<0>(rq, ox[k] + u * 16 * kCh, so);
+                for (int k = 0; k < 2; ++k) vx[k] = ld4(qdoc + (size_t)min(2 * sg + k, q_len - 1) * kD + dofs);
             };
             auto sq_acc = [](f2_t acc, const float4& v) {
                 acc = __builtin_elementwise_fma(f2_t{v.x, v.y}, f2_t{v.x, v.y}, acc);
                 return __builtin_elementwise_fma(f2_t{v.z, v.w}, f2_t{v.z, v.w}, acc);
             };
-            issue_loads(0, 0);
-            // the boxes are formed by the solver waves while the first loads fly; a wave whose first item gets here before them forms
-            // the query's box itself, from its staged rows (as an item of a job beyond the workgroup's kSpJobs boxes does)
+            issue_loads(0);
             if (!box_ready) {
                 box_ready = lds_load(&ctl[kCtlBox]) == (uint32_t)kSpSolvers;
                 if (box_ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             const bool have_box = box_ready && bslot < kSpJobs;                 // wave-uniform
-            const float* qcb = lds_all + kSpBoxOfs + (have_box ? bslot : 0) * 2 * kD + sc * 4;
-            const bool center = a.center != 0;
-
-            // one stage: registers -> LDS with the norm / box side products, the next stage's loads, the dot products on the matrix pipe
-            auto stage = [&](auto cached_tag, int sb, int u) {
-                constexpr bool CACHED = decltype(cached_tag)::value;
+            const float* qcb = lds_all + kSpBoxOfs + (have_box ? bslot : 0) * 2 * kD;
+#pragma unroll 1
+            for (int st = 0; st < kStages; ++st) {
                 float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 qn, qx;
-                if constexpr (CACHED) {
-                    qn = *reinterpret_cast<const float4*>(qcb + (sb * kSpUnroll + u) * 4 * kCh);
-                    qx = *reinterpret_cast<const float4*>(qcb + kD + (sb * kSpUnroll + u) * 4 * kCh);
-                }
-                if (center) {
-                    // centre of the rows at this lane's chunk: the mean of the eight staged query rows (fused.hip)
+                if (a.center) {
                     mu = make_float4(vx[0].x + vx[1].x, vx[0].y + vx[1].y, vx[0].z + vx[1].z, vx[0].w + vx[1].w);
                     mu.x += lane_xor<16>(mu.x); mu.y += lane_xor<16>(mu.y); mu.z += lane_xor<16>(mu.z); mu.w += lane_xor<16>(mu.w);
                     mu.x += lane_xor<32>(mu.x); mu.y += lane_xor<32>(mu.y); mu.z += lane_xor<32>(mu.z); mu.w += lane_xor<32>(mu.w);
@@ -262,70 +201,54 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
                     for (int k = 0; k < 2; ++k) {
                         vx[k].x -= mu.x; vx[k].y -= mu.y; vx[k].z -= mu.z; vx[k].w -= mu.w;
                     }
-                    if constexpr (CACHED) {          // the workgroup's box is that of the raw rows: the centre comes off here
-                        qn.x -= mu.x; qn.y -= mu.y; qn.z -= mu.z; qn.w -= mu.w;
-                        qx.x -= mu.x; qx.y -= mu.y; qx.z -= mu.z; qx.w -= mu.w;
-                    }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ny[j] = sq_acc(ny[j], vy[j]);
-#pragma unroll
-                for (int k = 0; k < 2; ++k) nx[k] = sq_acc(nx[k], vx[k]);
-                // the candidate's per-coordinate box over its eight rows (v_min3 / v_max3: four instructions per component and side),
-                // CACHED: the query's joined in the same chain
                 float4 mn, mx;
-                if constexpr (CACHED) {
-                    mn = vmin3_4(qn, vy[0], vy[1]);
-                    mx = vmax3_4(qx, vy[0], vy[1]);
-                } else {
-                    mn = vmin3_4(vy[0], vy[0], vy[1]);
-                    mx = vmax3_4(vy[0], vy[0], vy[1]);
-                }
-                mn = vmin3_4(mn, vy[2], vy[3]); mx = vmax3_4(mx, vy[2], vy[3]);
-                mn = vmin3_4(mn, vy[4], vy[5]); mx = vmax3_4(mx, vy[4], vy[5]);
-                mn = vmin3_4(mn, vy[6], vy[7]); mx = vmax3_4(mx, vy[6], vy[7]);
-                if constexpr (CACHED) {
-                    const f2_t dlo = {mx.x - mn.x, mx.y - mn.y}, dhi = {mx.z - mn.z, mx.w - mn.w};
-                    dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
-                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
+                for (int j = 0; j < 8; ++j) {
+                    ny[j] = sq_acc(ny[j], vy[j]);
+                    *reinterpret_cast<float4*>(lds + (8 + sg * 8 + j) * kRowStride + sc * 4) = vy[j];
+                }
+                mn = vmin3_4(vy[0], vy[1], vy[2]); mx = vmax3_4(vy[0], vy[1], vy[2]);
+                mn = vmin3_4(mn, vy[3], vy[4]); mx = vmax3_4(mx, vy[3], vy[4]);
+                mn = vmin3_4(mn, vy[5], vy[6]); mx = vmax3_4(mx, vy[5], vy[6]);
+                mn = vmin3_4(mn, vy[7], vy[7]); mx = vmax3_4(mx, vy[7], vy[7]);
 #pragma unroll
-                for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(lds + (2 * sg + k) * kRowStride + sc * 4) = vx[k];
-                // pin the side products HERE (the optimiser otherwise sinks these loop-carried sums below the loads)
-                if constexpr (CACHED)
-                    asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
-                                      "+v"(nx[0]), "+v"(nx[1]), "+v"(dsq) : : "memory");
-                else
-                    asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
-                                      "+v"(nx[0]), "+v"(nx[1]), "+v"(mn.x), "+v"(mn.y), "+v"(mn.z), "+v"(mn.w), "+v"(mx.x), "+v"(mx.y),
-                                      "+v"(mx.z), "+v"(mx.w) : : "memory");
-                if (sb * kSpUnroll + u + 1 < kStages) issue_loads(sb, u + 1);
+                for (int k = 0; k < 2; ++k) {
+                    nx[k] = sq_acc(nx[k], vx[k]);
+                    *reinterpret_cast<float4*>(lds + (2 * sg + k) * kRowStride + sc * 4) = vx[k];
+                }
+                asm volatile("" : "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]), "+v"(ny[4]), "+v"(ny[5]), "+v"(ny[6]), "+v"(ny[7]),
+                                  "+v"(nx[0]), "+v"(nx[1]), "+v"(mn.x), "+v"(mn.y), "+v"(mn.z), "+v"(mn.w), "+v"(mx.x), "+v"(mx.y),
+                                  "+v"(mx.z), "+v"(mx.w) : : "memory");
+                if (st + 1 < kStages) issue_loads(st + 1);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if constexpr (!CACHED) {
-                    // the query's box at this lane's chunk from the eight staged query rows (rows past the document's end are copies of
-                    // its last row), joined with the candidate's
-                    qn = qx = *reinterpret_cast<const float4*>(lds + sc * 4);
+                {
+                    float4 qn, qx;
+                    if (have_box) {
+                        qn = *reinterpret_cast<const float4*>(qcb + (st * kCh + sc) * 4);
+                        qx = *reinterpret_cast<const float4*>(qcb + kD + (st * kCh + sc) * 4);
+                        qn.x -= mu.x; qn.y -= mu.y; qn.z -= mu.z; qn.w -= mu.w;
+                        qx.x -= mu.x; qx.y -= mu.y; qx.z -= mu.z; qx.w -= mu.w;
+                    } else {
+                        qn = qx = *reinterpret_cast<const float4*>(lds + sc * 4);
 #pragma unroll
-                    for (int r = 1; r < 8; r += 2) {
-                        const float4 q0 = *reinterpret_cast<const float4*>(lds + r * kRowStride + sc * 4);
-                        const float4 q1 = *reinterpret_cast<const float4*>(lds + min(r + 1, 7) * kRowStride + sc * 4);
-                        qn = vmin3_4(qn, q0, q1);
-                        qx = vmax3_4(qx, q0, q1);
+                        for (int r = 1; r < 8; ++r) {
+                            const float4 qv = *reinterpret_cast<const float4*>(lds + r * kRowStride + sc * 4);
+                            qn.x = vmin1(qn.x, qv.x); qn.y = vmin1(qn.y, qv.y); qn.z = vmin1(qn.z, qv.z); qn.w = vmin1(qn.w, qv.w);
+                            qx.x = vmax1(qx.x, qv.x); qx.y = vmax1(qx.y, qv.y); qx.z = vmax1(qx.z, qv.z); qx.w = vmax1(qx.w, qv.w);
+                        }
                     }
                     const f2_t dlo = {vmax1(mx.x, qx.x) - vmin1(mn.x, qn.x), vmax1(mx.y, qx.y) - vmin1(mn.y, qn.y)};
                     const f2_t dhi = {vmax1(mx.z, qx.z) - vmin1(mn.z, qn.z), vmax1(mx.w, qx.w) - vmin1(mn.w, qn.w)};
                     dsq = __builtin_elementwise_fma(dhi, dhi, __builtin_elementwise_fma(dlo, dlo, dsq));
                 }
-                // ---- dot products on the matrix pipe: block b = lane >> 2 = (p, iq, jq) is the 4 x 4 sub-block (rows 4 iq .., columns
-                // 4 jq ..) of pair p; lane t = lane & 3 feeds query row 4 iq + t as A and candidate row 4 jq + t as B (fused.hip) ----
                 {
                     const int mb = lane >> 2, mt = lane & 3, miq = (mb >> 1) & 1, mjq = mb & 1;
                     const float* xm = lds + (4 * miq + mt) * kRowStride;
                     const float* ym = lds + (8 + p * 8 + 4 * mjq + mt) * kRowStride;
-#pragma unroll
+#pragma unroll 4
                     for (int c = 0; c < kCh; ++c) {
                         const float4 xa = *reinterpret_cast<const float4*>(xm + c * 4);
                         const float4 yb = *reinterpret_cast<const float4*>(ym + c * 4);
@@ -333,21 +256,11 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
                         macc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.y, yb.y, macc[1], 0, 0, 0);
                         macc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.z, yb.z, macc[2], 0, 0, 0);
                         macc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa.w, yb.w, macc[3], 0, 0, 0);
-                        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (operand reads stay four chunks ahead at most: registers)
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage buffer is rewritten next
                 __builtin_amdgcn_wave_barrier();
-            };
-            auto stages = [&](auto cached_tag) {
-#pragma unroll 1
-                for (int sb = 0; sb < kStages / kSpUnroll; ++sb) {
-#pragma unroll
-                    for (int u = 0; u < kSpUnroll; ++u) stage(cached_tag, sb, u);
-                }
-            };
-            if (have_box) stages(std::true_type{});
-            else stages(std::false_type{});
+            }
 
             // block columns -> the solve's 2 x 2 layout, through the (idle) stage buffer: pair p's 8 x 8 entries row-major
             float accg[2][2];
@@ -481,7 +394,7 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) lds_store(&ctl[kCtlSeq + slot], t + 1);
-            }      // pass
+            }
             ++n_done;
             S_STAMP(n_done);
             cur_it = nxt_it;
@@ -567,6 +480,10 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
                 rv[t] = 2 * li + t < q_len;
                 cv[t] = 2 * lj + t < c_len;
             }
+            if (a.skip_tail) {          // timing probe (SPLIT_PRIO=3): no solve -- what the streamers and the ring cost on their own
+                if (real && lp == 0) a.scores[c_idx] = diam2 + cost[0][0] + neg[0][0];
+                continue;
+            }
             Solve s;
             solve_begin<false>(s, a, cost, neg, rv, cv, fmaxf(sqrtf(diam2), kMinDiameter));
             s.out = real ? (int64_t)c_idx : (int64_t)-1;
@@ -607,15 +524,17 @@ int launch_split_as(const ScoreArgs& a, hipStream_t stream) {
 // the role-split form pays once every CU's eight streamers have a couple of items each
 bool split_path_ok(int64_t groups_bound, const aspire_ot_params* prm) {
     const int f = tuning().fused_split;
-    if (f == 2) return false;
-    return (f == 1 || groups_bound >= (int64_t)cu_count() * kSpStreamers) && prm->scaling >= 0.25 && tuning().fused_nosolve == 0 && !tuning().fused_valu &&
+    if (f != 1) return false;
+    return groups_bound >= (int64_t)cu_count() * 2 && prm->scaling >= 0.25 && tuning().fused_nosolve == 0 && !tuning().fused_valu &&
            !tuning().fused_noself;
 }
 
 // a: MAPPED jobs [job0, job1) (<= 64 of them), or CROSS with ONE query against candidates [cand0, cand1)
-int launch_pair_split(const ScoreArgs& a, hipStream_t stream) {
+int launch_pair_split(const ScoreArgs& a_in, hipStream_t stream) {
+    ScoreArgs a = a_in;
     const bool single = a.pairing == ASPIRE_PAIR_CROSS;
     const int prio = tuning().split_prio;
+    a.skip_tail = prio == 3;
     if (single) return prio == 1 ? launch_split_as<true, 1>(a, stream) : prio == 2 ? launch_split_as<true, 2>(a, stream) : launch_split_as<true, 0>(a, stream);
     return prio == 1 ? launch_split_as<false, 1>(a, stream) : prio == 2 ? launch_split_as<false, 2>(a, stream) : launch_split_as<false, 0>(a, stream);
 }

@@ -25,6 +25,8 @@ struct Tuning {
     int gram_pp = 0;         // ASPIRE_HIP_GRAM_PP=1: the 256 x 256 tiles in the ping-pong form (two wave groups a segment apart)
     int gram_ring = 0;       // ASPIRE_HIP_GRAM_RING=4: four-stage ring for the 256 x 256 tiles (default 3)
     int fused_waves = 0;     // ASPIRE_HIP_FUSED_WAVES: cap on the fused kernel's resident waves (0 = default; grid experiments)
+    int fused_split = 0;     // ASPIRE_HIP_FUSED_SPLIT: 0 / 2 the fused kernel, 1 the role-split kernel (split.hip) where it applies (experiments)
+    int split_prio = 0;      // ASPIRE_HIP_SPLIT_PRIO: the role-split kernel's solver mode: 0 solve, 3 skip the solves (timing probe: wrong scores)
 };
 
 const Tuning& tuning();

@@ -7,7 +7,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from aspire_amd import ops, _lib  # noqa: E402
 
 J, N, S, NP, REPS = (int(x) for x in (sys.argv[1:6] + [20, 1000, 8, 6, 30][len(sys.argv) - 1:]))
@@ -50,9 +51,10 @@ def timed(pin, label):
     return sc
 
 
-variants = [('fused (FUSED_SPLIT=2)', dict(FUSED_SPLIT=2)), ('split prio 0', dict(FUSED_SPLIT=1, SPLIT_PRIO=0)),
-            ('split prio 1', dict(FUSED_SPLIT=1, SPLIT_PRIO=1)), ('split prio 2', dict(FUSED_SPLIT=1, SPLIT_PRIO=2)),
-            ('fused again', dict(FUSED_SPLIT=2)), ('split prio 0 again', dict(FUSED_SPLIT=1, SPLIT_PRIO=0))]
+variants = [('fused (FUSED_SPLIT=2)', dict(FUSED_SPLIT=2)), ('split', dict(FUSED_SPLIT=1, SPLIT_PRIO=0)),
+            ('split, solves skipped', dict(FUSED_SPLIT=1, SPLIT_PRIO=3)),
+            ('fused again', dict(FUSED_SPLIT=2)), ('split again', dict(FUSED_SPLIT=1, SPLIT_PRIO=0)),
+            ('split, solves skipped again', dict(FUSED_SPLIT=1, SPLIT_PRIO=3))]
 import os
 if os.environ.get('SPLITAB_ONLY') == 'fused':
     variants = [('fused (FUSED_SPLIT=2)', dict(FUSED_SPLIT=2)), ('fused again', dict(FUSED_SPLIT=2))]
