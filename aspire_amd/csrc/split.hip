@@ -36,14 +36,14 @@ constexpr int kSpJobs = 3;             // query boxes a workgroup keeps (its run
 constexpr int kSpSlots = 12;           // hand-over ring
 constexpr int kSpItemWords = 2 * 256 + 16;      // a slot: cost [4][64] | neg [4][64] | meta: q_len, then per pair c_len | real << 8, c_idx, diam^2
 // LDS, in floats: control words | boxes [kSpJobs][2][768] | ring [kSpSlots][kSpItemWords] | stage buffers [kSpStreamers][kWaveLds]
-constexpr int kSpCtl = 64;
+constexpr int kSpCtl = 64 + 128;        // 64 control words, then the jobs' candidate ranges [2][64]
 constexpr int kSpBoxOfs = kSpCtl;
 constexpr int kSpRingOfs = kSpBoxOfs + kSpJobs * 2 * kD;
 constexpr int kSpStageOfs = kSpRingOfs + kSpSlots * kSpItemWords;
 constexpr int kSpLdsFloats = kSpStageOfs + kSpStreamers * kWaveLds;
 // control words
 constexpr int kCtlClaim = 0, kCtlTail = 1, kCtlHead = 2, kCtlBox = 3, kCtlDone = 4, kCtlSeq = 8;
-static_assert(kCtlSeq + kSpSlots <= kSpCtl, "control block");
+static_assert(kCtlSeq + kSpSlots <= 64, "control block");
 
 #ifdef ASPIRE_PHASE_CLOCK
 // debug build only (tools/splitphases.py): per-wave time stamps (100 MHz wall clock): [workgroup * 12 + wave][16] = start, then
@@ -70,8 +70,7 @@ __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) {
 }
 
 // SINGLE: ONE query (q.n == 1, CROSS pairing) against candidates [cand0, cand1) -- one job; else MAPPED jobs [job0, job1) of a batch.
-// PRIO: s_setprio of the streaming waves (the solver waves stay at 0).
-template <bool SINGLE, int PRIO>
+template <bool SINGLE>
 __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     uint32_t* ctl = reinterpret_cast<uint32_t*>(lds_all);
@@ -101,13 +100,16 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
     const uint32_t lo = blockIdx.x * per + min((uint32_t)blockIdx.x, rem);
     const uint32_t cnt = per + (blockIdx.x < rem ? 1u : 0u);
     const int job_lo = __popcll(__ballot(gend <= (int)lo));              // job of the run's first item
-    if (threadIdx.x < kSpCtl) ctl[threadIdx.x] = (threadIdx.x >= kCtlSeq && threadIdx.x < kCtlSeq + kSpSlots) ? threadIdx.x - kCtlSeq : 0u;
+    if (threadIdx.x < 64) {
+        ctl[threadIdx.x] = (threadIdx.x >= kCtlSeq && threadIdx.x < kCtlSeq + kSpSlots) ? threadIdx.x - kCtlSeq : 0u;
+        ctl[64 + threadIdx.x] = (uint32_t)jo0;           // (the ranges live in LDS: two registers less in every wave)
+        ctl[128 + threadIdx.x] = (uint32_t)jo1;
+    }
     __syncthreads();
     if (cnt == 0) return;
     S_STAMP(0);
 
     if (wave < kSpStreamers) {
-        if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
         float* lds = lds_all + kSpStageOfs + wave * kWaveLds;
         float* nscr = lds + kNormOfs;
         // lane roles as in fused.hip: p = candidate of this lane (compute AND staging); (li, lj) = its 2 x 2 block of the 8 x 8 entries;
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
             Ctx x;
             const int job = SINGLE ? 0 : __popcll(__ballot(gend <= (int)item));
             const int g0 = job > 0 ? __builtin_amdgcn_readlane(gend, job - 1) : 0;
-            const int cj0 = __builtin_amdgcn_readlane(jo0, job), cj1 = __builtin_amdgcn_readlane(jo1, job);
+            const int cj0 = (int)ctl[64 + job], cj1 = (int)ctl[128 + job];
             const int first = cj0 + 4 * ((int)item - g0);
             const int cand = min(first + p, cj1 - 1);
             const int q_idx = SINGLE ? 0 : a.job0 + job;
@@ -324,50 +326,32 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
                     neg[x][y] = -sqrtf(fmaxf(sq, 0.f));
                 }
             {
-                // direct-formula redo, the whole wave on one entry (12 coordinates per lane), two entries per memory round trip
+                // direct-formula redo, the whole wave on one entry (12 coordinates per lane), one entry per memory round trip (the fused
+                // kernel takes four: their 96 transient registers do not fit this kernel's 168)
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
                     for (int y = 0; y < 2; ++y) {
                         unsigned long long wm = __ballot(redo[x][y]);
                         while (wm != 0) {
-                            int owner[2];
-                            float part[2];
+                            const int o = (int)__builtin_ctzll(wm);
+                            wm &= wm - 1;
+                            const int ol = o & 15, i = 2 * (ol >> 2) + x, j = 2 * (ol & 3) + y;
+                            const int cs_e = __builtin_amdgcn_readlane(c_start, o);
+                            const float* qrow = reinterpret_cast<const float*>(qbase) + (size_t)i * kD + 4 * lane;
+                            const float* crow = a.c.rows + ((size_t)cs_e + j) * kD + 4 * lane;
+                            float part = 0.f;
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                owner[e] = wm != 0 ? (int)__builtin_ctzll(wm) : -1;
-                                wm = wm != 0 ? wm & (wm - 1) : 0;
+                            for (int t = 0; t < 3; ++t) {
+                                const float4 u = ld4(qrow + 256 * t), v = ld4(crow + 256 * t);
+                                const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+                                part = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, part))));
                             }
-                            float4 u[2][3], v[2][3];
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const int o = owner[e] >= 0 ? owner[e] : owner[0];
-                                const int ol = o & 15, i = 2 * (ol >> 2) + x;
-                                const int j = 2 * (ol & 3) + y;
-                                const int cs_e = __builtin_amdgcn_readlane(c_start, o);
-                                const float* qrow = reinterpret_cast<const float*>(qbase) + (size_t)i * kD + 4 * lane;
-                                const float* crow = a.c.rows + ((size_t)cs_e + j) * kD + 4 * lane;
-#pragma unroll
-                                for (int t = 0; t < 3; ++t) {
-                                    u[e][t] = ld4(qrow + 256 * t);
-                                    v[e][t] = ld4(crow + 256 * t);
-                                }
+                            const float tot = wave_sum(part);
+                            if (lane == o) {
+                                neg[x][y] = -sqrtf(tot);
+                                cost[x][y] = sqrtf(fmaxf(tot, 1e-8f));      // geomloss's cost from the same exact sum (fused.hip)
                             }
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                part[e] = 0.f;
-#pragma unroll
-                                for (int t = 0; t < 3; ++t) {
-                                    const float d0 = u[e][t].x - v[e][t].x, d1 = u[e][t].y - v[e][t].y, d2 = u[e][t].z - v[e][t].z, d3 = u[e][t].w - v[e][t].w;
-                                    part[e] = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, part[e]))));
-                                }
-                            }
-#pragma unroll
-                            for (int e = 0; e < 2; ++e)
-                                if (owner[e] >= 0) {
-                                    const float tot = wave_sum(part[e]);
-                                    if (lane == owner[e]) neg[x][y] = -sqrtf(tot);
-                                }
                         }
                     }
             }
@@ -401,7 +385,6 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_fetch_add(&ctl[kCtlDone]);           // (after the wave's last publication)
-        if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     } else {
         // ---- the solver waves first form the query boxes of the run's jobs (256 threads, three coordinates each) --------------------
         const int tid = threadIdx.x - kSpStreamers * 64;
@@ -505,16 +488,16 @@ int cu_count() {
     return n;
 }
 
-template <bool SINGLE, int PRIO>
+template <bool SINGLE>
 int launch_split_as(const ScoreArgs& a, hipStream_t stream) {
     static std::once_flag raised;
     static hipError_t raise_rc = hipSuccess;
     std::call_once(raised, [] {
-        raise_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_split_kernel<SINGLE, PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        raise_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_split_kernel<SINGLE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kSpLdsFloats * (int)sizeof(float));
     });
     ASPIRE_HIP_OK(raise_rc);
-    hipLaunchKernelGGL((pair_split_kernel<SINGLE, PRIO>), dim3((unsigned)cu_count()), dim3(kSpWaves * 64), kSpLdsFloats * sizeof(float), stream, a);
+    hipLaunchKernelGGL((pair_split_kernel<SINGLE>), dim3((unsigned)cu_count()), dim3(kSpWaves * 64), kSpLdsFloats * sizeof(float), stream, a);
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }
@@ -535,8 +518,7 @@ int launch_pair_split(const ScoreArgs& a_in, hipStream_t stream) {
     const bool single = a.pairing == ASPIRE_PAIR_CROSS;
     const int prio = tuning().split_prio;
     a.skip_tail = prio == 3;
-    if (single) return prio == 1 ? launch_split_as<true, 1>(a, stream) : prio == 2 ? launch_split_as<true, 2>(a, stream) : launch_split_as<true, 0>(a, stream);
-    return prio == 1 ? launch_split_as<false, 1>(a, stream) : prio == 2 ? launch_split_as<false, 2>(a, stream) : launch_split_as<false, 0>(a, stream);
+    return single ? launch_split_as<true>(a, stream) : launch_split_as<false>(a, stream);
 }
 
 }  // namespace aspire

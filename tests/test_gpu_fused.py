@@ -215,11 +215,12 @@ def test_role_split_kernel_gives_the_fused_kernels_bits(amd):
     q, c = mk(lens_q), mk(lens_c)
     c.rows[int(c.start[5])] = q.rows[0]                                    # a candidate of job 0 shares the query's first sentence
     job_off = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32).cuda()
+    q1 = mk([8])
     res = {}
     for name, pin in (('fused', dict(OT_FORM='fused')), ('split', dict(OT_FORM='fused', FUSED_SPLIT=1))):
         with amd.pinned(**pin):
             sc, ts, ti = amd.ops.ot_rank_batch(q, c, job_off, max(sizes), 10)
-            one = amd.ops.ot_sinkhorn(mk([8]), c, want=amd.lib.OT_SIMILARITY)
+            one = amd.ops.ot_sinkhorn(q1, c, want=amd.lib.OT_SIMILARITY)
         res[name] = (sc.cpu(), ts.cpu(), ti.cpu(), one.cpu())
     for a_, b_ in zip(res['fused'], res['split']):
         assert torch.equal(a_, b_)
