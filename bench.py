@@ -258,8 +258,10 @@ def config3_probe(device, Q=32, C=50000, s=8, reps=30, cpu=True):
                                   'algorithmic_bytes_per_call': nbytes}},
     }
     # HBM traffic of the kernel from the committed counter passes (not measured in this run): 2 x FETCH_SIZE + WRITE_SIZE
-    tpath = os.path.join(ROOT, 'profiles', 'r04_planes_32x50000x8_fetch_write_size.txt')
-    if os.path.exists(tpath) and (Q, C, s) == (32, 50000, 8):
+    tname = next((n for n in ('r05_planes_32x50000x8_fetch_write_size.txt', 'r04_planes_32x50000x8_fetch_write_size.txt')
+                  if os.path.exists(os.path.join(ROOT, 'profiles', n))), None)
+    tpath = os.path.join(ROOT, 'profiles', tname or '')
+    if tname and (Q, C, s) == (32, 50000, 8):
         kb = {}
         for line in open(tpath):
             f = line.split()
@@ -267,7 +269,7 @@ def config3_probe(device, Q=32, C=50000, s=8, reps=30, cpu=True):
                 kb[f[0]] = float(f[-1])
         if len(kb) == 2:
             res['roofline']['traffic'] = int((2 * kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024)
-            res['roofline']['traffic_source'] = 'profiles/r04_planes_32x50000x8_fetch_write_size.txt (2 x FETCH_SIZE + WRITE_SIZE, KB per launch)'
+            res['roofline']['traffic_source'] = f'profiles/{tname} (2 x FETCH_SIZE + WRITE_SIZE, KB per launch)'
     if cpu:
         res['cpu_baseline'] = cpu_l2max(qrows, crows, Q, s)
     return res
@@ -313,7 +315,7 @@ def config4_probe(device, J=50, NCAND=125, smax=20, reps=40):
     # the 1.5 rounds of items): SQ_ACTIVE_INST_VALU of the committed counter pass = cycles in which some wave of a SIMD issued a
     # VALU instruction, summed over SIMDs; spread evenly over 1024 SIMDs at 2.4 GHz it is the time below which no schedule of the
     # same instruction stream gets
-    for name in ('r04_csf_50x125_ot_sq_counters.txt', 'r03_csf_50x125_ot_sq_counters.txt'):
+    for name in ('r05_csf_50x125_ot_sq_counters.txt', 'r04_csf_50x125_ot_sq_counters.txt', 'r03_csf_50x125_ot_sq_counters.txt'):
         cpath = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(cpath):
             continue
@@ -708,7 +710,7 @@ def main():
             out['roofline']['sinkhorn'] = {k: {f: v[f] for f in ('what', 'kernel', 'ns_per_pair', 'valu_wave_instructions_per_pair', 'bound',
                                                                   'achieved_frac', 'issue_floor_us', 'kernel_us_per_call', 'algorithmic_floor') if f in v}
                                            for k, v in sj.items() if isinstance(v, dict)}
-            out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r4.sh)'
+            out['roofline']['sinkhorn']['source'] = 'profiles/sinkhorn_roofline.json (committed profile, tools/profile_r5.sh)'
         if rccl is not None:
             out['rccl'] = rccl
         out['cross_check'] = ('per-kernel durations (roofline.kernel_ms, profiles/*_kernel_stats.csv) add up to one_stream.ms_per_call; '
