@@ -47,7 +47,24 @@ struct GemmArgs {
     int gelu;
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU as HF BertModel's "gelu" (0.5 x (1 + erf(x / sqrt 2))), written around erfc: e = erfc(|x| / sqrt 2) = 2^q(|x|), q a degree-8 polynomial
+// (a weighted Chebyshev fit of log2 erfc(t / sqrt 2) on [0, 5.8]; beyond, erfc < 7e-9), then x - 0.5 x e for x > 0 and 0.5 x e otherwise: no
+// cancellation on either side, 15 VALU instructions where 0.5 x (1 + erff(.)) takes 37 (50 M activations per FFN1 launch at 64 x 256 tokens).
+// Max |error| against float64 over [-9, 9]: 2.5e-7 (the erff form, rounded in fp32: 4.5e-7).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float t = fminf(fabsf(x), 5.8f);
+    float q = -1.9605818124546204e-06f;
+    q = fmaf(q, t, 2.8825294066336937e-05f);
+    q = fmaf(q, t, -0.0001355033746222034f);
+    q = fmaf(q, t, -0.0002612900862004608f);
+    q = fmaf(q, t, 0.007229907438158989f);
+    q = fmaf(q, t, -0.05261624604463577f);
+    q = fmaf(q, t, -0.4591653645038605f);
+    q = fmaf(q, t, -1.1511112451553345f);
+    q = fmaf(q, t, 1.7379414884999278e-07f);
+    const float r = 0.5f * x * __builtin_amdgcn_exp2f(q);
+    return x > 0.f ? x - r : r;
+}
 
 template <int BM, int BN, int kBK, bool B_KN, int WAVES_N = 2>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {

@@ -163,8 +163,10 @@ size_t aspire_rep_planes_bytes(int64_t total_rows);
 /* rows [total_rows, D] -> blob; *out_host (a HOST struct) receives the pointers into it.
  *   mu   device [D] or NULL.  NULL: the mean of a sample of up to 4096 of the rows is formed (deterministic: rows
  *        k * stride) and kept in the blob.  Given: used as it is and out_host->mu == mu -- pass the store's mu when
- *        preparing query rows, and rank 0's mu on every shard of a sharded store (then sharded and un-sharded
- *        scores are the same bits). */
+ *        preparing query rows, and rank 0's mu on every shard of a sharded store: every shard then rounds its rows
+ *        around the same point, and wherever the plane tiles run (a shard of >= 128 candidate tiles; a smaller or
+ *        uneven last shard takes the kernels that read the fp32 rows, within 5e-5 of the tiles) sharded and
+ *        un-sharded scores are the same bits. */
 int aspire_rep_planes_prepare(const float* rows, int64_t total_rows, int64_t D, const float* mu, void* blob,
                               size_t blob_bytes, aspire_rep_planes* out_host, void* stream);
 
