@@ -605,7 +605,20 @@ __global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const uint32_t c0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
     const int tq = tid & 15, tc = tid >> 4;
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // per (query, candidate) pair and coordinate: one v_max, one v_min (bare instructions: fmaxf / fminf would canonicalise all 32 values
+    // read from LDS first), half a packed subtract and half a packed FMA -- 3 issue slots where the scalar form took 6
+    typedef float f2b __attribute__((ext_vector_type(2)));
+    f2b acc[2][2] = {{f2b{0.f, 0.f}, f2b{0.f, 0.f}}, {f2b{0.f, 0.f}, f2b{0.f, 0.f}}};
+    auto vmx = [](float a, float b) {
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    };
+    auto vmn = [](float a, float b) {
+        float r;
+        asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    };
     for (int ch = 0; ch < kD / 64; ++ch) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -631,11 +644,10 @@ __global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
-                    const float dx = fmaxf(qx[u].x, cx[v].x) - fminf(qn[u].x, cn[v].x);
-                    const float dy = fmaxf(qx[u].y, cx[v].y) - fminf(qn[u].y, cn[v].y);
-                    const float dz = fmaxf(qx[u].z, cx[v].z) - fminf(qn[u].z, cn[v].z);
-                    const float dw = fmaxf(qx[u].w, cx[v].w) - fminf(qn[u].w, cn[v].w);
-                    acc[u][v] = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, acc[u][v]))));
+                    const f2b hi0 = {vmx(qx[u].x, cx[v].x), vmx(qx[u].y, cx[v].y)}, lo0 = {vmn(qn[u].x, cn[v].x), vmn(qn[u].y, cn[v].y)};
+                    const f2b hi1 = {vmx(qx[u].z, cx[v].z), vmx(qx[u].w, cx[v].w)}, lo1 = {vmn(qn[u].z, cn[v].z), vmn(qn[u].w, cn[v].w)};
+                    const f2b d0 = hi0 - lo0, d1 = hi1 - lo1;
+                    acc[u][v] = __builtin_elementwise_fma(d1, d1, __builtin_elementwise_fma(d0, d0, acc[u][v]));
                 }
         }
         __syncthreads();
@@ -645,7 +657,7 @@ __global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const uint32_t q = q0 + 2 * tq + u, c = c0 + 2 * tc + v;
-            if (q < nq && c < ncand) diam2[(size_t)q * ncand + c] = acc[u][v];
+            if (q < nq && c < ncand) diam2[(size_t)q * ncand + c] = acc[u][v].x + acc[u][v].y;
         }
 }
 

@@ -134,6 +134,21 @@ if g1 and gk:
                        'note': 'SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs against the launch duration at the nominal 2.4 GHz and against the cycles '
                                'the chip actually ran (GRBM_GUI_ACTIVE / 8 XCDs, a separate counter pass of the same five launches)',
                        'wave_cycle_split': {k: g1.get(k) for k in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU')}}
+with open(os.path.join(DST, 'r05_attn_B32_L256_sq_counters.txt'), 'w') as out:
+    out.write('# rocprofv3 --pmc (two SQ passes) -- python tools/encbench.py 32 256 (13 forwards of 12 layers); summed per kernel by tools/pmcsum.py; '
+              'the flash_attn_f16x2_kernel block of each pass\n')
+    for s_ in ('attn_pmc1', 'attn_pmc2'):
+        p_ = os.path.join(SRC, s_ + '.summary.txt')
+        if os.path.exists(p_):
+            keep = False
+            for line in open(p_):
+                if 'dispatches' in line:
+                    keep = 'flash_attn' in line
+                if keep:
+                    out.write(line)
+p_ = os.path.join(SRC, 'e2e_full_share.log')
+if os.path.exists(p_):
+    shutil.copy(p_, os.path.join(DST, 'r05_e2e_full_share_125000.txt'))
 for name in ('gemmbench', 'poolbench'):
     p = os.path.join(SRC, name + '.log')
     if os.path.exists(p):

@@ -70,7 +70,8 @@ for form in ('small', 'tile'):
     except Exception as e:          # a form that does not take this shape
         print(f'OT_FORM={form}: {type(e).__name__}: {e}')
 # the CHUNK form's phases (timing experiments, invalid scores): streaming phase alone / everything but each wave's last solve
-for pin in (dict(FUSED_NOSOLVE=1), dict(FUSED_NOSOLVE=2), dict(FUSED_WAVES=1024), dict(FUSED_WAVES=1536)):
+for pin in (dict(FUSED_NOSOLVE=1), dict(FUSED_NOSOLVE=2), dict(FUSED_WAVES=1024), dict(FUSED_WAVES=1536), dict(FUSED_WAVES=2560), dict(FUSED_WAVES=3072),
+            dict(FUSED_WAVES=4096), dict(), dict(FUSED_WAVES=3072)):
     try:
         with _lib.pinned(**pin):
             t = timed(lambda: ops.ot_rank_batch(q, c, job_off, NC, NC, out=out))

@@ -31,8 +31,15 @@ run gemm_pmc2 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_W
 run gemm_pmc3 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/gemm_pmc3 -o pmc -- $GP
 run gemm_stats rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gemm_stats -o gemm -- $GP
 run gemmbench python $R/tools/gemmbench.py
+# 3b. the attention kernel's counters (none existed): two SQ passes over the encoder at B = 32, L = 256
+EB="python $R/tools/encbench.py 32 256"
+run attn_pmc1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/attn_pmc1 -o pmc -- $EB
+run attn_pmc2 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/attn_pmc2 -o pmc -- $EB
+for k in attn_pmc1 attn_pmc2; do python $R/tools/pmcsum.py $OUT/$k > $OUT/$k.summary.txt 2>&1; done
 # 4. config 5 end to end (one GPU's slice) and the pooling kernel
 run e2e_stats rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e_stats -o e2e -- python $R/tools/e2ebench.py
+# config 5's FULL per-GPU share (1 M documents / 8 GPUs = 125 000 documents of 256 tokens, 128 queries): encode -> store -> planes -> rank
+run e2e_full_share python $R/tools/e2ebench.py 125000 256 12 128
 run pool_stats rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pool_stats -o pool -- python $R/tools/poolbench.py
 run poolbench python $R/tools/poolbench.py
 # 5. the stand-alone Sinkhorn kernel's issue mix incl. transcendentals (configs 3 / 5 shapes)
