@@ -1120,7 +1120,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* _
     // fragment addresses: K rows 32 rb + lr, piece (2 ks + lk) ^ ((row >> 1) & 7); V^T rows 32 mb + lr, piece (2 s16 + lk) ^ (row & 15)
     const uint32_t k_rd = lr * 128 + 16 * (lk ^ ((lr >> 1) & 7)), k_sw = 0;
     (void)k_sw;
-    const uint32_t v_rd = lr * 256 + 16 * (lk ^ (lr & 15));
+    const uint32_t v_rd = lr * 256 + 16 * (lk ^ (lr & 15) ^ (2 * (lr >> 4)));      // piece ^ f(row), f(d) = (d & 15) ^ 2 (d >> 4): see the V^T store
 
     for (int k0 = 0; k0 < L; k0 += 128) {
         __syncthreads();                                               // previous tile fully consumed
@@ -1165,7 +1165,10 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* _
                     hh[kk] = t;
                     ll[kk] = (_Float16)(vv[kk][j] - (float)t);
                 }
-                const uint32_t at = d * 256 + 16 * (piece ^ (d & 15)) + 8 * half;
+                // the 16-byte piece XORed with f(d) = (d & 15) ^ 2 (d >> 4): the rows are 256 B = all 64 banks apart, and a wave's
+                // stores of one j go to rows d = 8 dg + j, dg = 0 .. 7 -- with d & 15 alone (round 3) only two different swizzles for
+                // eight rows: every store was a 4-way bank conflict (round-5 counters: 3.1 M conflict cycles of 5.9 M LDS cycles)
+                const uint32_t at = d * 256 + 16 * (piece ^ (d & 15) ^ (2 * (d >> 4))) + 8 * half;
                 *reinterpret_cast<f16x4_t*>(&Vp[0][at]) = hh;
                 *reinterpret_cast<f16x4_t*>(&Vp[1][at]) = ll;
             }
@@ -1231,7 +1234,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* _
                 const int s16 = 2 * rb + g2;
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
-                    const uint32_t at = (v_rd + mb * 32 * 256) ^ (32 * s16);
+                    const uint32_t at = (v_rd + mb * 32 * 256) ^ (32 * s16) ^ (64 * mb);      // (row >> 4 = 2 mb + (lr >> 4))
                     const f16x8_t vh = *reinterpret_cast<const f16x8_t*>(&Vp[0][at]), vl = *reinterpret_cast<const f16x8_t*>(&Vp[1][at]);
                     o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[mb], 0, 0, 0);
                     o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[mb], 0, 0, 0);
