@@ -1,7 +1,7 @@
 """Per-wave phase stamps of the role-split otAspire kernel (split.hip; debug build: tools/build_clock.sh) on the bench shape.
   ASPIRE_HIP_LIB=build/dbg/libaspire_hip_clock.so python tools/splitphases.py [J NC S]"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 import torch
 from aspire_amd import _lib, ops
