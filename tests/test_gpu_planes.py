@@ -294,3 +294,43 @@ def test_few_query_otaspire_on_a_plane_pool_with_cached_boxes(amd, nq, s):
             assert abs(got[qi, ci] - orc.get_similarity(qd[qi], cd[ci])) < 1e-4
     ranked = amd.scorer.rank_pool(qd, pool, k=10, method='ot')
     assert [i for i, _ in ranked[0]] == np.argsort(-got[0].astype(np.float64), kind='stable')[:10].tolist()
+
+
+def test_planes_and_boxes_follow_the_rows_when_a_store_is_refilled_in_place(amd):
+    """the fp16 planes and the cached boxes are a CACHE of the row matrix: refill the rows in place -- through torch, or
+    through the C ABI (span_mean_pool_rows reports its write) -- and the next call scores the NEW rows; queries whose planes ops
+    prepared for another pool's centre get new ones"""
+    from aspire_amd._lib import pinned
+    g = torch.Generator().manual_seed(77)
+    cd = [torch.randn(8, 768, generator=g) for _ in range(2100)]
+    qd = [torch.randn(8, 768, generator=g) for _ in range(6)]
+    pool = amd.scorer.CandidatePool(cd).prepare_planes()
+    q = _set(amd, qd)
+    with pinned(COST_PATH='mfma'):
+        a = amd.ops.l2max_scores(q, pool.repset).view(6, -1).cpu()
+        ot_a = amd.ops.ot_sinkhorn(q, pool.repset).view(6, -1).cpu()
+        old_planes = pool.repset.planes
+        # the store refilled in place (a torch write): planes and boxes must not describe the old rows
+        fresh = torch.randn(2100 * 8, 768, generator=g)
+        pool.repset.rows.copy_(fresh.cuda())
+        b = amd.ops.l2max_scores(q, pool.repset).view(6, -1).cpu()
+        ot_b = amd.ops.ot_sinkhorn(q, pool.repset).view(6, -1).cpu()
+    assert pool.repset.planes is not old_planes
+    want = -torch.cdist(torch.cat(qd).double(), fresh.double()).view(6, 8, 2100, 8).permute(0, 2, 1, 3).reshape(6, 2100, 64).min(-1).values
+    assert (b.double() - want).abs().max().item() < 1e-5
+    assert (a - b).abs().max().item() > 1.0                               # other rows, other scores
+    for j in (0, 1000, 2099):
+        assert -ot_b[0, j].item() == pytest.approx(orc.get_similarity(qd[0], fresh[8 * j:8 * j + 8]), abs=TOL)
+    assert not torch.equal(ot_a, ot_b)
+    # the query rows rewritten in place: their auto-prepared planes are stale too
+    q.rows.mul_(0.5)
+    with pinned(COST_PATH='mfma'):
+        c2 = amd.ops.l2max_scores(q, pool.repset).view(6, -1).cpu()
+    want2 = -torch.cdist(0.5 * torch.cat(qd).double(), fresh.double()).view(6, 8, 2100, 8).permute(0, 2, 1, 3).reshape(6, 2100, 64).min(-1).values
+    assert (c2.double() - want2).abs().max().item() < 1e-5
+    # the same queries against ANOTHER plane pool (another centre): planes made for the first pool are not reused
+    other = amd.scorer.CandidatePool([torch.randn(8, 768, generator=g) + 2.0 for _ in range(2100)]).prepare_planes()
+    with pinned(COST_PATH='mfma'):
+        d = amd.ops.l2max_scores(q, other.repset).view(6, -1)
+    assert q.planes.mu.data_ptr() == other.repset.planes.mu.data_ptr()
+    assert torch.isfinite(d).all()
