@@ -71,7 +71,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         if (f != 0 && f != 3 && f != 4) return false;
         t.gram_ring = f;
     } else if (!strcmp(key, "OT_FORM")) {
-        const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : !strcmp(v, "fused") ? 3 : !strcmp(v, "chunk") ? 4 : -1;
+        const int f = unset ? 0 : !strcmp(v, "small") ? 1 : !strcmp(v, "tile") ? 2 : !strcmp(v, "fused") ? 3 : !strcmp(v, "chunk") ? 4 : !strcmp(v, "one") ? 5 : -1;
         if (f < 0) return false;
         t.ot_form = f;
     } else {
@@ -107,7 +107,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "GRAM_TILE")) v = number(t.gram_tile);
     else if (!strcmp(key, "GRAM_RING")) v = number(t.gram_ring);
     else if (!strcmp(key, "GRAM_PP")) v = number(t.gram_pp);
-    else if (!strcmp(key, "OT_FORM")) v = t.ot_form == 1 ? "small" : t.ot_form == 2 ? "tile" : t.ot_form == 3 ? "fused" : t.ot_form == 4 ? "chunk" : "";
+    else if (!strcmp(key, "OT_FORM")) v = t.ot_form == 1 ? "small" : t.ot_form == 2 ? "tile" : t.ot_form == 3 ? "fused" : t.ot_form == 4 ? "chunk" : t.ot_form == 5 ? "one" : "";
     if (!v || strlen(v) + 1 > len) return false;
     strcpy(buf, v);
     return true;

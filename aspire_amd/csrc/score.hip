@@ -1610,6 +1610,115 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
 }
 
 // ---------------------------------------------------------------------------------------------
+// One wave = one PAIR, costs and solve in ONE launch (documents of <= 8 rows, CSR, a few dozen to a few thousand pairs: the
+// per-query call of evaluate.py:58-76 -- one query against its pool of ~10^2 .. 10^3 candidates).  The two-launch form
+// (pair_cost1_kernel: three waves per pair + sinkhorn_kernel<1>) costs a workspace round trip and a dependent launch: 12.1 + 7.5 us
+// of kernels and ~3.5 us between them at 1 x 1000.  Here a wave
+//   * issues ALL 24 loads of its candidate's rows at once (one HBM round trip; lane l owns coordinates 4 l + 256 s, s = 0 .. 2, of
+//     every row), reads the query's rows (L2) stage by stage,
+//   * accumulates the 64 dot products as 64 per-lane partial sums (each lane: all 8 x 8 pairs of rows over ITS twelve coordinates),
+//     the 16 squared norms and the joint box's extent (all sixteen rows of a coordinate sit in one lane),
+//   * folds them across the wave with the halving butterfly (common.h: butterfly_sum) so that lane l ends up with entry
+//     lane_ij<1>(l) -- the layout sinkhorn_pair<1> solves in -- and goes straight on to the solve.
+// Entries where the expansion cancels take -cdist and geomloss's cost from the exact sum, as everywhere (round 5).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pair_one_kernel(ScoreArgs a, int64_t n_slots) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+    if (a.pairing == kPairMapped) {
+        slot += a.job_off[a.job0];
+        n_slots = a.job_off[a.job1];
+    }
+    if (slot < n_slots) {
+    const PairIdx ix = pair_of_slot(a, slot);
+    const int q_len = a.q.len[ix.q_idx], c_len = a.c.len[ix.c_idx];
+    const float* qdoc = a.q.rows + (size_t)a.q.start[ix.q_idx] * kD;
+    const float* cdoc = a.c.rows + (size_t)a.c.start[ix.c_idx] * kD;
+    float4 y[3][8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[s][r] = ld4_stream(cdoc + (size_t)min(r, c_len - 1) * kD + 4 * lane + 256 * s);   // pad rows: copies of the last
+    float acc[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc[e] = 0.f;
+    float nrm[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) nrm[e] = 0.f;
+    float dsq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        float4 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = ld4(qdoc + (size_t)min(r, q_len - 1) * kD + 4 * lane + 256 * s);
+        if (a.center) {
+            // rows that share a large common component: the mean of the (padded) query rows comes off every row (fused.hip)
+            float4 mu = x[0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) { mu.x += x[r].x; mu.y += x[r].y; mu.z += x[r].z; mu.w += x[r].w; }
+            mu.x *= 0.125f; mu.y *= 0.125f; mu.z *= 0.125f; mu.w *= 0.125f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x[r].x -= mu.x; x[r].y -= mu.y; x[r].z -= mu.z; x[r].w -= mu.w;
+                y[s][r].x -= mu.x; y[s][r].y -= mu.y; y[s][r].z -= mu.z; y[s][r].w -= mu.w;
+            }
+        }
+        float4 mn = x[0], mx = x[0];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            nrm[r] += sq4(x[r]);
+            nrm[8 + r] += sq4(y[s][r]);
+            const float4 u = x[r], v = y[s][r];
+            mn.x = fminf(mn.x, fminf(u.x, v.x)); mn.y = fminf(mn.y, fminf(u.y, v.y)); mn.z = fminf(mn.z, fminf(u.z, v.z)); mn.w = fminf(mn.w, fminf(u.w, v.w));
+            mx.x = fmaxf(mx.x, fmaxf(u.x, v.x)); mx.y = fmaxf(mx.y, fmaxf(u.y, v.y)); mx.z = fmaxf(mx.z, fmaxf(u.z, v.z)); mx.w = fmaxf(mx.w, fmaxf(u.w, v.w));
+        }
+        const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z, dw = mx.w - mn.w;
+        dsq = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, dsq))));
+#pragma unroll
+        for (int e = 0; e < 64; ++e) {
+            // element e of the butterfly = the entry lane e will own: lane_ij<1>
+            const int ej = (e & 3) | ((e >> 2) & 4), ei = ((e >> 2) & 3) | ((e >> 3) & 4);
+            acc[e] = fmaf(x[ei].w, y[s][ej].w, fmaf(x[ei].z, y[s][ej].z, fmaf(x[ei].y, y[s][ej].y, fmaf(x[ei].x, y[s][ej].x, acc[e]))));
+        }
+    }
+    const float dot = butterfly_sum<64>(acc, lane);
+    const float nsum = butterfly_sum<16>(nrm, lane);              // lane l: element l >> 2 (0 .. 7 = |x_i|^2, 8 .. 15 = |y_j|^2)
+    const float diam2 = wave_sum(dsq);
+    int li, lj;
+    lane_ij<1>(lane, li, lj);
+    const float xx = __shfl(nsum, 4 * li), yy = __shfl(nsum, 32 + 4 * lj);
+    const float sq = fmaf(-2.f, dot, xx) + yy, ns = xx + yy;
+    PairState<1> st;
+    st.cost[0][0] = sqrtf(fmaxf(sq, 1e-8f));
+    st.neg[0][0] = -sqrtf(fmaxf(sq, 0.f));
+    const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+    unsigned long long todo = __ballot(!mm && li < q_len && lj < c_len && sq < 1e-4f * ns * ns);
+    while (todo != 0) {        // rare: the whole wave on one entry, from the rows as they are in memory (a common shift drops out)
+        const int o = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        int oi, oj;
+        lane_ij<1>(o, oi, oj);
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float4 u = ld4(qdoc + (size_t)oi * kD + 4 * lane + 256 * t), v = ld4(cdoc + (size_t)oj * kD + 4 * lane + 256 * t);
+            const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+            part = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, part))));
+        }
+        const float tot = wave_sum(part);
+        if (lane == o) {
+            st.neg[0][0] = -sqrtf(tot);
+            st.cost[0][0] = sqrtf(fmaxf(tot, 1e-8f));
+        }
+    }
+    const float diam = a.diameter == nullptr ? fmaxf(sqrtf(diam2), kMinDiameter) : group_diameter_of(a, ix);
+    sinkhorn_pair<1>(a, st, q_len, c_len, diam, ix.p, lane);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Kernel 2, block form (throughput form for big grids, any T): a pair occupies LD x LD lanes of one DPP row and
 // lane (li, lj) owns the R x R block of entries (R li + x, R lj + y), LD * R = 8 T:
 //     T = 1: LD 2, R 4 (16 solves per wave) or LD 1, R 8 (64);  T = 2: LD 4, R 3 / 4 (4 solves per wave) or LD 2, R 6 / 8 (16);
@@ -2376,6 +2485,8 @@ int64_t chunk_parts(int64_t max_job);
 int64_t chunk_items_bound(int64_t J, int64_t C, int64_t max_job);
 // smallest pool / batch (candidates) that takes the CHUNK / REC forms (below: the small-batch kernels; tools/csfbench.py sweeps)
 constexpr int64_t kChunkMinCands = 256;
+// pairs of short documents per single-pool call that take pair_one_kernel (tools/experiments/singlejob.py sweeps)
+constexpr int64_t kOneMinPairs = 1, kOneMaxPairs = 8192;        // (ONE form for every small grid: a pair scored alone, in a subset or in a shard gets the same bits)
 }  // namespace
 }  // namespace aspire
 namespace {
@@ -2516,6 +2627,18 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
             ws.neg = ws.cost + n_slots * PairWs<T>::kEntries;
             ws.diam2 = ws.neg + n_slots * PairWs<T>::kEntries;
             float* cbox = (float*)(((uintptr_t)(ws.diam2 + n_slots) + 15) & ~(uintptr_t)15);
+            if constexpr (T == 1) {
+                // a small pool of short documents (the per-query call of evaluate.py:58-76): one wave per pair, costs and solve in ONE
+                // launch (pair_one_kernel) instead of the cost launch + the Sinkhorn launch and the workspace between them
+                const int64_t groups4 = (a.cand1 - a.cand0 + 3) / 4 * (pairing == ASPIRE_PAIR_CROSS ? q->n : 1);
+                const bool small_grid = !(pairing == ASPIRE_PAIR_CROSS && groups4 >= 2048);        // (beyond: the tiled cost kernel's grid)
+                if (q->ext == 0 && c->ext == 0 && !gram && !cost_only && small_grid && n_slots >= kOneMinPairs && n_slots <= kOneMaxPairs &&
+                    (form_t == 5 || (form_t == 0 && tuning().sinkhorn_form == 0 && tuning().cost_path == 0 && tuning().cost1_blocks == 0))) {
+                    hipLaunchKernelGGL(pair_one_kernel, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, n_slots);
+                    ASPIRE_LAUNCH_OK();
+                    continue;
+                }
+            }
             if (int rc = launch_cost_stage<T>(a, q, c, ws, n_slots, qchunks, gram, qbox, cbox, c0 == 0, (hipStream_t)stream)) return rc;
             if (cost_only) continue;
             if (int rc = launch_sinkhorn_stage<T>(a, ws, n_slots, max_rows, extra, 0, (hipStream_t)stream)) return rc;
@@ -3010,6 +3133,16 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     } else {
         const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {
             constexpr int T = decltype(tc)::value;
+            if constexpr (T == 1) {
+                // a small batch of short documents: the single-pool calls' one-launch form (pair_one_kernel: one wave per pair) -- the
+                // same kernel whether a pair is scored in a batch or in a call of its own: the same bits
+                if (stages == kStageAll && !a.tile_form && C <= kOneMaxPairs &&
+                    (form_t == 5 || (form_t == 0 && tuning().sinkhorn_form == 0 && tuning().cost_path == 0 && tuning().cost1_blocks == 0))) {
+                    hipLaunchKernelGGL(pair_one_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s0, a, C);
+                    ASPIRE_LAUNCH_OK();
+                    return (int)ASPIRE_OK;
+                }
+            }
             PairWs<T> ws;
             ws.cost = (float*)(wsb + L.slots);
             ws.neg = ws.cost + C * PairWs<T>::kEntries;

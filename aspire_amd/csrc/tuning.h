@@ -17,7 +17,8 @@ struct Tuning {
     int gemm_ring = 0;       // ASPIRE_HIP_GEMM_RING=22 | 23 | 13 | 14: 10 x (k blocks per stage) + (stages in the LDS ring) of the P-layout GEMM; 113: ring 13 as a persistent tile loop
     int gemm_tile = 0;       // ASPIRE_HIP_GEMM_TILE=128 | 64: force 128 x 128 / 128 x 64 tiles in the bf16x3 form (tuning)
     int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
-                             // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch
+                             // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch, 4 chunk, 5 one = one wave per pair,
+                             // costs + solve in one launch (the default for a few dozen .. a few thousand pairs of short documents)
     int fused_valu = 0;      // ASPIRE_HIP_FUSED_VALU=1: the fused kernel's dot products as VALU FMAs instead of MFMA (A/B, parity tests)
     int fused_nosolve = 0;   // ASPIRE_HIP_FUSED_NOSOLVE=1: the fused kernel's cost phase alone (timing experiments)
     int fused_noself = 0;    // ASPIRE_HIP_FUSED_NOSELF=1: batches of <= 64 jobs also take the tables launch + the table-driven kernel (A/B)

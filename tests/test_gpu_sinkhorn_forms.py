@@ -146,11 +146,13 @@ def test_small_pool_cost_kernel_matches_oracle(amd, qlens, clens, blocks):
     -- bit for bit the same either way."""
     q, c = _docs(61, qlens), _docs(62, clens)
     want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
-    ref = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
-    with pinned(COST1_BLOCKS=blocks):
-        got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    with pinned(OT_FORM='small'):           # (the default for such a pool is the one-launch kernel, round 5: checked against the oracle too)
+        ref = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+        with pinned(COST1_BLOCKS=blocks):
+            got = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
     np.testing.assert_array_equal(got, ref)
+    np.testing.assert_allclose(amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy(), want, atol=TOL, rtol=0)
 
 
 def test_persistent_cost_kernel_with_duplicate_sentences(amd):
@@ -165,8 +167,9 @@ def test_persistent_cost_kernel_with_duplicate_sentences(amd):
             c[0] = query[i % 8]
         cands.append(c)
     want = np.array([orc.get_similarity(query, c) for c in cands], dtype=np.float32)
-    ref = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
-    with pinned(COST1_BLOCKS=3):
-        got = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
+    with pinned(OT_FORM='small'):
+        ref = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
+        with pinned(COST1_BLOCKS=3):
+            got = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
     np.testing.assert_allclose(ref, want, atol=2e-2, rtol=0)      # duplicate sentences: the expansion formula cancels, 1e-4 .. 1.6e-2 either way (see test_gpu_scoring.test_duplicate_sentence_pair)
     np.testing.assert_array_equal(got, ref)

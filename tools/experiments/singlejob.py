@@ -35,7 +35,7 @@ def run(label, **pin):
 
 
 base = run('default')
-for label, pin in (('small', dict(OT_FORM='small')), ('tile', dict(OT_FORM='tile')), ('fused', dict(OT_FORM='fused')),
-                   ('fused 512 waves', dict(OT_FORM='fused', FUSED_WAVES=512)), ('default again', {})):
+for label, pin in (('small', dict(OT_FORM='small')), ('one', dict(OT_FORM='one')), ('tile', dict(OT_FORM='tile')), ('fused', dict(OT_FORM='fused')),
+                   ('default again', {})):
     sc = run(label, **pin)
     print(f'   max |score - default| {float((sc - base).abs().max()):.2e}')
