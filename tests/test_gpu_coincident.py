@@ -44,6 +44,7 @@ FAMILIES = [
     # name, pins, queries, candidates, query rows, candidate rows, planes
     ('fused', dict(OT_FORM='fused'), 1, 4200, 8, 8, False),
     ('small', dict(OT_FORM='small'), 2, 60, 8, 8, False),
+    ('one wave per pair', dict(OT_FORM='one'), 2, 900, 8, 8, False),
     ('tile16', dict(), 1, 2600, 12, 14, False),
     ('gram bf16x3', dict(COST_PATH='mfma'), 24, 300, 8, 8, False),
     ('plane tiles', dict(COST_PATH='mfma'), 24, 2100, 8, 8, True),

@@ -173,3 +173,49 @@ def test_persistent_cost_kernel_with_duplicate_sentences(amd):
             got = amd.scorer.score_pool([query], cands, method='ot', schedule='pair').cpu().numpy()[0]
     np.testing.assert_allclose(ref, want, atol=2e-2, rtol=0)      # duplicate sentences: the expansion formula cancels, 1e-4 .. 1.6e-2 either way (see test_gpu_scoring.test_duplicate_sentence_pair)
     np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize('qlens,clens', [([8], [8] * 130), ([3, 8, 1], [1, 8, 4, 7, 2] * 30), ([5], [6])])
+def test_one_wave_per_pair_kernel_matches_oracle_and_the_two_launch_form(amd, qlens, clens):
+    """pair_one_kernel (round 5: costs + solve of a pair on ONE wave, one launch -- the default of every small grid of short documents)
+    against the oracle and against pair_cost1_kernel + sinkhorn_kernel<1>: ragged documents, several queries, every output of
+    compute_distance, rows with a common component (the centred form), PAIRED pairing through caching_score's padded call"""
+    q, c = _docs(71, qlens), _docs(72, clens)
+    want = np.array([[orc.get_similarity(x, y) for y in c] for x in q], dtype=np.float32)
+    with pinned(OT_FORM='one'):
+        one = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    with pinned(OT_FORM='small'):
+        two = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    dflt = amd.scorer.score_pool(q, c, method='ot', schedule='pair').cpu().numpy()
+    np.testing.assert_allclose(one, want, atol=TOL, rtol=0)
+    np.testing.assert_allclose(one, two, atol=5e-5, rtol=0)
+    np.testing.assert_array_equal(dflt, one)                       # the default IS this kernel
+    # rows that share a large common component: ops sets ASPIRE_OT_FLAG_CENTER from a sample of the pool
+    g = torch.Generator().manual_seed(73)
+    common = 3.0 * torch.randn(768, generator=g)
+    qc, cc = [x + common for x in q], [y + common for y in c]
+    wantc = np.array([[orc.get_similarity(x.double(), y.double()) for y in cc] for x in qc])
+    with pinned(OT_FORM='one'):
+        onec = amd.scorer.score_pool(qc, cc, method='ot', schedule='pair').cpu().numpy()
+    np.testing.assert_allclose(onec, wantc, atol=3e-4, rtol=0)
+
+
+def test_one_wave_per_pair_kernel_transport_plan_outputs(amd):
+    """the five return_pair_sims outputs through the one-launch kernel (sinkhorn_pair<1> writes them) = the two-launch form's"""
+    from aspire_amd import AllPairMaskedWasserstein, rep_len_tup
+    g = torch.Generator().manual_seed(74)
+    lens_q, lens_c = [7, 3, 8, 5], [6, 8, 2, 4]
+    qp = torch.zeros(4, 8, 768)
+    cp = torch.zeros(4, 8, 768)
+    for i, (a_, b_) in enumerate(zip(lens_q, lens_c)):
+        qp[i, :a_] = torch.randn(a_, 768, generator=g)
+        cp[i, :b_] = torch.randn(b_, 768, generator=g)
+    qt = rep_len_tup(embed=qp.permute(0, 2, 1), abs_lens=lens_q)
+    ct = rep_len_tup(embed=cp.permute(0, 2, 1), abs_lens=lens_c)
+    res = {}
+    for form in ('one', 'small'):
+        with pinned(OT_FORM=form):
+            wd, inter = AllPairMaskedWasserstein({}).compute_distance(qt, ct, return_pair_sims=True)
+        res[form] = [wd] + list(inter)
+    for a_, b_ in zip(res['one'], res['small']):
+        np.testing.assert_allclose(a_.numpy(), b_.numpy(), atol=5e-4, rtol=0)
