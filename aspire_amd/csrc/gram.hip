@@ -597,23 +597,18 @@ __global__ void __launch_bounds__(192) doc_box_range_kernel(RepSet d, int64_t fi
 
 // geomloss's diameter of one (query, candidate) call = norm of the joint bounding box's extent; squared here:
 // diam2[q_loc * ncand + c_loc] = sum_d (max(qmax_d, cmax_d) - min(qmin_d, cmin_d))^2.
-// Workgroup = 32 query docs x 64 candidate docs, thread = 4 x 2 of them, coordinates staged 64 at a time.
+// Workgroup = 32 query docs x 32 candidate docs, thread = 2 x 2 of them, coordinates staged 64 at a time.
 constexpr int kBoxLd = 68;
 __global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__ qbox, const float* __restrict__ cbox,
                                                        uint32_t nq, uint32_t ncand, float* __restrict__ diam2) {
-    // 32 query documents x 64 candidate documents per workgroup, a thread 4 x 2 of them: per 16-byte step 12 LDS reads for 8 pairs
-    // (the 2 x 2 form read 8 for 4: with the arithmetic at 3 issue slots per pair and coordinate the LDS pipe was what paced it)
-    __shared__ __attribute__((aligned(16))) float sq[2][32][kBoxLd];   // qmin, qmax
-    __shared__ __attribute__((aligned(16))) float sc[2][64][kBoxLd];   // cmin, cmax
+    __shared__ __attribute__((aligned(16))) float s[4][32][kBoxLd];   // qmin, qmax, cmin, cmax
     const int tid = threadIdx.x;
-    const uint32_t c0 = blockIdx.x * 64, q0 = blockIdx.y * 32;
-    const int tq = tid & 7, tc = tid >> 3;
-    // per (query, candidate) pair and coordinate: one v_max, one v_min (bare instructions: fmaxf / fminf would canonicalise every value
+    const uint32_t c0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
+    const int tq = tid & 15, tc = tid >> 4;
+    // per (query, candidate) pair and coordinate: one v_max, one v_min (bare instructions: fmaxf / fminf would canonicalise all 32 values
     // read from LDS first), half a packed subtract and half a packed FMA -- 3 issue slots where the scalar form took 6
     typedef float f2b __attribute__((ext_vector_type(2)));
-    f2b acc[4][2];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u][0] = acc[u][1] = f2b{0.f, 0.f};
+    f2b acc[2][2] = {{f2b{0.f, 0.f}, f2b{0.f, 0.f}}, {f2b{0.f, 0.f}, f2b{0.f, 0.f}}};
     auto vmx = [](float a, float b) {
         float r;
         asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -626,32 +621,27 @@ __global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__
     };
     for (int ch = 0; ch < kD / 64; ++ch) {
 #pragma unroll
-        for (int p = 0; p < 12; ++p) {
-            const int idx = tid + 256 * p;            // 0 .. 1023: [arr 2][doc 32][f4 16] of the queries; then [arr 2][doc 64][f4 16] of the candidates
-            const bool isq = idx < 1024;
-            const int e = isq ? idx : idx - 1024;
-            const int f4 = e & 15, doc = isq ? (e >> 4) & 31 : (e >> 4) & 63, arr = isq ? e >> 9 : e >> 10;
+        for (int p = 0; p < 8; ++p) {
+            const int idx = tid + 256 * p;            // [arr 4][doc 32][f4 16]
+            const int arr = idx >> 9, doc = (idx >> 4) & 31, f4 = idx & 15;
+            const bool isq = arr < 2;
             const uint32_t gdoc = isq ? min(q0 + doc, nq - 1) : min(c0 + doc, ncand - 1);
-            const float* src = (isq ? qbox : cbox) + (size_t)gdoc * 2 * kD + arr * kD + ch * 64 + f4 * 4;
-            float* dst = isq ? &sq[arr][doc][f4 * 4] : &sc[arr][doc][f4 * 4];
-            *reinterpret_cast<float4*>(dst) = ld4(src);
+            const float* src = (isq ? qbox : cbox) + (size_t)gdoc * 2 * kD + (arr & 1) * kD + ch * 64 + f4 * 4;
+            *reinterpret_cast<float4*>(&s[arr][doc][f4 * 4]) = ld4(src);
         }
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
         for (int f4 = 0; f4 < 16; ++f4) {
-            float4 qn[4], qx[4], cn[2], cx[2];
+            float4 qn[2], qx[2], cn[2], cx[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                qn[u] = *reinterpret_cast<const float4*>(&sq[0][tq + 8 * u][f4 * 4]);      // (rows tq + 8 u: the eight lanes of a row group on 32 different banks)
-                qx[u] = *reinterpret_cast<const float4*>(&sq[1][tq + 8 * u][f4 * 4]);
+            for (int u = 0; u < 2; ++u) {
+                qn[u] = *reinterpret_cast<const float4*>(&s[0][2 * tq + u][f4 * 4]);
+                qx[u] = *reinterpret_cast<const float4*>(&s[1][2 * tq + u][f4 * 4]);
+                cn[u] = *reinterpret_cast<const float4*>(&s[2][2 * tc + u][f4 * 4]);
+                cx[u] = *reinterpret_cast<const float4*>(&s[3][2 * tc + u][f4 * 4]);
             }
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                cn[v] = *reinterpret_cast<const float4*>(&sc[0][2 * tc + v][f4 * 4]);
-                cx[v] = *reinterpret_cast<const float4*>(&sc[1][2 * tc + v][f4 * 4]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     const f2b hi0 = {vmx(qx[u].x, cx[v].x), vmx(qx[u].y, cx[v].y)}, lo0 = {vmn(qn[u].x, cn[v].x), vmn(qn[u].y, cn[v].y)};
@@ -663,10 +653,10 @@ __global__ void __launch_bounds__(256) pair_box_kernel(const float* __restrict__
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            const uint32_t q = q0 + tq + 8 * u, c = c0 + 2 * tc + v;
+            const uint32_t q = q0 + 2 * tq + u, c = c0 + 2 * tc + v;
             if (q < nq && c < ncand) diam2[(size_t)q * ncand + c] = acc[u][v].x + acc[u][v].y;
         }
 }
@@ -712,7 +702,7 @@ int launch_pair_box(const float* qbox, const float* cbox, uint32_t nq, uint32_t 
         const uint32_t wgs = (ncand + 3) / 4 < 2048 ? (ncand + 3) / 4 : 2048;
         hipLaunchKernelGGL(pair_box_few_kernel, dim3(wgs), dim3(256), nq * 2 * kD * sizeof(float), stream, qbox, cbox, nq, ncand, diam2);
     } else {
-        hipLaunchKernelGGL(pair_box_kernel, dim3((ncand + 63) / 64, (nq + 31) / 32), dim3(256), 0, stream, qbox, cbox, nq, ncand, diam2);
+        hipLaunchKernelGGL(pair_box_kernel, dim3((ncand + 31) / 32, (nq + 31) / 32), dim3(256), 0, stream, qbox, cbox, nq, ncand, diam2);
     }
     ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
