@@ -456,6 +456,35 @@ __device__ __forceinline__ void p_store4(void* P, int64_t R, int64_t r, int k, f
     *reinterpret_cast<uint2*>(row + 16 * ((2 + kh) ^ sw)) = make_uint2(l0, l1);
 }
 
+// (the LayerNorm epilogue's form of the two: byte offsets in 32 bits from the uniform base -- a P matrix is far below 4 GB -- so that the
+// sixteen slots a lane reads and later rewrites cost sixteen registers of addresses, not sixty-four)
+__device__ __forceinline__ uint32_t p_slot(uint32_t R, uint32_t r, uint32_t k) {
+    return (((k >> 4) * R + r) << 6) + ((k >> 2) & 1) * 8 + 16 * (((k >> 3) & 1) ^ ((r >> 2) & 3));      // the h plane's 8 bytes; l: ^ 32
+}
+__device__ __forceinline__ float4 p_load4_at(const void* P, uint32_t slot) {
+    const uint2 h = *reinterpret_cast<const uint2*>((const char*)P + slot), l = *reinterpret_cast<const uint2*>((const char*)P + (slot ^ 32u));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h0 = __builtin_bit_cast(h2, h.x), h1 = __builtin_bit_cast(h2, h.y), l0 = __builtin_bit_cast(h2, l.x), l1 = __builtin_bit_cast(h2, l.y);
+    return make_float4((float)h0.x + (float)l0.x, (float)h0.y + (float)l0.y, (float)h1.x + (float)l1.x, (float)h1.y + (float)l1.y);
+}
+__device__ __forceinline__ void p_store4_at(void* P, uint32_t slot, float x, float y, float z, float w) {
+    uint32_t h0, l0, h1, l1;
+    split2_f16(x, y, h0, l0);
+    split2_f16(z, w, h1, l1);
+    *reinterpret_cast<uint2*>((char*)P + slot) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>((char*)P + (slot ^ 32u)) = make_uint2(l0, l1);
+}
+
+// ... and back: h + l of four consecutive k of row r (what p_store4 wrote, to 2^-24 relative / 2^-25 absolute: fp32's own rounding)
+__device__ __forceinline__ float4 p_load4(const void* P, int64_t R, int64_t r, int k) {
+    const int kb = k >> 4, kh = (k >> 3) & 1, half = (k >> 2) & 1, sw = (int)((r >> 2) & 3);
+    const char* row = (const char*)P + ((size_t)kb * R + r) * kPRowBytes + half * 8;
+    const uint2 h = *reinterpret_cast<const uint2*>(row + 16 * (kh ^ sw)), l = *reinterpret_cast<const uint2*>(row + 16 * ((2 + kh) ^ sw));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h0 = __builtin_bit_cast(h2, h.x), h1 = __builtin_bit_cast(h2, h.y), l0 = __builtin_bit_cast(h2, l.x), l1 = __builtin_bit_cast(h2, l.y);
+    return make_float4((float)h0.x + (float)l0.x, (float)h0.y + (float)l0.y, (float)h1.x + (float)l1.x, (float)h1.y + (float)l1.y);
+}
+
 // *too_big (optional) is raised when an element leaves fp16's range (|scale x| > 65504, or not finite)
 __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ X, int64_t R, int K, int ld, void* __restrict__ P,
                                                            float scale, int* __restrict__ too_big) {
@@ -479,7 +508,15 @@ struct PGemmArgs {
     int M, N, K, ldc, ldr;
     int n_off;           // first column of this launch (a GEMM may run as a launch of 128-wide and one of 64-wide column tiles)
     int probe;           // timing probes (ASPIRE_HIP_GEMM_PROBE): 1 no MFMAs, 2 no LDS-DMA
-    int tiles_x, tiles_y;   // PERSIST: the tile grid (a workgroup walks several tiles; the launch grid is the resident workgroups)
+    int tiles_x, tiles_y;   // PERSIST / LN: the tile grid (PERSIST: a workgroup walks several tiles; the launch grid is the resident workgroups)
+    // LN epilogue (N = 768 = the whole row): y = LayerNorm(acc + bias + residual) * gamma + beta -> C (fp32, optional) and Cp (P layout,
+    // optional); the residual is READ from a P layout [M, 768] (resp; h + l = the fp32 value to fp32's own rounding) and may BE Cp:
+    // every 8-byte slot is read and later written by the one lane that owns it
+    const void* resp;
+    const float *gamma, *beta;
+    float eps;
+    float2* ln_stats;    // [M][768 / BN] (mean, sum of squared deviations) of a row's BN columns, one entry per column tile
+    int* ln_count;       // [row blocks] zeroed before the launch: column tiles of the row block that have published their entry
 };
 
 // One 16-byte-per-lane LDS-DMA: 64 lanes x 16 B from global bytes [base + IMM + voff(lane)] to LDS bytes [lds_dst + IMM, .. + 1024).
@@ -527,9 +564,15 @@ __device__ __forceinline__ void glds_kblock(uint64_t a_base, uint64_t b_base, ui
 // the tiles; the k-block stream runs on across a tile boundary -- the first NS - 1 stages of the NEXT tile go out during the last
 // steps of this one and land under its epilogue's stores, so a tile's prologue (address set-up, the first DMA round trips, the
 // workgroup's own launch) is paid once per workgroup instead of once per tile.
-template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false>
-__global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
+// LN (SWAP form, N = 768): the 768 / BN workgroups of a row block exchange their rows' partial moments through global memory and each
+// normalises its own 128 x BN block out of its accumulators -- no separate LayerNorm pass over [M, 768], no fp32 round trip of the
+// pre-norm rows.  A workgroup WAITS for its row block's other column tiles: they are consecutive in the launch order of ONE XCD (below),
+// the hardware starts workgroups in order, so whatever waits has all its partners started or next in line; the tiles that can be
+// waiting at any time are the <= 8 row blocks at the launch frontier.
+template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false, bool LN = false>
+__device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
     static_assert(!PERSIST || KS == 1, "persistent form: one k block per stage");
+    static_assert(!LN || (SWAP && !PERSIST && KS == 1), "LayerNorm epilogue: swapped operands, one tile per workgroup");
     constexpr int TN = BN / 64;                             // 32-column blocks per wave
     constexpr int kBTile = BN * kPRowBytes;                 // B rows of one k block
     constexpr int kStage = KS * (kPTile + kBTile);          // [A k block 0 .. KS - 1][B k block 0 .. KS - 1]
@@ -549,6 +592,14 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     uint32_t tile_i = wg >> 3;
     if (PERSIST && tile_i >= tile_n) return;
     uint32_t bx = (tile_lo + tile_i) % gx, by = (tile_lo + tile_i) / gx;
+    if constexpr (LN) {
+        // whole row blocks per XCD: XCD x takes row blocks [rb_lo, rb_lo + rb_n), its workgroups (wg = x, x + 8, ..) walk them column tile by column tile
+        const uint32_t ty = (uint32_t)g.tiles_y, rq = ty >> 3, rr = ty & 7;
+        const uint32_t rb_lo = xcd * rq + (xcd < rr ? xcd : rr), rb_n = rq + (xcd < rr ? 1u : 0u);
+        if (tile_i >= rb_n * (uint32_t)g.tiles_x) return;
+        by = rb_lo + tile_i / (uint32_t)g.tiles_x;
+        bx = tile_i % (uint32_t)g.tiles_x;
+    }
     int m0 = G_PROBE(g) == 3 ? 0 : (int)by * 128, n0 = G_PROBE(g) == 3 ? g.n_off : g.n_off + (int)bx * BN;      // probe 3: every workgroup computes tile (0, 0)
     G_STAMP(0, __builtin_amdgcn_s_memrealtime());
     G_STAMP(4, __builtin_amdgcn_s_getreg(31 << 11 | 4));
@@ -717,10 +768,11 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 
     G_STAMP(2, __builtin_amdgcn_s_memrealtime());
     constexpr float kUnscale = 1.0f / kPWeightScale;
-    if constexpr (!PERSIST) load_bias();
+    if constexpr (!PERSIST && !LN) load_bias();       // (LN: fetched block by block beside the residual)
     // every bias register is consumed HERE, in front of the first store: the compiler waits for the bias loads once, now, instead of
     // in front of the first use of each -- behind stores, where it can only wait with vmcnt(0) = for every store's acknowledgement
-    if constexpr (!SWAP) {
+    if constexpr (LN) {
+    } else if constexpr (!SWAP) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias_n[j]));
     } else {
@@ -731,7 +783,114 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
                 asm volatile("" : "+v"(bias_m[j][q4].x), "+v"(bias_m[j][q4].y), "+v"(bias_m[j][q4].z), "+v"(bias_m[j][q4].w));
     }
     if (((G_PROBE(g) >= 4 && G_PROBE(g) <= 6) || (G_PROBE(g) >= 10 && G_PROBE(g) < 20)) && acc[0][0][0] != 12345.678f) return;      // probes 4+: no epilogue (4: all else, 5: no MFMAs, 6: no LDS-DMA)
-    if constexpr (!SWAP) {
+    if constexpr (LN) {
+        // lane = row m (col = lane & 31 of the swapped product), registers along n in groups of 4: a lane holds kCnt = 16 TN values of each
+        // of its two rows.  Moments are combined pairwise as (mean, M2 = sum of squared deviations) of equal-sized groups:
+        // M2 = M2a + M2b + (n / 2) (mean_a - mean_b)^2 -- no E[x^2] - E[x]^2 cancellation anywhere.
+        constexpr int kCnt = 16 * TN, kGX = kD / BN;
+        float mu[2], m2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mc = min(m0 + wr * 64 + 32 * i + lr, g.M - 1);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // one 32-column block at a time (eight 8-byte loads in flight): with all of a row's loads hoisted the kernel needs 186 registers
+                // and loses its third workgroup per CU
+                float4 rv[4], bv[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    rv[q4] = p_load4_at(g.resp, p_slot((uint32_t)g.M, (uint32_t)mc, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk)));
+                    bv[q4] = *reinterpret_cast<const float4*>(g.bias + n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk);
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 b4 = bv[q4];
+                    const float x0 = fmaf(acc[i][j][4 * q4 + 0], kUnscale, b4.x) + rv[q4].x, x1 = fmaf(acc[i][j][4 * q4 + 1], kUnscale, b4.y) + rv[q4].y;
+                    const float x2 = fmaf(acc[i][j][4 * q4 + 2], kUnscale, b4.z) + rv[q4].z, x3 = fmaf(acc[i][j][4 * q4 + 3], kUnscale, b4.w) + rv[q4].w;
+                    acc[i][j][4 * q4 + 0] = x0; acc[i][j][4 * q4 + 1] = x1; acc[i][j][4 * q4 + 2] = x2; acc[i][j][4 * q4 + 3] = x3;
+                    s += (x0 + x1) + (x2 + x3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float ml = s * (1.0f / kCnt);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[i][j][r] - ml;
+                    q = fmaf(d, d, q);
+                }
+            // the lane that holds the row's other 4-column groups (lk): both lanes end with the same pair of numbers
+            const float mo = __shfl_xor(ml, 32), qo = __shfl_xor(q, 32), dm = ml - mo;
+            mu[i] = 0.5f * (ml + mo);
+            m2[i] = fmaf(dm * dm, 0.5f * kCnt, q + qo);
+        }
+        float2* sst = reinterpret_cast<float2*>(p_smem);          // [wc][128 rows]; the ring is idle once everybody is past its last fragment read
+        float4* sgb = reinterpret_cast<float4*>(p_smem + 2048);   // gamma, beta of the tile's BN columns: read from LDS in the store loop (64 registers otherwise)
+        __syncthreads();
+        if (tid < BN / 2) sgb[tid] = *reinterpret_cast<const float4*>((tid < BN / 4 ? g.gamma + n0 + 4 * tid : g.beta + n0 + 4 * (tid - BN / 4)));
+        if (lk == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sst[wc * 128 + wr * 64 + 32 * i + lr] = make_float2(mu[i], m2[i]);
+        }
+        __syncthreads();
+        // The exchange runs on device-scope ATOMICS only (entries swapped in, the counter, entries read back) and no fence: an agent-scope
+        // release / acquire fence writes back / invalidates the XCD's whole L2 -- with every workgroup's output rows dirty in it (measured:
+        // 250 us per launch).  An entry's swap has RETURNED before its workgroup's barrier, the barrier precedes the count, and whoever
+        // has seen the full count reads the entries with atomic loads.
+        unsigned long long* st64 = reinterpret_cast<unsigned long long*>(g.ln_stats);
+        if (tid < 128 && m0 + tid < g.M) {
+            const float2 a = sst[tid], b = sst[128 + tid];
+            const float dm = a.x - b.x;
+            const float mean_t = 0.5f * (a.x + b.x), m2_t = fmaf(dm * dm, (float)kCnt, a.y + b.y);
+            const unsigned long long pk = (unsigned long long)__builtin_bit_cast(uint32_t, mean_t) | ((unsigned long long)__builtin_bit_cast(uint32_t, m2_t) << 32);
+            const unsigned long long was = __hip_atomic_exchange(st64 + (size_t)(m0 + tid) * kGX + bx, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(was));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(g.ln_count + by, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(g.ln_count + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGX) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wr * 64 + 32 * i + lr;
+            unsigned long long* srow = st64 + (size_t)min(m, g.M - 1) * kGX;
+            float mt[kGX], qt[kGX];
+#pragma unroll
+            for (int t = 0; t < kGX; ++t) {
+                const unsigned long long w = __hip_atomic_load(srow + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mt[t] = __builtin_bit_cast(float, (uint32_t)w);
+                qt[t] = __builtin_bit_cast(float, (uint32_t)(w >> 32));
+            }
+            float sm = 0.f, sq = 0.f, sd = 0.f;
+#pragma unroll
+            for (int t = 0; t < kGX; ++t) sm += mt[t], sq += qt[t];
+            const float mean = sm * (1.0f / kGX);
+#pragma unroll
+            for (int t = 0; t < kGX; ++t) sd = fmaf(mt[t] - mean, mt[t] - mean, sd);
+            const float rstd = 1.0f / sqrtf(fmaf(sd, (float)BN, sq) * (1.0f / kD) + g.eps);
+            if (m >= g.M) continue;
+            float* crow = g.C ? g.C + (size_t)m * g.ldc + n0 + wc * 32 * TN + 4 * lk : nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int c4 = (wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk) >> 2;
+                    const float4 gm = sgb[c4], bt = sgb[BN / 4 + c4];
+                    float4 o;
+                    o.x = (acc[i][j][4 * q4 + 0] - mean) * rstd * gm.x + bt.x;
+                    o.y = (acc[i][j][4 * q4 + 1] - mean) * rstd * gm.y + bt.y;
+                    o.z = (acc[i][j][4 * q4 + 2] - mean) * rstd * gm.z + bt.z;
+                    o.w = (acc[i][j][4 * q4 + 3] - mean) * rstd * gm.w + bt.w;
+                    if (crow) *reinterpret_cast<float4*>(crow + 32 * j + 8 * q4) = o;
+                    if (g.Cp) p_store4_at(g.Cp, p_slot((uint32_t)g.M, (uint32_t)m, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk)), o.x, o.y, o.z, o.w);
+                }
+        }
+    } else if constexpr (!SWAP) {
         // C/D layout of the 32 x 32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m): a store instruction
         // writes two full 128-byte lines.  Whole tiles (all but the last row of tiles) take the branch-free form: the residual's 16
         // loads of a block go out together, the 16 stores follow back to back (with per-element row checks the compiler put an
@@ -808,6 +967,16 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{};      // (constant trip counts: unrolled without being asked)
     }
   }
+}
+
+template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false>
+__global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
+    gemm_p_body<NS, KS, BN, SWAP, PERSIST, false>(g);
+}
+// the LayerNorm-epilogue form: THREE workgroups per CU asked of the register allocator (168 registers), as the plain forms get by themselves
+template <int BN>
+__global__ void __launch_bounds__(256, 3) gemm_p_ln_kernel(PGemmArgs g) {
+    gemm_p_body<3, 1, BN, true, false, true>(g);
 }
 
 // One wave per row of 768: lane holds 3 float4 (d = 4*lane + 256*c).
@@ -1324,10 +1493,13 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Workspace {
     float *x, *qkv, *scores, *ctx, *tmp, *ffn;
     void *actp, *ctxp, *ffnp;       // P-layout activations (pre-split GEMM operands): LayerNorm outputs, attention context, GELU(FFN1)
+    float2* ln_stats;               // the LayerNorm-epilogue GEMMs' per-row, per-column-tile moments [M][12]
+    int* ln_count;                  // their arrival counters [2 n_layers][row blocks], zeroed once per forward
+    size_t ln_count_bytes;
     size_t total;
 };
 
-Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim) {
+Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim, int n_layers) {
     const size_t M = (size_t)B * L, Lp = (size_t)(L + 3) / 4 * 4;
     char* p = (char*)base;
     Workspace w;
@@ -1351,6 +1523,9 @@ Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim) {
     w.actp = take_p(kD);
     w.ctxp = take_p(kD);
     w.ffnp = take_p(ffn_dim);
+    w.ln_stats = reinterpret_cast<float2*>(take(M * 24));
+    w.ln_count_bytes = (size_t)2 * (n_layers > 0 ? n_layers : 0) * ((M + 127) / 128) * sizeof(int);
+    w.ln_count = reinterpret_cast<int*>(take(w.ln_count_bytes / sizeof(float) + 1));
     w.total = off;
     return w;
 }
@@ -1414,6 +1589,30 @@ int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
         if (int rc = launch_gemm_p_ring<64, SWAP>(g, c1 * 128, (int)(n128 - c1) * 2, st)) return rc;
     return ASPIRE_OK;
 }
+// N = 768 GEMM + residual + LayerNorm in one launch (gemm_p_kernel's LN form): 128-wide column tiles, or 64-wide ones where the launch
+// would otherwise leave workgroup slots empty (as launch_gemm_p chooses).  g.ln_count: this use's zeroed counters.
+template <int BN>
+int launch_gemm_p_ln_bn(PGemmArgs g, hipStream_t st) {
+    constexpr int NS = 3, lds = NS * (kPTile + BN * kPRowBytes);
+    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_ln_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    ASPIRE_HIP_OK(raised);
+    g.n_off = 0;
+    g.probe = 0;
+    g.tiles_x = kD / BN;
+    g.tiles_y = (g.M + 127) / 128;
+    const unsigned per_xcd = (unsigned)((g.tiles_y + 7) / 8) * (unsigned)g.tiles_x;
+    hipLaunchKernelGGL((gemm_p_ln_kernel<BN>), dim3(8 * per_xcd), dim3(256), lds, st, g);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+int launch_gemm_p_ln(const PGemmArgs& g, hipStream_t st) {
+    ASPIRE_REQUIRE(g.N == kD && g.K % 32 == 0 && g.resp && (g.C || g.Cp) && g.gamma && g.beta && g.ln_stats && g.ln_count, ASPIRE_ERR_INVALID_ARG,
+                   "LayerNorm-epilogue GEMM: N = 768, a residual in the P layout, gamma / beta and the exchange buffers");
+    // 128-wide column tiles whatever the row count: the 64-wide form (twelve tiles per row block to wait for, half the columns per wave)
+    // measured 76 us against 36 + 14 for the plain 64-wide GEMM + layernorm_kernel at 8192 x 768 x 768; ASPIRE_HIP_GEMM_TILE=64 pins it (tests)
+    if (tuning().gemm_tile == 64) return launch_gemm_p_ln_bn<64>(g, st);
+    return launch_gemm_p_ln_bn<128>(g, st);
+}
 // where a layer's four weight matrices sit in the prepared planes buffer
 struct PlaneOffsets {
     size_t qkv, o, ffn1, ffn2, per_layer;
@@ -1436,7 +1635,7 @@ using namespace aspire;
 
 extern "C" size_t aspire_bert_workspace_bytes(const aspire_bert_weights* w, int64_t B, int64_t L) {
     if (!w || B <= 0 || L <= 0) return 0;
-    return carve(nullptr, B, L, w->n_heads, w->ffn_dim).total;
+    return carve(nullptr, B, L, w->n_heads, w->ffn_dim, w->n_layers).total;
 }
 
 extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64_t* tok_ids, const int64_t* type_ids,
@@ -1449,10 +1648,10 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
                    "sequence length %lld outside (0, min(512, max_position_embeddings=%d)]", (long long)L, w->max_pos);
     ASPIRE_REQUIRE(w->n_layers >= 0 && (w->n_layers == 0 || w->layers), ASPIRE_ERR_INVALID_ARG, "bad layer table");
     if (B == 0) return ASPIRE_OK;
-    const size_t need = carve(nullptr, B, L, w->n_heads, w->ffn_dim).total;
+    const size_t need = carve(nullptr, B, L, w->n_heads, w->ffn_dim, w->n_layers).total;
     ASPIRE_REQUIRE(workspace && workspace_bytes >= need, ASPIRE_ERR_INVALID_ARG, "workspace too small: need %zu bytes", need);
     hipStream_t st = (hipStream_t)stream;
-    Workspace ws = carve(workspace, B, L, w->n_heads, w->ffn_dim);
+    Workspace ws = carve(workspace, B, L, w->n_heads, w->ffn_dim, w->n_layers);
     const int64_t M = B * L;
     const int Lp = (int)((L + 3) / 4 * 4), H = w->n_heads, dh = kD / H;
     const unsigned row_blocks = (unsigned)((M + 3) / 4);
@@ -1469,6 +1668,13 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
                        w->type_emb, w->emb_ln_g, w->emb_ln_b, w->ln_eps, x, M, L, pp && w->n_layers > 0 ? ws.actp : nullptr);
     ASPIRE_LAUNCH_OK();
 
+    // LayerNorm in the N = 768 GEMMs' epilogue (ASPIRE_HIP_GEMM_LN=off: the separate layernorm_kernel pass)
+    // from 48 row tiles on (measured, fused / separate ms per batch: 64 x 256 9.00 - 9.18 / 9.45, 128 x 128 8.99 / 9.40, 64 x 128 5.05 / 5.15,
+    // 32 x 256 5.16 / 5.30, 40 x 100 3.09 / 3.17, 16 x 256 3.18 / 3.14, 8 x 256 2.37 / 2.30: below, the launch is a fraction of one round of
+    // workgroups and a waiting workgroup has nothing running under it)
+    const int64_t row_tiles = (M + 127) / 128;
+    const bool ln_fused = pp && (tuning().gemm_ln == 2 || (tuning().gemm_ln == 0 && row_tiles >= 48));
+    if (ln_fused && w->n_layers > 0) ASPIRE_HIP_OK(hipMemsetAsync(ws.ln_count, 0, ws.ln_count_bytes, st));
     for (int l = 0; l < w->n_layers; ++l) {
         const aspire_bert_layer& ly = w->layers[l];
         const bool last = l == w->n_layers - 1;
@@ -1519,7 +1725,15 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
             if (int rc = launch_gemm<true>(g, (int)(B * H), st)) return rc;
         }
         // 5. attention output projection + residual, LayerNorm
-        if (pp) {
+        if (ln_fused) {
+            // x lives in actp (written by the embedding LayerNorm / the previous layer's FFN2 epilogue, read by the QKV GEMM): read as the
+            // residual and replaced by h = LN1(.) slot by slot; no fp32 copy of x or h exists in this form
+            pg = PGemmArgs{ws.ctxp, lp + po.o, nullptr, ws.actp, ly.b_o, nullptr, (int)M, kD, kD, kD, kD, 0};
+            pg.resp = ws.actp;
+            pg.gamma = ly.ln1_g; pg.beta = ly.ln1_b; pg.eps = w->ln_eps;
+            pg.ln_stats = ws.ln_stats; pg.ln_count = ws.ln_count + (size_t)(2 * l) * row_tiles;
+            if (int rc = launch_gemm_p_ln(pg, st)) return rc;
+        } else if (pp) {
             pg = PGemmArgs{ws.ctxp, lp + po.o, ws.tmp, nullptr, ly.b_o, x, (int)M, kD, kD, kD, kD, 0};
             if (int rc = launch_gemm_p<false>(pg, st)) return rc;
         } else {
@@ -1528,15 +1742,25 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
             g.M = (int)M; g.N = kD; g.K = kD; g.lda = kD; g.ldb = kD; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
             if (int rc = launch_gemm<false>(g, 1, st)) return rc;
         }
-        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln1_g, ly.ln1_b, w->ln_eps, ws.ctx, M,
-                           pp ? ws.actp : nullptr);
-        ASPIRE_LAUNCH_OK();
+        if (!ln_fused) {
+            hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln1_g, ly.ln1_b, w->ln_eps, ws.ctx, M,
+                               pp ? ws.actp : nullptr);
+            ASPIRE_LAUNCH_OK();
+        }
         // 6. FFN: GELU(h . W1^T + b1) . W2^T + b2 + h, LayerNorm          (h = ws.ctx)
         if (pp) {
             pg = PGemmArgs{ws.actp, lp + po.ffn1, nullptr, ws.ffnp, ly.b_ffn1, nullptr, (int)M, w->ffn_dim, kD, 0, 0, 0};
             if (int rc = launch_gemm_p<true>(pg, st)) return rc;
-            pg = PGemmArgs{ws.ffnp, lp + po.ffn2, ws.tmp, nullptr, ly.b_ffn2, ws.ctx, (int)M, kD, w->ffn_dim, kD, kD, 0};
-            if (int rc = launch_gemm_p<false>(pg, st)) return rc;
+            if (ln_fused) {
+                pg = PGemmArgs{ws.ffnp, lp + po.ffn2, last ? hidden_out : nullptr, last ? nullptr : ws.actp, ly.b_ffn2, nullptr, (int)M, kD, w->ffn_dim, kD, kD, 0};
+                pg.resp = ws.actp;
+                pg.gamma = ly.ln2_g; pg.beta = ly.ln2_b; pg.eps = w->ln_eps;
+                pg.ln_stats = ws.ln_stats; pg.ln_count = ws.ln_count + (size_t)(2 * l + 1) * row_tiles;
+                if (int rc = launch_gemm_p_ln(pg, st)) return rc;
+            } else {
+                pg = PGemmArgs{ws.ffnp, lp + po.ffn2, ws.tmp, nullptr, ly.b_ffn2, ws.ctx, (int)M, kD, w->ffn_dim, kD, kD, 0};
+                if (int rc = launch_gemm_p<false>(pg, st)) return rc;
+            }
         } else {
             g = GemmArgs{};
             g.A = ws.ctx; g.B = ly.w_ffn1; g.C = ws.ffn; g.bias = ly.b_ffn1; g.gelu = 1;
@@ -1547,9 +1771,11 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
             g.M = (int)M; g.N = kD; g.K = w->ffn_dim; g.lda = w->ffn_dim; g.ldb = w->ffn_dim; g.ldc = kD; g.nz2 = 1; g.alpha = 1.f;
             if (int rc = launch_gemm<false>(g, 1, st)) return rc;
         }
-        hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln2_g, ly.ln2_b, w->ln_eps, out, M,
-                           pp && !last ? ws.actp : nullptr);
-        ASPIRE_LAUNCH_OK();
+        if (!ln_fused) {
+            hipLaunchKernelGGL(layernorm_kernel, dim3(row_blocks), dim3(256), 0, st, ws.tmp, ly.ln2_g, ly.ln2_b, w->ln_eps, out, M,
+                               pp && !last ? ws.actp : nullptr);
+            ASPIRE_LAUNCH_OK();
+        }
         x = out;
     }
     return ASPIRE_OK;

@@ -46,6 +46,9 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         if (f == 2 || f == 3) f += 20;        // the round-3 spellings: ring depth at two k blocks per stage
         if (f != 0 && f != 22 && f != 23 && f != 12 && f != 13 && f != 14 && f != 113) return false;
         t.gemm_ring = f;
+    } else if (!strcmp(key, "GEMM_LN")) {
+        if (!unset && strcmp(v, "off") && strcmp(v, "on")) return false;
+        t.gemm_ln = unset ? 0 : !strcmp(v, "off") ? 1 : 2;
     } else if (!strcmp(key, "GEMM_PROBE")) {
         t.gemm_probe = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "FUSED_VALU")) {
@@ -97,6 +100,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
     else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : t.gemm_form == 3 ? "planes" : "";
     else if (!strcmp(key, "GEMM_TILE")) v = number(t.gemm_tile);
     else if (!strcmp(key, "GEMM_RING")) v = number(t.gemm_ring);
+    else if (!strcmp(key, "GEMM_LN")) v = t.gemm_ln == 1 ? "off" : t.gemm_ln == 2 ? "on" : "";
     else if (!strcmp(key, "GEMM_PROBE")) v = number(t.gemm_probe);
     else if (!strcmp(key, "FUSED_VALU")) v = number(t.fused_valu);
     else if (!strcmp(key, "FUSED_NOSOLVE")) v = number(t.fused_nosolve);
@@ -114,7 +118,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
 }
 
 void tuning_from_env() {
-    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_SPLIT", "SPLIT_PRIO", "FUSED_NOSELF", "GRAM_TILE", "GRAM_RING", "GRAM_PP"};
+    static const char* keys[] = {"SINKHORN", "COST_PATH", "COST1_BLOCKS", "ATTN", "GEMM_TILE", "GEMM_RING", "GEMM_LN", "GEMM_PROBE", "GEMM", "OT_FORM", "FUSED_VALU", "FUSED_NOSOLVE", "FUSED_WAVES", "FUSED_SPLIT", "SPLIT_PRIO", "FUSED_NOSELF", "GRAM_TILE", "GRAM_RING", "GRAM_PP"};
     for (const char* k : keys) {
         char name[64];
         snprintf(name, sizeof(name), "ASPIRE_HIP_%s", k);

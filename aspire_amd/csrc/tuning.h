@@ -15,6 +15,7 @@ struct Tuning {
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
     int gemm_probe = 0;      // ASPIRE_HIP_GEMM_PROBE=1: the P-layout GEMM without its MFMAs, 2: without its LDS-DMA (timing probes, wrong results)
     int gemm_ring = 0;       // ASPIRE_HIP_GEMM_RING=22 | 23 | 13 | 14: 10 x (k blocks per stage) + (stages in the LDS ring) of the P-layout GEMM; 113: ring 13 as a persistent tile loop
+    int gemm_ln = 0;         // ASPIRE_HIP_GEMM_LN: 0 by size (LayerNorm in the N = 768 GEMMs' epilogue from 48 row tiles on), 1 off = always its own pass, 2 on = always fused
     int gemm_tile = 0;       // ASPIRE_HIP_GEMM_TILE=128 | 64: force 128 x 128 / 128 x 64 tiles in the bf16x3 form (tuning)
     int ot_form = 0;         // ASPIRE_HIP_OT_FORM: otAspire on documents of <= 8 rows: 0 by size, 1 small = small-pool kernels,
                              // 2 tile = throughput cost kernel + block Sinkhorn kernel, 3 fused = both in one launch, 4 chunk, 5 one = one wave per pair,

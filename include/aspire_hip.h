@@ -397,7 +397,7 @@ int aspire_topk_merge_keys(const uint64_t* keys, int64_t R, int64_t Q, int64_t k
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (tests, bench.py, tuning) -- not part of the surface that replaces reference code.
  *   aspire_debug_set   pin a kernel form / grid: key = "SINKHORN" (wave | block | block-norepair | block16 | block-dense | block-wide), "COST_PATH"
- *                      (mfma | valu), "OT_FORM" (small | tile | fused), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM" (f32 | bf16x3 | planes), "GEMM_TILE" (96 | 128 | 64), "GEMM_RING" (2 | 3),
+ *                      (mfma | valu), "OT_FORM" (small | tile | fused), "COST1_BLOCKS" (n), "ATTN" (gemm), "GEMM" (f32 | bf16x3 | planes), "GEMM_TILE" (96 | 128 | 64), "GEMM_RING" (2 | 3), "GEMM_LN" (on | off: LayerNorm in / behind the N = 768 GEMMs),
  *                      "FUSED_VALU" (1),
  *                      "FUSED_NOSELF" (1), "FUSED_WAVES" (n), "FUSED_NOSOLVE" (1 | 2: timing only, invalid scores);
  *                      value NULL or "" restores the default.  The same switches are read

@@ -277,6 +277,38 @@ def test_bert_forward_on_presplit_operands_small_shapes(n_layers, b, l):
     assert (got - other).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize('n_layers,b,l', [(2, 9, 130), (3, 64, 256), (1, 3, 37), (2, 40, 100)])
+def test_layernorm_in_the_gemm_epilogue_matches_the_separate_pass(n_layers, b, l):
+    """LayerNorm inside the N = 768 GEMMs' epilogue (gemm_p_kernel's LN form: the six / twelve column tiles of a row block exchange
+    (mean, sum of squared deviations) through global memory and normalise out of their accumulators; the residual stream lives in the
+    P layout only) against the same forward with ASPIRE_HIP_GEMM_LN=off (layernorm_kernel as its own pass) and against HuggingFace: row counts that are no multiple of 128, a
+    launch of more tiles than workgroup slots (64 x 256 = 16 384 rows: 768 tiles; 128 x 64 tiles at the smaller shapes), run twice --
+    the exchange counters are zeroed per forward -- with equal bits both times."""
+    from aspire_amd._lib import pinned
+    from aspire_amd.encoder import HipBertEncoder
+    m = _bert(n_layers, seed=11)
+    tok, seg, mask, _ = _batch(b, l, 3000, seed=300 + l)
+    enc = HipBertEncoder(m)
+    with pinned(GEMM='planes', GEMM_LN='on'):
+        got = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+        again = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+        with pinned(GEMM_TILE='64'):
+            narrow = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+    with pinned(GEMM='planes', GEMM_LN='off'):
+        sep = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+    with pinned(GEMM='planes'):
+        default = enc(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state.cpu()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, again)
+    assert torch.equal(default, got if (b * l + 127) // 128 >= 48 else sep)          # the default: fused from 48 row tiles on
+    assert (got - sep).abs().max().item() < 5e-6, (got - sep).abs().max().item()
+    assert (narrow - sep).abs().max().item() < 5e-6
+    if b * l <= 4096:
+        with torch.no_grad():
+            want = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
+        assert (got - want).abs().max().item() < TOL
+
+
 def test_weights_beyond_the_fp16_planes_are_left_to_the_fp32_input_kernels():
     """aspire_bert_prepare_planes rejects a weight beyond +-1023 (64 w must stay inside fp16); HipBertEncoder then runs without
     planes -- the on-the-fly bf16x3 GEMMs take any fp32 -- and still matches HuggingFace."""
