@@ -475,6 +475,27 @@ __device__ __forceinline__ void p_store4_at(void* P, uint32_t slot, float x, flo
     *reinterpret_cast<uint2*>((char*)P + (slot ^ 32u)) = make_uint2(l0, l1);
 }
 
+// EIGHT consecutive k (k % 8 == 0) of row r: one whole 16-byte piece per plane
+__device__ __forceinline__ uint32_t p_slot8(uint32_t R, uint32_t r, uint32_t k) {
+    return (((k >> 4) * R + r) << 6) + 16 * (((k >> 3) & 1) ^ ((r >> 2) & 3));      // the h plane's piece; l: ^ 32
+}
+__device__ __forceinline__ void p_load8_at(const void* P, uint32_t slot, float (&x)[8]) {
+    const f16x8_t h = *reinterpret_cast<const f16x8_t*>((const char*)P + slot), l = *reinterpret_cast<const f16x8_t*>((const char*)P + (slot ^ 32u));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = (float)h[c] + (float)l[c];
+}
+__device__ __forceinline__ void p_store8_at(void* P, uint32_t slot, const float (&x)[8]) {
+    f16x8_t h, l;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const _Float16 t = (_Float16)x[c];
+        h[c] = t;
+        l[c] = (_Float16)(x[c] - (float)t);
+    }
+    *reinterpret_cast<f16x8_t*>((char*)P + slot) = h;
+    *reinterpret_cast<f16x8_t*>((char*)P + (slot ^ 32u)) = l;
+}
+
 // ... and back: h + l of four consecutive k of row r (what p_store4 wrote, to 2^-24 relative / 2^-25 absolute: fp32's own rounding)
 __device__ __forceinline__ float4 p_load4(const void* P, int64_t R, int64_t r, int k) {
     const int kb = k >> 4, kh = (k >> 3) & 1, half = (k >> 2) & 1, sw = (int)((r >> 2) & 3);
@@ -784,10 +805,32 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
     }
     if (((G_PROBE(g) >= 4 && G_PROBE(g) <= 6) || (G_PROBE(g) >= 10 && G_PROBE(g) < 20)) && acc[0][0][0] != 12345.678f) return;      // probes 4+: no epilogue (4: all else, 5: no MFMAs, 6: no LDS-DMA)
     if constexpr (LN) {
-        // lane = row m (col = lane & 31 of the swapped product), registers along n in groups of 4: a lane holds kCnt = 16 TN values of each
-        // of its two rows.  Moments are combined pairwise as (mean, M2 = sum of squared deviations) of equal-sized groups:
-        // M2 = M2a + M2b + (n / 2) (mean_a - mean_b)^2 -- no E[x^2] - E[x]^2 cancellation anywhere.
+        // lane = row m (col = lane & 31 of the swapped product), registers along n in groups of 4 columns, the lane pair (lk) interleaved:
+        // n = 8 g + 4 lk + e.  One v_permlane32_swap per register pair first: lane half lk then holds columns 16 t + 8 lk + 0 .. 7 (t = 0, 1) of a
+        // 32-column block in registers 8 t .. 8 t + 7 -- one whole 16-byte piece per plane and 16-column k block: the residual comes in and the
+        // normalised row goes out in 16-byte accesses (8-byte ones before: 150 -> 147 us per launch at 16 384 rows).
+        // A lane holds kCnt = 16 TN values of each of its two rows.  Moments are combined pairwise as (mean, M2 = sum of squared deviations) of
+        // equal-sized groups: M2 = M2a + M2b + (n / 2) (mean_a - mean_b)^2 -- no E[x^2] - E[x]^2 cancellation anywhere.
         constexpr int kCnt = 16 * TN, kGX = kD / BN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float lo[4], hi[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (scalars first, both ways: a bit_cast applied to a vector ELEMENT reads element 0 with this clang)
+                        const float fa = acc[i][j][8 * t + e], fb = acc[i][j][8 * t + 4 + e];
+                        auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, fa), __builtin_bit_cast(int, fb), false, false);
+                        const int x0 = r[0], x1 = r[1];
+                        lo[e] = __builtin_bit_cast(float, x0);
+                        hi[e] = __builtin_bit_cast(float, x1);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][8 * t + e] = lo[e], acc[i][j][8 * t + 4 + e] = hi[e];
+                }
         float mu[2], m2[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -795,21 +838,26 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                // one 32-column block at a time (eight 8-byte loads in flight): with all of a row's loads hoisted the kernel needs 186 registers
+                // one 32-column block at a time (four 16-byte loads in flight): with all of a row's loads hoisted the kernel needs 186 registers
                 // and loses its third workgroup per CU
-                float4 rv[4], bv[4];
+                float rv[2][8];
+                float4 bv[2][2];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    rv[q4] = p_load4_at(g.resp, p_slot((uint32_t)g.M, (uint32_t)mc, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk)));
-                    bv[q4] = *reinterpret_cast<const float4*>(g.bias + n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk);
+                for (int t = 0; t < 2; ++t) {
+                    const int n = n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk;
+                    p_load8_at(g.resp, p_slot8((uint32_t)g.M, (uint32_t)mc, (uint32_t)n), rv[t]);
+                    bv[t][0] = *reinterpret_cast<const float4*>(g.bias + n);
+                    bv[t][1] = *reinterpret_cast<const float4*>(g.bias + n + 4);
                 }
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float4 b4 = bv[q4];
-                    const float x0 = fmaf(acc[i][j][4 * q4 + 0], kUnscale, b4.x) + rv[q4].x, x1 = fmaf(acc[i][j][4 * q4 + 1], kUnscale, b4.y) + rv[q4].y;
-                    const float x2 = fmaf(acc[i][j][4 * q4 + 2], kUnscale, b4.z) + rv[q4].z, x3 = fmaf(acc[i][j][4 * q4 + 3], kUnscale, b4.w) + rv[q4].w;
-                    acc[i][j][4 * q4 + 0] = x0; acc[i][j][4 * q4 + 1] = x1; acc[i][j][4 * q4 + 2] = x2; acc[i][j][4 * q4 + 3] = x3;
-                    s += (x0 + x1) + (x2 + x3);
+                for (int t = 0; t < 2; ++t) {
+                    const float b8[8] = {bv[t][0].x, bv[t][0].y, bv[t][0].z, bv[t][0].w, bv[t][1].x, bv[t][1].y, bv[t][1].z, bv[t][1].w};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float x = fmaf(acc[i][j][8 * t + c], kUnscale, b8[c]) + rv[t][c];
+                        acc[i][j][8 * t + c] = x;
+                        s += x;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -852,7 +900,7 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_fetch_add(g.ln_count + by, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(g.ln_count + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGX) __builtin_amdgcn_s_sleep(4);
+            while (!(g.probe & 8) && __hip_atomic_load(g.ln_count + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGX) __builtin_amdgcn_s_sleep(4);
         }
         __syncthreads();
 #pragma unroll
@@ -874,20 +922,22 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
             for (int t = 0; t < kGX; ++t) sd = fmaf(mt[t] - mean, mt[t] - mean, sd);
             const float rstd = 1.0f / sqrtf(fmaf(sd, (float)BN, sq) * (1.0f / kD) + g.eps);
             if (m >= g.M) continue;
-            float* crow = g.C ? g.C + (size_t)m * g.ldc + n0 + wc * 32 * TN + 4 * lk : nullptr;
+            float* crow = g.C ? g.C + (size_t)m * g.ldc + n0 + wc * 32 * TN + 8 * lk : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int c4 = (wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk) >> 2;
-                    const float4 gm = sgb[c4], bt = sgb[BN / 4 + c4];
-                    float4 o;
-                    o.x = (acc[i][j][4 * q4 + 0] - mean) * rstd * gm.x + bt.x;
-                    o.y = (acc[i][j][4 * q4 + 1] - mean) * rstd * gm.y + bt.y;
-                    o.z = (acc[i][j][4 * q4 + 2] - mean) * rstd * gm.z + bt.z;
-                    o.w = (acc[i][j][4 * q4 + 3] - mean) * rstd * gm.w + bt.w;
-                    if (crow) *reinterpret_cast<float4*>(crow + 32 * j + 8 * q4) = o;
-                    if (g.Cp) p_store4_at(g.Cp, p_slot((uint32_t)g.M, (uint32_t)m, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk)), o.x, o.y, o.z, o.w);
+                for (int t = 0; t < 2; ++t) {
+                    const int c4 = (wc * 32 * TN + 32 * j + 16 * t + 8 * lk) >> 2;
+                    const float4 g0 = sgb[c4], g1 = sgb[c4 + 1], b0 = sgb[BN / 4 + c4], b1 = sgb[BN / 4 + c4 + 1];
+                    const float g8[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    float o[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] = (acc[i][j][8 * t + c] - mean) * rstd * g8[c] + b8[c];
+                    if (crow) {
+                        *reinterpret_cast<float4*>(crow + 32 * j + 16 * t) = make_float4(o[0], o[1], o[2], o[3]);
+                        *reinterpret_cast<float4*>(crow + 32 * j + 16 * t + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    }
+                    if (g.Cp) p_store8_at(g.Cp, p_slot8((uint32_t)g.M, (uint32_t)m, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk)), o);
                 }
         }
     } else if constexpr (!SWAP) {
@@ -1597,7 +1647,7 @@ int launch_gemm_p_ln_bn(PGemmArgs g, hipStream_t st) {
     static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_ln_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     ASPIRE_HIP_OK(raised);
     g.n_off = 0;
-    g.probe = 0;
+    g.probe = tuning().gemm_probe >= 32 ? tuning().gemm_probe - 32 : 0;      // timing experiment: 40 = nobody waits for its row block (wrong results)
     g.tiles_x = kD / BN;
     g.tiles_y = (g.M + 127) / 128;
     const unsigned per_xcd = (unsigned)((g.tiles_y + 7) / 8) * (unsigned)g.tiles_x;
