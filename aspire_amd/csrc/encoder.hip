@@ -985,18 +985,27 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         // straight into the P layout [M, N] (k dimension = n) of the next GEMM's A operand
         // (the bias vectors were fetched before the first store: a load between stores makes the compiler wait for every store
         // issued so far -- vmcnt counts both)
+        // GELU in the accumulators' own layout (the bias vectors were fetched for it), then the lane pair exchanges register groups
+        // (v_permlane32_swap, as the LayerNorm epilogue does): a lane owns 8 consecutive columns = one whole 16-byte piece per plane
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + wr * 64 + 32 * i + lr;
-            if (m >= g.M) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int n = n0 + wc * 32 * TN + 32 * j + 8 * q4 + 4 * lk;
-                    const float4 b4 = bias_m[j][q4];
-                    p_store4(g.Cp, g.M, m, n, gelu_erf(fmaf(acc[i][j][4 * q4 + 0], kUnscale, b4.x)), gelu_erf(fmaf(acc[i][j][4 * q4 + 1], kUnscale, b4.y)),
-                             gelu_erf(fmaf(acc[i][j][4 * q4 + 2], kUnscale, b4.z)), gelu_erf(fmaf(acc[i][j][4 * q4 + 3], kUnscale, b4.w)));
+                for (int t = 0; t < 2; ++t) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 ba = bias_m[j][2 * t], bb = bias_m[j][2 * t + 1];
+                        const float b_a = e == 0 ? ba.x : e == 1 ? ba.y : e == 2 ? ba.z : ba.w, b_b = e == 0 ? bb.x : e == 1 ? bb.y : e == 2 ? bb.z : bb.w;
+                        const float fa = gelu_erf(fmaf(acc[i][j][8 * t + e], kUnscale, b_a)), fb = gelu_erf(fmaf(acc[i][j][8 * t + 4 + e], kUnscale, b_b));
+                        auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, fa), __builtin_bit_cast(int, fb), false, false);
+                        const int x0 = r[0], x1 = r[1];
+                        o[e] = __builtin_bit_cast(float, x0);
+                        o[4 + e] = __builtin_bit_cast(float, x1);
+                    }
+                    if (m < g.M) p_store8_at(g.Cp, p_slot8((uint32_t)g.M, (uint32_t)m, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk)), o);
                 }
         }
     }
@@ -1464,13 +1473,24 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* _
     // ---- normalise and store: lane = query, registers = head dims (4 consecutive per group) --------------------
     const float l_tot = l_run + lane_xor<32>(l_run);
     const float inv = 1.0f / l_tot;
-    if (q_ok && ctxp) {
+    if (ctxp) {
+        // the lane pair exchanges register groups (v_permlane32_swap, as the GEMM epilogues do): a lane owns dims 16 t + 8 lk .. + 7 of a
+        // 32-dim block = one whole 16-byte piece per plane (8-byte stores before)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                p_store4(ctxp, rows, (int64_t)b * L + q_row, h * 64 + 32 * mb + 8 * g4 + 4 * lk, o[mb][4 * g4 + 0] * inv,
-                         o[mb][4 * g4 + 1] * inv, o[mb][4 * g4 + 2] * inv, o[mb][4 * g4 + 3] * inv);
+            for (int t = 0; t < 2; ++t) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float fa = o[mb][8 * t + e] * inv, fb = o[mb][8 * t + 4 + e] * inv;
+                    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, fa), __builtin_bit_cast(int, fb), false, false);
+                    const int x0 = r[0], x1 = r[1];
+                    x[e] = __builtin_bit_cast(float, x0);
+                    x[4 + e] = __builtin_bit_cast(float, x1);
+                }
+                if (q_ok) p_store8_at(ctxp, p_slot8((uint32_t)rows, (uint32_t)(b * L + q_row), (uint32_t)(h * 64 + 32 * mb + 16 * t + 8 * lk)), x);
+            }
     } else if (q_ok) {
         float* op = ctx + ((size_t)b * L + q_row) * kD + h * 64;
 #pragma unroll
