@@ -139,13 +139,16 @@ class AspireConSent:
         return out
 
     @staticmethod
-    def _regroup_by_length(batches, docs_per_forward, window=8192):
+    def _regroup_by_length(batches, docs_per_forward, window=8192, rows_per_forward=None):
         """The documents of all prepare_abstracts batches regrouped into forwards of docs_per_forward documents of SIMILAR token
         length (longest first), each padded to its own longest sequence: on abstracts of 100 - 500 tokens the reference's batches
         in corpus order (pp_gen_nearest.py:141-160) spend a third and more of the encoder's work on pad tokens.  A document's reps
         do not depend on what it is batched with (_merge_batches).  Returns (batches, ids): ids[g][j] = the corpus position of
         document j of group g -- its rows of the store stay where the corpus order puts them.  Documents are sorted inside windows
-        of ~`window` consecutive documents (whole batches): the host never holds more than a window's token tensors twice."""
+        of ~`window` consecutive documents (whole batches): the host never holds more than a window's token tensors twice.
+        rows_per_forward: a forward takes as many documents as fit that many TOKEN ROWS at its longest document's length instead of
+        a fixed docs_per_forward (the encoder's GEMMs fill the chip's workgroup slots in whole rounds at 16 384 rows: 64 x 256,
+        128 x 128 and 256 x 64 all run at ~337 TFLOP/s; 64 x 128 at 297, 128 x 64 at 289)."""
         out, ids = [], []
         b0, doc0 = 0, 0
         while b0 < len(batches):
@@ -163,21 +166,25 @@ class AspireConSent:
             order = sorted(range(n), key=lambda d: -seq_lens[d])                  # stable: equal lengths keep corpus order
             as_given = order == list(range(n))                                     # documents of one length: slices, no gather
             order_t = None if as_given else torch.tensor(order, dtype=torch.long).to(big['tokid_tt'].device)      # ONE upload per window
-            for g0 in range(0, n, docs_per_forward):
-                sel = order[g0:g0 + docs_per_forward]
+            g0 = 0
+            while g0 < n:
+                # (longest first: the group's first document sets its padded length)
+                take = max(1, int(rows_per_forward) // max(1, seq_lens[order[g0]])) if rows_per_forward else docs_per_forward
+                sel = order[g0:g0 + take]
                 L = max(seq_lens[d] for d in sel)
                 if as_given:
-                    bb = {k: big[k][g0:g0 + docs_per_forward, :L].contiguous() for k in big}
+                    bb = {k: big[k][g0:g0 + take, :L].contiguous() for k in big}
                 else:
-                    bb = {k: big[k].index_select(0, order_t[g0:g0 + docs_per_forward])[:, :L].contiguous() for k in big}
+                    bb = {k: big[k].index_select(0, order_t[g0:g0 + take])[:, :L].contiguous() for k in big}
                 bb['seq_lens'] = [seq_lens[d] for d in sel]
                 out.append((bb, [abs_lens[d] for d in sel], [spans[d] for d in sel]))
                 ids.append([doc0 + d for d in sel])
+                g0 += take
             b0, doc0 = b1, doc0 + n
         return out, ids
 
     def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64, planes=False, sort_by_length=True,
-                       _full_range=False, stage_events=None):
+                       _full_range=False, stage_events=None, rows_per_forward=16384):
         """Encode document batches straight into a resident candidate pool.
 
         batches: iterable of (bert_batch, abs_lens, sent_tok_idxs) as prepare_abstracts returns them (it is consumed
@@ -190,6 +197,9 @@ class AspireConSent:
         (_regroup_by_length: fewer pad tokens per forward -- 4096 abstract-length documents 3 320 -> 6 100 docs/s, the same bits;
         documents of one length keep the given grouping).  The store keeps the corpus order.  False: consecutive batches joined as
         given (_merge_batches).
+        rows_per_forward (with sort_by_length; None: docs_per_forward documents per forward whatever their length): a forward takes
+        as many documents as fit this many token rows at its longest document's length -- 64 documents of 256 tokens, 128 of 128,
+        32 of 512: the shapes at which the encoder's GEMMs fill whole rounds of the chip.
         planes: also keep the rows as fp16 planes (CandidatePool.prepare_planes: one more pass over the finished store, ~2.5 ms per
         GB) for the many-query cost tiles.
         stage_events: a list that receives one (start, encoded, pooled) triple of HIP events per encoder call, recorded on the
@@ -202,7 +212,7 @@ class AspireConSent:
         all_lens = [int(n) for _, abs_lens, _ in batches for n in abs_lens]       # corpus order
         doc_ids = None                                                            # per forward: corpus positions of its documents
         if sort_by_length and docs_per_forward and batches:
-            batches, doc_ids = self._regroup_by_length(batches, docs_per_forward)
+            batches, doc_ids = self._regroup_by_length(batches, docs_per_forward, rows_per_forward=rows_per_forward)
         elif docs_per_forward:
             batches = self._merge_batches(batches, docs_per_forward)
         n_docs, total = len(all_lens), int(sum(all_lens))
@@ -284,7 +294,8 @@ class AspireConSent:
                 if stage_events is not None:
                     del stage_events[:]
                 return self.encode_to_pool(given, pids=pids, want_cls=want_cls, docs_per_forward=docs_per_forward, planes=planes,
-                                           sort_by_length=sort_by_length, _full_range=True, stage_events=stage_events)
+                                           sort_by_length=sort_by_length, _full_range=True, stage_events=stage_events,
+                                           rows_per_forward=rows_per_forward)
         repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0,
                                   lens_host=all_lens)
         pool = CandidatePool.from_repset(repset, pids=pids)

@@ -49,3 +49,19 @@ def test_regroup_by_length_leaves_equal_lengths_in_corpus_order():
     groups, ids = AspireConSent._regroup_by_length(batches, 4)
     assert ids == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
     assert torch.equal(torch.cat([bb['tokid_tt'] for bb, _, _ in groups]), tok)
+
+
+def test_regroup_by_token_rows_sizes_a_forward_by_its_longest_document():
+    """rows_per_forward: a forward takes as many documents as fit that many token rows at its longest document's length
+    (encode_to_pool's default, 16 384 rows: 64 documents of 256 tokens, 128 of 128); every document kept, corpus positions intact."""
+    rng = np.random.default_rng(1)
+    batches = _batches(rng, 12)
+    n_docs = sum(len(a) for _, a, _ in batches)
+    for budget in (100, 64, 39, 8):
+        groups, ids = AspireConSent._regroup_by_length(batches, 4, rows_per_forward=budget)
+        assert sorted(i for g in ids for i in g) == list(range(n_docs))
+        for (bb, _, _), g in zip(groups, ids):
+            b, L = bb['tokid_tt'].shape
+            assert b == len(g) and L == max(bb['seq_lens']) == bb['seq_lens'][0]
+            assert b == max(1, budget // L) or g is ids[-1]          # full groups but the last
+            assert b * L <= budget or b == 1
