@@ -523,13 +523,13 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
                     if (best > -INFINITY) atomicMax(&pairmax[(int)co * 16 + (int)qo], order_key(best));
                 } else {
                     if (!any_redo) {
-                        *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
+                        if (g.cost) *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
                         *reinterpret_cast<float4*>(g.neg + qo + co) = make_float4(neg[0], neg[1], neg[2], neg[3]);
                     } else {   // the work-list pass writes the flagged ones (-cdist AND geomloss's cost, from the same exact sum): no address is stored twice
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (!redo[k]) {
-                                g.cost[qo + co + k] = cost[k];
+                                if (g.cost) g.cost[qo + co + k] = cost[k];
                                 g.neg[qo + co + k] = neg[k];
                             }
                     }
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
                 if constexpr (L2MAX) atomicMax(&pairmax[(int)c_off[m] * 16 + (int)q_off[n]], order_key(negd));
                 else {
                     g.neg[q_off[n] + c_off[m]] = negd;
-                    g.cost[q_off[n] + c_off[m]] = sqrtf(fmaxf(part, 1e-8f));
+                    if (g.cost) g.cost[q_off[n] + c_off[m]] = sqrtf(fmaxf(part, 1e-8f));
                 }
             }
         }

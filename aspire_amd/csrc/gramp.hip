@@ -506,13 +506,13 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
                     }
                     const long long co = (long long)(ct * g.dpt_c + cd) * g.E + ci;
                     if (!any_redo) {
-                        *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
+                        if (g.cost) *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
                         *reinterpret_cast<float4*>(g.neg + qo + co) = make_float4(neg[0], neg[1], neg[2], neg[3]);
                     } else {   // the work-list pass writes the flagged ones (-cdist AND geomloss's cost, from the same exact sum): no address is stored twice
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (!redo[k]) {
-                                g.cost[qo + co + k] = cost[k];
+                                if (g.cost) g.cost[qo + co + k] = cost[k];
                                 g.neg[qo + co + k] = neg[k];
                             }
                     }
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
                     const long long qo = ((long long)(qt * g.dpt_q + (qdi & 255)) * g.ncand) * g.E + (long long)((qdi >> 8) & 255) * g.ld;
                     const long long co = (long long)(ct * g.dpt_c + (cdi & 255)) * g.E + ((cdi >> 8) & 255);
                     g.neg[qo + co] = negd;
-                    g.cost[qo + co] = sqrtf(fmaxf(part, 1e-8f));
+                    if (g.cost) g.cost[qo + co] = sqrtf(fmaxf(part, 1e-8f));
                 }
             }
         }

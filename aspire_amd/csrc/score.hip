@@ -477,7 +477,7 @@ __device__ __forceinline__ float cmax8(float v) {
 }
 
 template <int T>
-__device__ __forceinline__ void load_pair(PairState<T>& s, const PairWs<T>& ws, int64_t slot, int lane) {
+__device__ __forceinline__ void load_pair(PairState<T>& s, const PairWs<T>& ws, int64_t slot, int lane, bool cost_from_neg = false) {
     int li, lj;
     lane_ij<T>(lane, li, lj);
 #pragma unroll
@@ -485,8 +485,9 @@ __device__ __forceinline__ void load_pair(PairState<T>& s, const PairWs<T>& ws, 
 #pragma unroll
         for (int tb = 0; tb < T; ++tb) {
             const int64_t o = slot * (64 * T * T) + (ta * 8 + li) * (8 * T) + tb * 8 + lj;
-            s.cost[ta][tb] = ws.cost[o];
             s.neg[ta][tb] = ws.neg[o];
+            // (the matrix-pipe cost tiles store -cdist only: sqrt(max(sq, 1e-8)) = max(sqrt(max(sq, 0)), sqrt(1e-8)) bit for bit)
+            s.cost[ta][tb] = cost_from_neg ? fmaxf(-s.neg[ta][tb], __builtin_sqrtf(1e-8f)) : ws.cost[o];
         }
 }
 
@@ -1603,7 +1604,7 @@ __global__ void __launch_bounds__(256) sinkhorn_kernel(ScoreArgs a, PairWs<T> ws
     if (slot < n_slots) {
         const PairIdx ix = pair_of_slot(a, slot);
         PairState<T> st;
-        load_pair<T>(st, ws, slot, lane);
+        load_pair<T>(st, ws, slot, lane, a.cost_from_neg != 0);
         const float diam = a.diameter == nullptr ? fmaxf(sqrtf(ws.diam2[slot]), kMinDiameter) : group_diameter_of(a, ix);
         sinkhorn_pair<T>(a, st, a.q.len[ix.q_idx], a.c.len[ix.c_idx], diam, ix.p, lane);
     }
@@ -1880,7 +1881,14 @@ __global__ void __launch_bounds__(256) sinkhorn_block_kernel(ScoreArgs a, PairWs
             wb[t] = cv[t] ? fast_exp(cm[t] - mc - lsc) : 0.f;   // log-weight -100000
         }
     }
-    load_block(ws.cost, cost);
+    if (a.cost_from_neg) {      // `cost` still holds the pair's -cdist block (zeros outside its rectangle)
+#pragma unroll
+        for (int x = 0; x < R; ++x)
+#pragma unroll
+            for (int y = 0; y < R; ++y) cost[x][y] = (rv[x] && cv[y]) ? fmaxf(-cost[x][y], __builtin_sqrtf(1e-8f)) : 0.f;
+    } else {
+        load_block(ws.cost, cost);
+    }
     const float diam = a.diameter == nullptr ? fmaxf(sqrtf(ws.diam2[slot]), kMinDiameter) : group_diameter_of(a, ix);
     // ---- epsilon schedule: step 0 = diam, 1 .. n_mid = exp(ld + (k-1) lsc), n_mid+1 = blur, n_mid+2 = blur (final)
     float ldf;
@@ -2061,7 +2069,7 @@ __global__ void __launch_bounds__(256) sinkhorn_repair_kernel(ScoreArgs a, PairW
         const int64_t slot = base + k;
         const PairIdx ix = pair_of_slot(a, slot);
         PairState<T> st;
-        load_pair<T>(st, ws, slot, lane);
+        load_pair<T>(st, ws, slot, lane, a.cost_from_neg != 0);
         const float diam = a.diameter == nullptr ? fmaxf(sqrtf(ws.diam2[slot]), kMinDiameter) : group_diameter_of(a, ix);
         sinkhorn_pair<T>(a, st, a.q.len[ix.q_idx], a.c.len[ix.c_idx], diam, ix.p, lane);
     }
@@ -2350,7 +2358,8 @@ int launch_cost_stage(const ScoreArgs& a, const aspire_repset* q, const aspire_r
     const bool csr = q->ext == 0 && c->ext == 0;
     if (gram) {
         // many queries or long documents: Gram tiles on the matrix cores (gram.hip)
-        return launch_pair_gram_ot(a, T, q->max_len, c->max_len, ws.cost, ws.neg, a.diameter ? nullptr : ws.diam2, qbox, cbox, stream);
+        return launch_pair_gram_ot(a, T, q->max_len, c->max_len, a.cost_from_neg ? nullptr : ws.cost, ws.neg, a.diameter ? nullptr : ws.diam2, qbox, cbox,
+                                   stream);
     }
     if (T == 1 && csr) {
         PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
@@ -2578,6 +2587,9 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
     a.out_cdistr = out_cdistr;
     a.out_pairsims = out_pairsims;
     a.out_plan = out_plan;
+    // the matrix-pipe cost tiles derive -cdist and geomloss's cost from ONE distance: they store -cdist only and the solve stage takes
+    // cost = max(cdist, 1e-4) from it -- half the tile bytes written and read (the debug cost stage keeps both buffers)
+    a.cost_from_neg = gram && !cost_only;
     const int qchunks = query_chunks(a);
     const int64_t cand_per_chunk = (int64_t)((((workspace_bytes - qbox_bytes(q)) & ~(size_t)15) - 32) / per_cand);
     const int64_t pairs_per_cand = pairing == ASPIRE_PAIR_PAIRED ? 1 : q->n;

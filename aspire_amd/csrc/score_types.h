@@ -51,6 +51,7 @@ struct ScoreArgs {
     int32_t job0, job1;       // the jobs this launch covers (chunks of a batch run side by side on two streams)
     int32_t max_job_groups;   // host-side launch geometry: upper bound of a job's groups of four
     int32_t tile_form;        // host-side: the batch runs on the throughput kernels
+    int32_t cost_from_neg;    // the cost stage wrote -cdist tiles only (the matrix-pipe tiles: both numbers come from one d there): geomloss's cost = max(-(-cdist), 1e-4)
     int32_t skip_tail;        // diagnostics (FUSED_NOSOLVE=2): the fused kernel drops every wave's LAST solve (timing of the exposed tail)
     // CHUNK items without a counter: with <= 64 classification blocks ("slices") every block writes its item count to grp_off[slice]
     // and its records into its own region of chunk_region_cap records; a wave of the scoring kernel prefix-scans the 64 counts
