@@ -140,20 +140,33 @@ class AspireConSent:
 
     @staticmethod
     def _regroup_by_length(batches, docs_per_forward, window=8192, rows_per_forward=None):
+        """All windows of _regroup_windows at once: (forwards, ids)."""
+        out, ids = [], []
+        for o, i in AspireConSent._regroup_windows(batches, docs_per_forward, window, rows_per_forward):
+            out += o
+            ids += i
+        return out, ids
+
+    @staticmethod
+    def _regroup_windows(batches, docs_per_forward, window=8192, rows_per_forward=None, first_window=None):
         """The documents of all prepare_abstracts batches regrouped into forwards of docs_per_forward documents of SIMILAR token
         length (longest first), each padded to its own longest sequence: on abstracts of 100 - 500 tokens the reference's batches
         in corpus order (pp_gen_nearest.py:141-160) spend a third and more of the encoder's work on pad tokens.  A document's reps
         do not depend on what it is batched with (_merge_batches).  Returns (batches, ids): ids[g][j] = the corpus position of
         document j of group g -- its rows of the store stay where the corpus order puts them.  Documents are sorted inside windows
         of ~`window` consecutive documents (whole batches): the host never holds more than a window's token tensors twice.
+        A GENERATOR, one (forwards, ids) pair per window: encode_to_pool regroups window w + 1 while the GPU encodes window w, and asks
+        for a small first window (`first_window` documents) so that the first encoder call goes out after a few milliseconds of host work
+        instead of after the regrouping of the whole corpus (~2 ms per 1000 documents: a few thousand small tensor operations).
         rows_per_forward: a forward takes as many documents as fit that many TOKEN ROWS at its longest document's length instead of
         a fixed docs_per_forward (the encoder's GEMMs fill the chip's workgroup slots in whole rounds at 16 384 rows: 64 x 256,
         128 x 128 and 256 x 64 all run at ~337 TFLOP/s; 64 x 128 at 297, 128 x 64 at 289)."""
-        out, ids = [], []
         b0, doc0 = 0, 0
         while b0 < len(batches):
+            out, ids = [], []
             b1, n = b0, 0
-            while b1 < len(batches) and (n == 0 or n + len(batches[b1][1]) <= window):
+            limit = first_window if (first_window and b0 == 0) else window
+            while b1 < len(batches) and (n == 0 or n + len(batches[b1][1]) <= limit):
                 n += len(batches[b1][1])
                 b1 += 1
             part = batches[b0:b1]
@@ -181,7 +194,7 @@ class AspireConSent:
                 ids.append([doc0 + d for d in sel])
                 g0 += take
             b0, doc0 = b1, doc0 + n
-        return out, ids
+            yield out, ids
 
     def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64, planes=False, sort_by_length=True,
                        _full_range=False, stage_events=None, rows_per_forward=16384):
@@ -210,11 +223,6 @@ class AspireConSent:
         batches = list(batches)
         given = batches
         all_lens = [int(n) for _, abs_lens, _ in batches for n in abs_lens]       # corpus order
-        doc_ids = None                                                            # per forward: corpus positions of its documents
-        if sort_by_length and docs_per_forward and batches:
-            batches, doc_ids = self._regroup_by_length(batches, docs_per_forward, rows_per_forward=rows_per_forward)
-        elif docs_per_forward:
-            batches = self._merge_batches(batches, docs_per_forward)
         n_docs, total = len(all_lens), int(sum(all_lens))
         lens_t = torch.tensor(all_lens, dtype=torch.int32)
         start_t = (torch.cumsum(lens_t, 0) - lens_t).to(torch.int32)
@@ -234,55 +242,67 @@ class AspireConSent:
         # kernels queued before it, and the next batch's kernels were launched late: the GPU sat idle ~0.5 ms per batch of 32
         # documents, 5 % of the encode stage.)  A group's tables are built while the GPU works on the group before it; the first
         # groups are small so that it starts at once (all tables up front: ~80 ms of host loops per 16 384 documents with the GPU idle).
+        # The forwards, one window of the corpus at a time (a generator: the next window is regrouped while the GPU encodes this one; the
+        # first window is small so that the GPU starts after a few milliseconds of host work).  doc_ids: per forward the corpus positions
+        # of its documents (None: consecutive).
+        if sort_by_length and docs_per_forward and batches:
+            window_iter = self._regroup_windows(batches, docs_per_forward, rows_per_forward=rows_per_forward, first_window=1024)
+        elif docs_per_forward:
+            window_iter = iter([(self._merge_batches(batches, docs_per_forward), None)])
+        else:
+            window_iter = iter([(batches, None)])
         start_np = start_t.numpy()
-        bounds, nxt = [0], 2
-        while bounds[-1] < len(batches):
-            bounds.append(min(len(batches), bounds[-1] + nxt))
-            nxt = min(64, nxt * 4)
         doc0 = 0
-        for g0, g1 in zip(bounds[:-1], bounds[1:]):
-            chunk, parts, offs, o = [], [], [], 0
-            for bi in range(g0, g1):
-                bert_batch, abs_lens, sent_tok_idxs = batches[bi]
-                b = len(abs_lens)
-                ids = np.asarray(doc_ids[bi], dtype=np.int64) if doc_ids is not None else np.arange(doc0, doc0 + b)
-                max_sents = max(abs_lens)
-                max_seq_len = max(bert_batch['seq_lens'])
-                assert bert_batch['tokid_tt'].shape == (b, max_seq_len)
-                tok_idx, span_off = spans_to_csr(sent_tok_idxs, max_sents)
-                if tok_idx.numel() and (int(tok_idx.min()) < 0 or int(tok_idx.max()) >= max_seq_len):
-                    raise IndexError('sentence token index out of range')
-                # slot (b, s) -> row of the store, -1 beyond the document's sentence count
-                lens_b = np.asarray(abs_lens, dtype=np.int32)[:, None]
-                slot = np.arange(max_sents, dtype=np.int32)[None, :]
-                out_row = np.where(slot < lens_b, start_np[ids, None] + slot, -1).astype(np.int32)
-                for arr in (tok_idx.numpy(), span_off.numpy(), out_row.reshape(-1)):
-                    offs.append((o, o + arr.size))
-                    parts.append(arr.astype(np.int32, copy=False))
-                    o += arr.size
-                chunk.append((max_sents, doc0, b))
-                doc0 += b
-            flat = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.int32)).to(dev)
-            for i, (bert_batch, _, _) in enumerate(batches[g0:g1]):
-                max_sents, d0, b = chunk[i]
-                (t0, t1), (s0, s1), (r0, r1) = offs[3 * i:3 * i + 3]
-                if stage_events is not None:
-                    evs = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
-                    evs[0].record()
-                hidden = self.bert_encoder.forward_hidden(bert_batch['tokid_tt'], token_type_ids=bert_batch['seg_tt'],
-                                                          attention_mask=bert_batch['attnmask_tt'], check_ids=False)
-                if stage_events is not None:
-                    evs[1].record()
-                if want_cls and doc_ids is not None:       # regrouped documents: the forward's CLS rows go to their corpus positions
-                    cls_b = torch.empty(b, 768, device=dev, dtype=torch.float32)
-                    ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows, cls_b)
-                    cls_all.index_copy_(0, torch.tensor(doc_ids[g0 + i], dtype=torch.long, device=dev), cls_b)
-                else:
-                    ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows,
-                                            cls_all[d0:d0 + b] if want_cls else None)
-                if stage_events is not None:
-                    evs[2].record()
-                    stage_events.append(evs)
+        first = True
+        for batches, doc_ids in window_iter:
+            bounds, nxt = [0], 2 if first else 64
+            first = False
+            while bounds[-1] < len(batches):
+                bounds.append(min(len(batches), bounds[-1] + nxt))
+                nxt = min(64, nxt * 4)
+            for g0, g1 in zip(bounds[:-1], bounds[1:]):
+                chunk, parts, offs, o = [], [], [], 0
+                for bi in range(g0, g1):
+                    bert_batch, abs_lens, sent_tok_idxs = batches[bi]
+                    b = len(abs_lens)
+                    ids = np.asarray(doc_ids[bi], dtype=np.int64) if doc_ids is not None else np.arange(doc0, doc0 + b)
+                    max_sents = max(abs_lens)
+                    max_seq_len = max(bert_batch['seq_lens'])
+                    assert bert_batch['tokid_tt'].shape == (b, max_seq_len)
+                    tok_idx, span_off = spans_to_csr(sent_tok_idxs, max_sents)
+                    if tok_idx.numel() and (int(tok_idx.min()) < 0 or int(tok_idx.max()) >= max_seq_len):
+                        raise IndexError('sentence token index out of range')
+                    # slot (b, s) -> row of the store, -1 beyond the document's sentence count
+                    lens_b = np.asarray(abs_lens, dtype=np.int32)[:, None]
+                    slot = np.arange(max_sents, dtype=np.int32)[None, :]
+                    out_row = np.where(slot < lens_b, start_np[ids, None] + slot, -1).astype(np.int32)
+                    for arr in (tok_idx.numpy(), span_off.numpy(), out_row.reshape(-1)):
+                        offs.append((o, o + arr.size))
+                        parts.append(arr.astype(np.int32, copy=False))
+                        o += arr.size
+                    chunk.append((max_sents, doc0, b))
+                    doc0 += b
+                flat = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.int32)).to(dev)
+                for i, (bert_batch, _, _) in enumerate(batches[g0:g1]):
+                    max_sents, d0, b = chunk[i]
+                    (t0, t1), (s0, s1), (r0, r1) = offs[3 * i:3 * i + 3]
+                    if stage_events is not None:
+                        evs = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                        evs[0].record()
+                    hidden = self.bert_encoder.forward_hidden(bert_batch['tokid_tt'], token_type_ids=bert_batch['seg_tt'],
+                                                              attention_mask=bert_batch['attnmask_tt'], check_ids=False)
+                    if stage_events is not None:
+                        evs[1].record()
+                    if want_cls and doc_ids is not None:       # regrouped documents: the forward's CLS rows go to their corpus positions
+                        cls_b = torch.empty(b, 768, device=dev, dtype=torch.float32)
+                        ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows, cls_b)
+                        cls_all.index_copy_(0, torch.tensor(doc_ids[g0 + i], dtype=torch.long, device=dev), cls_b)
+                    else:
+                        ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows,
+                                                cls_all[d0:d0 + b] if want_cls else None)
+                    if stage_events is not None:
+                        evs[2].record()
+                        stage_events.append(evs)
         if total and not _full_range and not bool(torch.isfinite(rows).all() & (torch.isfinite(cls_all).all() if want_cls else True)):
             # an activation left the fp16 planes' range somewhere (one check over the finished store): encode again on the kernels
             # that take any fp32 value
