@@ -1323,7 +1323,14 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* _
     __shared__ float kbias[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lk = lane >> 5;
     const int qblocks = (L + 127) / 128;
-    const int qb = blockIdx.x % qblocks, h = (blockIdx.x / qblocks) % H, b = blockIdx.x / (qblocks * H);
+    // XCD-aware order (as the GEMMs'): XCD x = workgroup id mod 8 takes a contiguous run of the (document, head, query block) sequence, so the
+    // query blocks of one (document, head) -- which stage the same K and V -- share an L2
+    uint32_t wl;
+    {
+        const uint32_t nb = gridDim.x, bid = blockIdx.x, x = bid & 7, q8 = nb >> 3, r8 = nb & 7;
+        wl = x * q8 + (x < r8 ? x : r8) + (bid >> 3);
+    }
+    const int qb = wl % qblocks, h = (wl / qblocks) % H, b = wl / (qblocks * H);
     const size_t ld = 3 * kD;
     const float* base = qkv + (size_t)b * L * ld + h * 64;
     const int q_row = qb * 128 + wave * 32 + lr;                      // this lane's query
