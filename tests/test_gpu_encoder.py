@@ -309,6 +309,32 @@ def test_layernorm_in_the_gemm_epilogue_matches_the_separate_pass(n_layers, b, l
         assert (got - want).abs().max().item() < TOL
 
 
+@pytest.mark.timeout(240)
+def test_layernorm_epilogue_forwards_on_two_streams_at_once():
+    """Two encoders' forwards in flight at the same time on two streams (each with its own workspace): the LayerNorm-epilogue GEMMs WAIT
+    inside the kernel for their row block's other column tiles, so two such launches share the chip's workgroup slots while tiles of
+    both wait -- the launch-order argument (a waiting tile's partners are resident or next in line in their own launch) has to hold
+    with slots taken by the other launch.  Same bits as each forward alone; 2 x 96 x 128 rows = more tiles than slots for either."""
+    from aspire_amd._lib import pinned
+    from aspire_amd.encoder import HipBertEncoder
+    encs = [HipBertEncoder(_bert(2, seed=21 + i)) for i in range(2)]
+    ins = [_batch(96, 128, 3000, seed=500 + i) for i in range(2)]
+    with pinned(GEMM='planes', GEMM_LN='on'):
+        alone = [e.forward_hidden(t[0], t[1], t[2]).clone() for e, t in zip(encs, ins)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        dev_in = [tuple(x.cuda() for x in t[:3]) for t in ins]
+        outs = [[], []]
+        for _ in range(6):
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    outs[k].append(encs[k].forward_hidden(*dev_in[k], check_ids=False))
+        torch.cuda.synchronize()
+    for k in range(2):
+        for o in outs[k]:
+            assert torch.equal(o, alone[k])
+
+
 def test_weights_beyond_the_fp16_planes_are_left_to_the_fp32_input_kernels():
     """aspire_bert_prepare_planes rejects a weight beyond +-1023 (64 w must stay inside fp16); HipBertEncoder then runs without
     planes -- the on-the-fly bf16x3 GEMMs take any fp32 -- and still matches HuggingFace."""
