@@ -821,7 +821,7 @@ int launch_pair_gram_ot(const ScoreArgs& a, int T, int mr_q, int mr_c, float* co
     g.E = 64 * T * T;
     g.center = a.center;
     g.ld = 8 * T;
-    g.cost = cost;
+    g.cost = a.cost_from_neg ? nullptr : cost;      // (ScoreArgs::cost_from_neg: the solve stage derives geomloss's cost from the -cdist tile)
     g.neg = neg;
     if (gram_planes_ok(a) && bn < 128 && (a.c_box || !diam2)) {
         // few queries on a plane pool (gram_planes_wanted_ot): the 128-column plane tiles, diameters from the cached boxes

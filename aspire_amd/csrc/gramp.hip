@@ -74,6 +74,7 @@ struct GramPArgs {
     float* cost;
     float* neg;
     float* scores;
+    int skip_cost;       // the 128 x 128 tiles leave geomloss's cost to the solve stage (ScoreArgs::cost_from_neg); the wide tiles always store it
 };
 
 // The 1 KB pieces of one k block that a wave moves (two of the candidate tile, NB of the query tile) in one statement; M0
@@ -166,6 +167,9 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lk = lane >> 5;
+    // (a run-time guard around the cost stores costs the wide tiles 576 bytes of scratch: they keep storing it, the solve stage ignores it)
+    const bool put_cost = (BM == 128 && BN == 128) ? !g.skip_cost : true;
+    (void)put_cost;
     // workgroups that share a candidate tile sit next to each other in an XCD's launch order (gram.hip)
     uint32_t L;
     {
@@ -506,13 +510,13 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
                     }
                     const long long co = (long long)(ct * g.dpt_c + cd) * g.E + ci;
                     if (!any_redo) {
-                        if (g.cost) *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
+                        if (put_cost) *reinterpret_cast<float4*>(g.cost + qo + co) = make_float4(cost[0], cost[1], cost[2], cost[3]);
                         *reinterpret_cast<float4*>(g.neg + qo + co) = make_float4(neg[0], neg[1], neg[2], neg[3]);
                     } else {   // the work-list pass writes the flagged ones (-cdist AND geomloss's cost, from the same exact sum): no address is stored twice
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (!redo[k]) {
-                                if (g.cost) g.cost[qo + co + k] = cost[k];
+                                if (put_cost) g.cost[qo + co + k] = cost[k];
                                 g.neg[qo + co + k] = neg[k];
                             }
                     }
@@ -554,7 +558,7 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
                     const long long qo = ((long long)(qt * g.dpt_q + (qdi & 255)) * g.ncand) * g.E + (long long)((qdi >> 8) & 255) * g.ld;
                     const long long co = (long long)(ct * g.dpt_c + (cdi & 255)) * g.E + ((cdi >> 8) & 255);
                     g.neg[qo + co] = negd;
-                    if (g.cost) g.cost[qo + co] = sqrtf(fmaxf(part, 1e-8f));
+                    if (put_cost) g.cost[qo + co] = sqrtf(fmaxf(part, 1e-8f));
                 }
             }
         }
@@ -680,6 +684,7 @@ int launch_pair_gram_planes(const ScoreArgs& a, const GramGeometry& geo, bool l2
     g.cost = cost;
     g.neg = neg;
     g.scores = a.scores;
+    g.skip_cost = a.cost_from_neg;
     const dim3 grid((unsigned)(g.n_ct * g.n_qt));
     auto launch = [&](auto kern, int bm, int bn, int ring) {
         const int lds = ring * (bm + bn) * kRowB;

@@ -2358,8 +2358,7 @@ int launch_cost_stage(const ScoreArgs& a, const aspire_repset* q, const aspire_r
     const bool csr = q->ext == 0 && c->ext == 0;
     if (gram) {
         // many queries or long documents: Gram tiles on the matrix cores (gram.hip)
-        return launch_pair_gram_ot(a, T, q->max_len, c->max_len, a.cost_from_neg ? nullptr : ws.cost, ws.neg, a.diameter ? nullptr : ws.diam2, qbox, cbox,
-                                   stream);
+        return launch_pair_gram_ot(a, T, q->max_len, c->max_len, ws.cost, ws.neg, a.diameter ? nullptr : ws.diam2, qbox, cbox, stream);
     }
     if (T == 1 && csr) {
         PairWs<1> ws1{ws.cost, ws.neg, ws.diam2};
