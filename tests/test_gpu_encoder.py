@@ -277,12 +277,13 @@ def test_bert_forward_on_presplit_operands_small_shapes(n_layers, b, l):
     assert (got - other).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize('n_layers,b,l', [(2, 9, 130), (3, 64, 256), (1, 3, 37), (2, 40, 100)])
+@pytest.mark.parametrize('n_layers,b,l', [(2, 9, 130), (3, 64, 256), (1, 3, 37), (2, 40, 100), (1, 128, 500)])
 def test_layernorm_in_the_gemm_epilogue_matches_the_separate_pass(n_layers, b, l):
     """LayerNorm inside the N = 768 GEMMs' epilogue (gemm_p_kernel's LN form: the six / twelve column tiles of a row block exchange
     (mean, sum of squared deviations) through global memory and normalise out of their accumulators; the residual stream lives in the
     P layout only) against the same forward with ASPIRE_HIP_GEMM_LN=off (layernorm_kernel as its own pass) and against HuggingFace: row counts that are no multiple of 128, a
-    launch of more tiles than workgroup slots (64 x 256 = 16 384 rows: 768 tiles; 128 x 64 tiles at the smaller shapes), run twice --
+    launch that fills every workgroup slot (64 x 256 = 16 384 rows: 768 tiles) and one of four rounds (128 x 500 = 64 000 rows: tiles wait at the
+    launch frontier while later ones start), 128 x 64 tiles pinned as well, run twice --
     the exchange counters are zeroed per forward -- with equal bits both times."""
     from aspire_amd._lib import pinned
     from aspire_amd.encoder import HipBertEncoder
