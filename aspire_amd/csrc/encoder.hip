@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPRowBytes = 64;                       // one row of one k block: 2 planes x 2 halves x 16 bytes
 constexpr int kPTile = 128 * kPRowBytes;             // 128 rows of one k block (8 KB)
-constexpr int kPPadRows = 128;                       // rows of slack behind a P matrix: the last row tile may read past R
+constexpr int kPPadRows = 256;                       // rows of slack behind a P matrix: the last row tile (128 or 256 rows) may read past R
 constexpr int kPRingDefault = 13;                    // 10 KS + NS: stages of one k block, three-stage ring = 48 KB, three workgroups per CU
 constexpr float kPWeightScale = 64.f;                // weights are split as 64 w (module comment)
 
@@ -590,14 +590,19 @@ __device__ __forceinline__ void glds_kblock(uint64_t a_base, uint64_t b_base, ui
 // pre-norm rows.  A workgroup WAITS for its row block's other column tiles: they are consecutive in the launch order of ONE XCD (below),
 // the hardware starts workgroups in order, so whatever waits has all its partners started or next in line; the tiles that can be
 // waiting at any time are the <= 8 row blocks at the launch frontier.
-template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false, bool LN = false>
+// BM = 256 (eight waves, 4 x 2 of 64 x 64; two workgroups per CU = four waves per SIMD): the A tile of a k block is 16 KB, every wave still
+// moves two 1 KB pieces of it and ONE of B -- 24 KB of LDS-DMA per k block for 24 k-steps' worth of MFMAs per wave pair where two 128 x 128
+// tiles move 32 KB: a quarter less traffic through the CU's vector-memory path and LDS per product.
+template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false, bool LN = false, int BM = 128>
 __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
+    static_assert(BM == 128 || (BM == 256 && !PERSIST && !LN), "tile rows");
+    constexpr int kATile = BM * kPRowBytes;                 // A rows of one k block
     static_assert(!PERSIST || KS == 1, "persistent form: one k block per stage");
     static_assert(!LN || (SWAP && !PERSIST && KS == 1), "LayerNorm epilogue: swapped operands, one tile per workgroup");
     constexpr int TN = BN / 64;                             // 32-column blocks per wave
     constexpr int kBTile = BN * kPRowBytes;                 // B rows of one k block
-    constexpr int kStage = KS * (kPTile + kBTile);          // [A k block 0 .. KS - 1][B k block 0 .. KS - 1]
-    constexpr int kBPerWave = kBTile / 4096;                // 1 KB pieces per wave and k block: 2 (BN = 128) or 1
+    constexpr int kStage = KS * (kATile + kBTile);          // [A k block 0 .. KS - 1][B k block 0 .. KS - 1]
+    constexpr int kBPerWave = kBTile / (32 * BM);           // 1 KB pieces per wave and k block: 2 (128 x 128) or 1
     constexpr int kPerWave = KS * (2 + kBPerWave);          // LDS-DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -621,7 +626,7 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         by = rb_lo + tile_i / (uint32_t)g.tiles_x;
         bx = tile_i % (uint32_t)g.tiles_x;
     }
-    int m0 = G_PROBE(g) == 3 ? 0 : (int)by * 128, n0 = G_PROBE(g) == 3 ? g.n_off : g.n_off + (int)bx * BN;      // probe 3: every workgroup computes tile (0, 0)
+    int m0 = G_PROBE(g) == 3 ? 0 : (int)by * BM, n0 = G_PROBE(g) == 3 ? g.n_off : g.n_off + (int)bx * BN;      // probe 3: every workgroup computes tile (0, 0)
     G_STAMP(0, __builtin_amdgcn_s_memrealtime());
     G_STAMP(4, __builtin_amdgcn_s_getreg(31 << 11 | 4));
     G_STAMP(5, __builtin_amdgcn_s_getreg(31 << 11 | 20));
@@ -639,8 +644,8 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         for (int s = 0; s < KS; ++s) {
             const uint64_t kb = (uint64_t)t * KS + s;
             // (an instruction's offset moves the LDS address along with the global one)
-            glds_kblock<kBPerWave == 2>(a_from + kb * a_step, b_from + kb * b_step, lane16, dst + s * kPTile + (2 * wave) * 1024,
-                                        dst + KS * kPTile + s * kBTile + (kBPerWave * wave) * 1024);
+            glds_kblock<kBPerWave == 2>(a_from + kb * a_step, b_from + kb * b_step, lane16, dst + s * kATile + (2 * wave) * 1024,
+                                        dst + KS * kATile + s * kBTile + (kBPerWave * wave) * 1024);
         }
     };
     auto issue = [&](int slot, int t) { issue_from(a_src, b_src, slot, t); };
@@ -648,7 +653,7 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
     // and wave tiles start on multiples of 32)
     const uint32_t frag0 = 16 * (lk ^ ((lr >> 2) & 3));
     const unsigned char* a_rd = p_smem + (wr * 64 + lr) * kPRowBytes;
-    const unsigned char* b_rd = p_smem + KS * kPTile + (wc * 32 * TN + lr) * kPRowBytes;
+    const unsigned char* b_rd = p_smem + KS * kATile + (wc * 32 * TN + lr) * kPRowBytes;
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -674,7 +679,7 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
                 const uint32_t fo = frag0 ^ (32 * pl);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    f.a[i][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(a_rd + slot * kStage + s * kPTile + i * 32 * kPRowBytes + fo));
+                    f.a[i][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(a_rd + slot * kStage + s * kATile + i * 32 * kPRowBytes + fo));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     f.b[j][pl][s] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(b_rd + slot * kStage + s * kBTile + j * 32 * kPRowBytes + fo));
@@ -946,7 +951,7 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         // loads of a block go out together, the 16 stores follow back to back (with per-element row checks the compiler put an
         // s_waitcnt vmcnt(0) in front of every element: 64 serialised stores per wave, 4 us per workgroup on an idle chip and
         // 12 us when every CU stores at once -- 32 of the 120 us of an 8192 x 2304 x 768 launch)
-        const bool whole = m0 + 128 <= g.M;
+        const bool whole = m0 + BM <= g.M;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1031,6 +1036,11 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
 template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false>
 __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     gemm_p_body<NS, KS, BN, SWAP, PERSIST, false>(g);
+}
+// 256 x BN tiles on eight waves (launch_gemm_p: ASPIRE_HIP_GEMM_TILE=256)
+template <int BN, bool SWAP>
+__global__ void __launch_bounds__(512, 2) gemm_p_w8_kernel(PGemmArgs g) {
+    gemm_p_body<3, 1, BN, SWAP, false, false, 256>(g);
 }
 // the LayerNorm-epilogue form: THREE workgroups per CU asked of the register allocator (168 registers), as the plain forms get by themselves
 template <int BN>
@@ -1654,8 +1664,25 @@ int launch_gemm_p_ring(const PGemmArgs& g, int n_off, int col_tiles, hipStream_t
     }
 }
 template <bool SWAP>
+int launch_gemm_p_w8(PGemmArgs g, hipStream_t st) {
+    constexpr int lds = 3 * (256 + 128) * kPRowBytes;
+    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_w8_kernel<128, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    ASPIRE_HIP_OK(raised);
+    g.n_off = 0;
+    g.probe = 0;
+    hipLaunchKernelGGL((gemm_p_w8_kernel<128, SWAP>), dim3(g.N / 128, (g.M + 255) / 256), dim3(512), lds, st, g);
+    ASPIRE_LAUNCH_OK();
+    return ASPIRE_OK;
+}
+template <bool SWAP>
 int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
     ASPIRE_REQUIRE(g.N % 128 == 0 && g.K % 32 == 0, ASPIRE_ERR_UNSUPPORTED, "P-layout GEMM needs N %% 128 == 0 and K %% 32 == 0");
+    // 256 x 128 tiles on eight waves: pinned (ASPIRE_HIP_GEMM_TILE=256), and by default for the GELU GEMM (the one SWAP launch of a layer, N = 3072)
+    // when its tiles fill the 512 slots of that form in whole rounds or many of them (64 x 256 tokens: 1536 tiles = 3 rounds)
+    {
+        const long long t8 = (long long)(g.N / 128) * ((g.M + 255) / 256);
+        if (tuning().gemm_tile == 256 || (tuning().gemm_tile == 0 && SWAP && (t8 % 512 == 0 || t8 >= 2048))) return launch_gemm_p_w8<SWAP>(g, st);
+    }
     const long long slots = 768, rows = (g.M + 127) / 128, n128 = g.N / 128;
     // 128 x 64 tiles (twice the workgroups) where 128 x 128 ones cannot give every workgroup slot a tile and the k loop is short
     int c1 = (int)n128;

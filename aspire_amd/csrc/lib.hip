@@ -38,7 +38,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.gemm_form = f;
     } else if (!strcmp(key, "GEMM_TILE")) {
         const int f = unset ? 0 : atoi(v);
-        if (f != 0 && f != 96 && f != 128 && f != 64) return false;
+        if (f != 0 && f != 96 && f != 128 && f != 64 && f != 256) return false;
         t.gemm_tile96 = f == 96;
         t.gemm_tile = f;
     } else if (!strcmp(key, "GEMM_RING")) {

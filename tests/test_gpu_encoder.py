@@ -192,7 +192,7 @@ def test_gemm_on_presplit_operands_is_fp32_accurate():
         with _lib.pinned(GEMM='bf16x3'):
             assert L.aspire_debug_gemm_f32(A.data_ptr(), B.data_ptr(), C0.data_ptr(), bias.data_ptr(), M, N, K, st) == 0
         Ap, Bp = planes(A), planes(B, 1)
-        for pin in ({}, {'GEMM_RING': '3'}, {'GEMM_TILE': '64'}, {'GEMM_RING': '113'}):      # 113: the persistent tile loop (> 768 tiles)
+        for pin in ({}, {'GEMM_RING': '3'}, {'GEMM_TILE': '64'}, {'GEMM_RING': '113'}, {'GEMM_TILE': '256'}):      # 113: the persistent tile loop (> 768 tiles); 256: 256 x 128 tiles on eight waves
             C = torch.full((M, N), float('nan'), device='cuda')
             with _lib.pinned(**pin):
                 assert L.aspire_debug_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), None, bias.data_ptr(), M, N, K, 0, st) == 0
