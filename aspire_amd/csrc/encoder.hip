@@ -1681,7 +1681,11 @@ int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
     // when its tiles fill the 512 slots of that form in whole rounds or many of them (64 x 256 tokens: 1536 tiles = 3 rounds)
     {
         const long long t8 = (long long)(g.N / 128) * ((g.M + 255) / 256);
-        if (tuning().gemm_tile == 256 || (tuning().gemm_tile == 0 && SWAP && (t8 % 512 == 0 || t8 >= 2048))) return launch_gemm_p_w8<SWAP>(g, st);
+        // (... and for the QKV GEMM when its tiles balance over the 256 CUs: 32 768 rows x 2304 columns = 2304 tiles, 9 per CU; at 16 384 rows
+        // 1152 tiles are 4.5 per CU and the 128 x 128 form wins)
+        if (tuning().gemm_tile == 256 || (tuning().gemm_tile == 0 && SWAP && (t8 % 512 == 0 || t8 >= 2048)) ||
+            (tuning().gemm_tile == 0 && !SWAP && !g.res && g.N > kD && t8 % 256 == 0 && t8 >= 2048))
+            return launch_gemm_p_w8<SWAP>(g, st);
     }
     const long long slots = 768, rows = (g.M + 127) / 128, n128 = g.N / 128;
     // 128 x 64 tiles (twice the workgroups) where 128 x 128 ones cannot give every workgroup slot a tile and the k loop is short

@@ -95,7 +95,8 @@ def run(n_docs=16384, L=256, S=12, n_queries=128, k=100, check=True, seed=2, pla
     torch.cuda.synchronize()
     stage_events = []
     t0 = time.perf_counter()
-    pool = model.encode_to_pool(batches, planes=planes, stage_events=stage_events)      # planes: + one pass over the finished store (inside the timed stage)
+    extra = {'rows_per_forward': int(os.environ['E2E_ROWS_PER_FORWARD'])} if os.environ.get('E2E_ROWS_PER_FORWARD') else {}      # (A/B of the default)
+    pool = model.encode_to_pool(batches, planes=planes, stage_events=stage_events, **extra)      # planes: + one pass over the finished store (inside the timed stage)
     torch.cuda.synchronize()
     t_encode = time.perf_counter() - t0
     # the stage's own split: HIP events recorded INSIDE the timed call, around every encoder forward and every pooling launch
