@@ -1039,7 +1039,7 @@ __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
 }
 // 256 x BN tiles on eight waves (launch_gemm_p: ASPIRE_HIP_GEMM_TILE=256)
 template <int BN, bool SWAP>
-__global__ void __launch_bounds__(512, 2) gemm_p_w8_kernel(PGemmArgs g) {
+__global__ void __launch_bounds__(512, 4) gemm_p_w8_kernel(PGemmArgs g) {       // (the second bound is waves per SIMD: two workgroups of eight waves per CU)
     gemm_p_body<3, 1, BN, SWAP, false, false, 256>(g);
 }
 // the LayerNorm-epilogue form: THREE workgroups per CU asked of the register allocator (168 registers), as the plain forms get by themselves

@@ -85,7 +85,16 @@ template <int NB>
 __device__ __forceinline__ void glds_kblock_gather(uint64_t a_base, uint64_t b_base, const uint32_t (&va)[2], const uint32_t (&vb)[NB],
                                                    uint32_t a_dst, uint32_t b_dst) {
     uint32_t keep;
-    if constexpr (NB == 2)
+    if constexpr (NB == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %4 offset:0\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %3, %5 offset:0\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(va[0]), "v"(va[1]), "v"(vb[0]), "s"(a_base), "s"(b_base), "s"(a_dst), "s"(b_dst)
+                     : "memory");
+    else if constexpr (NB == 2)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %5 offset:0\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
                      "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
@@ -135,6 +144,9 @@ __device__ __forceinline__ float4 ldrow4(const float* rows, int32_t row, int ofs
 // (BN / 2) wc ..), a ring of RING stages:
 //   128 x 128: four waves of 64 x 64, three workgroups per CU (the encoder GEMM's geometry)
 //   128 x 256: four waves of 64 x 128, two per CU
+//   256 x 128: eight waves of 64 x 64 (the encoder's gemm_p_w8_kernel geometry, which wins there at 118 registers = two workgroups per CU, four
+//              waves per SIMD).  HERE the loop needs 141 registers (gathered DMA offsets, two fragment sets): one workgroup per CU, 539 us
+//              against 496 - 502 at 32 x 50 000 x 8; capped at 128 it spills inside the loop (2 189 us).  Pinned form only (GRAM_TILE=256128).
 //   256 x 256: eight waves of 64 x 128, one per CU -- a row is moved into LDS once per 256 rows of the other side: half the LDS-DMA
 //              bytes per product of the 128 x 128 form, which is what that form runs out of (16 KB per workgroup and stage through
 //              the CU's vector-memory path for 384 matrix-pipe cycles per SIMD), and two thirds of its fragment reads
@@ -146,7 +158,8 @@ __device__ __forceinline__ float4 ldrow4(const float* rows, int32_t row, int ofs
 // second fragment set or MFMAs threaded between loads.  (All waves in step -- the non-PP form of this tile -- leaves both waves of a
 // SIMD loading at the same time, then both competing for the pipe: 45 % busy.)
 template <int BM, int BN, int RING, bool L2MAX, bool PP = false>
-__global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 128 ? 2 : 1) pair_gram_p_kernel(GramPArgs g) {
+// (the second launch bound is WAVES PER SIMD on this toolchain: 3 for the 128 x 128 form's three workgroups per CU, 4 for 256 x 128's two)
+__global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 256 && BN == 128) ? 3 : BM == 128 ? 2 : 1) pair_gram_p_kernel(GramPArgs g) {
     static_assert(!PP || (BM == 256 && BN == 256), "ping-pong: two groups of four waves");
     constexpr int NT = 2 * BM;                      // threads
     constexpr int TN = BN / 64;                     // 32-column blocks per wave
@@ -155,7 +168,7 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : BM == 1
     constexpr int kStageB = kATileB + kBTileB;      // [candidate rows][query rows]
     constexpr int kPerWave = 2 + NB;                // LDS-DMA instructions per wave and stage
     constexpr int NMMA = 3 * 2 * TN;                // MFMAs per wave and stage
-    static_assert(NB == 2 || NB == 4, "pieces per wave");
+    static_assert(NB == 1 || NB == 2 || NB == 4, "pieces per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     __shared__ int32_t c_row[BM], q_row[BN];        // fp32 row of the tile row, -1 = none
     __shared__ int32_t c_di[BM], q_di[BN];          // document slot | row in the document << 8 | (len > 25) << 16, -1 = no document
@@ -709,6 +722,9 @@ int launch_pair_gram_planes(const ScoreArgs& a, const GramGeometry& geo, bool l2
             if (l2max) launch(pair_gram_p_kernel<256, 256, 3, true>, 256, 256, 3);
             else launch(pair_gram_p_kernel<256, 256, 3, false>, 256, 256, 3);
         }
+    } else if (form == 256128) {
+        if (l2max) launch(pair_gram_p_kernel<256, 128, 3, true>, 256, 128, 3);
+        else launch(pair_gram_p_kernel<256, 128, 3, false>, 256, 128, 3);
     } else if (form == 128256) {
         if (l2max) launch(pair_gram_p_kernel<128, 256, 3, true>, 128, 256, 3);
         else launch(pair_gram_p_kernel<128, 256, 3, false>, 128, 256, 3);

@@ -65,7 +65,7 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
         t.split_prio = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "GRAM_TILE")) {
         const int f = unset ? 0 : atoi(v);
-        if (f != 0 && f != 128128 && f != 128256 && f != 256256) return false;
+        if (f != 0 && f != 128128 && f != 128256 && f != 256128 && f != 256256) return false;
         t.gram_tile = f;
     } else if (!strcmp(key, "GRAM_PP")) {
         t.gram_pp = unset ? 0 : atoi(v);

@@ -183,9 +183,9 @@ def test_pools_as_index_lists_share_the_store_planes(amd):
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize('tile,pp', [('128256', ''), ('256256', ''), ('256256', '1')])
+@pytest.mark.parametrize('tile,pp', [('128256', ''), ('256128', ''), ('256256', ''), ('256256', '1')])
 def test_wider_tile_forms_give_the_same_scores(amd, tile, pp):
-    """GRAM_TILE pins the 128 x 256 / 256 x 256 tiles (wider wave tiles, one or two workgroups per CU), GRAM_PP the ping-pong
+    """GRAM_TILE pins the 128 x 256 / 256 x 128 / 256 x 256 tiles (wider wave tiles, one or two workgroups per CU), GRAM_PP the ping-pong
     schedule of the 256 x 256 form -- kept for A/B runs, none beats the 128 x 128 default (NOTES.md, round 4): the same
     products in the same order per entry, so the same bits; ragged documents and tail tiles included"""
     from aspire_amd._lib import pinned
