@@ -175,7 +175,7 @@ def test_persistent_cost_kernel_with_duplicate_sentences(amd):
     np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize('qlens,clens', [([8], [8] * 130), ([3, 8, 1], [1, 8, 4, 7, 2] * 30), ([5], [6])])
+@pytest.mark.parametrize('qlens,clens', [([8], [8] * 70), ([3, 8, 1], [1, 8, 4, 7, 2] * 12), ([5], [6])])
 def test_one_wave_per_pair_kernel_matches_oracle_and_the_two_launch_form(amd, qlens, clens):
     """pair_one_kernel (round 5: costs + solve of a pair on ONE wave, one launch -- the default of every small grid of short documents)
     against the oracle and against pair_cost1_kernel + sinkhorn_kernel<1>: ragged documents, several queries, every output of
