@@ -80,6 +80,7 @@ SIGNATURES = {
     'aspire_bert_workspace_bytes': (c_size_t, [ctypes.POINTER(BertWeights), c_int64, c_int64]),
     'aspire_bert_forward_f32': (c_int, [ctypes.POINTER(BertWeights), c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    'aspire_bert_status': (c_int, [ctypes.POINTER(ctypes.c_int32), c_void_p]),
     'aspire_rep_planes_bytes': (c_size_t, [c_int64]),
     'aspire_rep_planes_prepare': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, ctypes.POINTER(RepPlanes),
                                           c_void_p]),

@@ -75,6 +75,16 @@ class AspireConSent:
         tok_idx, span_off = spans_to_csr(batch_senttok_idxs, max_sents)
         dev = final_hidden_state.device
         doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
+        if self.bert_encoder.status():
+            # a LayerNorm-epilogue GEMM gave up waiting for its row block (encoder.hip: gemm_p_ln_kernel's bounded wait): once more with
+            # the LayerNorm as its own pass
+            from ._lib import pinned
+            import warnings
+            warnings.warn('AspireConSent: the fused GEMM + LayerNorm exchange timed out; encoding again with ASPIRE_HIP_GEMM_LN=off')
+            with pinned(GEMM_LN='off'):
+                final_hidden_state = self.bert_encoder.forward_hidden(tokid_tt, token_type_ids=seg_tt, attention_mask=attnmask_tt,
+                                                                      check_ids=False)
+            doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
         if not bool(torch.isfinite(sent_reps).all() & torch.isfinite(doc_cls_reps).all()):      # (the CLS token belongs to no sentence span)
             # an activation beyond the fp16 planes' range (encoder.py: forward_full_range): once more on the full-range kernels
             final_hidden_state = self.bert_encoder.forward_full_range(tokid_tt, seg_tt, attnmask_tt)
@@ -197,7 +207,7 @@ class AspireConSent:
             yield out, ids
 
     def encode_to_pool(self, batches, pids=None, want_cls=False, docs_per_forward=64, planes=False, sort_by_length=True,
-                       _full_range=False, stage_events=None, rows_per_forward=16384):
+                       _full_range=False, stage_events=None, rows_per_forward=16384, streams=1, _ln_off=False):
         """Encode document batches straight into a resident candidate pool.
 
         batches: iterable of (bert_batch, abs_lens, sent_tok_idxs) as prepare_abstracts returns them (it is consumed
@@ -215,6 +225,9 @@ class AspireConSent:
         32 of 512: the shapes at which the encoder's GEMMs fill whole rounds of the chip.
         planes: also keep the rows as fp16 planes (CandidatePool.prepare_planes: one more pass over the finished store, ~2.5 ms per
         GB) for the many-query cost tiles.
+        streams: encoder calls alternate over this many HIP streams (each with its own encoder workspace; forked from and joined to the
+        current stream inside this call): a forward's one-round launches end with their tiles' epilogues under an idle matrix pipe, a
+        second forward in flight fills those slots.  1: everything on the current stream.
         stage_events: a list that receives one (start, encoded, pooled) triple of HIP events per encoder call, recorded on the
         current stream INSIDE this call (tools/e2ebench.py: the stage's own time split; the caller reads them after a sync).
         Returns a scorer.CandidatePool (and the [N, 768] CLS reps on the GPU with want_cls)."""
@@ -254,6 +267,14 @@ class AspireConSent:
         start_np = start_t.numpy()
         doc0 = 0
         first = True
+        cur = torch.cuda.current_stream()
+        n_streams = max(1, int(streams))
+        side = [cur] if n_streams == 1 else [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        if n_streams > 1:
+            fork = cur.record_event()            # the store's allocation and the id check precede every side stream's work
+            for st in side:
+                st.wait_event(fork)
+        n_fwd = 0
         for batches, doc_ids in window_iter:
             bounds, nxt = [0], 2 if first else 64
             first = False
@@ -283,26 +304,52 @@ class AspireConSent:
                     chunk.append((max_sents, doc0, b))
                     doc0 += b
                 flat = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.int32)).to(dev)
+                if n_streams > 1:
+                    up = cur.record_event()          # the tables' upload happens on the caller's stream
+                    for st in side:
+                        st.wait_event(up)
+                        flat.record_stream(st)
                 for i, (bert_batch, _, _) in enumerate(batches[g0:g1]):
                     max_sents, d0, b = chunk[i]
                     (t0, t1), (s0, s1), (r0, r1) = offs[3 * i:3 * i + 3]
-                    if stage_events is not None:
-                        evs = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
-                        evs[0].record()
-                    hidden = self.bert_encoder.forward_hidden(bert_batch['tokid_tt'], token_type_ids=bert_batch['seg_tt'],
-                                                              attention_mask=bert_batch['attnmask_tt'], check_ids=False)
-                    if stage_events is not None:
-                        evs[1].record()
-                    if want_cls and doc_ids is not None:       # regrouped documents: the forward's CLS rows go to their corpus positions
-                        cls_b = torch.empty(b, 768, device=dev, dtype=torch.float32)
-                        ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows, cls_b)
-                        cls_all.index_copy_(0, torch.tensor(doc_ids[g0 + i], dtype=torch.long, device=dev), cls_b)
-                    else:
-                        ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows,
-                                                cls_all[d0:d0 + b] if want_cls else None)
-                    if stage_events is not None:
-                        evs[2].record()
-                        stage_events.append(evs)
+                    with torch.cuda.stream(side[n_fwd % n_streams]):
+                        n_fwd += 1
+                        if stage_events is not None:
+                            evs = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                            evs[0].record()
+                        hidden = self.bert_encoder.forward_hidden(bert_batch['tokid_tt'], token_type_ids=bert_batch['seg_tt'],
+                                                                  attention_mask=bert_batch['attnmask_tt'], check_ids=False)
+                        if stage_events is not None:
+                            evs[1].record()
+                        if want_cls and doc_ids is not None:       # regrouped documents: the forward's CLS rows go to their corpus positions
+                            cls_b = torch.empty(b, 768, device=dev, dtype=torch.float32)
+                            ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows, cls_b)
+                            cls_all.index_copy_(0, torch.tensor(doc_ids[g0 + i], dtype=torch.long, device=dev), cls_b)
+                        else:
+                            ops.span_mean_pool_rows(hidden, flat[t0:t1], flat[s0:s1], max_sents, flat[r0:r1], rows,
+                                                    cls_all[d0:d0 + b] if want_cls else None)
+                        if stage_events is not None:
+                            evs[2].record()
+                            stage_events.append(evs)
+        if n_streams > 1:
+            for st in side:                          # join: what follows on the caller's stream sees the finished store
+                cur.wait_event(st.record_event())
+                rows.record_stream(st)
+                if cls_all is not None:
+                    cls_all.record_stream(st)
+        if total and not _ln_off and self.bert_encoder.status():
+            # a LayerNorm-epilogue GEMM gave up waiting for its row block (encoder.hip: gemm_p_ln_kernel's bounded wait): the whole corpus
+            # once more with the LayerNorm as its own pass (one sync over the finished store, as the range check below)
+            from ._lib import pinned
+            import warnings
+            warnings.warn('AspireConSent.encode_to_pool: the fused GEMM + LayerNorm exchange timed out; encoding again with '
+                          'ASPIRE_HIP_GEMM_LN=off')
+            with pinned(GEMM_LN='off'):
+                if stage_events is not None:
+                    del stage_events[:]
+                return self.encode_to_pool(given, pids=pids, want_cls=want_cls, docs_per_forward=docs_per_forward, planes=planes,
+                                           sort_by_length=sort_by_length, _full_range=_full_range, stage_events=stage_events,
+                                           rows_per_forward=rows_per_forward, streams=streams, _ln_off=True)
         if total and not _full_range and not bool(torch.isfinite(rows).all() & (torch.isfinite(cls_all).all() if want_cls else True)):
             # an activation left the fp16 planes' range somewhere (one check over the finished store): encode again on the kernels
             # that take any fp32 value
@@ -315,7 +362,7 @@ class AspireConSent:
                     del stage_events[:]
                 return self.encode_to_pool(given, pids=pids, want_cls=want_cls, docs_per_forward=docs_per_forward, planes=planes,
                                            sort_by_length=sort_by_length, _full_range=True, stage_events=stage_events,
-                                           rows_per_forward=rows_per_forward)
+                                           rows_per_forward=rows_per_forward, streams=streams, _ln_off=True)
         repset = ops.DeviceRepSet(rows, start_t.to(dev), lens_t.to(dev), ext=0, max_len=max(all_lens) if all_lens else 0,
                                   lens_host=all_lens)
         pool = CandidatePool.from_repset(repset, pids=pids)

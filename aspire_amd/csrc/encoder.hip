@@ -519,6 +519,13 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
     if (too_big && !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) * scale <= 65504.f)) *too_big = 1;
 }
 
+// Sticky per-device status word of the encoder's kernels (include/aspire_hip.h: aspire_bert_status reads and clears it).
+__device__ int g_bert_status;
+// how long a LayerNorm-epilogue tile waits for its row block's partners: 20 ms of the constant 100 MHz clock (s_memrealtime) -- two orders
+// of magnitude above the longest kernel any stream of this library keeps the chip busy with, so that only a broken progress assumption
+// (not a busy GPU) runs into it
+constexpr uint64_t kLnWaitTicks = 2000000;
+
 struct PGemmArgs {
     const void* Ap;      // P layout [M, K]
     const void* Bp;      // P layout [N, K] (nn.Linear weight, scaled by kPWeightScale)
@@ -903,9 +910,29 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
             asm volatile("" ::"v"(was));
         }
         __syncthreads();
+        // MEMORY MODEL: relaxed agent-scope atomics order nothing but themselves; that the entries are visible to whoever sees the full count
+        // rests on (a) the swap being a RETURNING atomic performed at the L2 / memory side, complete before the barrier that precedes the count,
+        // and (b) the readers using atomic loads, which bypass the non-coherent per-CU / per-XCD caches -- how gfx950 executes device-scope
+        // atomics as measured, NOT something the HIP memory model promises for relaxed order.  A port to another part re-derives this.
+        // FORWARD PROGRESS: a waiting tile needs its row block's other column tiles resident or next in line (launch_gemm_p_ln_bn: whole row
+        // blocks per XCD, in dispatch order; ln_fused_supported() gates the form on the part this was measured on).  The wait is BOUNDED: after
+        // kLnWaitTicks of the 100 MHz clock (or as soon as any workgroup of the process has given up) the tile sets g_bert_status and goes on
+        // with whatever it reads -- the forward's output is then invalid, the host reads the word (aspire_bert_status) and runs that forward
+        // again with the separate layernorm_kernel pass.
         if (tid == 0) {
-            __hip_atomic_fetch_add(g.ln_count + by, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (!(g.probe & 8) && __hip_atomic_load(g.ln_count + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGX) __builtin_amdgcn_s_sleep(4);
+            if (!((g.probe & 16) && bx == 0))          // probe 16 (tests): the row block's first tile never counts itself -- its partners time out
+                __hip_atomic_fetch_add(g.ln_count + by, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(g.probe & 8)) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(g.ln_count + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGX) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kLnWaitTicks ||
+                        (__hip_atomic_load(&g_bert_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ASPIRE_BERT_STATUS_LN_TIMEOUT)) {
+                        __hip_atomic_fetch_or(&g_bert_status, ASPIRE_BERT_STATUS_LN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -1705,7 +1732,7 @@ int launch_gemm_p_ln_bn(PGemmArgs g, hipStream_t st) {
     static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_ln_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     ASPIRE_HIP_OK(raised);
     g.n_off = 0;
-    g.probe = tuning().gemm_probe >= 32 ? tuning().gemm_probe - 32 : 0;      // timing experiment: 40 = nobody waits for its row block (wrong results)
+    g.probe = tuning().gemm_probe >= 32 ? tuning().gemm_probe - 32 : 0;      // 40 (timing experiment): nobody waits for its row block (wrong results); 48 (tests): a tile per row block never reports, its partners run into the wait's bound
     g.tiles_x = kD / BN;
     g.tiles_y = (g.M + 127) / 128;
     const unsigned per_xcd = (unsigned)((g.tiles_y + 7) / 8) * (unsigned)g.tiles_x;
@@ -1720,6 +1747,21 @@ int launch_gemm_p_ln(const PGemmArgs& g, hipStream_t st) {
     // measured 76 us against 36 + 14 for the plain 64-wide GEMM + layernorm_kernel at 8192 x 768 x 768; ASPIRE_HIP_GEMM_TILE=64 pins it (tests)
     if (tuning().gemm_tile == 64) return launch_gemm_p_ln_bn<64>(g, st);
     return launch_gemm_p_ln_bn<128>(g, st);
+}
+// The LayerNorm-epilogue form's forward-progress argument (gemm_p_ln_kernel) was made and measured on ONE part: gfx950 in SPX mode -- 256 CUs
+// in 8 XCDs, workgroup id mod 8 = the XCD, three workgroups of this kernel per CU.  Anywhere else (another partition mode, CU masking that
+// changes the CU count the runtime reports, another chip) the default is the separate layernorm_kernel pass; ASPIRE_HIP_GEMM_LN=on still pins
+// the fused form (its wait is bounded either way).
+bool ln_fused_supported() {
+    static int cached[64];          // per device ordinal: 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!cached[dev]) {
+        hipDeviceProp_t prop;
+        bool ok = hipGetDeviceProperties(&prop, dev) == hipSuccess && !strncmp(prop.gcnArchName, "gfx950", 6) && prop.multiProcessorCount == 256;
+        cached[dev] = ok ? 1 : 2;
+    }
+    return cached[dev] == 1;
 }
 // where a layer's four weight matrices sit in the prepared planes buffer
 struct PlaneOffsets {
@@ -1781,7 +1823,10 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
     // 32 x 256 5.16 / 5.30, 40 x 100 3.09 / 3.17, 16 x 256 3.18 / 3.14, 8 x 256 2.37 / 2.30: below, the launch is a fraction of one round of
     // workgroups and a waiting workgroup has nothing running under it)
     const int64_t row_tiles = (M + 127) / 128;
-    const bool ln_fused = pp && (tuning().gemm_ln == 2 || (tuning().gemm_ln == 0 && row_tiles >= 48));
+    const bool ln_fused = pp && (tuning().gemm_ln == 2 || (tuning().gemm_ln == 0 && row_tiles >= 48 && ln_fused_supported()));
+    // the P layout's slot offsets are 32-bit byte offsets (p_slot / p_slot8: ((k >> 4) R + r) << 6): the widest operand is [M, ffn_dim]
+    ASPIRE_REQUIRE(!pp || (uint64_t)M * (uint64_t)(w->ffn_dim > 3 * kD ? w->ffn_dim : 3 * kD) * 4 < (1ull << 32), ASPIRE_ERR_UNSUPPORTED,
+                   "%lld token rows in one forward: the fp16-plane layout addresses < 4 GB per operand (split the batch)", (long long)M);
     if (ln_fused && w->n_layers > 0) ASPIRE_HIP_OK(hipMemsetAsync(ws.ln_count, 0, ws.ln_count_bytes, st));
     for (int l = 0; l < w->n_layers; ++l) {
         const aspire_bert_layer& ly = w->layers[l];
@@ -1886,6 +1931,21 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         }
         x = out;
     }
+    return ASPIRE_OK;
+}
+
+extern "C" int aspire_bert_status(int32_t* status_host, void* stream) {
+    ASPIRE_REQUIRE(status_host, ASPIRE_ERR_INVALID_ARG, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int v = 0;
+    const int zero = 0;
+    ASPIRE_HIP_OK(hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_bert_status), sizeof(int), 0, hipMemcpyDeviceToHost, st));
+    ASPIRE_HIP_OK(hipStreamSynchronize(st));
+    if (v) {
+        ASPIRE_HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bert_status), &zero, sizeof(int), 0, hipMemcpyHostToDevice, st));
+        ASPIRE_HIP_OK(hipStreamSynchronize(st));
+    }
+    *status_host = v;
     return ASPIRE_OK;
 }
 

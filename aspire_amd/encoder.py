@@ -57,7 +57,7 @@ class HipBertEncoder:
             put(sd[emb + 'LayerNorm.bias']), self._layers, n_layers, cfg.num_attention_heads, cfg.hidden_size,
             cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size,
             float(cfg.layer_norm_eps), None)
-        self._ws = None
+        self._ws = {}                       # one workspace per HIP stream: forwards on different streams overlap
         # the nn.Linear weights' fp16 planes, formed once (include/aspire_hip.h: aspire_bert_prepare_planes)
         nbytes = lib.aspire_bert_planes_bytes(ctypes.byref(self._w))
         if nbytes and cfg.intermediate_size % 128 == 0:
@@ -95,11 +95,22 @@ class HipBertEncoder:
             else torch.ones_like(tok)
         out = torch.empty(b, l, 768, device=dev, dtype=torch.float32)
         need = lib.aspire_bert_workspace_bytes(ctypes.byref(self._w), b, l)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        sid = torch.cuda.current_stream().cuda_stream
+        ws = self._ws.get(sid)
+        if ws is None or ws.numel() < need:
+            self._ws[sid] = ws = torch.empty(need, device=dev, dtype=torch.uint8)
         check(lib.aspire_bert_forward_f32(ctypes.byref(self._w), ops._ptr(tok), ops._ptr(typ), ops._ptr(msk), b, l,
-                                          ops._ptr(out), ops._ptr(self._ws), self._ws.numel(), ops._stream()))
+                                          ops._ptr(out), ops._ptr(ws), ws.numel(), ops._stream()))
         return out
+
+    @staticmethod
+    def status():
+        """The encoder kernels' sticky status word (include/aspire_hip.h: aspire_bert_status), read and cleared; synchronises the current
+        stream.  Non-zero: a LayerNorm-epilogue GEMM gave up waiting for its row block (ASPIRE_BERT_STATUS_LN_TIMEOUT) -- the forwards
+        since the last check are invalid; the callers in consent.py run them again under pinned(GEMM_LN='off')."""
+        v = ctypes.c_int32(0)
+        check(lib.aspire_bert_status(ctypes.byref(v), ops._stream()))
+        return int(v.value)
 
     def __call__(self, tokid_tt, token_type_ids=None, attention_mask=None):
         return SimpleNamespace(last_hidden_state=self.forward_hidden(tokid_tt, token_type_ids, attention_mask))

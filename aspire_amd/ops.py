@@ -47,15 +47,34 @@ def set_center_hint(mode):
 
 
 def _rows_key(rows):
-    """What a cache derived from a row matrix is valid for: the same memory, the same number of rows, not written since.  torch
-    counts in-place writes (rows._version, shared by a matrix and its views); the entry points of this module that write rows
-    through the C ABI report theirs (_rows_written)."""
-    return (rows.data_ptr(), int(rows.shape[0]), rows._version)
+    """What a cache derived from a row matrix is valid for: the same memory, the same number of rows, not written since.  Two
+    counters: the library's own generation (`_aspire_gen` on the tensor object, bumped by _rows_written: the entry points of this
+    module that write rows through the C ABI report theirs) and torch's count of in-place writes (rows._version, shared by a matrix
+    and its views) where torch keeps one -- a tensor made under torch.inference_mode() tracks no version (reading it raises): for
+    those only the library's own writes are seen, a torch write into such a store needs drop_planes() / prepare_planes() by hand."""
+    version = None if rows.is_inference() else rows._version
+    return (rows.data_ptr(), int(rows.shape[0]), version, getattr(rows, '_aspire_gen', 0))
 
 
 def _rows_written(t):
     """The library wrote into `t` behind torch's back (a kernel given its data pointer): caches keyed by _rows_key(t) are stale."""
-    torch.autograd.graph.increment_version(t)
+    t._aspire_gen = getattr(t, '_aspire_gen', 0) + 1
+    if not t.is_inference():
+        torch.autograd.graph.increment_version(t)
+
+
+_REBUILD_WARNED = False
+
+
+def _warn_rebuild(what):
+    """An automatic rebuild of a cache (planes: ~2.5 ms per GB of rows; boxes: 6 KB per document) inside a scoring call: said once."""
+    global _REBUILD_WARNED
+    if not _REBUILD_WARNED:
+        _REBUILD_WARNED = True
+        import warnings
+        warnings.warn(f'aspire_amd: the rows of a resident store were written after its {what} were prepared; they are formed again '
+                      'inside this scoring call (and on every call that follows a write -- torch counts writes through ANY view of the '
+                      'buffer).  Prepare the caches after the last write to keep this out of the scoring path.')
 
 
 def _match_planes(q, c, pairing):
@@ -148,6 +167,7 @@ class DeviceRepSet:
         box = getattr(self, 'doc_box', None)
         if box is not None and getattr(self, '_doc_box_key', None) not in (None, _rows_key(self.rows)):
             self.doc_box = None                                  # the rows were written since: formed again
+            _warn_rebuild('per-document boxes')
             self.prepare_boxes()
             box = self.doc_box
         return box
@@ -176,10 +196,18 @@ class DeviceRepSet:
     def planes(self):
         """The matrix's fp16 planes, or None.  Planes are a cache of the rows: when the rows have been written since they were
         made (or the tensor now points elsewhere), planes the caller prepared are made again the same way (own centre / the centre
-        given then), planes made for a call (_match_planes) are dropped."""
+        given then), planes made for a call (_match_planes) are dropped.  The rebuild keeps the CENTRE the planes had (a copy of it):
+        the shards of one pool share rank 0's centre (parallel.py), and a shard that formed a new one on its own would leave the
+        bit-equality of sharded and un-sharded scores behind; any common vector serves as a centre, L2 distances do not move."""
         pl = getattr(self.rows, '_aspire_planes', None)
         if pl is not None and pl.key != _rows_key(self.rows):
-            self.rows._aspire_planes = pl = None if pl.auto else RowPlanes(self.rows, pl.mu if pl.mu_given else None)
+            if pl.auto:
+                self.rows._aspire_planes = pl = None
+            else:
+                _warn_rebuild('fp16 planes')
+                was_given = pl.mu_given
+                self.rows._aspire_planes = pl = RowPlanes(self.rows, pl.mu.clone())
+                pl.mu_given = was_given
         return pl
 
     def prepare_planes(self, like=None, mu=None):

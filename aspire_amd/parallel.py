@@ -9,6 +9,14 @@ gloo in the CPU tests -- followed by a k-way merge.  The reference has no collec
 
 Tie rule: equal scores are ordered by ascending GLOBAL candidate index, which is what Python's stable
 sorted(..., reverse=True) over the un-sharded pool gives (evaluate.py:76).
+
+Which split a BASELINE config takes:
+  configs 2, 3, 5 (few / many queries against ONE big pool)   candidate blocks: ShardedPoolRanker (queries replicated, top-k merge)
+  config 4 (CSFCube: every query has its OWN pool of ~125 candidates, evaluate.py:58-76)   JOB blocks: rank_pools_sharded /
+      evaluate.score(..., group=...) -- a pool is never cut (125 candidates over 8 ranks on multiples of 64 would leave six ranks
+      empty); the 50 (query, pool) jobs are dealt out in contiguous blocks, each rank makes ONE aspire_ot_rank_batch_f32 call on its
+      block, and ONE all-gather of the ranked [jobs, k] lists (score bits + in-pool index in one int64 each) gives every rank
+      every job's ranking.  No merge: a job's ranking is complete on the rank that owns it.
 """
 import torch
 import torch.distributed as dist
@@ -199,3 +207,93 @@ class ShardedPoolRanker:
         if full.shape[1] == 0:
             return full, torch.empty(qn, 0, dtype=torch.int64, device=dev)
         return ops.topk_desc(full, full.shape[1])
+
+
+# ---- config 4: per-query pools, sharded by JOB ----------------------------------------------------------------------------------
+def job_bounds(n_jobs, world_size, rank):
+    """Contiguous block [lo, hi) of the (query, pool) jobs that rank `rank` owns: sizes differ by at most one, earlier ranks take
+    the longer blocks (50 jobs over 8 ranks: 7 7 6 6 6 6 6 6)."""
+    return shard_bounds(n_jobs, world_size, rank, 1)
+
+
+def pack_ranked(top_s, top_i):
+    """[J, k] fp32 scores + [J, k] in-pool indices (-1 = beyond the pool's end) -> [J, k] int64: score bits in the high word, the
+    index in the low word -- what one all-gather moves per job and rank."""
+    bits = top_s.contiguous().view(torch.int32).to(torch.int64)
+    return (bits << 32) | (top_i.to(torch.int64) & 0xffffffff)
+
+
+def unpack_ranked(packed):
+    """Inverse of pack_ranked: (scores fp32 [J, k], idx int64 [J, k])."""
+    scores = (packed >> 32).to(torch.int32).view(torch.float32)
+    idx = (packed & 0xffffffff).to(torch.int32).to(torch.int64)          # the low word, sign-extended: -1 stays -1
+    return scores, idx
+
+
+def all_gather_ranked_jobs(local_s, local_i, n_jobs, k, group=None, device=None):
+    """Every rank holds the rankings of ITS block of jobs (job_bounds): local_s / local_i [jobs of this rank, <= k] (fewer columns
+    when the rank's longest pool is shorter than k; None for a rank without jobs or whose pools are all empty).  ONE all-gather of
+    [ceil(n_jobs / world), k] int64 per rank (50 jobs x 125 at world 8: 7 KB per rank) -> (scores [n_jobs, k], idx [n_jobs, k]) on every
+    rank, jobs in the caller's order, columns beyond a pool's size (-inf, -1)."""
+    dev = device if device is not None else (local_s.device if local_s is not None else ops_device())
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = job_bounds(n_jobs, world, rank)
+    per = (n_jobs + world - 1) // world if n_jobs else 0
+    s = torch.full((per, k), float('-inf'), device=dev, dtype=torch.float32)
+    i = torch.full((per, k), -1, device=dev, dtype=torch.int64)
+    if local_s is not None and hi > lo:
+        assert local_s.shape[0] == hi - lo, (local_s.shape, lo, hi)
+        kl = min(k, local_s.shape[1])
+        s[:hi - lo, :kl] = local_s[:, :kl]
+        i[:hi - lo, :kl] = local_i[:, :kl]
+    packed = pack_ranked(s, i)
+    if world > 1 and per * k:
+        out = torch.empty(world * per * k, dtype=torch.int64, device=dev)
+        all_gather_flat(out, packed.view(-1), group)
+        out = out.view(world, per, k)
+        packed = torch.cat([out[r, :job_bounds(n_jobs, world, r)[1] - job_bounds(n_jobs, world, r)[0]] for r in range(world)], 0)
+    else:
+        packed = packed[:n_jobs]
+    return unpack_ranked(packed.contiguous())
+
+
+def rank_pools_sharded(query_reps_list, pools, k=None, hparams=None, method='ot', deterministic=False, group=None, pool_sizes=None):
+    """scorer.rank_pools across the ranks of `group` (config 4: 50 CSFCube queries, each against its own ~125-candidate pool,
+    evaluate.py:58-76, on the 8 GPUs of a node): job j = (query j, pools[j]).  Rank r owns the contiguous block job_bounds(J, world, r)
+    and only ever touches ITS queries and pools -- entries of `query_reps_list` / `pools` outside the block may be None (with
+    `pool_sizes`, the pools' lengths, given on every rank), so a rank uploads only its block's candidates.  Each rank makes one
+    aspire_ot_rank_batch_f32 (or aspire_l2max_rank_batch_f32) call; one all-gather exchanges the ranked lists; no merge.
+    Returns (scores [J, k], idx [J, k]) on every rank: idx = position in the job's own pool, best first, ties in pool order
+    (evaluate.py:76), (-inf, -1) beyond a pool's size.  k: default the longest pool (full ranking).  ranked_lists_from maps them
+    to the [(pid, score), ...] lists rank_pools returns."""
+    from . import scorer
+    n_jobs = len(pools)
+    assert len(query_reps_list) == n_jobs, 'one pool per query'
+    sizes = [int(n) for n in pool_sizes] if pool_sizes is not None else [len(p) for p in pools]
+    assert len(sizes) == n_jobs
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    max_job = max(sizes) if sizes else 0
+    k = max_job if k is None else min(int(k), max_job)
+    if n_jobs == 0 or k == 0:
+        dev = ops_device()
+        return torch.empty(n_jobs, 0, device=dev), torch.empty(n_jobs, 0, dtype=torch.int64, device=dev)
+    lo, hi = job_bounds(n_jobs, world, rank)
+    top_s = top_i = None
+    if hi > lo:
+        assert all(len(pools[j]) == sizes[j] for j in range(lo, hi)), 'pool_sizes disagree with this rank\'s pools'
+        _, top_s, top_i = scorer._launch_rank_pools(query_reps_list[lo:hi], pools[lo:hi], k, hparams, method, deterministic)
+    return all_gather_ranked_jobs(top_s, top_i, n_jobs, k, group)
+
+
+def ops_device():
+    from . import ops
+    return ops.require_gpu()
+
+
+def ranked_lists_from(pids_lists, top_s, top_i):
+    """(scores [J, k], idx [J, k]) of rank_pools_sharded + every job's candidate ids -> per job [(pid, score), ...], as
+    scorer.rank_pools returns them."""
+    top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
+    return [[(pids[i], float(sc)) for sc, i in zip(rs, ri) if i >= 0] for pids, rs, ri in zip(pids_lists, top_s, top_i)]

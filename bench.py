@@ -258,7 +258,8 @@ def config3_probe(device, Q=32, C=50000, s=8, reps=30, cpu=True):
                                   'algorithmic_bytes_per_call': nbytes}},
     }
     # HBM traffic of the kernel from the committed counter passes (not measured in this run): 2 x FETCH_SIZE + WRITE_SIZE
-    tname = next((n for n in ('r05_planes_32x50000x8_fetch_write_size.txt', 'r04_planes_32x50000x8_fetch_write_size.txt')
+    tname = next((n for n in ('r06_planes_32x50000x8_fetch_write_size.txt', 'r05_planes_32x50000x8_fetch_write_size.txt',
+                              'r04_planes_32x50000x8_fetch_write_size.txt')
                   if os.path.exists(os.path.join(ROOT, 'profiles', n))), None)
     tpath = os.path.join(ROOT, 'profiles', tname or '')
     if tname and (Q, C, s) == (32, 50000, 8):
@@ -323,7 +324,8 @@ def config4_probe(device, J=50, NCAND=125, smax=20, reps=40):
     # the 1.5 rounds of items): SQ_ACTIVE_INST_VALU of the committed counter pass = cycles in which some wave of a SIMD issued a
     # VALU instruction, summed over SIMDs; spread evenly over 1024 SIMDs at 2.4 GHz it is the time below which no schedule of the
     # same instruction stream gets
-    for name in ('r05_csf_50x125_ot_sq_counters.txt', 'r04_csf_50x125_ot_sq_counters.txt', 'r03_csf_50x125_ot_sq_counters.txt'):
+    for name in ('r06_csf_50x125_ot_sq_counters.txt', 'r05_csf_50x125_ot_sq_counters.txt', 'r04_csf_50x125_ot_sq_counters.txt',
+                 'r03_csf_50x125_ot_sq_counters.txt'):
         cpath = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(cpath):
             continue
@@ -341,6 +343,72 @@ def config4_probe(device, J=50, NCAND=125, smax=20, reps=40):
     res['workload'] = (f'{J} jobs x {NCAND} candidates of 3 .. {smax} sentence rows, facet-selected queries of 1 .. 8 rows, k = {NCAND} '
                        f'(full ranking), reps resident; data {sum(r["roofline"]["algorithmic_bytes_per_call"] for r in res.values()) // 2 / 2**20:.0f} MiB'
                        f' < L3: warm')
+    return res
+
+
+def config4_sharded_probe(device, rank, world, J=50, NCAND=125, smax=20, reps=30):
+    """BASELINE config 4 as the N-GPU job runs it (outside the timed headline): every CSFCube query has its OWN pool of ~125 candidates
+    (evaluate.py:58-76), so the split is by JOB (aspire_amd/parallel.py: job_bounds -- 50 jobs over 8 ranks: 7 7 6 6 6 6 6 6), a pool is
+    never cut: each rank holds only ITS jobs' candidates, makes ONE aspire_ot_rank_batch_f32 call on them, and ONE all-gather of the ranked
+    [jobs, 125] lists (score bits + in-pool index, one int64 each) hands every rank the whole result.  The same synthetic jobs as
+    config4_probe.  Returns this rank's numbers; rank 0 also ranks all 50 jobs alone and compares."""
+    from aspire_amd import ops
+    from aspire_amd.parallel import job_bounds, all_gather_ranked_jobs
+    g = torch.Generator().manual_seed(4)
+    c_lens = torch.randint(3, smax + 1, (J * NCAND,), generator=g)
+    q_lens = torch.randint(1, 9, (J,), generator=g)
+    c_rows = torch.randn(int(c_lens.sum()), D, generator=g)
+    q_rows = torch.randn(int(q_lens.sum()), D, generator=g)
+    c_start, q_start = torch.cumsum(c_lens, 0) - c_lens, torch.cumsum(q_lens, 0) - q_lens
+
+    def block(j0, j1):
+        """rep sets of jobs [j0, j1): only their rows are uploaded"""
+        def cut(rows, start, lens, a, b):
+            r0, r1 = (int(start[a]), int(start[b - 1] + lens[b - 1])) if b > a else (0, 0)
+            return ops.DeviceRepSet(rows[r0:r1].to(device), (start[a:b] - r0).to(torch.int32).to(device), lens[a:b].to(torch.int32).to(device),
+                                    ext=0, max_len=int(lens[a:b].max()) if b > a else 0)
+        return (cut(q_rows, q_start, q_lens, j0, j1), cut(c_rows, c_start, c_lens, j0 * NCAND, j1 * NCAND),
+                (torch.arange(j1 - j0 + 1, dtype=torch.int32) * NCAND).to(device))
+
+    lo, hi = job_bounds(J, world, rank)
+    res = {'rank': rank, 'jobs': [lo, hi]}
+    q, c, job_off = block(lo, hi) if hi > lo else (None, None, None)
+    out = ops.ot_rank_batch(q, c, job_off, NCAND, NCAND) if hi > lo else None
+
+    def step(exchange=True):
+        if hi > lo:
+            ops.ot_rank_batch(q, c, job_off, NCAND, NCAND, out=out)
+        if exchange:
+            return all_gather_ranked_jobs(out[1] if out else None, out[2] if out else None, J, NCAND, device=device)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.08:          # warm-up by time (config4_probe)
+        for _ in range(20):
+            step(exchange=False)
+        torch.cuda.synchronize()
+    if hi > lo:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            step(exchange=False)
+        b.record()
+        torch.cuda.synchronize()
+        res['score_rank_us_per_call'] = a.elapsed_time(b) / reps * 1e3
+    ts = []
+    for _ in range(12):                                # the whole step: the rank's call + the exchange, every rank starting together
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        top_s, top_i = step()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e6)
+    ts.sort()
+    res['step_us'] = {'median': ts[len(ts) // 2], 'min': ts[0]}
+    res['result_digest'] = int((top_i.to(torch.int64) * torch.arange(1, top_i.numel() + 1, device=device).view_as(top_i)).sum().item() % (1 << 31))
+    if rank == 0:
+        qa, ca, joa = block(0, J)
+        _, ws_, wi_ = ops.ot_rank_batch(qa, ca, joa, NCAND, NCAND)
+        res['order_equals_one_gpu'] = bool(torch.equal(wi_, top_i))
+        res['max_abs_score_diff_vs_one_gpu'] = float((ws_ - top_s).abs().max())
     return res
 
 
@@ -731,6 +799,20 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, 'tools'))
                 import e2ebench
                 out['e2e'] = e2ebench.run(check=False)
+        # the calling patterns and the other configs' figures as PLAIN NUMBERS inside `roofline` and `config` (the driver's record keeps the
+        # scalar fields of those two objects; the nested blocks above stay)
+        out['roofline']['one_stream_value'] = out['one_stream_value']
+        out['roofline']['one_stream_frac'] = out['roofline']['step']['one_stream_frac']
+        out['roofline']['single_job_us'] = out['single_job']['us_per_call']
+        out['roofline']['calls_in_flight'] = n_lanes
+        if 'config3' in out:
+            out['config']['config3_us'] = out['config3']['us_per_call']
+            out['config']['config3_frac'] = out['config3']['roofline']['frac']
+        if 'config4' in out:
+            out['config']['config4_ot_us'] = out['config4']['otAspire']['us_per_call']
+        if 'e2e' in out and 'docs_per_s' in out['e2e']:
+            out['config']['e2e_docs_per_s'] = out['e2e']['docs_per_s']
+            out['config']['e2e_encoder_frac'] = out['e2e']['encoder_roofline']['frac']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(queries[:S], cands[:NC * S])
     if world > 1 and not args.no_probes and not os.environ.get('ASPIRE_BENCH_NO_E2E'):
@@ -753,6 +835,12 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import e2ebench
         try:
+            c4 = config4_sharded_probe(device, rank, world)
+        except Exception as e:
+            c4 = {'rank': rank, 'error': repr(e)}
+        c4_ranks = [None] * world
+        dist.all_gather_object(c4_ranks, c4)
+        try:
             mine = e2ebench.run_sharded(rank, world, n_docs=int(os.environ.get('ASPIRE_BENCH_E2E_DOCS', '8192')))
         except Exception as e:
             mine = {'rank': rank, 'error': repr(e)}
@@ -760,6 +848,18 @@ def main():
         dist.all_gather_object(e2e_ranks, mine)
         watchdog.cancel()
         if rank == 0:
+            if any('error' in r for r in c4_ranks):
+                out['config4'] = {'errors': [r for r in c4_ranks if 'error' in r]}
+            else:
+                step_us = max(r['step_us']['median'] for r in c4_ranks)
+                out['config4'] = {'what': 'config 4 sharded by JOB (config4_sharded_probe): 50 (query, own pool of 125) jobs in contiguous blocks over the '
+                                          'ranks, one aspire_ot_rank_batch_f32 call per rank on its block, ONE all-gather of the ranked lists, no merge; '
+                                          'step = call + exchange, every rank starting together, the slowest rank\'s median',
+                                  'step_us': step_us, 'pairs_per_s': 50 * 125 / (step_us * 1e-6),
+                                  'all_ranks_hold_the_same_result': len({r['result_digest'] for r in c4_ranks}) == 1,
+                                  'order_equals_one_gpu': c4_ranks[0].get('order_equals_one_gpu'),
+                                  'max_abs_score_diff_vs_one_gpu': c4_ranks[0].get('max_abs_score_diff_vs_one_gpu'), 'ranks': c4_ranks}
+                out['config']['config4_sharded_step_us'] = step_us
             if any('error' in r for r in e2e_ranks):
                 out['e2e'] = {'errors': [r for r in e2e_ranks if 'error' in r]}
             else:
@@ -771,6 +871,7 @@ def main():
                               'docs_per_s': sum(r['docs_per_s'] for r in e2e_ranks),
                               'pairs_per_s': sum(r['pairs_per_s'] for r in e2e_ranks),
                               'merged_top1_agrees': len({r['top1_of_query0'] for r in e2e_ranks}) == 1, 'ranks': e2e_ranks}
+                out['config']['e2e_docs_per_s'] = out['e2e']['docs_per_s']
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

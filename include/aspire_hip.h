@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ASPIRE_ABI_VERSION 5
+#define ASPIRE_ABI_VERSION 6
 
 typedef enum {
     ASPIRE_OK = 0,
@@ -109,6 +109,16 @@ size_t aspire_bert_workspace_bytes(const aspire_bert_weights* w, int64_t B, int6
 int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64_t* tok_ids, const int64_t* type_ids,
                             const int64_t* attn_mask, int64_t B, int64_t L, float* hidden_out,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The encoder kernels' sticky per-device status word.  From 6144 token rows on (gfx950 in SPX mode) the two N = 768 GEMMs of a layer
+ * carry the LayerNorm in their epilogue: the six column tiles of a 128-row block exchange their rows' moments through device memory
+ * and a tile WAITS inside the kernel for its partners.  The wait is bounded (20 ms): a tile that gives up sets
+ * ASPIRE_BERT_STATUS_LN_TIMEOUT and the outputs of the forwards in flight are invalid.  aspire_bert_status copies the word to
+ * *status_host, SYNCHRONISES `stream`, and clears it; on a non-zero word run the forwards since the last check again with
+ * aspire_debug_set("GEMM_LN", "off") (the separate LayerNorm pass; aspire_amd/encoder.py and consent.py do exactly that).  Never seen
+ * set outside the fault-injection test (tests/test_gpu_encoder.py); the bound turns a hang under a broken dispatch-order assumption
+ * (CU masking, a serialising debugger) into an error. */
+#define ASPIRE_BERT_STATUS_LN_TIMEOUT 1
+int aspire_bert_status(int32_t* status_host, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * caching_score's document-level term (src/learning/facetid_models/disent_models.py:305-307, taken when

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f'{name} declared in aspire_hip.h but not exported'
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature in aspire_amd/_lib.py'
     assert sorted(_lib.SIGNATURES) == declared
-    assert _lib.lib.aspire_abi_version() == 5
+    assert _lib.lib.aspire_abi_version() == 6
     assert _lib.lib.aspire_max_sents() == 128
 
 

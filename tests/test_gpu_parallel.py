@@ -141,3 +141,9 @@ def test_bench_two_ranks_on_one_gpu():
     e = j['e2e']
     assert len(e['ranks']) == 2 and e['merged_top1_agrees'] and e['docs_per_s'] > 0 and e['pairs_per_s'] > 0
     assert all(r['shards_in_top_k'] == 2 for r in e['ranks'])
+    # config 4 sharded by JOB (bench.py: config4_sharded_probe): 25 + 25 jobs, one all-gather, the one-GPU ranking
+    c4 = j['config4']
+    assert [r['jobs'] for r in c4['ranks']] == [[0, 25], [25, 50]]
+    assert c4['all_ranks_hold_the_same_result'] is True and c4['order_equals_one_gpu'] is True
+    assert c4['max_abs_score_diff_vs_one_gpu'] < 1e-4 and c4['step_us'] > 0
+    assert j['config']['config4_sharded_step_us'] == c4['step_us'] and j['config']['e2e_docs_per_s'] == e['docs_per_s']

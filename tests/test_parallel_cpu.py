@@ -86,3 +86,54 @@ def test_all_gather_topk_world2_gloo(n_cand, k):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, n_cand, k, ret), nprocs=2, join=True)
     assert ret[0] is True and ret[1] is True
+
+
+# ---- config 4: per-query pools sharded by JOB (parallel.rank_pools_sharded's exchange) ------------------------------------------------
+def test_job_bounds_and_packing():
+    from aspire_amd.parallel import job_bounds, pack_ranked, unpack_ranked
+    assert [job_bounds(50, 8, r) for r in range(8)] == [(0, 7), (7, 14), (14, 20), (20, 26), (26, 32), (32, 38), (38, 44), (44, 50)]
+    assert [job_bounds(3, 8, r) for r in range(8)] == [(0, 1), (1, 2), (2, 3)] + [(3, 3)] * 5
+    s = torch.tensor([[1.5, -2.25, float('-inf'), 0.0, -0.0, float('nan')]])
+    i = torch.tensor([[0, 124, -1, 7, 2 ** 31 - 1, 3]])
+    s2, i2 = unpack_ranked(pack_ranked(s, i))
+    assert torch.equal(s2.view(torch.int32), s.view(torch.int32)) and torch.equal(i2, i)
+
+
+def _jobs_worker(rank, world, port, n_jobs, k, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from aspire_amd.parallel import job_bounds, all_gather_ranked_jobs
+        g = torch.Generator().manual_seed(7)
+        sizes = torch.randint(1, k + 1, (n_jobs,), generator=g).tolist()          # ragged pools, the longest <= k
+        full = torch.randn(n_jobs, k, generator=g)
+        full[:, ::4] = 0.75                                                       # ties: pool order
+        want_s = torch.full((n_jobs, k), float('-inf'))
+        want_i = torch.full((n_jobs, k), -1, dtype=torch.int64)
+        for j, n in enumerate(sizes):
+            order = orc.rank_descending(full[j, :n].tolist())
+            want_s[j, :n] = full[j, :n][order]
+            want_i[j, :n] = torch.tensor(order)
+        lo, hi = job_bounds(n_jobs, world, rank)
+        # what this rank's aspire_ot_rank_batch_f32 call hands back: its jobs, columns up to ITS longest pool
+        if hi > lo:
+            kl = max(sizes[lo:hi])
+            ls, li = want_s[lo:hi, :kl].clone(), want_i[lo:hi, :kl].clone()
+        else:
+            ls = li = None
+        s, i = all_gather_ranked_jobs(ls, li, n_jobs, k, device=torch.device('cpu'))
+        ret[rank] = bool(torch.equal(s, want_s) and torch.equal(i, want_i))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_jobs,k', [(2, 50, 125), (8, 50, 125), (8, 5, 40)])
+def test_all_gather_ranked_jobs_gloo(world, n_jobs, k):
+    """50 CSFCube-sized jobs over 2 and 8 ranks (7 7 6 6 6 6 6 6), and fewer jobs than ranks: every rank ends with every job's
+    ranking in the caller's order, (-inf, -1) beyond a pool's size."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_jobs_worker, args=(world, port, n_jobs, k, ret), nprocs=world, join=True)
+    assert all(ret[r] is True for r in range(world)), dict(ret)

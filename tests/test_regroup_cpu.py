@@ -65,3 +65,24 @@ def test_regroup_by_token_rows_sizes_a_forward_by_its_longest_document():
             assert b == len(g) and L == max(bb['seq_lens']) == bb['seq_lens'][0]
             assert b == max(1, budget // L) or g is ids[-1]          # full groups but the last
             assert b * L <= budget or b == 1
+
+
+def test_rows_key_under_inference_mode():
+    """a store built under torch.inference_mode() tracks no torch version (reading `_version` raises): the cache key falls back
+    to the library's own generation counter, which every C-ABI write bumps."""
+    import torch
+    from aspire_amd import ops
+    with torch.inference_mode():
+        rows = torch.zeros(16, 768)
+        assert rows.is_inference()
+        k0 = ops._rows_key(rows)
+        ops._rows_written(rows)
+        k1 = ops._rows_key(rows)
+    assert k0 != k1 and k0[:2] == k1[:2] and k0[2] is None
+    plain = torch.zeros(16, 768)
+    a = ops._rows_key(plain)
+    plain.add_(1.0)                      # a torch write: seen through _version
+    b = ops._rows_key(plain)
+    ops._rows_written(plain)             # a library write: both counters move
+    c = ops._rows_key(plain)
+    assert a != b and b != c and c[3] == 1
