@@ -87,6 +87,9 @@ class AspireConSent:
             doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
         if not bool(torch.isfinite(sent_reps).all() & torch.isfinite(doc_cls_reps).all()):      # (the CLS token belongs to no sentence span)
             # an activation beyond the fp16 planes' range (encoder.py: forward_full_range): once more on the full-range kernels
+            import warnings
+            warnings.warn('AspireConSent.forward: non-finite sentence reps on the fp16-plane encoder path (an activation beyond 65504); '
+                          'encoding the batch again with ASPIRE_HIP_GEMM=bf16x3, ASPIRE_HIP_ATTN=f32')
             final_hidden_state = self.bert_encoder.forward_full_range(tokid_tt, seg_tt, attnmask_tt)
             doc_cls_reps, sent_reps = ops.span_mean_pool(final_hidden_state, tok_idx.to(dev), span_off.to(dev), max_sents)
         # the reference squeezes and re-unsqueezes (:76, :46-49): shapes are [B,768] and [B,S,768] for every B.

@@ -30,9 +30,9 @@ def heavy_tailed_bert(n_layers=12, seed=0, vocab=3000, ffn_overflow=False):
         lns = [m.embeddings.LayerNorm] + [ln for ly in m.encoder.layer for ln in (ly.attention.output.LayerNorm, ly.output.LayerNorm)]
         for li, ln in enumerate(lns):
             # The outlier dimensions carry most of a row's variance (sum of squares ~ 16 500 of ~ 17 500), so a LayerNorm divides the
-            # ordinary dimensions by ~ 4.8: a trained model's gains undo that (ordinary gains around 2.2 here), or every layer would
+            # ordinary dimensions by ~ 4.8: a trained model's gains undo that (ordinary gains around 3.5 here), or every layer would
             # shrink the signal 5 x.  The outliers keep gain ~ 1 and a large bias: (x - mean) / std ~ 8 - 20 on them, + bias = 30 - 100.
-            ln.weight.copy_(2.2 + 0.3 * rnd(768))
+            ln.weight.copy_(3.5 + 0.5 * rnd(768))
             ln.bias.copy_(0.3 * rnd(768))                              # biases of O(1)
             big = torch.randperm(768, generator=g)[:5]
             ln.weight[big] = torch.tensor([10.0, 14.0, 18.0, 24.0, 30.0])    # a few gains of 10 - 30
@@ -46,10 +46,6 @@ def heavy_tailed_bert(n_layers=12, seed=0, vocab=3000, ffn_overflow=False):
             # trained projections do not read the outlier dimensions at full weight (they would drown everything else)
             for lin in (att.query, att.key, att.value, ly.intermediate.dense):
                 lin.weight[:, list(OUTLIER_DIMS)] *= 0.05
-            # attention logits of +-50: the query / key rows of four heads scaled up
-            for h in ((li + 0) % 12, (li + 5) % 12, (li + 7) % 12, (li + 10) % 12):
-                att.query.weight[64 * h:64 * h + 64] *= 1.8
-                att.key.weight[64 * h:64 * h + 64] *= 1.8
             # FFN rows x 20 (their output columns scaled down: the unit still matters, the layer stays conditioned)
             units = torch.randperm(3072, generator=g)[:40]
             ly.intermediate.dense.weight[units] *= 20.0
@@ -58,8 +54,25 @@ def heavy_tailed_bert(n_layers=12, seed=0, vocab=3000, ffn_overflow=False):
                 # one unit whose activation leaves fp16's range (|x| > 65504): the fp16-plane path must hand over to the full-range kernels
                 u = int(units[0])
                 ly.intermediate.dense.weight[u] *= 60.0
-                ly.intermediate.dense.bias[u] = 30000.0
+                ly.intermediate.dense.bias[u] = 90000.0
                 ly.output.dense.weight[:, u] *= 1e-4
+        # attention logits of +-50: the query / key projections of four heads per layer scaled until the largest |q.k / 8| over a
+        # calibration batch is 50 (layer by layer: a layer's input depends on the layers below it)
+        gc = torch.Generator().manual_seed(seed + 2)
+        tok = torch.randint(5, vocab, (4, 96), generator=gc)
+        mask = (torch.arange(96)[None, :] < torch.tensor([96, 70, 96, 33])[:, None]).long()
+        tok, seg = tok * mask, torch.zeros_like(tok)
+        for li, ly in enumerate(m.encoder.layer):
+            att = ly.attention.self
+            hs = m(tok, token_type_ids=seg, attention_mask=mask, output_hidden_states=True).hidden_states[li]
+            q = att.query(hs).view(4, 96, 12, 64).transpose(1, 2)
+            k = att.key(hs).view(4, 96, 12, 64).transpose(1, 2)
+            sc = ((q @ k.transpose(-1, -2)) / 8.0).masked_fill(~mask.bool()[:, None, None, :], 0.0).masked_fill(~mask.bool()[:, None, :, None], 0.0)
+            for h in ((li + 0) % 12, (li + 5) % 12, (li + 7) % 12, (li + 10) % 12):
+                f = float((50.0 / sc[:, h].abs().max().clamp_min(1e-3)).sqrt().clamp(1.0, 40.0))
+                for lin in (att.query, att.key):
+                    lin.weight[64 * h:64 * h + 64] *= f
+                    lin.bias[64 * h:64 * h + 64] *= f
     return m
 
 
