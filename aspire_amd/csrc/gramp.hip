@@ -158,7 +158,9 @@ __device__ __forceinline__ float4 ldrow4(const float* rows, int32_t row, int ofs
 // second fragment set or MFMAs threaded between loads.  (All waves in step -- the non-PP form of this tile -- leaves both waves of a
 // SIMD loading at the same time, then both competing for the pipe: 45 % busy.)
 template <int BM, int BN, int RING, bool L2MAX, bool PP = false>
-// (the second launch bound is WAVES PER SIMD on this toolchain: 3 for the 128 x 128 form's three workgroups per CU, 4 for 256 x 128's two)
+// (the second launch bound is WAVES PER SIMD on this toolchain: 3 for the 128 x 128 form's three workgroups per CU; the 256 x 128 form would
+// want 4 (two workgroups of eight waves per CU) but its loop needs 141 registers -- bounded to 4 it spills inside the loop (2 189 us) -- so it
+// says 3 and runs ONE workgroup per CU: the measured 539 us of NOTES.md round 5)
 __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 256 && BN == 128) ? 3 : BM == 128 ? 2 : 1) pair_gram_p_kernel(GramPArgs g) {
     static_assert(!PP || (BM == 256 && BN == 256), "ping-pong: two groups of four waves");
     constexpr int NT = 2 * BM;                      // threads
