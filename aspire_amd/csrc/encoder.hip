@@ -437,6 +437,16 @@ static __device__ long long* g_gdbg = nullptr;
 
 __host__ __device__ inline size_t p_bytes(int64_t R, int64_t K) { return (size_t)(R + kPPadRows) * K * 4; }
 
+// eight values -> the two planes' 16-byte pieces
+__device__ __forceinline__ void split8_f16(const float (&v)[8], f16x8_t& h, f16x8_t& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hj = (_Float16)v[j];
+        h[j] = hj;
+        l[j] = (_Float16)(v[j] - (float)hj);
+    }
+}
+
 // (x, y) -> packed fp16 pairs of the two planes
 __device__ __forceinline__ void split2_f16(float x, float y, uint32_t& h, uint32_t& l) {
     const _Float16 hx = (_Float16)x, hy = (_Float16)y;
@@ -545,6 +555,9 @@ struct PGemmArgs {
     float eps;
     float2* ln_stats;    // [M][768 / BN] (mean, sum of squared deviations) of a row's BN columns, one entry per column tile
     int* ln_count;       // [row blocks] zeroed before the launch: column tiles of the row block that have published their entry
+    // QKV epilogue (EPI 1, launch_gemm_p_qkv): the attention kernel's operands, already split -- Xp = the planes
+    // [plane h | l][Q | K | V][head][M][64] fp16 (flash_attn_p_kernel)
+    void* Xp;
 };
 
 // One 16-byte-per-lane LDS-DMA: 64 lanes x 16 B from global bytes [base + IMM + voff(lane)] to LDS bytes [lds_dst + IMM, .. + 1024).
@@ -600,9 +613,10 @@ __device__ __forceinline__ void glds_kblock(uint64_t a_base, uint64_t b_base, ui
 // BM = 256 (eight waves, 4 x 2 of 64 x 64; two workgroups per CU = four waves per SIMD): the A tile of a k block is 16 KB, every wave still
 // moves two 1 KB pieces of it and ONE of B -- 24 KB of LDS-DMA per k block for 24 k-steps' worth of MFMAs per wave pair where two 128 x 128
 // tiles move 32 KB: a quarter less traffic through the CU's vector-memory path and LDS per product.
-template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false, bool LN = false, int BM = 128>
+template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false, bool LN = false, int BM = 128, int EPI = 0>
 __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
     static_assert(BM == 128 || (BM == 256 && !PERSIST && !LN), "tile rows");
+    static_assert(EPI == 0 || (EPI == 1 && BM == 128 && BN == 128 && !PERSIST && !LN && SWAP), "QKV epilogue: 128 x 128 tiles, swapped orientation");
     constexpr int kATile = BM * kPRowBytes;                 // A rows of one k block
     static_assert(!PERSIST || KS == 1, "persistent form: one k block per stage");
     static_assert(!LN || (SWAP && !PERSIST && KS == 1), "LayerNorm epilogue: swapped operands, one tile per workgroup");
@@ -1031,13 +1045,24 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
                     for (int e = 0; e < 4; ++e) {
                         const float4 ba = bias_m[j][2 * t], bb = bias_m[j][2 * t + 1];
                         const float b_a = e == 0 ? ba.x : e == 1 ? ba.y : e == 2 ? ba.z : ba.w, b_b = e == 0 ? bb.x : e == 1 ? bb.y : e == 2 ? bb.z : bb.w;
-                        const float fa = gelu_erf(fmaf(acc[i][j][8 * t + e], kUnscale, b_a)), fb = gelu_erf(fmaf(acc[i][j][8 * t + 4 + e], kUnscale, b_b));
+                        float fa = fmaf(acc[i][j][8 * t + e], kUnscale, b_a), fb = fmaf(acc[i][j][8 * t + 4 + e], kUnscale, b_b);
+                        if constexpr (EPI == 0) fa = gelu_erf(fa), fb = gelu_erf(fb);
                         auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, fa), __builtin_bit_cast(int, fb), false, false);
                         const int x0 = r[0], x1 = r[1];
                         o[e] = __builtin_bit_cast(float, x0);
                         o[4 + e] = __builtin_bit_cast(float, x1);
                     }
-                    if (m < g.M) p_store8_at(g.Cp, p_slot8((uint32_t)g.M, (uint32_t)m, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk)), o);
+                    if constexpr (EPI == 1) {
+                        // planes [plane][Q | K | V][head][M][64]: the lane's 8 columns are one 16-byte piece of its row in one head
+                        const int n = n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk;        // 0 .. 2303: n / 64 = 12 (Q | K | V) + head
+                        if (m < g.M) {
+                            f16x8_t hh, ll;
+                            split8_f16(o, hh, ll);
+                            unsigned char* dst = (unsigned char*)g.Xp + ((size_t)(n >> 6) * (size_t)g.M + (size_t)m) * 128 + 2 * (n & 63);
+                            *reinterpret_cast<f16x8_t*>(dst) = hh;
+                            *reinterpret_cast<f16x8_t*>(dst + (size_t)36 * (size_t)g.M * 128) = ll;
+                        }
+                    } else if (m < g.M) p_store8_at(g.Cp, p_slot8((uint32_t)g.M, (uint32_t)m, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk)), o);
                 }
         }
     }
@@ -1063,6 +1088,10 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
 template <int NS, int KS, int BN, bool SWAP, bool PERSIST = false>
 __global__ void __launch_bounds__(256, 2) gemm_p_kernel(PGemmArgs g) {
     gemm_p_body<NS, KS, BN, SWAP, PERSIST, false>(g);
+}
+// the QKV projection for flash_attn_p_kernel (launch_gemm_p_qkv): swapped orientation, the epilogue writes the planes [plane][Q | K | V][head][M][64]
+__global__ void __launch_bounds__(256, 3) gemm_p_qkv_kernel(PGemmArgs g) {
+    gemm_p_body<3, 1, 128, true, false, false, 128, 1>(g);
 }
 // 256 x BN tiles on eight waves (launch_gemm_p: ASPIRE_HIP_GEMM_TILE=256)
 template <int BN, bool SWAP>
@@ -1343,15 +1372,6 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f32_kernel(const float* __r
 //                  pieces XORed with the dim's low 4 bits).  V is transposed while it is staged: a thread owns 4 consecutive
 //                  keys x 8 dims and writes 8-byte runs of 4 keys.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split8_f16(const float (&v)[8], f16x8_t& h, f16x8_t& l) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const _Float16 hj = (_Float16)v[j];
-        h[j] = hj;
-        l[j] = (_Float16)(v[j] - (float)hj);
-    }
-}
-
 __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                                   float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp,
                                                                   int64_t rows) {
@@ -1546,6 +1566,225 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the same attention on operands the QKV GEMM has ALREADY split (launch_gemm_p_qkv): nothing is converted here but
+// the probabilities, and the K / V tiles come into LDS by LDS-DMA -- asynchronously, a whole phase ahead -- instead of through
+// global loads -> 300 VALU conversions per thread and tile -> ds_write (round-5 counters: VALU issue 9.7 k of a wave's 37 k
+// cycles, the matrix pipe 6.1 k, 45 % of the wave cycles parked at waits behind the synchronous staging).
+//   qkvp  fp16 [plane h | l][Q | K | V][head][M rows][64 dims]   (128-byte rows: one DMA instruction = 8 keys = 1 KB contiguous)
+// V stays ROW-MAJOR in LDS ([key][64 dims], as K); the V^T fragments of O^T += V^T P^T come out of it through the LDS transpose
+// read ds_read_b64_tr_b16: the 16 lanes of a group hand in four rows of 16 dims (lane i: row i >> 2, dims 4 (i & 3) .. + 3) and
+// lane i receives dim i of the four rows (tools/ubench/trread.hip prints the mapping) -- the rows may be ANY four keys, so a lane
+// half takes exactly the keys its S^T accumulators hold ({4 lk .. + 3} and {8 + 4 lk .. + 3} of a 16-key group) and P^T goes back
+// in from the registers as before; no transposed image, no transposing store anywhere.
+// Key tiles, planes and every sum are those of flash_attn_f16x2_kernel: the same bits.  Rows of a tile beyond the document are the
+// next document's (or row M - 1 again): finite, weighted exactly 0.
+// Schedule of a tile t (two barriers, as before): [K(t) landed, barrier X] issue V(t) DMA, key biases, S^T(t) [V(t) landed,
+// barrier Y] issue K(t + 1) DMA, soft-max, O^T += V^T P^T.  Every DMA batch has a whole compute phase to land in.
+// ---------------------------------------------------------------------------------------------------------------
+// one LDS-DMA instruction: lane i moves 16 bytes from [sbase + voff(i)] to LDS [lds_dst + 16 i]  (M0 saved / restored: compiler-reserved)
+__device__ __forceinline__ void glds16(uint64_t sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+// four keys x 16 dims, transposed: see above
+typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ f16x8_t lds_tr_pair(const unsigned char* a0, const unsigned char* a1) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const fp16x4_raw x = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)a0);
+    const fp16x4_raw y = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)a1);
+    const h4 xh = __builtin_bit_cast(h4, x), yh = __builtin_bit_cast(h4, y);
+    return __builtin_shufflevector(xh, yh, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned char* __restrict__ qkvp, const int64_t* __restrict__ mask,
+                                                              float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp, int64_t rows) {
+    __shared__ __attribute__((aligned(16))) unsigned char Kp[2][128 * 128];    // [plane][key][64 dims fp16], piece ^ ((key >> 1) & 7)
+    __shared__ __attribute__((aligned(16))) unsigned char Vp[2][128 * 128];    // [plane][key][64 dims fp16], piece ^ 4 ((key >> 1) & 1)
+    __shared__ float kbias[128];
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qblocks = (L + 127) / 128;
+    uint32_t wl;
+    {
+        const uint32_t nb = gridDim.x, bid = blockIdx.x, x = bid & 7, q8 = nb >> 3, r8 = nb & 7;
+        wl = x * q8 + (x < r8 ? x : r8) + (bid >> 3);
+    }
+    const int qb = wl % qblocks, h = (wl / qblocks) % H, b = wl / (qblocks * H);
+    const int64_t doc0 = (int64_t)b * L;                               // first row of the document
+    const int q_row = qb * 128 + wave * 32 + lr;                       // this lane's query
+    const bool q_ok = q_row < L;
+    const size_t plane_b = (size_t)3 * H * rows * 128;                 // bytes of one plane
+    f16x8_t qh[4], ql[4];                                              // k step ks: dims 16 ks + 8 lk .. + 7 = piece 2 ks + lk of the row
+    {
+        const unsigned char* qp = qkvp + ((size_t)h * rows + (size_t)(doc0 + min(q_row, L - 1))) * 128 + 16 * lk;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qh[ks] = *reinterpret_cast<const f16x8_t*>(qp + 32 * ks);
+            ql[ks] = *reinterpret_cast<const f16x8_t*>(qp + plane_b + 32 * ks);
+        }
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mb][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;
+    const uint32_t k_rd = lr * 128 + 16 * (lk ^ ((lr >> 1) & 7));
+    // V transpose read: lane = (lk, dim half dh, i): hands in row 4 lk + (i >> 2) (+ 8 for the second read) of a 16-key group, dims 32 mb + 16 dh + 4 (i & 3) ..:
+    // piece 4 mb + 2 dh + ((i & 3) >> 1), byte 8 (i & 1) in it; the piece is XORed with 4 ((key >> 1) & 1) = 4 ((i >> 3) & 1): keys two apart, 256 B
+    // apart in the image, sit in different halves of the bank row
+    const int vi = lane & 15, vdh = (lane >> 4) & 1;
+    const uint32_t v_rd = (4 * lk + (vi >> 2)) * 128 + 16 * ((2 * vdh + ((vi & 3) >> 1)) ^ (4 * ((vi >> 3) & 1))) + 8 * (vi & 1);
+    const uint32_t lds_k = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&Kp[0][0];
+    const uint32_t lds_v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&Vp[0][0];
+    const int n_tiles = (L + 127) / 128;
+    // wave w moves keys 32 w .. 32 w + 31 of both planes of K (and of V), 8 keys per instruction: lane i -> key 8 c + (i >> 3), LDS piece i & 7 =
+    // the row's piece (i & 7) ^ swizzle(key)
+    const uint64_t k_base = (uint64_t)(uintptr_t)qkvp + ((size_t)(H + h) * rows) * 128;
+    const uint64_t v_base = (uint64_t)(uintptr_t)qkvp + ((size_t)(2 * H + h) * rows) * 128;
+    auto issue_kv = [&](int t, bool is_v) {
+        const int64_t g = doc0 + (int64_t)t * 128;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int key = 32 * wave + 8 * c + (lane >> 3);
+            const int64_t row = min(g + key, rows - 1);
+            const int sw = is_v ? 4 * ((key >> 1) & 1) : (key >> 1) & 7;
+            const uint32_t voff = (uint32_t)(row * 128) + 16 * ((lane & 7) ^ sw);      // (< 4 GB per head: launch_gemm_p_qkv checks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                glds16((is_v ? v_base : k_base) + pl * plane_b, voff, (is_v ? lds_v : lds_k) + pl * 16384 + (32 * wave + 8 * c) * 128);
+        }
+    };
+
+    issue_kv(0, false);
+    for (int t = 0; t < n_tiles; ++t) {
+        const int k0 = t * 128;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // X: this wave's pieces of K(t) have landed ...
+        __syncthreads();                                               // ... everybody's; and everybody is past PV(t - 1): the V image is free
+        issue_kv(t, true);
+        if (tid < 128) {
+            const int kk = k0 + tid;
+            // additive mask; keys past L are tile padding (the next document's rows) and must weigh exactly 0
+            // (stored times log2(e), as the soft-max below wants it: the same product as flash_attn_f16x2_kernel forms per score)
+            kbias[tid] = (kk >= L ? -INFINITY : (mask[(size_t)doc0 + kk] != 0 ? 0.f : -3.4028234663852886e38f)) * 1.44269504088896340736f;
+        }
+        // ---- S^T tile: 4 blocks of 32 keys x this wave's 32 queries; per k step the products l.h, h.l, h.h ----
+        f32x16 sacc[4];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // (consecutive MFMAs go to DIFFERENT accumulators -- the three products of a term run across the four key blocks -- so that none waits
+        // for its predecessor's result; every accumulator still takes its products in the order l.h, h.l, h.h: the same sums)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8_t kh[4], kl[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const uint32_t at = (k_rd + rb * 32 * 128) ^ (32 * ks);
+                kh[rb] = *reinterpret_cast<const f16x8_t*>(&Kp[0][at]);
+                kl[rb] = *reinterpret_cast<const f16x8_t*>(&Kp[1][at]);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[rb], qh[ks], ks == 0 ? zero16 : sacc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[rb], ql[ks], sacc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[rb], qh[ks], sacc[rb], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // Y: this wave's pieces of V(t) have landed ...
+        __syncthreads();                                               // ... everybody's, the key biases too; and everybody is past S^T(t): the K image is free
+        if (t + 1 < n_tiles) issue_kv(t + 1, false);
+        // ---- online soft-max over this tile's keys (registers of this lane + the other half-wave) -------------
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * rb + 8 * (r >> 2) + 4 * lk + (r & 3);
+                sacc[rb][r] = fmaf(sacc[rb][r], kScaleLog2, kbias[key]);
+                tmax = fmaxf(tmax, sacc[rb][r]);
+            }
+        tmax = fmaxf(tmax, lane_xor<32>(tmax));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // exp2(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[rb][r] = __builtin_amdgcn_exp2f(sacc[rb][r] - m_new);
+                psum += sacc[rb][r];
+            }
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[mb][r] *= alpha;
+        // ---- O^T += V^T P^T: registers 8 g .. 8 g + 7 of S^T block rb are the 8 keys of k step 2 rb + g in this lane half: keys
+        // 16 s16 + {4 lk .. + 3} and 16 s16 + 8 + {4 lk .. + 3} -- the two transpose reads of the V^T fragment take exactly those rows ----
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const float pv[8] = {sacc[rb][8 * g2 + 0], sacc[rb][8 * g2 + 1], sacc[rb][8 * g2 + 2], sacc[rb][8 * g2 + 3],
+                                     sacc[rb][8 * g2 + 4], sacc[rb][8 * g2 + 5], sacc[rb][8 * g2 + 6], sacc[rb][8 * g2 + 7]};
+                f16x8_t ph, pl;
+                split8_f16(pv, ph, pl);
+                const int s16 = 2 * rb + g2;
+                f16x8_t vh[2], vl[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    // rows 16 s16 + 4 lk + (i >> 2) and + 8: (key >> 1) & 1 is the same for both ((i >> 3) & 1: 16 s16, 4 lk and 8 leave bit 1 alone);
+                    // dims 32 mb ..: pieces 4 mb .. -> ^ (64 mb) on the byte offset
+                    const uint32_t at = (v_rd + s16 * 16 * 128) ^ (64 * mb);
+                    vh[mb] = lds_tr_pair(&Vp[0][at], &Vp[0][at + 8 * 128]);
+                    vl[mb] = lds_tr_pair(&Vp[1][at], &Vp[1][at + 8 * 128]);
+                }
+                // (the two dim blocks alternate: no MFMA directly behind the one whose result it accumulates onto)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[mb], ph, o[mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mb], pl, o[mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mb], ph, o[mb], 0, 0, 0);
+            }
+    }
+    // ---- normalise and store (as flash_attn_f16x2_kernel) --------------------------------------------------------
+    const float l_tot = l_run + lane_xor<32>(l_run);
+    const float inv = 1.0f / l_tot;
+    if (ctxp) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float fa = o[mb][8 * t + e] * inv, fb = o[mb][8 * t + 4 + e] * inv;
+                    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, fa), __builtin_bit_cast(int, fb), false, false);
+                    const int x0 = r[0], x1 = r[1];
+                    x[e] = __builtin_bit_cast(float, x0);
+                    x[4 + e] = __builtin_bit_cast(float, x1);
+                }
+                if (q_ok) p_store8_at(ctxp, p_slot8((uint32_t)rows, (uint32_t)(doc0 + q_row), (uint32_t)(h * 64 + 32 * mb + 16 * t + 8 * lk)), x);
+            }
+    } else if (q_ok) {
+        float* op = ctx + ((size_t)doc0 + q_row) * kD + h * 64;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4*>(op + 32 * mb + 8 * g4 + 4 * lk) =
+                    make_float4(o[mb][4 * g4 + 0] * inv, o[mb][4 * g4 + 1] * inv, o[mb][4 * g4 + 2] * inv, o[mb][4 * g4 + 3] * inv);
+    }
+}
+
 // fraction of the last round of workgroups that runs empty, at 3 resident workgroups per CU
 double gemm_rounds_waste(long long blocks) {
     const double rounds = (double)blocks / 768.0;
@@ -1610,6 +1849,7 @@ struct Workspace {
     float2* ln_stats;               // the LayerNorm-epilogue GEMMs' per-row, per-column-tile moments [M][12]
     int* ln_count;                  // their arrival counters [2 n_layers][row blocks], zeroed once per forward
     size_t ln_count_bytes;
+    unsigned char* qkvp;            // round 6: the attention's operands as the QKV GEMM splits them (flash_attn_p_kernel): [plane][Q | K | V][head][M][64] fp16
     size_t total;
 };
 
@@ -1640,6 +1880,7 @@ Workspace carve(void* base, int64_t B, int64_t L, int heads, int ffn_dim, int n_
     w.ln_stats = reinterpret_cast<float2*>(take(M * 24));
     w.ln_count_bytes = (size_t)2 * (n_layers > 0 ? n_layers : 0) * ((M + 127) / 128) * sizeof(int);
     w.ln_count = reinterpret_cast<int*>(take(w.ln_count_bytes / sizeof(float) + 1));
+    w.qkvp = reinterpret_cast<unsigned char*>(take(M * 3 * kD));                     // 2 planes x [Q | K | V] x M x 768 fp16 = the bytes of the fp32 qkv
     w.total = off;
     return w;
 }
@@ -1722,6 +1963,20 @@ int launch_gemm_p(const PGemmArgs& g, hipStream_t st) {
         if (int rc = launch_gemm_p_ring<128, SWAP>(g, 0, c1, st)) return rc;
     if (c1 < n128)
         if (int rc = launch_gemm_p_ring<64, SWAP>(g, c1 * 128, (int)(n128 - c1) * 2, st)) return rc;
+    return ASPIRE_OK;
+}
+// The QKV projection for flash_attn_p_kernel: one launch of 18 column tiles in the swapped orientation (a lane owns 8 consecutive columns of its
+// token row = one 16-byte piece per plane), the epilogue writes Q, K and V as fp16 planes per head.
+int launch_gemm_p_qkv(PGemmArgs g, hipStream_t st) {
+    constexpr int lds = 3 * (kPTile + 128 * kPRowBytes);
+    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    ASPIRE_HIP_OK(raised);
+    ASPIRE_REQUIRE(g.N == 3 * kD && g.K == kD && g.bias && g.Xp, ASPIRE_ERR_INVALID_ARG, "QKV projection: [M, 768] x [2304, 768]^T + bias -> planes");
+    ASPIRE_REQUIRE((uint64_t)g.M * 128 < (1ull << 32), ASPIRE_ERR_UNSUPPORTED, "%d token rows: the planes of a head are addressed in 32 bits", g.M);
+    g.probe = 0;
+    g.n_off = 0;
+    hipLaunchKernelGGL(gemm_p_qkv_kernel, dim3(3 * kD / 128, (g.M + 127) / 128), dim3(256), lds, st, g);
+    ASPIRE_LAUNCH_OK();
     return ASPIRE_OK;
 }
 // N = 768 GEMM + residual + LayerNorm in one launch (gemm_p_kernel's LN form): 128-wide column tiles, or 64-wide ones where the launch
@@ -1828,6 +2083,9 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
     ASPIRE_REQUIRE(!pp || (uint64_t)M * (uint64_t)(w->ffn_dim > 3 * kD ? w->ffn_dim : 3 * kD) * 4 < (1ull << 32), ASPIRE_ERR_UNSUPPORTED,
                    "%lld token rows in one forward: the fp16-plane layout addresses < 4 GB per operand (split the batch)", (long long)M);
     if (ln_fused && w->n_layers > 0) ASPIRE_HIP_OK(hipMemsetAsync(ws.ln_count, 0, ws.ln_count_bytes, st));
+    // Round 6 (default on the plane path; ASPIRE_HIP_ATTN=f16x2 pins round 5's form, which splits fp32 Q / K / V inside the attention kernel):
+    // the QKV GEMM writes the attention's operands as fp16 planes, the attention stages them by LDS-DMA (flash_attn_p_kernel)
+    const bool attn_p = pp && w->n_layers > 0 && tuning().attn_form == 0 && !tuning().attn_f32 && tuning().gemm_tile == 0;
     for (int l = 0; l < w->n_layers; ++l) {
         const aspire_bert_layer& ly = w->layers[l];
         const bool last = l == w->n_layers - 1;
@@ -1836,7 +2094,12 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         GemmArgs g{};
         PGemmArgs pg{};
         // 1. fused QKV projection: qkv [M, 2304] = x . Wqkv^T + bqkv
-        if (pp) {
+        if (attn_p) {
+            // Q, K and V go out as the attention kernel's fp16 planes (no fp32 qkv exists in this form)
+            pg = PGemmArgs{ws.actp, lp + po.qkv, nullptr, nullptr, ly.b_qkv, nullptr, (int)M, 3 * kD, kD, 0, 0, 0};
+            pg.Xp = ws.qkvp;
+            if (int rc = launch_gemm_p_qkv(pg, st)) return rc;
+        } else if (pp) {
             pg = PGemmArgs{ws.actp, lp + po.qkv, ws.qkv, nullptr, ly.b_qkv, nullptr, (int)M, 3 * kD, kD, 3 * kD, 0, 0};
             if (int rc = launch_gemm_p<false>(pg, st)) return rc;
         } else {
@@ -1847,7 +2110,11 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         }
         // 2-4. attention.  Fused kernel (scores never leave the chip) unless ASPIRE_HIP_ATTN=gemm pins the
         // three-kernel form (QK^T GEMM, masked soft-max, PV GEMM) that the fused one is tested against.
-        if (dh == 64 && !tuning().attn_gemm) {
+        if (attn_p) {
+            const unsigned qblocks = (unsigned)((L + 127) / 128);
+            hipLaunchKernelGGL(flash_attn_p_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkvp, attn_mask, ws.ctx, (int)L, H, ws.ctxp, M);
+            ASPIRE_LAUNCH_OK();
+        } else if (dh == 64 && !tuning().attn_gemm) {
             const unsigned qblocks = (unsigned)((L + 127) / 128);
             if (tuning().attn_f32)
                 hipLaunchKernelGGL(flash_attn_f32_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkv, attn_mask, ws.ctx,

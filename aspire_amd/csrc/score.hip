@@ -2608,9 +2608,12 @@ int ot_run_tiles(const aspire_repset* q, const aspire_repset* c, int64_t D, int 
             hipLaunchKernelGGL(doc_box_kernel, dim3((unsigned)q->n), dim3(192), 0, (hipStream_t)stream, a.q, qbox);
             ASPIRE_LAUNCH_OK();
         }
+#ifdef ASPIRE_EXPERIMENT_SPLIT      // round 5's role-split kernel: an experiment that lost, built only by tools/experiments/split/build.sh
         if (inbox && split_path_ok(groups4_all, prm) && c->n < ((int64_t)1 << 31) - 8) {
             if (int rc = launch_pair_split(a, (hipStream_t)stream)) return rc;
-        } else if (int rc = launch_pair_fused(a, groups4_all, inbox ? nullptr : qbox, (hipStream_t)stream)) return rc;
+        } else
+#endif
+        if (int rc = launch_pair_fused(a, groups4_all, inbox ? nullptr : qbox, (hipStream_t)stream)) return rc;
     }
     if (chunk1) {
         a.cand0 = 0;
@@ -3137,9 +3140,12 @@ int ot_rank_batch(const aspire_repset* q, const aspire_repset* c, int64_t D, con
     if (fused) {
         if (stages & (kStageCost | kStageSolve))
         {
+#ifdef ASPIRE_EXPERIMENT_SPLIT
             if (self && stages == kStageAll && split_path_ok(groups_bound, prm)) {
                 if (int rc = launch_pair_split(a, s0)) return rc;
-            } else if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0)) return rc;
+            } else
+#endif
+            if (int rc = launch_pair_fused(a, groups_bound, self ? nullptr : qbox, s0)) return rc;
         }
     } else {
         const int rc_run = dispatch_T(max_rows, [&](auto tc) -> int {

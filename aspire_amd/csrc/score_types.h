@@ -152,8 +152,10 @@ bool fused_path_ok(const aspire_repset* q, const aspire_repset* c);
 int launch_pair_fused(const ScoreArgs& a, int64_t groups_bound, const float* qbox, hipStream_t stream);
 // split.hip: the same work with streaming waves and solver waves as two roles of one workgroup (where the fused kernel's SELF / QBOX
 // forms apply and the launch fills the chip)
+#ifdef ASPIRE_EXPERIMENT_SPLIT      // tools/experiments/split/split.hip (round 5's role-split kernel; not part of the product library)
 bool split_path_ok(int64_t groups_bound, const aspire_ot_params* prm);
 int launch_pair_split(const ScoreArgs& a, hipStream_t stream);
+#endif
 // CHUNK form: items = four 8-row chunks (chunk_prep_kernel's records in a.grp_rec, their count in a.grp_off[0])
 int launch_pair_fused_chunk(const ScoreArgs& a, int64_t items_bound, const float* qbox, hipStream_t stream);
 int launch_pair_fused_chunk_l2max(const ScoreArgs& a, int64_t items_bound, hipStream_t stream);

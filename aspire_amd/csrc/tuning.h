@@ -11,6 +11,7 @@ struct Tuning {
     int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
     int attn_f32 = 0;        // ASPIRE_HIP_ATTN=f32: the fused attention kernel on fp32-input MFMAs (round 2) instead of the fp16-plane form
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
+    int attn_form = 0;       // ASPIRE_HIP_ATTN=f16x2: round 5's fused kernel (fp32 Q / K / V split into planes inside the attention kernel) instead of round 6's (planes from the QKV GEMM, LDS-DMA staging)
     int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default (pre-split operands from 1024 token rows on, else bf16x3), 1 f32 = fp32-input MFMA everywhere, 2 bf16x3 = operands split on the fly, 3 planes = pre-split operands at any size
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
     int gemm_probe = 0;      // ASPIRE_HIP_GEMM_PROBE=1: the P-layout GEMM without its MFMAs, 2: without its LDS-DMA (timing probes, wrong results)
@@ -27,7 +28,7 @@ struct Tuning {
     int gram_pp = 0;         // ASPIRE_HIP_GRAM_PP=1: the 256 x 256 tiles in the ping-pong form (two wave groups a segment apart)
     int gram_ring = 0;       // ASPIRE_HIP_GRAM_RING=4: four-stage ring for the 256 x 256 tiles (default 3)
     int fused_waves = 0;     // ASPIRE_HIP_FUSED_WAVES: cap on the fused kernel's resident waves (0 = default; grid experiments)
-    int fused_split = 0;     // ASPIRE_HIP_FUSED_SPLIT: 0 / 2 the fused kernel, 1 the role-split kernel (split.hip) where it applies (experiments)
+    int fused_split = 0;     // ASPIRE_HIP_FUSED_SPLIT: 0 / 2 the fused kernel, 1 the role-split kernel where it applies -- ONLY in the experiment build (tools/experiments/split/build.sh: -DASPIRE_EXPERIMENT_SPLIT); ignored by the product library
     int split_prio = 0;      // ASPIRE_HIP_SPLIT_PRIO: the role-split kernel's solver mode: 0 solve, 3 skip the solves (timing probe: wrong scores)
 };
 

@@ -1,4 +1,5 @@
-// EXPERIMENT, off by default (ASPIRE_HIP_FUSED_SPLIT=1 turns it on; tests/test_gpu_fused.py pins its bits to the fused kernel's): round 5's attempt
+// EXPERIMENT, NOT part of libaspire_hip.so since round 6 (tools/experiments/split/build.sh builds a variant library with it; there
+// ASPIRE_HIP_FUSED_SPLIT=1 turns it on and tools/experiments/split/test_split.py pins its bits to the fused kernel's): round 5's attempt
 // to take the Sinkhorn solves off the streaming waves.  On par with the fused kernel (106.5 - 109 us per 20 x 1000 call against 105 - 107); with the
 // solves skipped (ASPIRE_HIP_SPLIT_PRIO=3) 91.5 -- the structure's floor.  NOTES.md, round 5 log; profiles/r05_split_*.
 // otAspire throughput kernel, role-split form: the fused kernel's two halves on DIFFERENT waves of one workgroup (A5-A8; reference
