@@ -225,6 +225,16 @@ def config3_probe(device, Q=32, C=50000, s=8, reps=30, cpu=True):
         torch.cuda.synchronize()
         blocks.append(a.elapsed_time(b) / reps * 1e3)
     us = sorted(blocks)[1]
+    # ... and call by call: the kernel runs power-limited and its duration follows the clock governor -- 420 us for the
+    # first calls of a cold process, up to ~600 a few calls later, 450 - 490 settled, with periodic excursions (profiles/r06_config3_per_call_trace*):
+    # a block average depends on where the block falls; min / median / p90 of 60 single calls say what the spread is
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+    for ea, eb in evs:
+        ea.record()
+        call()
+        eb.record()
+    torch.cuda.synchronize()
+    per_call = sorted(ea.elapsed_time(eb) * 1e3 for ea, eb in evs)
     ghz = ops.clock_under(call)
     with _pinned(GEMM='bf16x3'):
         for _ in range(2):
@@ -246,6 +256,8 @@ def config3_probe(device, Q=32, C=50000, s=8, reps=30, cpu=True):
         'workload': f'tsAspire biomed: {Q} queries x {C} candidates, {s} sents x {D}d, max-sim single match, one call; resident store with fp16 '
                     f'planes (prepared once: {t_prepare * 1e3:.1f} ms), query planes prepared per call; reps ~ N(0,1); {nbytes / 2**20:.0f} MiB > L3',
         'us_per_call': us, 'us_per_call_blocks': blocks, 'pairs_per_s': Q * C / (us * 1e-6), 'clock_ghz_under_kernel': ghz,
+        'us_per_single_call': {'min': per_call[0], 'median': per_call[30], 'p90': per_call[54], 'max': per_call[-1], 'n': 60,
+                               'what': 'single calls (query planes + the scoring kernel) under their own HIP events, after the blocks'},
         'us_per_call_fp32_row_tiles': us_rows, 'max_abs_err_vs_float64_on_64_pairs': err,
         'roofline': {'bound': 'mfma', 'achieved': flop / (us * 1e-6) / 1e12, 'peak': peak, 'unit': 'TFLOP/s', 'frac': flop / (us * 1e-6) / 1e12 / peak,
                      'kernel': 'pair_gram_p_kernel<128,128,3,true>', 'algorithmic_flop_per_call': flop,
@@ -808,6 +820,8 @@ def main():
         if 'config3' in out:
             out['config']['config3_us'] = out['config3']['us_per_call']
             out['config']['config3_frac'] = out['config3']['roofline']['frac']
+            out['config']['config3_us_min'] = out['config3']['us_per_single_call']['min']
+            out['config']['config3_us_p90'] = out['config3']['us_per_single_call']['p90']
         if 'config4' in out:
             out['config']['config4_ot_us'] = out['config4']['otAspire']['us_per_call']
         if 'e2e' in out and 'docs_per_s' in out['e2e']:
