@@ -71,7 +71,11 @@ int aspire_span_mean_pool_rows_f32(const float* hidden, int64_t B, int64_t L, in
  * attention_mask=attnmask_tt).last_hidden_state` at examples/ex_aspire_consent.py:72-73 (HuggingFace
  * BertModel: embeddings + LayerNorm, 12 x [QKV, masked softmax attention, output proj + residual +
  * LayerNorm, 768->3072 GELU(erf) 3072->768 + residual + LayerNorm]; the pooler is not computed, the
- * reference never reads it).  fp32 throughout on the fp32-input MFMA matrix cores.
+ * reference never reads it).  fp32 ACCURACY throughout (1e-4 of HuggingFace's fp32 CPU forward, also on weights with a trained
+ * checkpoint's outliers: tests/test_gpu_encoder_heavy.py): with `planes` prepared and >= 1024 token rows every GEMM and the
+ * attention run on the fp16 matrix pipe over operands held as two fp16 planes (three exact products per term, fp32 sums); otherwise
+ * on operands split on the fly / the fp32-input matrix cores.  An activation beyond fp16's range (|x| > 65504) makes the plane path
+ * return non-finite rows: check the output and run again after aspire_debug_set("GEMM", "bf16x3") + ("ATTN", "f32") (aspire_amd does).
  *   weights are borrowed device pointers in nn.Linear layout ([out, in] row-major);
  *   w_qkv is query/key/value weights concatenated along `out` ([2304, 768]), b_qkv likewise.
  *   tok_ids / type_ids / attn_mask  int64 [B, L] (type_ids may be NULL = all zero); attn_mask != 0 = real token
