@@ -42,13 +42,18 @@ def _dataset(n_jobs=50, pool_size=125, seed=91):
     return reps, labels, test_pool
 
 
-def _score_worker(rank, world, port, out_dir, deterministic, method):
+def _score_worker(rank, world, port, out_dir, deterministic, method, backend='gloo'):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if backend == 'nccl':              # one process per GPU over RCCL / xGMI: the real thing
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from aspire_amd import evaluate as ev
     from aspire_amd.parallel import job_bounds
     from aspire_amd.repstore import RepStore
@@ -101,6 +106,24 @@ def test_score_step_sharded_by_job_equals_the_single_process_step(tmp_path, worl
     q3 = [c for c, _ in written['p3']]
     assert q3.index('p400') + 1 == q3.index('p401')
     assert written['p11'] == [] and len(written['p29']) == 5
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs at least two GPUs (the build boxes have one)')
+def test_score_step_sharded_by_job_over_rccl(tmp_path):
+    """the same step with one process per GPU over RCCL (torch.distributed backend 'nccl'): the ranked lists' all-gather moves GPU tensors
+    over xGMI.  Runs wherever a driver offers two or more GPUs."""
+    import torch.multiprocessing as mp
+    from aspire_amd import evaluate as ev
+    from aspire_amd.repstore import RepStore
+    world = min(torch.cuda.device_count(), 8)
+    reps, labels, test_pool = _dataset()
+    one = ev.score(str(tmp_path / 'one'), test_pool, RepStore(reps), facet='method', pred_labels=labels, deterministic=True, sharded=False)
+    mp.spawn(_score_worker, args=(world, _free_port(), str(tmp_path), True, 'ot', 'nccl'), nprocs=world, join=True)
+    written = json.load(open(ev.get_scores_filename(str(tmp_path / 'sharded'), 'method')))
+    assert written == json.loads(json.dumps(one))
+    outs = [json.load(open(tmp_path / f'r{r}.json')) for r in range(world)]
+    assert all(o['res'] == written for o in outs)
 
 
 def _rank_worker(rank, world, port, out_dir):
