@@ -33,6 +33,12 @@ enough to stay in the Infinity Cache; `step` prices the whole step (all kernels,
 `two_kernel_form` gives the durations of the separate cost and Sinkhorn kernels (OT_FORM=tile) for comparison.  `cpu_baseline` times the CPU oracle (a
 port of the reference's PyTorch CPU path; its Sinkhorn solver is a parity-unpinned restatement of geomloss 0.2.4) on the
 host cores of this box, with 1 thread and with all cores.
+
+Beside the headline (N = 1): `config3` (tsAspire 32 x 50 000 x 8, blocks + single calls), `config4` (CSFCube shape), `e2e` (config 5's one-GPU
+slice: tokens -> encoder -> store -> 128 queries otAspire + top-100), each with its own roofline.  The calling patterns and those figures are
+ALSO plain numbers inside `roofline` (`one_stream_value`, `one_stream_frac`, `single_job_us`) and `config` (`config3_us`, `config3_us_min`,
+`config3_us_p90`, `config4_ot_us`, `e2e_docs_per_s`, `e2e_encoder_frac`).  At N > 1: `rccl` (what the backend saw), `config4` (the jobs dealt
+out over the ranks, one all-gather of ranked lists: config4_sharded_probe) and `e2e` (every rank encodes its block, shards, merges).
 """
 import argparse
 import ctypes
