@@ -683,6 +683,11 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // LN: the tile's bias values in LDS from the start (visible behind the first k step's barrier; read by the epilogue)
+    __shared__ float4 ln_bias[LN ? BN / 4 : 1];
+    if constexpr (LN) {
+        if (tid < BN / 4) ln_bias[tid] = *reinterpret_cast<const float4*>(g.bias + n0 + 4 * tid);
+    }
 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -838,6 +843,24 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         // A lane holds kCnt = 16 TN values of each of its two rows.  Moments are combined pairwise as (mean, M2 = sum of squared deviations) of
         // equal-sized groups: M2 = M2a + M2b + (n / 2) (mean_a - mean_b)^2 -- no E[x^2] - E[x]^2 cancellation anywhere.
         constexpr int kCnt = 16 * TN, kGX = kD / BN;
+        // The residual's planes of BOTH 32-row blocks go out in one batch (16 x 16-byte loads per lane: 64 registers in flight; round 5 fetched one
+        // 32-column block at a time -- four dependent round trips per tile at the end of a launch whose every tile is in this phase at once); the bias
+        // comes from LDS (staged when the tile begins: no global load sits in this phase beside the residual's).  Issued FIRST: the register-pair
+        // exchange below runs under the loads' flight.
+        f16x8_t rh[2][TN][2], rl[2][TN][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mc = min(m0 + wr * 64 + 32 * i + lr, g.M - 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t slot = p_slot8((uint32_t)g.M, (uint32_t)mc, (uint32_t)(n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk));
+                    rh[i][j][t] = *reinterpret_cast<const f16x8_t*>((const char*)g.resp + slot);
+                    rl[i][j][t] = *reinterpret_cast<const f16x8_t*>((const char*)g.resp + (slot ^ 32u));
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // (left alone the scheduler sinks the loads to their uses again, four at a time)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -860,32 +883,21 @@ __device__ __forceinline__ void gemm_p_body(const PGemmArgs& g) {
         float mu[2], m2[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int mc = min(m0 + wr * 64 + 32 * i + lr, g.M - 1);
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                // one 32-column block at a time (four 16-byte loads in flight): with all of a row's loads hoisted the kernel needs 186 registers
-                // and loses its third workgroup per CU
-                float rv[2][8];
-                float4 bv[2][2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int n = n0 + wc * 32 * TN + 32 * j + 16 * t + 8 * lk;
-                    p_load8_at(g.resp, p_slot8((uint32_t)g.M, (uint32_t)mc, (uint32_t)n), rv[t]);
-                    bv[t][0] = *reinterpret_cast<const float4*>(g.bias + n);
-                    bv[t][1] = *reinterpret_cast<const float4*>(g.bias + n + 4);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float b8[8] = {bv[t][0].x, bv[t][0].y, bv[t][0].z, bv[t][0].w, bv[t][1].x, bv[t][1].y, bv[t][1].z, bv[t][1].w};
+                    const int c4 = (wc * 32 * TN + 32 * j + 16 * t + 8 * lk) >> 2;
+                    const float4 b0 = ln_bias[c4], b1 = ln_bias[c4 + 1];
+                    const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        const float x = fmaf(acc[i][j][8 * t + c], kUnscale, b8[c]) + rv[t][c];
+                        const float x = fmaf(acc[i][j][8 * t + c], kUnscale, b8[c]) + ((float)rh[i][j][t][c] + (float)rl[i][j][t][c]);
                         acc[i][j][8 * t + c] = x;
                         s += x;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             const float ml = s * (1.0f / kCnt);
             float q = 0.f;
