@@ -1614,11 +1614,15 @@ __device__ __forceinline__ f16x8_t lds_tr_pair(const unsigned char* a0, const un
     return __builtin_shufflevector(xh, yh, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned char* __restrict__ qkvp, const int64_t* __restrict__ mask,
-                                                              float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp, int64_t rows) {
-    __shared__ __attribute__((aligned(16))) unsigned char Kp[2][128 * 128];    // [plane][key][64 dims fp16], piece ^ ((key >> 1) & 7)
-    __shared__ __attribute__((aligned(16))) unsigned char Vp[2][128 * 128];    // [plane][key][64 dims fp16], piece ^ 4 ((key >> 1) & 1)
-    __shared__ float kbias[128];
+// KT = keys per tile: 128 (two workgroups per CU: 66 KB of LDS each) or 64 (ASPIRE_HIP_ATTN=p64: 33 KB and 32 accumulator registers fewer -- three per CU;
+// other tile edges, so other online-soft-max groupings: equal to the 128-key form to rounding, not bit for bit)
+template <int KT>
+__device__ __forceinline__ void flash_attn_p_body(const unsigned char* __restrict__ qkvp, const int64_t* __restrict__ mask,
+                                                  float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp, int64_t rows) {
+    constexpr int NRB = KT / 32;                                               // 32-key blocks per tile
+    __shared__ __attribute__((aligned(16))) unsigned char Kp[2][KT * 128];    // [plane][key][64 dims fp16], piece ^ ((key >> 1) & 7)
+    __shared__ __attribute__((aligned(16))) unsigned char Vp[2][KT * 128];    // [plane][key][64 dims fp16], piece ^ 4 ((key >> 1) & 1)
+    __shared__ float kbias[KT];
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lk = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qblocks = (L + 127) / 128;
@@ -1656,57 +1660,57 @@ __global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned cha
     const uint32_t v_rd = (4 * lk + (vi >> 2)) * 128 + 16 * ((2 * vdh + ((vi & 3) >> 1)) ^ (4 * ((vi >> 3) & 1))) + 8 * (vi & 1);
     const uint32_t lds_k = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&Kp[0][0];
     const uint32_t lds_v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&Vp[0][0];
-    const int n_tiles = (L + 127) / 128;
+    const int n_tiles = (L + KT - 1) / KT;
     // wave w moves keys 32 w .. 32 w + 31 of both planes of K (and of V), 8 keys per instruction: lane i -> key 8 c + (i >> 3), LDS piece i & 7 =
     // the row's piece (i & 7) ^ swizzle(key)
     const uint64_t k_base = (uint64_t)(uintptr_t)qkvp + ((size_t)(H + h) * rows) * 128;
     const uint64_t v_base = (uint64_t)(uintptr_t)qkvp + ((size_t)(2 * H + h) * rows) * 128;
     auto issue_kv = [&](int t, bool is_v) {
-        const int64_t g = doc0 + (int64_t)t * 128;
+        const int64_t g = doc0 + (int64_t)t * KT;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int key = 32 * wave + 8 * c + (lane >> 3);
+        for (int c = 0; c < KT / 32; ++c) {
+            const int key = (KT / 4) * wave + 8 * c + (lane >> 3);
             const int64_t row = min(g + key, rows - 1);
             const int sw = is_v ? 4 * ((key >> 1) & 1) : (key >> 1) & 7;
             const uint32_t voff = (uint32_t)(row * 128) + 16 * ((lane & 7) ^ sw);      // (< 4 GB per head: launch_gemm_p_qkv checks)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                glds16((is_v ? v_base : k_base) + pl * plane_b, voff, (is_v ? lds_v : lds_k) + pl * 16384 + (32 * wave + 8 * c) * 128);
+                glds16((is_v ? v_base : k_base) + pl * plane_b, voff, (is_v ? lds_v : lds_k) + pl * (KT * 128) + ((KT / 4) * wave + 8 * c) * 128);
         }
     };
 
     issue_kv(0, false);
     for (int t = 0; t < n_tiles; ++t) {
-        const int k0 = t * 128;
+        const int k0 = t * KT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // X: this wave's pieces of K(t) have landed ...
         __syncthreads();                                               // ... everybody's; and everybody is past PV(t - 1): the V image is free
         issue_kv(t, true);
-        if (tid < 128) {
+        if (tid < KT) {
             const int kk = k0 + tid;
             // additive mask; keys past L are tile padding (the next document's rows) and must weigh exactly 0
             // (stored times log2(e), as the soft-max below wants it: the same product as flash_attn_f16x2_kernel forms per score)
             kbias[tid] = (kk >= L ? -INFINITY : (mask[(size_t)doc0 + kk] != 0 ? 0.f : -3.4028234663852886e38f)) * 1.44269504088896340736f;
         }
         // ---- S^T tile: 4 blocks of 32 keys x this wave's 32 queries; per k step the products l.h, h.l, h.h ----
-        f32x16 sacc[4];
+        f32x16 sacc[NRB];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // (consecutive MFMAs go to DIFFERENT accumulators -- the three products of a term run across the four key blocks -- so that none waits
         // for its predecessor's result; every accumulator still takes its products in the order l.h, h.l, h.h: the same sums)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            f16x8_t kh[4], kl[4];
+            f16x8_t kh[NRB], kl[NRB];
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
+            for (int rb = 0; rb < NRB; ++rb) {
                 const uint32_t at = (k_rd + rb * 32 * 128) ^ (32 * ks);
                 kh[rb] = *reinterpret_cast<const f16x8_t*>(&Kp[0][at]);
                 kl[rb] = *reinterpret_cast<const f16x8_t*>(&Kp[1][at]);
             }
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[rb], qh[ks], ks == 0 ? zero16 : sacc[rb], 0, 0, 0);
+            for (int rb = 0; rb < NRB; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[rb], qh[ks], ks == 0 ? zero16 : sacc[rb], 0, 0, 0);
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[rb], ql[ks], sacc[rb], 0, 0, 0);
+            for (int rb = 0; rb < NRB; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[rb], ql[ks], sacc[rb], 0, 0, 0);
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[rb], qh[ks], sacc[rb], 0, 0, 0);
+            for (int rb = 0; rb < NRB; ++rb) sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[rb], qh[ks], sacc[rb], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // Y: this wave's pieces of V(t) have landed ...
         __syncthreads();                                               // ... everybody's, the key biases too; and everybody is past S^T(t): the K image is free
@@ -1714,7 +1718,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned cha
         // ---- online soft-max over this tile's keys (registers of this lane + the other half-wave) -------------
         float tmax = -INFINITY;
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * rb + 8 * (r >> 2) + 4 * lk + (r & 3);
@@ -1726,7 +1730,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned cha
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // exp2(-inf) = 0 on the first tile
         float psum = 0.f;
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 sacc[rb][r] = __builtin_amdgcn_exp2f(sacc[rb][r] - m_new);
@@ -1741,7 +1745,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned cha
         // ---- O^T += V^T P^T: registers 8 g .. 8 g + 7 of S^T block rb are the 8 keys of k step 2 rb + g in this lane half: keys
         // 16 s16 + {4 lk .. + 3} and 16 s16 + 8 + {4 lk .. + 3} -- the two transpose reads of the V^T fragment take exactly those rows ----
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
                 const float pv[8] = {sacc[rb][8 * g2 + 0], sacc[rb][8 * g2 + 1], sacc[rb][8 * g2 + 2], sacc[rb][8 * g2 + 3],
@@ -1795,6 +1799,15 @@ __global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned cha
                 *reinterpret_cast<float4*>(op + 32 * mb + 8 * g4 + 4 * lk) =
                     make_float4(o[mb][4 * g4 + 0] * inv, o[mb][4 * g4 + 1] * inv, o[mb][4 * g4 + 2] * inv, o[mb][4 * g4 + 3] * inv);
     }
+}
+
+__global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned char* __restrict__ qkvp, const int64_t* __restrict__ mask,
+                                                              float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp, int64_t rows) {
+    flash_attn_p_body<128>(qkvp, mask, ctx, L, H, ctxp, rows);
+}
+__global__ void __launch_bounds__(256, 3) flash_attn_p64_kernel(const unsigned char* __restrict__ qkvp, const int64_t* __restrict__ mask,
+                                                                float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp, int64_t rows) {
+    flash_attn_p_body<64>(qkvp, mask, ctx, L, H, ctxp, rows);
 }
 
 // fraction of the last round of workgroups that runs empty, at 3 resident workgroups per CU
@@ -2097,7 +2110,7 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
     if (ln_fused && w->n_layers > 0) ASPIRE_HIP_OK(hipMemsetAsync(ws.ln_count, 0, ws.ln_count_bytes, st));
     // Round 6 (default on the plane path; ASPIRE_HIP_ATTN=f16x2 pins round 5's form, which splits fp32 Q / K / V inside the attention kernel):
     // the QKV GEMM writes the attention's operands as fp16 planes, the attention stages them by LDS-DMA (flash_attn_p_kernel)
-    const bool attn_p = pp && w->n_layers > 0 && tuning().attn_form == 0 && !tuning().attn_f32 && tuning().gemm_tile == 0;
+    const bool attn_p = pp && w->n_layers > 0 && tuning().attn_form != 1 && !tuning().attn_f32 && tuning().gemm_tile == 0;
     for (int l = 0; l < w->n_layers; ++l) {
         const aspire_bert_layer& ly = w->layers[l];
         const bool last = l == w->n_layers - 1;
@@ -2124,7 +2137,10 @@ extern "C" int aspire_bert_forward_f32(const aspire_bert_weights* w, const int64
         // three-kernel form (QK^T GEMM, masked soft-max, PV GEMM) that the fused one is tested against.
         if (attn_p) {
             const unsigned qblocks = (unsigned)((L + 127) / 128);
-            hipLaunchKernelGGL(flash_attn_p_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkvp, attn_mask, ws.ctx, (int)L, H, ws.ctxp, M);
+            if (tuning().attn_form == 2)
+                hipLaunchKernelGGL(flash_attn_p64_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkvp, attn_mask, ws.ctx, (int)L, H, ws.ctxp, M);
+            else
+                hipLaunchKernelGGL(flash_attn_p_kernel, dim3((unsigned)(B * H) * qblocks), dim3(256), 0, st, ws.qkvp, attn_mask, ws.ctx, (int)L, H, ws.ctxp, M);
             ASPIRE_LAUNCH_OK();
         } else if (dh == 64 && !tuning().attn_gemm) {
             const unsigned qblocks = (unsigned)((L + 127) / 128);

@@ -29,10 +29,10 @@ bool apply_tuning(Tuning& t, const char* key, const char* v) {
     } else if (!strcmp(key, "COST1_BLOCKS")) {
         t.cost1_blocks = unset ? 0 : atoi(v);
     } else if (!strcmp(key, "ATTN")) {
-        if (!unset && strcmp(v, "gemm") && strcmp(v, "f32") && strcmp(v, "f16x2")) return false;
+        if (!unset && strcmp(v, "gemm") && strcmp(v, "f32") && strcmp(v, "f16x2") && strcmp(v, "p64")) return false;
         t.attn_gemm = !unset && !strcmp(v, "gemm");
         t.attn_f32 = !unset && !strcmp(v, "f32");
-        t.attn_form = !unset && !strcmp(v, "f16x2");
+        t.attn_form = unset ? 0 : !strcmp(v, "f16x2") ? 1 : !strcmp(v, "p64") ? 2 : 0;
     } else if (!strcmp(key, "GEMM")) {
         const int f = unset ? 0 : !strcmp(v, "f32") ? 1 : !strcmp(v, "bf16x3") ? 2 : !strcmp(v, "planes") ? 3 : -1;
         if (f < 0) return false;
@@ -97,7 +97,7 @@ bool render_tuning(const Tuning& t, const char* key, char* buf, size_t len) {
         v = names[t.sinkhorn_form];
     } else if (!strcmp(key, "COST_PATH")) v = t.cost_path == 1 ? "mfma" : t.cost_path == 2 ? "valu" : "";
     else if (!strcmp(key, "COST1_BLOCKS")) v = number(t.cost1_blocks);
-    else if (!strcmp(key, "ATTN")) v = t.attn_gemm ? "gemm" : t.attn_f32 ? "f32" : t.attn_form ? "f16x2" : "";
+    else if (!strcmp(key, "ATTN")) v = t.attn_gemm ? "gemm" : t.attn_f32 ? "f32" : t.attn_form == 1 ? "f16x2" : t.attn_form == 2 ? "p64" : "";
     else if (!strcmp(key, "GEMM")) v = t.gemm_form == 1 ? "f32" : t.gemm_form == 2 ? "bf16x3" : t.gemm_form == 3 ? "planes" : "";
     else if (!strcmp(key, "GEMM_TILE")) v = number(t.gemm_tile);
     else if (!strcmp(key, "GEMM_RING")) v = number(t.gemm_ring);

@@ -11,7 +11,7 @@ struct Tuning {
     int cost1_blocks = 0;    // ASPIRE_HIP_COST1_BLOCKS: cap on the small-pool cost kernel's workgroups (0 = default)
     int attn_f32 = 0;        // ASPIRE_HIP_ATTN=f32: the fused attention kernel on fp32-input MFMAs (round 2) instead of the fp16-plane form
     int attn_gemm = 0;       // ASPIRE_HIP_ATTN=gemm: three-kernel attention instead of the fused kernel
-    int attn_form = 0;       // ASPIRE_HIP_ATTN=f16x2: round 5's fused kernel (fp32 Q / K / V split into planes inside the attention kernel) instead of round 6's (planes from the QKV GEMM, LDS-DMA staging)
+    int attn_form = 0;       // ASPIRE_HIP_ATTN=p64 (2): round 6's kernel on 64-key tiles, three workgroups per CU (A/B form); ASPIRE_HIP_ATTN=f16x2 (1): round 5's fused kernel (fp32 Q / K / V split into planes inside the attention kernel) instead of round 6's (planes from the QKV GEMM, LDS-DMA staging)
     int gemm_form = 0;       // ASPIRE_HIP_GEMM: 0 default (pre-split operands from 1024 token rows on, else bf16x3), 1 f32 = fp32-input MFMA everywhere, 2 bf16x3 = operands split on the fly, 3 planes = pre-split operands at any size
     int gemm_tile96 = 0;     // ASPIRE_HIP_GEMM_TILE=96: force 128 x 96 GEMM tiles where N allows
     int gemm_probe = 0;      // ASPIRE_HIP_GEMM_PROBE=1: the P-layout GEMM without its MFMAs, 2: without its LDS-DMA (timing probes, wrong results)

@@ -67,3 +67,24 @@ def test_neighbours_with_huge_rows_do_not_leak_into_a_document():
             old = enc.forward_hidden(tok, None, mask).cpu()
     assert torch.isfinite(both).all()
     assert torch.equal(both, old)
+
+
+@pytest.mark.parametrize('n_layers,b,l', [(2, 8, 128), (1, 64, 256), (2, 3, 400), (1, 3, 37), (2, 9, 130), (12, 6, 173)])
+def test_plane_attention_on_64_key_tiles(n_layers, b, l):
+    """ASPIRE_HIP_ATTN=p64: the same kernel on 64-key tiles (33 KB of LDS, three workgroups per CU): other tile edges, so other online-soft-max
+    groupings -- equal to the 128-key form to rounding, and to HuggingFace at 1e-4"""
+    from aspire_amd._lib import pinned
+    from aspire_amd.encoder import HipBertEncoder
+    m = _bert(n_layers, seed=60 + l)
+    enc = HipBertEncoder(m)
+    tok, seg, mask, _ = _batch(b, l, 3000, seed=980 + l)
+    with pinned(GEMM='planes'):
+        ref = enc.forward_hidden(tok, seg, mask).cpu()
+        with pinned(ATTN='p64'):
+            got = enc.forward_hidden(tok, seg, mask).cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 5e-6 * max(1, n_layers // 2), (got - ref).abs().max().item()     # (rounding differences add up over layers)
+    if b * l <= 4096:
+        with torch.no_grad():
+            want = m(tok, token_type_ids=seg, attention_mask=mask).last_hidden_state
+        assert (got - want).abs().max().item() < 1e-4
