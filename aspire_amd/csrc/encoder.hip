@@ -1805,7 +1805,10 @@ __global__ void __launch_bounds__(256, 2) flash_attn_p_kernel(const unsigned cha
                                                               float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp, int64_t rows) {
     flash_attn_p_body<128>(qkvp, mask, ctx, L, H, ctxp, rows);
 }
-__global__ void __launch_bounds__(256, 3) flash_attn_p64_kernel(const unsigned char* __restrict__ qkvp, const int64_t* __restrict__ mask,
+#ifndef ASPIRE_ATTN64_WAVES      // (experiment builds: 2 = leave a third of the SIMD's registers to another stream's GEMM waves)
+#define ASPIRE_ATTN64_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, ASPIRE_ATTN64_WAVES) flash_attn_p64_kernel(const unsigned char* __restrict__ qkvp, const int64_t* __restrict__ mask,
                                                                 float* __restrict__ ctx, int L, int H, void* __restrict__ ctxp, int64_t rows) {
     flash_attn_p_body<64>(qkvp, mask, ctx, L, H, ctxp, rows);
 }
