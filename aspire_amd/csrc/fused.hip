@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel
 
         // ---- finish the entries.  Only x.y was accumulated: -cdist comes from the same expansion as geomloss's cost, and
         // the entries where it cancels (torch.cdist's direct formula differs there) are redone below ----------------------
-        const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+        // (round 6: a cancelling entry is redone from the exact sum whatever formula torch.cdist would pick -- also beyond 25 rows: include/aspire_hip.h, SHARED SENTENCES)
         float cost[2][2], neg[2][2];
         bool redo[2][2];
 #pragma unroll
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256, ASPIRE_FUSED_MIN_WAVES) pair_fused_kernel
                 const int i = 2 * li + x, j = row0 + 2 * lj + y;
                 const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
                 const float ns = xx[x] + yy[y];
-                redo[x][y] = !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
+                redo[x][y] = i < q_len && j < c_len && sq < 1e-4f * ns * ns;
                 cost[x][y] = sqrtf(fmaxf(sq, 1e-8f));
                 neg[x][y] = -sqrtf(fmaxf(sq, 0.f));
             }

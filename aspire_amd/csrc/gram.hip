@@ -484,13 +484,12 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
             const long long qo = q_off[n];
             const float xx = q_nrm[n];
             const unsigned long long qp = q_ptr[n];
-            const bool qmm = q_mm[n];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int m0 = wr * WM + 32 * i + 8 * g4 + 4 * lk;
                 const long long co = c_off[m0];
                 if (qo < 0 || co < 0) continue;
-                const bool mm = g.cdist_mode == ASPIRE_CDIST_MM || (g.cdist_mode == ASPIRE_CDIST_AUTO && (qmm || c_mm[m0]));
+                // (round 6: a cancelling entry is redone from the exact sum whatever formula torch.cdist would pick -- also beyond 25 rows: include/aspire_hip.h, SHARED SENTENCES)
                 const float4 yy4 = *reinterpret_cast<const float4*>(&c_nrm[m0]);
                 const float yy[4] = {yy4.x, yy4.y, yy4.z, yy4.w};
                 float cost[4], neg[4];
@@ -502,7 +501,7 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
                     cost[k] = sqrtf(fmaxf(sq, 1e-8f));
                     neg[k] = -sqrtf(fmaxf(sq, 0.f));
                     const float ns = xx + yy[k];
-                    redo[k] = !mm && sq < kDirectTau * ns * ns && qp != zrow && c_ptr[m0 + k] != zrow;
+                    redo[k] = sq < kDirectTau * ns * ns && qp != zrow && c_ptr[m0 + k] != zrow;
                     if (redo[k]) {
                         const uint32_t slot = atomicAdd(&wl_count, 1u);
                         if (slot < (uint32_t)kCap) wlist[slot] = ((uint32_t)(m0 + k) << 16) | (uint32_t)n;

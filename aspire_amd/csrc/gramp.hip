@@ -422,7 +422,6 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 
 #pragma unroll
         for (int e = tid; e < kPairs; e += NT) pairmin[e] = 0x7F800000u;
         __syncthreads();
-        const bool mm_all = g.cdist_mode == ASPIRE_CDIST_MM;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -430,14 +429,12 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 
                 const int n = wc * 32 * TN + 32 * j + lr;
                 const int32_t qdi = q_di[n];
                 const float xx = q_nrm[n], qis2 = -2.f * q_is[n];
-                const bool qmm = (qdi >> 16) & 1;
                 const int qd = qdi & 255;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int m0 = wr * 64 + 32 * i + 8 * g4 + 4 * lk;
                     const int32_t cdi = c_di[m0];
                     if (qdi < 0 || cdi < 0) continue;
-                    const bool mm = mm_all || (g.cdist_mode == ASPIRE_CDIST_AUTO && (qmm || ((cdi >> 16) & 1)));
                     const float4 yy4 = *reinterpret_cast<const float4*>(&c_nrm[m0]);
                     const float4 is4 = *reinterpret_cast<const float4*>(&c_is[m0]);
                     const float yy[4] = {yy4.x, yy4.y, yy4.z, yy4.w};
@@ -447,7 +444,7 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 
                     for (int k = 0; k < 4; ++k) {
                         const float ns = xx + yy[k];
                         const float sq = fmaf(acc[i][j][4 * g4 + k], qis2 * cis[k], ns);       // the scales are powers of two: exact
-                        const bool redo = !mm && sq < kDirectTau * ns * ns;
+                        const bool redo = sq < kDirectTau * ns * ns;
                         if (__builtin_expect(redo, 0)) {
                             const uint32_t slot = atomicAdd(&wl_count, 1u);
                             if (slot < (uint32_t)kCap) {
@@ -478,7 +475,6 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 
                 const int32_t qdi = q_di[n];
                 const float xx = q_nrm[n], qis = q_is[n];
                 const int32_t qrow = q_row[n];
-                const bool qmm = (qdi >> 16) & 1;
                 const int qd = qdi & 255, qi = (qdi >> 8) & 255;
                 const long long qo = ((long long)(qt * g.dpt_q + qd) * g.ncand) * g.E + (long long)qi * g.ld;
 #pragma unroll
@@ -487,7 +483,6 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 
                     const int32_t cdi = c_di[m0];
                     if (qdi < 0 || cdi < 0) continue;
                     const int cd = cdi & 255, ci = (cdi >> 8) & 255;
-                    const bool mm = g.cdist_mode == ASPIRE_CDIST_MM || (g.cdist_mode == ASPIRE_CDIST_AUTO && (qmm || ((cdi >> 16) & 1)));
                     const float4 yy4 = *reinterpret_cast<const float4*>(&c_nrm[m0]);
                     const float4 is4 = *reinterpret_cast<const float4*>(&c_is[m0]);
                     const float yy[4] = {yy4.x, yy4.y, yy4.z, yy4.w};
@@ -503,7 +498,10 @@ __global__ void __launch_bounds__(2 * BM, (BM == 128 && BN == 128) ? 3 : (BM == 
                         cost[k] = fmaxf(d, __builtin_sqrtf(1e-8f));                   // = sqrt(max(sq, 1e-8)): geomloss's clamp
                         neg[k] = -d;
                         const float ns = xx + yy[k];
-                        redo[k] = !mm && sq < kDirectTau * ns * ns && qrow >= 0 && c_row[m0 + k] >= 0;
+                        // (otAspire: ALSO under torch.cdist's matmul formula -- a side beyond 25 rows -- where the reference's own -cdist is the expansion: geomloss's
+                        // cost of the entry is derived from this tile (cost_from_neg), and the rule for a cancelling entry is the exact sum for both:
+                        // include/aspire_hip.h, SHARED SENTENCES; round 6, tools/fuzz_parity.py 24 412 planes)
+                        redo[k] = sq < kDirectTau * ns * ns && qrow >= 0 && c_row[m0 + k] >= 0;
                         if (redo[k]) {
                             const uint32_t slot = atomicAdd(&wl_count, 1u);
                             if (slot < (uint32_t)kCap) {

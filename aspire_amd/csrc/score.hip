@@ -396,7 +396,7 @@ __device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want
             const int i = ta * 8 + li, j = tb * 8 + lj;
             const float ns = xx + yy;
             float negv = -sqrtf(fmaxf(sq, 0.f));
-            if (!mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns) {   // rare: this thread walks the two rows itself
+            if (i < q_len && j < c_len && sq < 1e-4f * ns * ns) {   // rare: this thread walks the two rows itself
                 const float* xr = qdoc + (size_t)i * kD;
                 const float* yr = cdoc + (size_t)j * kD;
                 float s0 = 0.f, s1 = 0.f;
@@ -1126,9 +1126,9 @@ __device__ __forceinline__ void pair_cost1_body(const ScoreArgs& a, const PairWs
             }
             const float sq = fmaf(-2.f, gsum, xx) + yy;
             const float ns = xx + yy;
-            const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+            // (round 6: a cancelling entry is redone from the exact sum whatever formula torch.cdist would pick -- also beyond 25 rows: include/aspire_hip.h, SHARED SENTENCES)
             const int gi = 8 * ta + li, gj = 8 * tb + lj;                  // entry of the pair's 8T x 8T slot
-            const bool redo = !mm && gi < q_len && gj < c_len && sq < 1e-4f * ns * ns;
+            const bool redo = gi < q_len && gj < c_len && sq < 1e-4f * ns * ns;
             const int64_t o = slot * n_ent + gi * ld_e + gj;
             if (!redo) {
                 ws.cost[o] = sqrtf(fmaxf(sq, 1e-8f));
@@ -1492,7 +1492,7 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
         // ---- finish the entries and hand them to the Sinkhorn kernel -----------------------------------------
         // Only x.y was accumulated: -cdist comes from the same expansion as the cost, and the entries where it cancels
         // (torch.cdist's direct formula differs there) are redone below.  See pair_cost1_kernel.
-        const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+        // (round 6: a cancelling entry is redone from the exact sum whatever formula torch.cdist would pick -- also beyond 25 rows: include/aspire_hip.h, SHARED SENTENCES)
         const int64_t slot = (paired || mapped) ? (int64_t)my_c_loc : (int64_t)q_loc * ncand + my_c_loc;
         bool redo[R][R];
 #pragma unroll
@@ -1502,7 +1502,7 @@ __global__ void __launch_bounds__(256) pair_tile_kernel(ScoreArgs a, PairWs<1> w
                 const int i = R * li + x, j = R * lj + y;
                 const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
                 const float ns = xx[x] + yy[y];
-                redo[x][y] = my_c_real && !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
+                redo[x][y] = my_c_real && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
                 if (my_c_real && !redo[x][y]) {
                     ws.cost[slot * 64 + i * 8 + j] = sqrtf(fmaxf(sq, 1e-8f));
                     ws.neg[slot * 64 + i * 8 + j] = -sqrtf(fmaxf(sq, 0.f));
@@ -1693,8 +1693,8 @@ __global__ void __launch_bounds__(256) pair_one_kernel(ScoreArgs a, int64_t n_sl
     PairState<1> st;
     st.cost[0][0] = sqrtf(fmaxf(sq, 1e-8f));
     st.neg[0][0] = -sqrtf(fmaxf(sq, 0.f));
-    const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
-    unsigned long long todo = __ballot(!mm && li < q_len && lj < c_len && sq < 1e-4f * ns * ns);
+    // (round 6: a cancelling entry is redone from the exact sum whatever formula torch.cdist would pick -- also beyond 25 rows: include/aspire_hip.h, SHARED SENTENCES)
+    unsigned long long todo = __ballot(li < q_len && lj < c_len && sq < 1e-4f * ns * ns);
     while (todo != 0) {        // rare: the whole wave on one entry, from the rows as they are in memory (a common shift drops out)
         const int o = (int)__builtin_ctzll(todo);
         todo &= todo - 1;

@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
         __builtin_amdgcn_wave_barrier();
 
         // ---- the pair's entries (i = 8 s + 4 iq + r, j = 8 hp + 4 jq + t) ---------------------------------------------
-        const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
+        // (round 6: a cancelling entry is redone from the exact sum whatever formula torch.cdist would pick -- also beyond 25 rows: include/aspire_hip.h, SHARED SENTENCES)
         const int j = crow0 + 8 * hp + 4 * mjq + mt;
         bool redo[2][4];
         float negv[2][4];
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, 2) pair_tile16_kernel(ScoreArgs a, PairWs
                 const float dot = macc[s][0][r] + macc[s][1][r];
                 const float sq = fmaf(-2.f, dot, xx[s][r]) + yy;
                 const float ns = xx[s][r] + yy;
-                redo[s][r] = my_c_real && !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
+                redo[s][r] = my_c_real && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
                 negv[s][r] = -sqrtf(fmaxf(sq, 0.f));
                 if constexpr (!L2MAX)
                     if (my_c_real && (!REC || (i < LDW && j < LDW))) ws.cost[slot * EW + i * LDW + j] = sqrtf(fmaxf(sq, 1e-8f));

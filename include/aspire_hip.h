@@ -288,8 +288,10 @@ typedef struct {
  * the bar is absolute, hence the squared norm on the right) and takes BOTH -cdist and geomloss's cost of such an entry from the exact
  * sum of squared differences: within 1.3e-5 of the float64 oracle (tests/test_gpu_coincident.py), and therefore up to 5e-2 away from
  * what the fp32 reference happens to return for that pair.  Rankings: a shared sentence gives the pair a cost entry of ~1e-4 instead
- * of ~2e-2, i.e. it scores (correctly) slightly better than the reference scores it.  There is no flag that reproduces the
- * reference's noise. */
+ * of ~2e-2, i.e. it scores (correctly) slightly better than the reference scores it.  The rule holds at ANY document length: also
+ * where torch.cdist itself would pick its matmul formula (a side beyond 25 rows, ASPIRE_CDIST_MM) a cancelling entry's -cdist and cost
+ * come from the exact sum (round 6; before, the kernels left those entries on the expansion, and geomloss's cost with them).  There is
+ * no flag that reproduces the reference's noise. */
 #define ASPIRE_OT_DISTANCE 0 /* return_pair_sims=False: OT_eps = <a,f> + <b,g>  (positive)          */
 #define ASPIRE_OT_PLAN_SIM 1 /* return_pair_sims=True : sum_ij P_ij * neg_ij     (negative)         */
 #define ASPIRE_OT_SIMILARITY 2 /* -OT_eps: what AspireModel.get_similarity returns (models.py:197), the ranking key */

@@ -48,6 +48,13 @@ FAMILIES = [
     ('tile16', dict(), 1, 2600, 12, 14, False),
     ('gram bf16x3', dict(COST_PATH='mfma'), 24, 300, 8, 8, False),
     ('plane tiles', dict(COST_PATH='mfma'), 24, 2100, 8, 8, True),
+    # documents beyond 25 rows: torch.cdist's matmul formula for -cdist (the reference's own max-sim there is sqrt(noise): 5e-2 bar), geomloss's cost
+    # still from the exact sum where it cancels (round 6: tools/fuzz_parity.py 24 412 planes found the plane tiles deriving it from the noisy -cdist)
+    ('small, 30 rows', dict(OT_FORM='small'), 2, 60, 28, 30, False),
+    ('tile16 records, 32 rows', dict(), 1, 2600, 30, 32, False),
+    ('generic, 40 rows', dict(), 1, 40, 40, 40, False),
+    ('gram bf16x3, 32 rows', dict(COST_PATH='mfma'), 24, 300, 30, 32, False),
+    ('plane tiles, 32 rows', dict(COST_PATH='mfma'), 2, 2300, 30, 32, True),
 ]
 
 
@@ -75,5 +82,6 @@ def test_shared_sentence_against_float64(amd, family, sigma):
         l64 = -torch.cdist(q[0].double(), c[j].double()).min().item()
         # max-sim of a shared sentence: the best match is the pair of equal rows, -cdist = -0 exactly in float64; torch.cdist's
         # fp32 direct formula gives exactly 0 too (<= 25 rows), and so must the kernels' redo of cancelling entries
-        assert abs(float(l2[0, j]) - l64) < TOL, (name, sigma, j, float(l2[0, j]), l64)
+        tol_l2 = 5e-2 if (j in shared and max(qlen, len(c[j])) > 25) else TOL      # beyond 25 rows the reference's own -cdist of equal rows is sqrt(noise)
+        assert abs(float(l2[0, j]) - l64) < tol_l2, (name, sigma, j, float(l2[0, j]), l64)
     print(f'{name:12s} sigma {sigma}: max |HIP - float64 oracle| {worst:.2e}; the fp32 oracle itself is {ref_gap:.2e} from float64')

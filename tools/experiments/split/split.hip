@@ -312,7 +312,6 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
 
             // finish the entries.  Only x.y was accumulated: -cdist comes from the same expansion as geomloss's cost, and the
             // entries where it cancels (torch.cdist's direct formula differs there) are redone below
-            const bool mm = use_mm_formula(a.cdist_mode, q_len, c_len);
             float cost[2][2], neg[2][2];
             bool redo[2][2];
 #pragma unroll
@@ -322,7 +321,7 @@ __global__ void __launch_bounds__(kSpWaves * 64) pair_split_kernel(ScoreArgs a) 
                     const int i = 2 * li + x, j = 2 * lj + y;
                     const float sq = fmaf(-2.f, accg[x][y], xx[x]) + yy[y];
                     const float ns = xx[x] + yy[y];
-                    redo[x][y] = !mm && i < q_len && j < c_len && sq < 1e-4f * ns * ns;
+                    redo[x][y] = i < q_len && j < c_len && sq < 1e-4f * ns * ns;
                     cost[x][y] = sqrtf(fmaxf(sq, 1e-8f));
                     neg[x][y] = -sqrtf(fmaxf(sq, 0.f));
                 }
