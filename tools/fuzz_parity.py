@@ -181,27 +181,30 @@ for case in range(n3):
             vals = [s for _, s in ranked[j]]
             assert all(vals[t] >= vals[t + 1] for t in range(len(vals) - 1)), ('order', case, method, j, vals[:6])
             assert all(np.isfinite(v) for v in vals), ('non-finite', case, method, j, [(i, v) for i, v in ranked[j] if not np.isfinite(v)][:5], len(queries[j]), [len(pools[j][i]) for i, v in ranked[j] if not np.isfinite(v)][:5], smax, bscale, pool_sizes[j])
-            # a shared sentence: geomloss's own cancellation noise (otAspire), torch.cdist's matmul formula beyond 25 rows (tsAspire)
-            noisy = lambda i: j in shared and i == 0 and (method == 'ot' or max(len(queries[j]), len(pools[j][0])) > 25)
+            # a shared sentence (round 6: held to the FLOAT64 oracle like part 1 -- every kernel form takes a cancelling entry from the exact sum, at
+            # any document length; only tsAspire beyond 25 rows keeps a 5e-2 bar: the fp32 reference's own value there is sqrt(noise))
+            is_shared = lambda i: j in shared and i == 0
+            loose = lambda i: is_shared(i) and method == 'l2max' and max(len(queries[j]), len(pools[j][0])) > 25
             for i, s in ranked[j]:
-                assert abs(s - float(one[i])) <= (5e-2 * bscale if noisy(i) else 2e-4 * bscale), (case, method, j, i, s, float(one[i]))
+                assert abs(s - float(one[i])) <= (5e-2 * bscale if loose(i) else 2e-4 * bscale), (case, method, j, i, s, float(one[i]))
             if len(vals) < n:                   # nothing outside the list beats its last entry
                 rest = [float(one[i]) for i in range(n) if i not in got]
-                assert max(rest) <= vals[-1] + (5e-2 * bscale if j in shared else 2e-4 * bscale), ('rest', case, method, j, max(rest), vals[-1])
+                assert max(rest) <= vals[-1] + (5e-2 * bscale if (j in shared and method == 'l2max') else 2e-4 * bscale), ('rest', case, method, j, max(rest), vals[-1])
             for i in ([0] if j in shared else []) + [int(rng.integers(n)) for _ in range(2)]:      # sampled pairs against the oracle
                 if i not in got:
                     continue
+                qd, cd = (queries[j].double(), pools[j][i].double()) if is_shared(i) else (queries[j], pools[j][i])
                 if method == 'ot':
                     try:
-                        w = orc.get_similarity(queries[j], pools[j][i])
+                        w = orc.get_similarity(qd, cd)
                     except ValueError:          # a one-sentence candidate equal to its one-sentence query: diameter 0, geomloss's
                         continue                # schedule (arange from log 0) raises -- the GPU side gives the entry's cost (kMinDiameter)
                 else:
-                    w = -orc.allpair_masked_dist_l2max(orc.RepLen(queries[j][None].permute(0, 2, 1), [len(queries[j])]),
-                                                       orc.RepLen(pools[j][i][None].permute(0, 2, 1), [len(pools[j][i])])).item()
+                    w = -torch.cdist(qd, cd).min().item() if is_shared(i) else -orc.allpair_masked_dist_l2max(
+                        orc.RepLen(qd[None].permute(0, 2, 1), [len(qd)]), orc.RepLen(cd[None].permute(0, 2, 1), [len(cd)])).item()
                 e = abs(got[i] - w)
-                assert e <= (5e-2 * bscale if noisy(i) else 1e-4 * bscale), (case, method, j, i, got[i], w, bscale)
-                if not noisy(i):
+                assert e <= (5e-2 * bscale if loose(i) else 1e-4 * bscale), (case, method, j, i, got[i], w, bscale, len(queries[j]), len(pools[j][i]), is_shared(i))
+                if not is_shared(i):
                     worst_b[method] = max(worst_b[method], e / bscale)
     print(f'batched case {case}: J={J} pools={pool_sizes[:8]}{"..." if J > 8 else ""} S<={smax} few_long={few_long} k={k} scale={bscale} shared={len(shared)} ok', flush=True)
 print(f'{n3} batched cases ok; worst errors {worst_b}')
