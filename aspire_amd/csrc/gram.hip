@@ -139,7 +139,6 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
     __shared__ long long q_off[BN];
     __shared__ __attribute__((aligned(16))) float c_nrm[kBM];
     __shared__ float q_nrm[BN];
-    __shared__ unsigned char c_mm[kBM], q_mm[BN];
     __shared__ uint32_t pairmax[L2MAX ? 256 : 1];
     __shared__ int c_len_s[16];                  // BOX: lengths of the tile's candidate documents (0 = none)
 
@@ -167,7 +166,6 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
         }
         c_ptr[tid] = (doc_ok && i < len) ? (unsigned long long)(uintptr_t)(g.c.rows + (size_t)(start + i) * kD) : zrow;
         c_off[tid] = !doc_ok ? -1 : L2MAX ? (long long)d : (long long)c_loc * g.E + i;
-        c_mm[tid] = len > 25;
     } else if (tid < kBM + BN) {
         const int r = tid - kBM;
         const int d = r / g.mr_q, i = r - d * g.mr_q;
@@ -180,7 +178,6 @@ __global__ void __launch_bounds__(256, 2) pair_gram_kernel(GramArgs g) {
         }
         q_ptr[r] = (doc_ok && i < len) ? (unsigned long long)(uintptr_t)(g.q.rows + (size_t)(start + i) * kD) : zrow;
         q_off[r] = !doc_ok ? -1 : L2MAX ? (long long)d : ((long long)q_loc * g.ncand) * g.E + (long long)i * g.ld;
-        q_mm[r] = len > 25;
     }
     if constexpr (BOX) {
         if (tid >= kBM + BN && tid < kBM + BN + 16) {   // every slot of the table is written (0 = no document)
