@@ -121,8 +121,10 @@ __device__ __forceinline__ void pair_generic_body(const ScoreArgs& a, int mode, 
         const float ns = lds[L.xx + i] + lds[L.yy + j];
         // (where the expansion cancels -- the streaming kernels' test -- geomloss's cost comes from the exact sum too: what its own
         // formula gives in float64; in fp32 the reference returns the square root of rounding noise there)
-        cost[i * ld + j] = sqrtf(fmaxf(sq < 1e-4f * ns * ns ? d0 + d1 : sq, 1e-8f));
-        neg[i * ld + j] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d0 + d1);
+        // (round 6: ... and so does -cdist, also under torch.cdist's matmul formula: one rule for a cancelling entry in every kernel family)
+        const bool cancels = sq < 1e-4f * ns * ns;
+        cost[i * ld + j] = sqrtf(fmaxf(cancels ? d0 + d1 : sq, 1e-8f));
+        neg[i * ld + j] = (mm && !cancels) ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d0 + d1);
     }
     __syncthreads();
 

@@ -266,7 +266,23 @@ __global__ void __launch_bounds__(kBlock, 3) l2max_kernel(ScoreArgs a) {
                             xx += lds[Lds<T>::kRed + w * T * 16 + ta * 16 + li];
                             yy += lds[Lds<T>::kRed + w * T * 16 + tb * 16 + 8 + lj];
                         }
-                        d2 = fmaxf(fmaf(-2.f, g, xx) + yy, 0.f);
+                        const float sqv = fmaf(-2.f, g, xx) + yy, ns = xx + yy;
+                        d2 = fmaxf(sqv, 0.f);
+                        // (round 6: where the expansion cancels the entry comes from the exact sum under this formula too -- one rule in every kernel family:
+                        // include/aspire_hip.h, SHARED SENTENCES.  Rare: the lane walks the two rows itself)
+                        if (i < q_len && j < c_len && sqv < 1e-4f * ns * ns) {
+                            const float* xr = qdoc + (size_t)i * kD;
+                            const float* yr = cdoc + (size_t)j * kD;
+                            float s0 = 0.f, s1 = 0.f;
+                            for (int d = 0; d < kD; d += 8) {
+                                const float4 u0 = ld4(xr + d), v0 = ld4(yr + d), u1 = ld4(xr + d + 4), v1 = ld4(yr + d + 4);
+                                const float a0 = u0.x - v0.x, a1 = u0.y - v0.y, a2 = u0.z - v0.z, a3 = u0.w - v0.w;
+                                const float b0 = u1.x - v1.x, b1 = u1.y - v1.y, b2 = u1.z - v1.z, b3 = u1.w - v1.w;
+                                s0 = fmaf(a3, a3, fmaf(a2, a2, fmaf(a1, a1, fmaf(a0, a0, s0))));
+                                s1 = fmaf(b3, b3, fmaf(b2, b2, fmaf(b1, b1, fmaf(b0, b0, s1))));
+                            }
+                            d2 = s0 + s1;
+                        }
                     } else {
                         d2 = 0.f;
 #pragma unroll
@@ -388,9 +404,10 @@ __device__ __forceinline__ void finish_pair(const float* lds, bool mm, bool want
         float costv = sqrtf(fmaxf(sq, 1e-8f));
         if constexpr (DIRECT) {
             const float ns = xx + yy;
-            if (sq < 1e-4f * ns * ns) costv = sqrtf(fmaxf(d2, 1e-8f));
+            const bool cancels = sq < 1e-4f * ns * ns;
+            if (cancels) costv = sqrtf(fmaxf(d2, 1e-8f));
             ws.cost[o] = costv;
-            ws.neg[o] = mm ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);
+            ws.neg[o] = (mm && !cancels) ? -sqrtf(fmaxf(sq, 0.f)) : -sqrtf(d2);      // (round 6: a cancelling entry from the exact sum under either formula)
         } else {
             // only x.y was accumulated (see pair_cost1_kernel): -cdist from the expansion, except where it cancels
             const int i = ta * 8 + li, j = tb * 8 + lj;
